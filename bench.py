@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — GiB/s of the chunk-transform hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the chain over one batch of synthetic 4 MiB chunks that is ALREADY RESIDENT IN HBM when
+the timed region starts (device pointers through the C ABI; the PCIe-inclusive rate is reported separately in
+DESIGN.md, never as `value`).  Workloads (config.workload):
+  full     BASELINE configs[3]: 8 x 1 GiB segments per GPU, Zstd(level 3) -> AES-256-GCM -> CRC32C
+  gcm_crc  BASELINE configs[2]: 1 GiB segment, AES-256-GCM + CRC32C
+  crc      BASELINE configs[1]: 1 GiB segment, CRC32C only
+N > 1: one process per GPU (torch.distributed.run), segments sharded segment-major, no data-path collective
+ — weak scaling: every GPU gets the same number of segments.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+GiB = float(1 << 30)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="auto", choices=["auto", "full", "gcm_crc", "crc"])
+    ap.add_argument("--segments", type=int, default=0, help="1 GiB segments per GPU (default: 8 for full, 1 otherwise)")
+    ap.add_argument("--dist", default="K", choices=["K", "R"], help="synthetic content: K Kafka-like, R random")
+    ap.add_argument("--profile", default="1.5.7", choices=["1.5.6", "1.5.7"], help="libzstd release reproduced")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch  # before libtsxform: one shared HIP runtime
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import tsxform
+    from tsxform import synth
+    nat = tsxform._native
+    N = nat.Native()
+    N.init(1, [local_rank])
+    have_zstd = getattr(tsxform, "HAVE_ZSTD", False)
+    workload = args.workload
+    if workload == "auto":
+        workload = "full" if have_zstd else "gcm_crc"
+    flags = {"full": nat.COMPRESS | nat.ENCRYPT | nat.CRC, "gcm_crc": nat.ENCRYPT | nat.CRC, "crc": nat.CRC}[workload]
+    nseg = args.segments or (8 if workload == "full" else 1)
+    CH = synth.CHUNK
+    cps = 256                                            # chunks per 1 GiB segment
+    n = nseg * cps
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic segments, generated directly in HBM; global segment id = rank * nseg + s ------------
+    src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+    for s in range(nseg):
+        gs = rank * nseg + s
+        for c in range(cps):
+            i = s * cps + c
+            src[i * CH:(i + 1) * CH] = synth.gen_chunk(args.dist, 1000 + gs, gs, c, CH, device=dev)
+    slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
+    dst = torch.empty(n * slot if workload != "crc" else 64, dtype=torch.uint8, device=dev)
+    d = np.zeros(n, nat.DESC_DTYPE)
+    d["src_off"] = np.arange(n, dtype=np.uint64) * CH
+    d["src_len"] = CH
+    d["dst_off"] = np.arange(n, dtype=np.uint64) * slot
+    d["dst_cap"] = slot
+    for s in range(nseg):
+        for c in range(cps):
+            d["iv"][s * cps + c] = np.frombuffer(synth.iv_for(rank * nseg + s, c), np.uint8)
+    profile = nat.ZSTD_PROFILE_1_5_7 if args.profile == "1.5.7" else nat.ZSTD_PROFILE_1_5_6
+    params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=profile)
+    ctx = N.ctx_create(0, n, CH)
+
+    def step():
+        if workload == "crc":
+            N.crc32c_batch(d, src.data_ptr(), nat.MEM_DEVICE, ctx=ctx)
+        else:
+            N.transform_batch(params, d, src.data_ptr(), dst.data_ptr(), dst.numel(), nat.MEM_DEVICE, ctx=ctx)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    stage = {"crc": 0.0, "zstd": 0.0, "gcm": 0.0}
+    launches = {"crc": 0, "zstd": 0, "gcm": 0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()                                          # synchronous: returns when the batch is done on the device
+        t = N.ctx_timing(ctx)
+        stage["crc"] += t.crc_ms; stage["zstd"] += t.zstd_ms; stage["gcm"] += t.gcm_ms
+        launches["crc"] += 1; launches["zstd"] += 1; launches["gcm"] += 1
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert (d["status"] == 0).all(), "chunk failures: %s" % d["status"][d["status"] != 0][:8]
+    total_bytes = float(n) * CH * world * args.steps
+    value = total_bytes / GiB / elapsed
+    out_sizes = d["dst_len"].astype(np.int64) if workload != "crc" else np.zeros(n, np.int64)
+
+    # ---- parity spot-check against the oracle (outside the timed region) ------------------------------
+    verified = None
+    if rank == 0 and not args.no_verify:
+        from oracle import oracle as o
+        verified = 0
+        for i in sorted(set([0, 1, n // 2, n - 1])):
+            chunk = src[i * CH:(i + 1) * CH].cpu().numpy()
+            assert d["crc32c"][i] == o.crc32c(chunk), "crc mismatch chunk %d" % i
+            if workload != "crc":
+                got = dst[i * slot:i * slot + int(d["dst_len"][i])].cpu().numpy().tobytes()
+                of = (o.COMPRESS if flags & nat.COMPRESS else 0) | o.ENCRYPT | o.OPENSSL
+                exp, _ = o.transform_chunk(of, synth.KEY, synth.AAD, d["iv"][i].tobytes(), chunk.tobytes())
+                assert got == exp, "transformed bytes differ from the oracle for chunk %d (libzstd %s)" % (i, o.zstd_version())
+            verified += 1
+
+    # ---- roofline of the dominant kernel (HIP events on the library's own stream, per launch) ----------
+    dom = max(stage, key=lambda k: stage[k])
+    ms = stage[dom] / max(launches[dom], 1)
+    mean_out = float(out_sizes.mean()) if workload != "crc" else 0.0
+    if dom == "crc":
+        alg = n * (CH + 4.0)                                                   # N read + 4 B written per chunk
+    elif dom == "gcm":
+        m = mean_out - 28 if workload != "crc" else CH                        # GCM input = frame (or chunk)
+        alg = n * (m + m + 28.0)                                               # m read + m + 28 written
+    else:
+        alg = n * (CH + (mean_out - 28 if flags & nat.ENCRYPT else mean_out)) # N read + frame written
+    achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": {"crc": "crc32c_partial_kernel", "gcm": "gcm_ctr_ghash_kernel", "zstd": "zstd_compress_kernel"}[dom],
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None, "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage.items()}}
+
+    # ---- CPU baseline: the oracle port (libzstd + OpenSSL GCM + CRC32C), all host cores, bounded sample --
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as o
+        cores = os.cpu_count() or 1
+        sample = {"full": 48, "gcm_crc": 256, "crc": 256}[workload]
+        sample = min(sample, n)
+        host = src[:sample * CH].cpu().numpy()
+        ivs = np.ascontiguousarray(d["iv"][:sample]).reshape(-1)
+        of = ((o.COMPRESS if flags & nat.COMPRESS else 0) | (o.ENCRYPT if flags & nat.ENCRYPT else 0) | o.CRC | o.OPENSSL)
+        secs, _, _, _, _ = o.chain_run_threads(of, synth.KEY, synth.AAD, host, CH, ivs, cores)
+        cpu = {"value": round(sample * CH / GiB / secs, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
+               "sample": "%d x 4 MiB chunks (%s) through oracle/chain.c: libzstd %s level 3 + OpenSSL AES-256-GCM + CRC32C, %d threads"
+                         % (sample, args.dist, o.zstd_version() if flags & nat.COMPRESS else "n/a", cores)}
+
+    if rank == 0:
+        line = {
+            "metric": "GiB/s segment chunk transform (Zstd+AES+CRC), 4MiB chunks",
+            "value": round(value, 4), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": {"full": "8x1GiB segments/GPU, 4 MiB chunks, Zstd(L3)+AES-256-GCM+CRC32C (BASELINE configs[3])",
+                                    "gcm_crc": "1 GiB segment, 4 MiB chunks, AES-256-GCM+CRC32C (BASELINE configs[2])",
+                                    "crc": "1 GiB segment, 4 MiB chunks, CRC32C only (BASELINE configs[1])"}[workload],
+                       "stages": workload, "segments_per_gpu": nseg, "chunks_per_gpu": n, "chunk_bytes": CH, "content": args.dist,
+                       "zstd_profile": args.profile if flags & nat.COMPRESS else None,
+                       "mean_transformed_chunk_bytes": round(mean_out, 1), "residency": "device (HBM) in/out",
+                       "parallelism": "segment-major shard, %d rank(s), no data-path collective" % world,
+                       "verified_chunks_vs_oracle": verified},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    N.ctx_destroy(ctx)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

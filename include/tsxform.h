@@ -1,0 +1,146 @@
+/*
+ * tsxform — C ABI of the MI355X-native chunk-transform library (libtsxform.so).
+ *
+ * This is the drop-in boundary for the hot path of aiven/tiered-storage-for-apache-kafka:
+ * the per-chunk  compress -> AES-256-GCM encrypt (-> CRC32C)  chain of copyLogSegmentData() and its
+ * inverse in fetchLogSegment().  A JNI shim (java/ sources) binds exactly these entry
+ * points from GpuTransformChunkEnumeration / GpuDetransformChunkEnumeration / GpuChunkManager, which
+ * implement the reference's own interfaces:
+ *   core/src/main/java/io/aiven/kafka/tieredstorage/transform/TransformChunkEnumeration.java:28-42
+ *   core/src/main/java/io/aiven/kafka/tieredstorage/transform/DetransformChunkEnumeration.java:28
+ *   core/src/main/java/io/aiven/kafka/tieredstorage/fetch/ChunkManager.java:26-31
+ *
+ * Conventions: plain pointers and sizes only; caller owns every buffer; the library never keeps a
+ * caller pointer after a call returns; nothing throws across the ABI.  Batch-level failures are the
+ * (negative) return value; per-chunk failures are tsx_chunk_desc.status.  All entry points are
+ * re-entrant: a tsx_ctx is a per-thread handle (own HIP stream + device workspace), and the
+ * ctx-less convenience calls take one from an internal pool (reference threading: >=10 RLM upload
+ * threads + the ChunkCache ForkJoinPool call concurrently).
+ *
+ * There is NO CPU implementation behind this ABI: without a usable gfx950 device tsx_init() fails
+ * with TSX_E_DEVICE and every compute entry point returns TSX_E_DEVICE.
+ */
+#ifndef TSXFORM_H
+#define TSXFORM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSX_ABI_VERSION 1
+
+/* flags: which stages of the chain run.  Replaces the reference's chain construction
+ * RemoteStorageManager.transformation(), core/.../RemoteStorageManager.java:434-453
+ * (Base -> [Compression] -> [Encryption]) and DefaultChunkManager.getChunk(),
+ * core/.../fetch/DefaultChunkManager.java:56-67 (Base -> [Decryption] -> [Decompression]). */
+#define TSX_COMPRESS 0x1u /* Zstd frame per chunk   (CompressionChunkEnumeration.java:50-63)      */
+#define TSX_ENCRYPT  0x2u /* IV||C||TAG, AES-256-GCM (EncryptionChunkEnumeration.java:66-84)       */
+#define TSX_CRC      0x4u /* CRC32C of the ORIGINAL chunk bytes, out of band       */
+
+/* where src/dst live */
+#define TSX_MEM_HOST   0 /* host pointers: staged through pinned memory + H2D/D2H on the ctx stream */
+#define TSX_MEM_DEVICE 1 /* device pointers (same HIP runtime/process): no copies                    */
+
+/* status / error codes (0 = ok, negative = error) */
+#define TSX_OK               0
+#define TSX_E_INVAL         -1  /* bad argument                                                   */
+#define TSX_E_DEVICE        -2  /* no usable gfx950 device / HIP failure                          */
+#define TSX_E_NOMEM         -3
+#define TSX_E_DST_TOO_SMALL -4  /* dst_cap < transformed size                                     */
+#define TSX_E_TAG_MISMATCH  -5  /* GCM tag check failed  (JCE AEADBadTagException,
+                                   DecryptionChunkEnumeration.java:59-61)                           */
+#define TSX_E_BAD_FRAME     -6  /* corrupt Zstd frame (zstd-jni ZstdException)                    */
+#define TSX_E_BAD_SIZE      -7  /* frame without usable content size: reference throws
+                                   "Invalid decompressed size: n" (DecompressionChunkEnumeration.java:42-44) */
+#define TSX_E_SHORT_CHUNK   -8  /* encrypted chunk shorter than IV+TAG                            */
+#define TSX_E_UNSUPPORTED   -9
+
+/* Per-chunk descriptor; mirrors io.aiven.kafka.tieredstorage.Chunk (core/.../Chunk.java:21-36:
+ * id, originalPosition, originalSize, transformedPosition, transformedSize) with the in/out split
+ * a batch call needs.  48 bytes, no padding. */
+typedef struct tsx_chunk_desc {
+    uint64_t src_off;  /* in : offset of this chunk's input within src                              */
+    uint64_t dst_off;  /* in : offset of this chunk's output slot within dst                        */
+    uint32_t src_len;  /* in : input bytes (originalSize on transform, transformedSize on detransform) */
+    uint32_t dst_cap;  /* in : capacity of the output slot                                          */
+    uint32_t dst_len;  /* out: bytes produced                                                       */
+    uint32_t crc32c;   /* out: CRC32C of the original (pre-transform / restored) bytes if TSX_CRC   */
+    int32_t  status;   /* out: TSX_OK or a TSX_E_* code for this chunk                              */
+    uint8_t  iv[12];   /* in : GCM IV for transform (host SecureRandom, AesEncryptionProvider.java:66-71);
+                          detransform reads the IV from the chunk's first 12 bytes and ignores this    */
+} tsx_chunk_desc;
+
+/* Per-batch parameters: one (data key, AAD) pair per segment
+ * (AesEncryptionProvider.createDataKeyAndAAD, core/.../security/AesEncryptionProvider.java:52-58). */
+typedef struct tsx_batch_params {
+    uint32_t flags;        /* TSX_COMPRESS | TSX_ENCRYPT | TSX_CRC                                  */
+    uint32_t aad_len;      /* reference: 32                                                         */
+    uint8_t  key[32];      /* AES-256 data key (SecretKey.getEncoded())                             */
+    uint8_t  aad[64];
+    int32_t  zstd_level;   /* 0 = library default (3), what the reference uses; only 3 is implemented */
+    uint32_t zstd_profile; /* TSX_ZSTD_PROFILE_*                                                    */
+} tsx_batch_params;
+
+/* Which libzstd release the compressor reproduces byte for byte (the reference ships 1.5.6 inside
+ * zstd-jni 1.5.6-9, core/build.gradle:29).  1.5.7 adds a block pre-splitter at level 3. */
+#define TSX_ZSTD_PROFILE_1_5_6 0u
+#define TSX_ZSTD_PROFILE_1_5_7 1u
+
+typedef struct tsx_ctx tsx_ctx;
+
+/* Timing of the last batch on a ctx, measured with HIP events on the ctx's own stream. */
+typedef struct tsx_timing {
+    float total_ms;    /* first enqueue -> last kernel/copy done                                    */
+    float h2d_ms, d2h_ms;
+    float crc_ms, zstd_ms, gcm_ms, unzstd_ms;
+    uint32_t crc_launches, zstd_launches, gcm_launches, unzstd_launches;
+} tsx_timing;
+
+/* ---- library lifetime ---------------------------------------------------------------------- */
+uint32_t    tsx_abi_version(void);
+const char* tsx_version(void);           /* "tsxform x.y (gfx950; zstd parity target 1.5.7/1.5.6 L3)" */
+const char* tsx_strerror(int code);
+/* device_ids == NULL: use devices 0..device_count-1; device_count <= 0: all visible devices.
+ * Returns the number of devices in use (>0) or TSX_E_DEVICE. */
+int  tsx_init(int device_count, const int* device_ids);
+void tsx_shutdown(void);
+int  tsx_device_count(void);
+
+/* ---- contexts ------------------------------------------------------------------------------ */
+/* max_chunks/max_chunk_size size the device workspace (grown on demand when exceeded). */
+int  tsx_ctx_create(int device_index, uint32_t max_chunks, uint32_t max_chunk_size, tsx_ctx** out);
+void tsx_ctx_destroy(tsx_ctx* ctx);
+int  tsx_ctx_timing(const tsx_ctx* ctx, tsx_timing* out);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* Upper bound of the transformed size of an n-byte chunk: ZSTD_compressBound(n) if compressing,
+ * +28 (IV 12 + tag 16, EncryptionChunkEnumeration.java:82-84) if encrypting. */
+size_t tsx_transformed_bound(size_t n, uint32_t flags);
+
+/* Forward chain over a batch of n chunks: [Zstd frame] -> [IV||AES-256-GCM(C)||TAG], CRC32C(original).
+ * Replaces CompressionChunkEnumeration.nextElement + EncryptionChunkEnumeration.nextElement for the
+ * whole batch.  ctx == NULL borrows a pooled context on device 0. */
+int tsx_transform_batch(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n,
+                        const void* src, void* dst, size_t dst_size, int mem_kind);
+
+/* Inverse chain: [verify tag + AES-256-GCM decrypt] -> [Zstd decode], CRC32C(restored).
+ * Replaces DecryptionChunkEnumeration.nextElement + DecompressionChunkEnumeration.nextElement. */
+int tsx_detransform_batch(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n,
+                          const void* src, void* dst, size_t dst_size, int mem_kind);
+
+/* CRC32C only (BASELINE.json configs[1]); equals java.util.zip.CRC32C over each chunk. */
+int tsx_crc32c_batch(tsx_ctx* ctx, tsx_chunk_desc* descs, uint32_t n, const void* src, int mem_kind);
+
+/* ---- device memory helpers for hosts that do not link HIP themselves (the JNI shim) --------- */
+int tsx_device_malloc(int device_index, size_t bytes, void** out);
+int tsx_device_free(int device_index, void* p);
+int tsx_memcpy_h2d(int device_index, void* dst_dev, const void* src_host, size_t bytes);
+int tsx_memcpy_d2h(int device_index, void* dst_host, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSXFORM_H */

@@ -1,0 +1,195 @@
+// TEST HARNESS ONLY — a single-threaded, deterministic CPU emulator of the small HIP subset the
+// csrc/ kernels use.  It exists because this container has no GPU: the very same kernel sources are
+// compiled with g++ against THIS header (-Itests/emu shadows <hip/hip_runtime.h>) into
+// tests/emu/_build/libtsxform_emu.so so their logic can be checked against the oracle at small sizes
+// under `pytest -m "not gpu"`.  The product package never loads that library and there is no CPU
+// fallback in the product path (see tiered-storage-for-apache-kafka_amd/_native.py).
+//
+// Model: every thread of a block is a fiber (own stack, hand-rolled context switch); a block's fibers
+// run round-robin on one OS thread; __syncthreads() and the wave collectives (__shfl*, __ballot, …)
+// are rendezvous points.  Blocks run one after another, so `__shared__` maps to `static`.
+// Wave = 64 lanes, as on gfx950.  Collectives must be reached by every live lane of a wave.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define HIPEMU 1
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+template <class T> inline T min(T a, T b) { return b < a ? b : a; }
+template <class T> inline T max(T a, T b) { return a < b ? b : a; }
+
+typedef int hipError_t;
+typedef struct hipemu_stream* hipStream_t;
+typedef struct hipemu_event* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0 };
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
+
+namespace hipemu {
+struct Ctx {
+    uint3_emu tid, bid;
+    dim3 bdim, gdim;
+    unsigned flat_tid;  // within block
+};
+extern Ctx* g_ctx;  // context of the running fiber
+void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry);
+void block_barrier();
+void wave_barrier();
+uint64_t* wave_slots();      // 64 x u64 scratch for the current wave
+uint64_t wave_live_mask();   // lanes of the current wave that have not exited
+unsigned lane_id();
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_ctx->tid)
+#define blockIdx (hipemu::g_ctx->bid)
+#define blockDim (hipemu::g_ctx->bdim)
+#define gridDim (hipemu::g_ctx->gdim)
+#define warpSize 64
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__
+#endif
+
+inline void __syncthreads() { hipemu::block_barrier(); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+// ---- wave collectives -------------------------------------------------------------------------
+template <class T>
+inline T hipemu_xchg(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "shfl payload");
+    uint64_t bits = 0;
+    std::memcpy(&bits, &v, sizeof(T));
+    uint64_t* s = hipemu::wave_slots();
+    s[hipemu::lane_id()] = bits;
+    hipemu::wave_barrier();
+    uint64_t r = s[src_lane & 63];
+    hipemu::wave_barrier();
+    T out;
+    std::memcpy(&out, &r, sizeof(T));
+    return out;
+}
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+    int l = (int)hipemu::lane_id();
+    return hipemu_xchg(v, (l & ~(width - 1)) | (src & (width - 1)));
+}
+template <class T> inline T __shfl_xor(T v, int m, int width = 64) {
+    int l = (int)hipemu::lane_id();
+    return hipemu_xchg(v, (l & ~(width - 1)) | ((l ^ m) & (width - 1)));
+}
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = (int)hipemu::lane_id();
+    int s = (l & (width - 1)) + (int)d;
+    return hipemu_xchg(v, s < width ? l + (int)d : l);
+}
+template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int l = (int)hipemu::lane_id();
+    int s = (l & (width - 1)) - (int)d;
+    return hipemu_xchg(v, s >= 0 ? l - (int)d : l);
+}
+inline unsigned long long __ballot(int pred) {
+    uint64_t* s = hipemu::wave_slots();
+    s[hipemu::lane_id()] = pred ? 1 : 0;
+    hipemu::wave_barrier();
+    unsigned long long m = 0, live = hipemu::wave_live_mask();
+    for (int i = 0; i < 64; i++) if (((live >> i) & 1) && s[i]) m |= 1ull << i;
+    hipemu::wave_barrier();
+    return m;
+}
+inline int __any(int p) { return __ballot(p) != 0; }
+inline int __all(int p) { return __ballot(!p) == 0; }
+inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) {
+    unsigned long long live = hipemu::wave_live_mask();
+    return hipemu_xchg(v, __builtin_ctzll(live));
+}
+inline unsigned __builtin_amdgcn_readlane(unsigned v, int lane) { return hipemu_xchg(v, lane); }
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
+    unsigned l = hipemu::lane_id();
+    unsigned m = l >= 32 ? mask : (mask & ((1u << l) - 1));
+    return base + (unsigned)__builtin_popcount(m);
+}
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
+    unsigned l = hipemu::lane_id();
+    unsigned m = l <= 32 ? 0u : (mask & ((1u << (l - 32)) - 1));
+    return base + (unsigned)__builtin_popcount(m);
+}
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+inline unsigned __brev(unsigned v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(v);
+}
+inline unsigned __byte_perm(unsigned a, unsigned b, unsigned sel) {
+    uint64_t ab = ((uint64_t)b << 32) | a;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) r |= (unsigned)((ab >> (8 * ((sel >> (4 * i)) & 7))) & 0xFF) << (8 * i);
+    return r;
+}
+
+// ---- atomics (blocks and fibers never run concurrently) -----------------------------------------
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// ---- host runtime -------------------------------------------------------------------------------
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
+hipError_t hipHostFree(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
+hipError_t hipMemset(void* d, int v, size_t n);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr);
+hipError_t hipStreamCreate(hipStream_t* s);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipDeviceSynchronize();
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipGetLastError();
+hipError_t hipPeekAtLastError();
+const char* hipGetErrorString(hipError_t e);
+
+template <typename... KArgs, typename... Args>
+inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t /*stream*/,
+                               Args... args) {
+    std::function<void()> entry = [=]() { kernel(static_cast<KArgs>(args)...); };
+    hipemu::run_grid(grid, block, entry);
+}

@@ -1,0 +1,185 @@
+"""ctypes binding of the C ABI in include/tsxform.h (libtsxform.so, built in-tree by csrc/Makefile).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is usable, loading or
+tsx_init() raises.  (The CPU emulator under tests/emu is a test harness for kernel logic and is never
+loaded from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsxform.so")
+
+COMPRESS, ENCRYPT, CRC = 1, 2, 4
+MEM_HOST, MEM_DEVICE = 0, 1
+OK, E_INVAL, E_DEVICE, E_NOMEM, E_DST_TOO_SMALL, E_TAG_MISMATCH, E_BAD_FRAME, E_BAD_SIZE, E_SHORT_CHUNK, E_UNSUPPORTED = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+ZSTD_PROFILE_1_5_6, ZSTD_PROFILE_1_5_7 = 0, 1
+
+
+class ChunkDesc(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64), ("src_len", C.c_uint32), ("dst_cap", C.c_uint32),
+                ("dst_len", C.c_uint32), ("crc32c", C.c_uint32), ("status", C.c_int32), ("iv", C.c_uint8 * 12)]
+
+
+class BatchParams(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("aad_len", C.c_uint32), ("key", C.c_uint8 * 32), ("aad", C.c_uint8 * 64),
+                ("zstd_level", C.c_int32), ("zstd_profile", C.c_uint32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("h2d_ms", C.c_float), ("d2h_ms", C.c_float), ("crc_ms", C.c_float),
+                ("zstd_ms", C.c_float), ("gcm_ms", C.c_float), ("unzstd_ms", C.c_float),
+                ("crc_launches", C.c_uint32), ("zstd_launches", C.c_uint32), ("gcm_launches", C.c_uint32),
+                ("unzstd_launches", C.c_uint32)]
+
+
+DESC_DTYPE = np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("src_len", "<u4"), ("dst_cap", "<u4"), ("dst_len", "<u4"),
+                       ("crc32c", "<u4"), ("status", "<i4"), ("iv", "u1", (12,))])
+assert DESC_DTYPE.itemsize == C.sizeof(ChunkDesc) == 48
+
+EXPORTS = ["tsx_abi_version", "tsx_version", "tsx_strerror", "tsx_init", "tsx_shutdown", "tsx_device_count",
+           "tsx_ctx_create", "tsx_ctx_destroy", "tsx_ctx_timing", "tsx_transformed_bound", "tsx_transform_batch",
+           "tsx_detransform_batch", "tsx_crc32c_batch", "tsx_device_malloc", "tsx_device_free", "tsx_memcpy_h2d",
+           "tsx_memcpy_d2h"]
+
+
+class TsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d)" % (msg, code))
+        self.code = code
+
+
+class Native:
+    """One loaded libtsxform with typed prototypes."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError("tsxform: HIP library %s is missing - run `make -C %s` (there is no CPU fallback)"
+                               % (path, os.path.join(_HERE, "csrc")))
+        L = C.CDLL(path)
+        vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+        L.tsx_abi_version.restype = u32
+        L.tsx_version.restype = C.c_char_p
+        L.tsx_strerror.restype = C.c_char_p; L.tsx_strerror.argtypes = [C.c_int]
+        L.tsx_init.restype = C.c_int; L.tsx_init.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.tsx_shutdown.restype = None
+        L.tsx_device_count.restype = C.c_int
+        L.tsx_ctx_create.restype = C.c_int; L.tsx_ctx_create.argtypes = [C.c_int, u32, u32, C.POINTER(vp)]
+        L.tsx_ctx_destroy.restype = None; L.tsx_ctx_destroy.argtypes = [vp]
+        L.tsx_ctx_timing.restype = C.c_int; L.tsx_ctx_timing.argtypes = [vp, C.POINTER(Timing)]
+        L.tsx_transformed_bound.restype = sz; L.tsx_transformed_bound.argtypes = [sz, u32]
+        for name in ("tsx_transform_batch", "tsx_detransform_batch"):
+            f = getattr(L, name); f.restype = C.c_int
+            f.argtypes = [vp, C.POINTER(BatchParams), vp, u32, vp, vp, sz, C.c_int]
+        L.tsx_crc32c_batch.restype = C.c_int; L.tsx_crc32c_batch.argtypes = [vp, vp, u32, vp, C.c_int]
+        L.tsx_device_malloc.restype = C.c_int; L.tsx_device_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
+        L.tsx_device_free.restype = C.c_int; L.tsx_device_free.argtypes = [C.c_int, vp]
+        L.tsx_memcpy_h2d.restype = C.c_int; L.tsx_memcpy_h2d.argtypes = [C.c_int, vp, vp, sz]
+        L.tsx_memcpy_d2h.restype = C.c_int; L.tsx_memcpy_d2h.argtypes = [C.c_int, vp, vp, sz]
+        self.lib = L
+        self.path = path
+        self._inited = False
+
+    # ---- lifetime -----------------------------------------------------------------------------
+    def check(self, rc):
+        if rc < 0:
+            raise TsxError(rc, self.lib.tsx_strerror(rc).decode())
+        return rc
+
+    def init(self, device_count=0, device_ids=None):
+        ids = (C.c_int * len(device_ids))(*device_ids) if device_ids else None
+        n = self.check(self.lib.tsx_init(device_count, ids))
+        self._inited = True
+        return n
+
+    def version(self):
+        return self.lib.tsx_version().decode()
+
+    def strerror(self, code):
+        return self.lib.tsx_strerror(code).decode()
+
+    def ctx_create(self, device_index=0, max_chunks=0, max_chunk_size=0):
+        h = C.c_void_p()
+        self.check(self.lib.tsx_ctx_create(device_index, max_chunks, max_chunk_size, C.byref(h)))
+        return h
+
+    def ctx_destroy(self, h):
+        self.lib.tsx_ctx_destroy(h)
+
+    def ctx_timing(self, h):
+        t = Timing()
+        self.check(self.lib.tsx_ctx_timing(h, C.byref(t)))
+        return t
+
+    def transformed_bound(self, n, flags):
+        return self.lib.tsx_transformed_bound(n, flags)
+
+    # ---- device memory ------------------------------------------------------------------------
+    def device_malloc(self, nbytes, device_index=0):
+        p = C.c_void_p()
+        self.check(self.lib.tsx_device_malloc(device_index, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, p, device_index=0):
+        self.check(self.lib.tsx_device_free(device_index, p))
+
+    def h2d(self, dptr, arr, device_index=0):
+        a = np.ascontiguousarray(arr)
+        self.check(self.lib.tsx_memcpy_h2d(device_index, dptr, a.ctypes.data, a.nbytes))
+
+    def d2h(self, arr, dptr, device_index=0):
+        assert arr.flags["C_CONTIGUOUS"]
+        self.check(self.lib.tsx_memcpy_d2h(device_index, arr.ctypes.data, dptr, arr.nbytes))
+
+    # ---- batches ------------------------------------------------------------------------------
+    @staticmethod
+    def make_params(flags, key=b"", aad=b"", zstd_level=0, zstd_profile=ZSTD_PROFILE_1_5_7):
+        p = BatchParams()
+        p.flags = flags
+        p.aad_len = len(aad)
+        if len(aad) > 64:
+            raise ValueError("aad longer than 64 bytes")
+        if flags & ENCRYPT and len(key) != 32:
+            raise ValueError("AES-256 key must be 32 bytes")
+        C.memmove(p.key, bytes(key).ljust(32, b"\0"), 32)
+        C.memmove(p.aad, bytes(aad).ljust(64, b"\0"), 64)
+        p.zstd_level = zstd_level
+        p.zstd_profile = zstd_profile
+        return p
+
+    def _ptr(self, x):
+        if x is None:
+            return None
+        if isinstance(x, np.ndarray):
+            return x.ctypes.data
+        return x  # raw device pointer (int)
+
+    def transform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None):
+        assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
+        return self.check(self.lib.tsx_transform_batch(ctx, C.byref(params), descs.ctypes.data, len(descs), self._ptr(src),
+                                                       self._ptr(dst), dst_size, mem_kind))
+
+    def detransform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None):
+        assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
+        return self.check(self.lib.tsx_detransform_batch(ctx, C.byref(params), descs.ctypes.data, len(descs), self._ptr(src),
+                                                         self._ptr(dst), dst_size, mem_kind))
+
+    def crc32c_batch(self, descs, src, mem_kind=MEM_HOST, ctx=None):
+        assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
+        return self.check(self.lib.tsx_crc32c_batch(ctx, descs.ctypes.data, len(descs), self._ptr(src), mem_kind))
+
+
+_native = None
+
+
+def get():
+    """The process-wide product library (libtsxform.so, HIP).  Raises when it or the GPU is missing."""
+    global _native
+    if _native is None:
+        n = Native(LIB_PATH)
+        n.init()
+        _native = n
+    return _native

@@ -1,0 +1,344 @@
+// AES-256-GCM over every chunk of a batch — gfx950.
+//
+// Replaces the JCE calls of
+//   core/src/main/java/io/aiven/kafka/tieredstorage/transform/EncryptionChunkEnumeration.java:66-84
+//       cipher.doFinal(chunk, 0, n, out, ivLen)  ->  out = IV(12) || C(n) || TAG(16)
+//   core/.../transform/DecryptionChunkEnumeration.java:54-62
+//       cipher.doFinal(chunk, ivSize, len - ivSize) (verify TAG, return plaintext)
+// with the cipher parameters of core/.../security/AesEncryptionProvider.java:36-39,60-84
+// ("AES/GCM/NoPadding", 256-bit key, 128-bit tag, 12-byte IV, AAD via updateAAD).
+//
+// Layout of the work.  A chunk is cut into 64 KiB sub-blocks (4096 AES blocks), one per 256-thread
+// workgroup.  Thread t owns blocks t, t+256, … so that plaintext loads and ciphertext stores of a wave
+// are contiguous 16 B per lane.  For each block the thread
+//   * encrypts the counter block IV || BE32(2 + j) with T-table AES-256 (the T0 table is replicated
+//     once per LDS bank — 32 copies, 32 KiB — so the 224 data-dependent lookups per block are
+//     bank-conflict free; T1..T3 are rotations of T0; round keys sit in SGPRs),
+//   * XORs, stores, and folds the ciphertext block into a private GHASH accumulator with stride 256:
+//         Y <- Y * H^256  xor  C_j            (4-bit Shoup tables of H^256 in LDS, 8 KiB,
+//                                              one conflict-free ds_read_b128 per nibble).
+// After its last block the thread scales Y by H^(blocks to the end of the sub-block) (bit-serial
+// multiply, once), the workgroup XOR-reduces, and a second small kernel (one wave per chunk) applies
+// H^(distance to the end) to every sub-block, adds the AAD and length blocks, encrypts J0 and writes /
+// verifies the tag.  GF(2^128) has no carry-less multiply on CDNA4: everything is shifts, XORs and
+// table lookups.  Algorithmic traffic: n bytes read + n + 28 bytes written per chunk.
+#include "tsx_internal.h"
+
+// ---------------------------------------------------------------------------------------------------
+// host: AES tables (FIPS-197 5.1.1: S(x) = affine(x^-1)); built with log/antilog tables over generator 3
+// ---------------------------------------------------------------------------------------------------
+void tsx_aes_build_tables(tsx_aes_tables* t) {
+    uint8_t exp3[256], log3[256];
+    uint8_t v = 1;
+    for (int i = 0; i < 255; i++) {
+        exp3[i] = v; log3[v] = (uint8_t)i;
+        uint8_t v2 = (uint8_t)((v << 1) ^ ((v & 0x80) ? 0x1B : 0));
+        v = (uint8_t)(v2 ^ v);                              // v * 3
+    }
+    exp3[255] = exp3[0];
+    for (int x = 0; x < 256; x++) {
+        uint8_t inv = x ? exp3[(255 - log3[x]) % 255] : 0;
+        uint8_t s = inv;
+        for (int k = 1; k <= 4; k++) s ^= (uint8_t)((inv << k) | (inv >> (8 - k)));
+        s ^= 0x63;
+        uint8_t s2 = (uint8_t)((s << 1) ^ ((s & 0x80) ? 0x1B : 0));
+        uint8_t s3 = (uint8_t)(s2 ^ s);
+        t->te0[x] = (uint32_t)s2 | ((uint32_t)s << 8) | ((uint32_t)s << 16) | ((uint32_t)s3 << 24);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ static inline uint32_t bswap32(uint32_t v) { return __byte_perm(v, 0, 0x0123); }
+__device__ static inline uint32_t rotl32(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+
+// AES-256 encryption of one block given as four little-endian column words.  `T0(x)` returns T0[x].
+template <class Lookup>
+__device__ static inline void aes256_encrypt(const uint32_t* __restrict__ rk, Lookup T0, uint32_t& w0, uint32_t& w1,
+                                             uint32_t& w2, uint32_t& w3) {
+    uint32_t s0 = w0 ^ rk[0], s1 = w1 ^ rk[1], s2 = w2 ^ rk[2], s3 = w3 ^ rk[3];
+#pragma unroll
+    for (int r = 1; r < 14; r++) {
+        uint32_t t0 = T0(s0 & 0xFF) ^ rotl32(T0((s1 >> 8) & 0xFF), 8) ^ rotl32(T0((s2 >> 16) & 0xFF), 16) ^ rotl32(T0(s3 >> 24), 24) ^ rk[4 * r + 0];
+        uint32_t t1 = T0(s1 & 0xFF) ^ rotl32(T0((s2 >> 8) & 0xFF), 8) ^ rotl32(T0((s3 >> 16) & 0xFF), 16) ^ rotl32(T0(s0 >> 24), 24) ^ rk[4 * r + 1];
+        uint32_t t2 = T0(s2 & 0xFF) ^ rotl32(T0((s3 >> 8) & 0xFF), 8) ^ rotl32(T0((s0 >> 16) & 0xFF), 16) ^ rotl32(T0(s1 >> 24), 24) ^ rk[4 * r + 2];
+        uint32_t t3 = T0(s3 & 0xFF) ^ rotl32(T0((s0 >> 8) & 0xFF), 8) ^ rotl32(T0((s1 >> 16) & 0xFF), 16) ^ rotl32(T0(s2 >> 24), 24) ^ rk[4 * r + 3];
+        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+    }
+    // final round: SubBytes + ShiftRows only; S(x) is byte 1 of T0[x]
+    #define SB(x) ((T0(x) >> 8) & 0xFFu)
+    w0 = (SB(s0 & 0xFF) | (SB((s1 >> 8) & 0xFF) << 8) | (SB((s2 >> 16) & 0xFF) << 16) | (SB(s3 >> 24) << 24)) ^ rk[56];
+    w1 = (SB(s1 & 0xFF) | (SB((s2 >> 8) & 0xFF) << 8) | (SB((s3 >> 16) & 0xFF) << 16) | (SB(s0 >> 24) << 24)) ^ rk[57];
+    w2 = (SB(s2 & 0xFF) | (SB((s3 >> 8) & 0xFF) << 8) | (SB((s0 >> 16) & 0xFF) << 16) | (SB(s1 >> 24) << 24)) ^ rk[58];
+    w3 = (SB(s3 & 0xFF) | (SB((s0 >> 8) & 0xFF) << 8) | (SB((s1 >> 16) & 0xFF) << 16) | (SB(s2 >> 24) << 24)) ^ rk[59];
+    #undef SB
+}
+
+__device__ static inline tsx_gf128 gf_from_le_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    tsx_gf128 r;
+    r.hi = ((uint64_t)bswap32(w0) << 32) | bswap32(w1);
+    r.lo = ((uint64_t)bswap32(w2) << 32) | bswap32(w3);
+    return r;
+}
+__device__ static inline void gf_to_le_words(const tsx_gf128& g, uint32_t w[4]) {
+    w[0] = bswap32((uint32_t)(g.hi >> 32)); w[1] = bswap32((uint32_t)g.hi);
+    w[2] = bswap32((uint32_t)(g.lo >> 32)); w[3] = bswap32((uint32_t)g.lo);
+}
+__device__ static inline tsx_gf128 gf_from_bytes(const uint8_t* p, uint32_t n) {   // zero padded
+    uint8_t b[16];
+    for (uint32_t i = 0; i < 16; i++) b[i] = i < n ? p[i] : 0;
+    tsx_gf128 r; r.hi = 0; r.lo = 0;
+    for (int i = 0; i < 8; i++) { r.hi = (r.hi << 8) | b[i]; r.lo = (r.lo << 8) | b[8 + i]; }
+    return r;
+}
+// multiply by x: one step to the right in GCM bit order, reduction by R = 0xE1 || 0^120
+__device__ static inline void gf_mulx(tsx_gf128& v) {
+    uint64_t carry = v.lo & 1u;
+    v.lo = (v.lo >> 1) | (v.hi << 63);
+    v.hi = (v.hi >> 1) ^ (0xE100000000000000ull & (0ull - carry));
+}
+// generic bit-serial product (SP 800-38D Algorithm 1)
+__device__ static tsx_gf128 gf_mul(const tsx_gf128& x, tsx_gf128 v) {
+    tsx_gf128 z; z.hi = 0; z.lo = 0;
+    for (int i = 0; i < 64; i++) {
+        uint64_t m = 0ull - ((x.hi >> (63 - i)) & 1u);
+        z.hi ^= v.hi & m; z.lo ^= v.lo & m;
+        gf_mulx(v);
+    }
+    for (int i = 0; i < 64; i++) {
+        uint64_t m = 0ull - ((x.lo >> (63 - i)) & 1u);
+        z.hi ^= v.hi & m; z.lo ^= v.lo & m;
+        gf_mulx(v);
+    }
+    return z;
+}
+__device__ static tsx_gf128 gf_pow_h(const tsx_gcm_key* key, uint32_t e) {
+    tsx_gf128 r; r.hi = 0x8000000000000000ull; r.lo = 0;
+    bool first = true;
+    for (int k = 0; e; k++, e >>= 1) {
+        if (!(e & 1u)) continue;
+        if (first) { r = key->hpow2[k]; first = false; }
+        else r = gf_mul(r, key->hpow2[k]);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-key setup: round keys, H, powers of H, Shoup tables of H^256.  One 256-thread workgroup.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gcm_setup_kernel(const tsx_aes_tables* __restrict__ aes, const uint8_t* __restrict__ key32,
+                                                        const uint8_t* __restrict__ aad, uint32_t aad_len,
+                                                        tsx_gcm_key* __restrict__ out) {
+    __shared__ uint32_t s_rk[60];
+    __shared__ tsx_gf128 s_v[128];
+    __shared__ tsx_gf128 s_pow[512];
+    __shared__ tsx_gf128 s_pow2[32];
+    const uint32_t t = threadIdx.x;
+    auto T0 = [&](uint32_t x) { return aes->te0[x]; };
+    if (t == 0) {
+        // FIPS-197 5.2 key expansion, Nk = 8
+        for (int i = 0; i < 8; i++)
+            s_rk[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);
+        uint32_t rcon = 1;
+        for (int i = 8; i < 60; i++) {
+            uint32_t tmp = s_rk[i - 1];
+            #define SBX(x) ((aes->te0[(x) & 0xFF] >> 8) & 0xFFu)
+            if ((i & 7) == 0) {
+                tmp = (tmp >> 8) | (tmp << 24);                         // RotWord on little-endian packing
+                tmp = SBX(tmp) | (SBX(tmp >> 8) << 8) | (SBX(tmp >> 16) << 16) | (SBX(tmp >> 24) << 24);
+                tmp ^= rcon;
+                rcon = ((rcon << 1) ^ ((rcon & 0x80) ? 0x1B : 0)) & 0xFF;
+            } else if ((i & 7) == 4) {
+                tmp = SBX(tmp) | (SBX(tmp >> 8) << 8) | (SBX(tmp >> 16) << 16) | (SBX(tmp >> 24) << 24);
+            }
+            #undef SBX
+            s_rk[i] = s_rk[i - 8] ^ tmp;
+        }
+        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        aes256_encrypt(s_rk, T0, w0, w1, w2, w3);
+        tsx_gf128 h = gf_from_le_words(w0, w1, w2, w3);
+        s_pow2[0] = h;
+        for (int k = 1; k < 32; k++) s_pow2[k] = gf_mul(s_pow2[k - 1], s_pow2[k - 1]);
+        tsx_gf128 one; one.hi = 0x8000000000000000ull; one.lo = 0;
+        s_pow[0] = one; s_pow[1] = h;
+        tsx_gf128 v = s_pow2[8];                                        // H^256 * x^i, i = 0..127
+        for (int i = 0; i < 128; i++) { s_v[i] = v; gf_mulx(v); }
+        out->h = h;
+        out->aad_len = aad_len;
+    }
+    __syncthreads();
+    for (int k = 1; k < 9; k++) {                                       // hpow[2^k + d] = hpow[d] * H^(2^k)
+        uint32_t half = 1u << k;
+        for (uint32_t d = t; d < half; d += 256) s_pow[half + d] = gf_mul(s_pow[d], s_pow2[k]);
+        __syncthreads();
+    }
+    if (t < 60) out->rk[t] = s_rk[t];
+    if (t < 64) out->aad[t] = t < aad_len ? aad[t] : 0;
+    if (t < 32) out->hpow2[t] = s_pow2[t];
+    for (uint32_t d = t; d < 512; d += 256) out->hpow[d] = s_pow[d];
+    for (uint32_t e = t; e < 512; e += 256) {                           // Shoup tables
+        uint32_t p = e >> 4, val = e & 15;
+        tsx_gf128 r; r.hi = 0; r.lo = 0;
+        for (int b = 0; b < 4; b++)
+            if ((val >> (3 - b)) & 1u) { r.hi ^= s_v[4 * p + b].hi; r.lo ^= s_v[4 * p + b].lo; }
+        out->hstride_tab[p][val] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TSX_GCM_THREADS) void gcm_ctr_ghash_kernel(
+        const tsx_aes_tables* __restrict__ aes, const tsx_gcm_key* __restrict__ key, const tsx_gcm_chunk* __restrict__ chunks,
+        uint32_t max_sub, const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t* __restrict__ partials, int decrypt) {
+    __shared__ uint32_t lds_t0[256 * 32];          // T0 replicated per bank: entry x, copy b at [x*32 + b]
+    __shared__ tsx_gf128 lds_hs[32 * 16];          // Shoup tables of H^256
+    __shared__ tsx_gf128 lds_red[TSX_GCM_THREADS / 64];
+    const uint32_t t = threadIdx.x;
+    const uint32_t ci = blockIdx.x / max_sub, sub = blockIdx.x % max_sub;
+    const tsx_gcm_chunk ch = chunks[ci];
+    const uint32_t n = ch.len;
+    const uint32_t nb = (n + 15) >> 4;                                  // ciphertext blocks incl. a partial one
+    const uint32_t j0 = sub * TSX_GCM_SUB_BLOCKS;
+    uint32_t* my_partial = partials + ((size_t)ci * max_sub + sub) * 4;
+    if (ch.skip || j0 >= nb) {                                          // uniform exit
+        if (t < 4) my_partial[t] = 0;
+        return;
+    }
+    const uint32_t j1 = min(j0 + (uint32_t)TSX_GCM_SUB_BLOCKS, nb);
+    for (uint32_t i = t; i < 256 * 32; i += TSX_GCM_THREADS) lds_t0[i] = aes->te0[i >> 5];
+    for (uint32_t i = t; i < 512; i += TSX_GCM_THREADS) lds_hs[i] = (&key->hstride_tab[0][0])[i];
+    __syncthreads();
+    const uint32_t bank = t & 31;
+    auto T0 = [&](uint32_t x) { return lds_t0[(x << 5) | bank]; };
+    // encrypt: in = plaintext, out = IV||C||TAG.  decrypt: in = IV||C||TAG, out = plaintext.
+    const uint8_t* src = in + ch.in_off + (decrypt ? 12 : 0);
+    uint8_t* dst = out + ch.out_off + (decrypt ? 0 : 12);
+    const uint8_t* ivp = decrypt ? in + ch.in_off : ch.iv;
+    const uint32_t iv0 = (uint32_t)ivp[0] | ((uint32_t)ivp[1] << 8) | ((uint32_t)ivp[2] << 16) | ((uint32_t)ivp[3] << 24);
+    const uint32_t iv1 = (uint32_t)ivp[4] | ((uint32_t)ivp[5] << 8) | ((uint32_t)ivp[6] << 16) | ((uint32_t)ivp[7] << 24);
+    const uint32_t iv2 = (uint32_t)ivp[8] | ((uint32_t)ivp[9] << 8) | ((uint32_t)ivp[10] << 16) | ((uint32_t)ivp[11] << 24);
+    tsx_gf128 y; y.hi = 0; y.lo = 0;
+    uint32_t last = 0;
+    bool any = false;
+    for (uint32_t j = j0 + t; j < j1; j += TSX_GCM_THREADS) {
+        uint32_t k0 = iv0, k1 = iv1, k2 = iv2, k3 = bswap32(2u + j);    // GCTR: first block uses inc32(J0) = IV||2
+        aes256_encrypt(key->rk, T0, k0, k1, k2, k3);
+        const uint32_t m = min(16u, n - (j << 4));
+        uint32_t p[4];
+        if (m == 16) {
+            tsx_u128a4 v = *reinterpret_cast<const tsx_u128a4*>(src + ((size_t)j << 4));
+            p[0] = v.v[0]; p[1] = v.v[1]; p[2] = v.v[2]; p[3] = v.v[3];
+        } else {
+            p[0] = p[1] = p[2] = p[3] = 0;
+            for (uint32_t b = 0; b < m; b++) p[b >> 2] |= (uint32_t)src[((size_t)j << 4) + b] << (8 * (b & 3));
+        }
+        uint32_t c[4] = {p[0] ^ k0, p[1] ^ k1, p[2] ^ k2, p[3] ^ k3};
+        if (m == 16) {
+            tsx_u128a4 v; v.v[0] = c[0]; v.v[1] = c[1]; v.v[2] = c[2]; v.v[3] = c[3];
+            *reinterpret_cast<tsx_u128a4*>(dst + ((size_t)j << 4)) = v;
+        } else {
+            for (uint32_t b = 0; b < m; b++) dst[((size_t)j << 4) + b] = (uint8_t)(c[b >> 2] >> (8 * (b & 3)));
+            for (uint32_t b = m; b < 16; b++) c[b >> 2] &= ~(0xFFu << (8 * (b & 3)));   // GHASH sees zero padding
+        }
+        const uint32_t* gx = decrypt ? p : c;                           // GHASH always runs over the ciphertext
+        // Y <- Y * H^256 xor X
+        tsx_gf128 z; z.hi = 0; z.lo = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            tsx_gf128 e0 = lds_hs[q * 16 + ((y.hi >> (60 - 4 * q)) & 15u)];
+            tsx_gf128 e1 = lds_hs[(16 + q) * 16 + ((y.lo >> (60 - 4 * q)) & 15u)];
+            z.hi ^= e0.hi ^ e1.hi; z.lo ^= e0.lo ^ e1.lo;
+        }
+        tsx_gf128 x = gf_from_le_words(gx[0], gx[1], gx[2], gx[3]);
+        y.hi = z.hi ^ x.hi; y.lo = z.lo ^ x.lo;
+        last = j; any = true;
+    }
+    tsx_gf128 r; r.hi = 0; r.lo = 0;
+    if (any) r = gf_mul(y, key->hpow[j1 - 1 - last]);
+    for (int o = 32; o; o >>= 1) { r.hi ^= __shfl_xor(r.hi, o); r.lo ^= __shfl_xor(r.lo, o); }
+    if ((t & 63) == 0) lds_red[t >> 6] = r;
+    __syncthreads();
+    if (t == 0) {
+        tsx_gf128 s; s.hi = 0; s.lo = 0;
+        for (int w = 0; w < TSX_GCM_THREADS / 64; w++) { s.hi ^= lds_red[w].hi; s.lo ^= lds_red[w].lo; }
+        my_partial[0] = (uint32_t)s.hi; my_partial[1] = (uint32_t)(s.hi >> 32);
+        my_partial[2] = (uint32_t)s.lo; my_partial[3] = (uint32_t)(s.lo >> 32);
+    }
+}
+
+// One wave per chunk: stitch the sub-block GHASH values, add AAD and length blocks, E_K(J0), tag.
+__global__ __launch_bounds__(64) void gcm_final_kernel(const tsx_aes_tables* __restrict__ aes, const tsx_gcm_key* __restrict__ key,
+                                                       const tsx_gcm_chunk* __restrict__ chunks, uint32_t max_sub,
+                                                       const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                       const uint32_t* __restrict__ partials, int32_t* __restrict__ status, int decrypt) {
+    const uint32_t ci = blockIdx.x, lane = threadIdx.x;
+    const tsx_gcm_chunk ch = chunks[ci];
+    if (ch.skip) return;
+    const uint32_t n = ch.len, nb = (n + 15) >> 4;
+    tsx_gf128 acc; acc.hi = 0; acc.lo = 0;
+    for (uint32_t sub = lane; sub * TSX_GCM_SUB_BLOCKS < nb; sub += 64) {
+        const uint32_t* pp = partials + ((size_t)ci * max_sub + sub) * 4;
+        tsx_gf128 z; z.hi = ((uint64_t)pp[1] << 32) | pp[0]; z.lo = ((uint64_t)pp[3] << 32) | pp[2];
+        uint32_t jend = min((sub + 1) * (uint32_t)TSX_GCM_SUB_BLOCKS, nb);
+        tsx_gf128 r = gf_mul(z, gf_pow_h(key, nb - jend + 2));         // block j carries H^(nb-j+1): length block follows
+        acc.hi ^= r.hi; acc.lo ^= r.lo;
+    }
+    for (int o = 32; o; o >>= 1) { acc.hi ^= __shfl_xor(acc.hi, o); acc.lo ^= __shfl_xor(acc.lo, o); }
+    if (lane != 0) return;
+    // AAD blocks: Horner with H, then scaled past the ciphertext and the length block
+    const uint32_t alen = key->aad_len;
+    if (alen) {
+        tsx_gf128 a; a.hi = 0; a.lo = 0;
+        for (uint32_t o = 0; o < alen; o += 16) {
+            tsx_gf128 x = gf_from_bytes(key->aad + o, min(16u, alen - o));
+            a.hi ^= x.hi; a.lo ^= x.lo;
+            a = gf_mul(a, key->h);
+        }
+        tsx_gf128 r = gf_mul(a, gf_pow_h(key, nb + 1));
+        acc.hi ^= r.hi; acc.lo ^= r.lo;
+    }
+    {   // length block [len(A)]64 || [len(C)]64 in bits, times H
+        tsx_gf128 l; l.hi = (uint64_t)alen * 8; l.lo = (uint64_t)n * 8;
+        tsx_gf128 r = gf_mul(l, key->h);
+        acc.hi ^= r.hi; acc.lo ^= r.lo;
+    }
+    const uint8_t* ivp = decrypt ? in + ch.in_off : ch.iv;
+    uint32_t k0 = (uint32_t)ivp[0] | ((uint32_t)ivp[1] << 8) | ((uint32_t)ivp[2] << 16) | ((uint32_t)ivp[3] << 24);
+    uint32_t k1 = (uint32_t)ivp[4] | ((uint32_t)ivp[5] << 8) | ((uint32_t)ivp[6] << 16) | ((uint32_t)ivp[7] << 24);
+    uint32_t k2 = (uint32_t)ivp[8] | ((uint32_t)ivp[9] << 8) | ((uint32_t)ivp[10] << 16) | ((uint32_t)ivp[11] << 24);
+    uint32_t k3 = 0x01000000u;                                          // J0 = IV || 0^31 || 1
+    auto T0 = [&](uint32_t x) { return aes->te0[x]; };
+    aes256_encrypt(key->rk, T0, k0, k1, k2, k3);
+    uint32_t tagw[4];
+    gf_to_le_words(acc, tagw);
+    tagw[0] ^= k0; tagw[1] ^= k1; tagw[2] ^= k2; tagw[3] ^= k3;
+    if (!decrypt) {
+        uint8_t* o = out + ch.out_off;
+        for (int i = 0; i < 12; i++) o[i] = ch.iv[i];
+        for (int i = 0; i < 16; i++) o[12 + n + i] = (uint8_t)(tagw[i >> 2] >> (8 * (i & 3)));
+    } else {
+        const uint8_t* tg = in + ch.in_off + 12 + n;
+        uint32_t diff = 0;
+        for (int i = 0; i < 16; i++) diff |= (uint32_t)(tg[i] ^ (uint8_t)(tagw[i >> 2] >> (8 * (i & 3))));
+        if (diff) status[ci] = TSX_E_TAG_MISMATCH;
+    }
+}
+
+void tsx_launch_gcm_setup(hipStream_t st, const tsx_aes_tables* d_aes, const uint8_t* d_key32, const uint8_t* d_aad,
+                          uint32_t aad_len, tsx_gcm_key* d_key) {
+    hipLaunchKernelGGL(gcm_setup_kernel, dim3(1), dim3(256), 0, st, d_aes, d_key32, d_aad, aad_len, d_key);
+}
+
+void tsx_launch_gcm(hipStream_t st, const tsx_aes_tables* d_aes, const tsx_gcm_key* d_key, const tsx_gcm_chunk* d_chunks,
+                    uint32_t n, uint32_t max_len, const uint8_t* in, uint8_t* out, uint32_t* d_partials, int32_t* d_status,
+                    int decrypt) {
+    if (!n) return;
+    uint32_t max_sub = (max_len + TSX_GCM_SUB_BYTES - 1) / TSX_GCM_SUB_BYTES;
+    if (max_sub == 0) max_sub = 1;
+    hipLaunchKernelGGL(gcm_ctr_ghash_kernel, dim3(n * max_sub), dim3(TSX_GCM_THREADS), 0, st, d_aes, d_key, d_chunks, max_sub,
+                       in, out, d_partials, decrypt);
+    hipLaunchKernelGGL(gcm_final_kernel, dim3(n), dim3(64), 0, st, d_aes, d_key, d_chunks, max_sub, in, out,
+                       (const uint32_t*)d_partials, d_status, decrypt);
+}

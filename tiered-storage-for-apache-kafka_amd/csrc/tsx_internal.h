@@ -1,0 +1,73 @@
+// Internal declarations shared by the kernel translation units and the C-ABI front end.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/tsxform.h"
+
+// 16 bytes that are only guaranteed 4-byte aligned (the ciphertext of IV(12)||C||TAG starts at +12).
+struct __attribute__((packed, aligned(4))) tsx_u128a4 { uint32_t v[4]; };
+
+// ---------------------------------------------------------------------------------------------------
+// CRC32C
+// ---------------------------------------------------------------------------------------------------
+#define TSX_CRC_THREADS 256
+#define TSX_CRC_ROW_BYTES (TSX_CRC_THREADS * 16)        /* 4 KiB: one 16-byte piece per thread per row   */
+#define TSX_CRC_ROWS 64
+#define TSX_CRC_SUB_BYTES (TSX_CRC_ROW_BYTES * TSX_CRC_ROWS) /* 256 KiB per workgroup                    */
+#define TSX_CRC_SUB_PIECES (TSX_CRC_SUB_BYTES / 16)
+
+struct tsx_crc_tables {          // device-resident constants, built once per device at tsx_init
+    uint32_t slice[16][256];     // slice[d][b]: byte b followed by d zero bytes (slicing tables 0..15)
+    uint32_t stride[4][256];     // stride[k][b]: state byte k advanced by one 4 KiB row
+    uint32_t piece_pow[512];     // x^(128*d) mod P, d = 0..511 (reflected; x^0 = 0x80000000)
+    uint32_t pow2[32];           // x^(128*2^k) mod P
+};
+void tsx_crc_build_tables(tsx_crc_tables* host_out);
+
+// One launch pair: partial CRCs per 256 KiB sub-block, then per-chunk combine.  `partials` needs
+// n * max_sub u32.  Input chunk i = src + descs[i].src_off (16-byte aligned), length descs[i].src_len;
+// result in descs[i].crc32c (device copy of the descriptors).
+void tsx_launch_crc32c(hipStream_t st, const tsx_crc_tables* d_tab, const uint8_t* src, tsx_chunk_desc* d_descs,
+                       uint32_t n, uint32_t max_len, uint32_t* d_partials, int use_dst_side);
+
+// ---------------------------------------------------------------------------------------------------
+// AES-256-GCM
+// ---------------------------------------------------------------------------------------------------
+#define TSX_GCM_THREADS 256
+#define TSX_GCM_SUB_BLOCKS 4096                          /* AES blocks per workgroup (64 KiB)            */
+#define TSX_GCM_SUB_BYTES (TSX_GCM_SUB_BLOCKS * 16)
+
+struct alignas(16) tsx_gf128 { uint64_t hi, lo; };   // GF(2^128) element, big-endian halves: bit 63 of hi = x^0
+
+struct tsx_gcm_key {             // device-resident, derived per batch key by the setup kernel
+    uint32_t rk[60];             // AES-256 round keys, little-endian words of the FIPS-197 byte schedule
+    uint32_t aad_len;
+    uint8_t  aad[64];
+    uint8_t  pad_[12];
+    tsx_gf128 h;                 // H = E_K(0^128)
+    tsx_gf128 hstride_tab[32][16];  // 4-bit tables of H^256: [nibble position][value]
+    tsx_gf128 hpow[512];         // H^d, d = 0..511 (d = 0 is the identity)
+    tsx_gf128 hpow2[32];         // H^(2^k)
+};
+
+struct tsx_aes_tables {          // device-resident constants, built once per device at tsx_init
+    uint32_t te0[256];           // T0[x] = {02.S(x), S(x), S(x), 03.S(x)} packed little-endian
+};
+void tsx_aes_build_tables(tsx_aes_tables* host_out);
+
+struct tsx_gcm_chunk {           // per-chunk work item (device)
+    uint64_t in_off;             // plaintext (encrypt) / IV||C||TAG (decrypt) offset within `in`
+    uint64_t out_off;            // IV||C||TAG (encrypt) / plaintext (decrypt) offset within `out`
+    uint32_t len;                // plaintext length n
+    int32_t  skip;               // != 0: chunk already failed, do nothing
+    uint8_t  iv[12];
+};
+
+void tsx_launch_gcm_setup(hipStream_t st, const tsx_aes_tables* d_aes, const uint8_t* d_key32, const uint8_t* d_aad, uint32_t aad_len, tsx_gcm_key* d_key);
+// encrypt: writes IV||C||TAG.  decrypt: verifies TAG (status[i] = TSX_E_TAG_MISMATCH on failure) and
+// writes the plaintext.  d_partials: n * max_sub * 4 u32.
+void tsx_launch_gcm(hipStream_t st, const tsx_aes_tables* d_aes, const tsx_gcm_key* d_key, const tsx_gcm_chunk* d_chunks, uint32_t n,
+                    uint32_t max_len, const uint8_t* in, uint8_t* out, uint32_t* d_partials, int32_t* d_status,
+                    int decrypt);
