@@ -60,6 +60,10 @@ def lib():
         L.orc_detransform_chunk.argtypes = [C.c_uint, u8p, u8p, sz, u8p, sz, u8p, sz, u8p, C.POINTER(u32)]
         L.orc_chain_run_threads.restype = C.c_double
         L.orc_chain_run_threads.argtypes = [C.c_uint, u8p, u8p, sz, u8p, sz, sz, u8p, u8p, sz, u8p, u8p, C.c_int]
+        L.orc_l3_compress.restype = sz; L.orc_l3_compress.argtypes = [u8p, sz, u8p, sz, C.c_int]
+        L.orc_l3_compress_bound.restype = sz; L.orc_l3_compress_bound.argtypes = [sz]
+        L.orc_l3_cparams.restype = None; L.orc_l3_cparams.argtypes = [C.c_uint64, C.POINTER(C.c_uint32 * 7)]
+        L.orc_l3_set_tap.restype = None; L.orc_l3_set_tap.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -195,3 +199,39 @@ def chain_run_threads(flags, key, aad, src: np.ndarray, chunk: int, ivs: np.ndar
     secs = lib().orc_chain_run_threads(flags, kp, ap, a.size, src.ctypes.data, chunk, n, ivs.ctypes.data,
                                        dst.ctypes.data, stride, sizes.ctypes.data, crcs.ctypes.data, nthreads)
     return secs, sizes, crcs, dst, stride
+
+
+def zstd_l3_compress(data, profile=1) -> bytes:
+    """oracle/zstd_l3.c: serial restatement of libzstd's level-3 one-shot compressor (profile 0 = 1.5.6, 1 = 1.5.7)."""
+    d, dp = _buf(data)
+    cap = lib().orc_l3_compress_bound(d.size) + 64
+    out = np.zeros(cap, np.uint8)
+    r = lib().orc_l3_compress(dp, d.size, out.ctypes.data, cap, profile)
+    if r == 0:
+        raise RuntimeError("zstd_l3 failed")
+    return out[:r].tobytes()
+
+
+def zstd_l3_cparams(n: int):
+    a = (C.c_uint32 * 7)()
+    lib().orc_l3_cparams(n, C.byref(a))
+    return tuple(a)
+
+
+_SEQ_TAP = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_size_t, C.c_size_t, C.c_size_t)
+
+
+def zstd_l3_sequences(data, profile=1):
+    """Per block: (list of (litLength, matchLength, offBase), litSize, blockSize) as found by the restatement."""
+    blocks = []
+
+    def tap(ctx, bi, seqs, nb, lit, bs):
+        arr = np.ctypeslib.as_array(seqs, shape=(nb * 3,)).reshape(-1, 3).copy() if nb else np.zeros((0, 3), np.uint32)
+        blocks.append(([(int(r[1]), int(r[2]) + 3, int(r[0])) for r in arr], int(lit), int(bs)))
+    cb = _SEQ_TAP(tap)
+    lib().orc_l3_set_tap(C.cast(cb, C.c_void_p), None)
+    try:
+        zstd_l3_compress(data, profile)
+    finally:
+        lib().orc_l3_set_tap(None, None)
+    return blocks
