@@ -70,8 +70,10 @@ unsigned lane_id();
 #endif
 
 inline void __syncthreads() { hipemu::block_barrier(); }
-inline void __threadfence() {}
-inline void __threadfence_block() {}
+// On hardware the lanes of a wave run in lockstep, so a fence orders EVERY lane's earlier stores before every
+// lane's later loads.  Fibers do not run in lockstep: model the fence as a wave rendezvous.
+inline void __threadfence() { hipemu::wave_barrier(); }
+inline void __threadfence_block() { hipemu::wave_barrier(); }
 
 // ---- wave collectives -------------------------------------------------------------------------
 template <class T>

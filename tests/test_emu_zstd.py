@@ -1,0 +1,101 @@
+"""Zstandard kernels (csrc/zstd_enc.hip, csrc/zstd_dec.hip) under the CPU emulator: the HIP compressor must
+produce libzstd's bytes (real library, 1.5.7, via the oracle), the HIP decoder must restore them.  Sizes are
+kept small because every wave collective is a fiber rendezvous; the full-size cases run on the GPU."""
+import numpy as np
+import pytest
+
+import tsxform
+from tests import parity_cases as pc
+from tests import zstd_inspect as zi
+from tsxform import synth
+
+nat = tsxform._native
+
+
+def _cases():
+    rng = np.random.default_rng(7)
+    K = synth.gen_chunk("K", 5, 0, 0, 400000); R = synth.gen_chunk("R", 5, 0, 0, 200000)
+    return {
+        "golden15": np.frombuffer(bytes.fromhex("000000030000000A01000A0000001E"), np.uint8),
+        "empty": K[:0], "one": K[:1], "K7": K[:7], "K8": K[:8], "K63": K[:63], "K64": K[:64], "K255": K[:255], "K256": K[:256],
+        "K1000": K[:1000], "K4096": K[:4096], "K16385": K[:16385], "K70000": K[:70000], "K131073": K[:131073], "K200000": K[:200000],
+        "R50000": R[:50000], "zeros": np.zeros(200000, np.uint8), "period7": np.tile(np.frombuffer(b"abcdefg", np.uint8), 20000),
+        "mixKR": np.concatenate([K[:140000], R[:140000], K[140000:280000], np.zeros(30000, np.uint8)]),
+        "lowent": rng.integers(0, 4, 150000, dtype=np.uint8),
+        "skewed": np.minimum(rng.geometric(0.3, 150000), 255).astype(np.uint8),
+        "ramp": (np.arange(150000) % 256).astype(np.uint8),
+    }
+
+
+CASES = _cases()
+
+
+def _need157(oracle):
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+
+
+def test_compressor_is_byte_identical_to_libzstd(emu, oracle):
+    _need157(oracle)
+    names = list(CASES)
+    outs, d = pc.run_transform(emu, nat.COMPRESS, [CASES[n] for n in names])
+    for i, n in enumerate(names):
+        assert d["status"][i] == 0, n
+        assert outs[i] == oracle.zstd_compress_chunk(CASES[n].tobytes()), "%s: frame differs from libzstd %s" % (n, oracle.zstd_version())
+
+
+def test_reference_golden_frame(emu):
+    # CT/manifest/index/ChunkIndexSerializationTest.java:39-61
+    outs, _ = pc.run_transform(emu, nat.COMPRESS, [CASES["golden15"]])
+    assert outs[0].hex() == "28b52ffd200f79000000000003" "0000000a01000a0000001e"
+
+
+def test_profile_1_5_6_matches_restatement_and_decodes(emu, oracle):
+    names = ["K200000", "mixKR", "zeros"]
+    outs, d = pc.run_transform(emu, nat.COMPRESS, [CASES[n] for n in names], profile=nat.ZSTD_PROFILE_1_5_6)
+    for i, n in enumerate(names):
+        assert outs[i] == oracle.zstd_l3_compress(CASES[n].tobytes(), 0), n
+        assert oracle.zstd_decompress_chunk(outs[i]) == CASES[n].tobytes()
+
+
+def test_full_chain_vs_oracle(emu, oracle):
+    _need157(oracle)
+    chunks = [CASES[n] for n in ("K70000", "R50000", "K1000", "empty")]
+    pc.check_transform_vs_oracle(emu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
+    pc.check_roundtrip(emu, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
+    pc.check_roundtrip(emu, nat.COMPRESS, chunks)
+
+
+@pytest.mark.parametrize("level", [0, 1, 19])
+def test_decoder_accepts_libzstd_frames(emu, oracle, level):
+    names = ["empty", "one", "K1000", "K70000", "K200000", "R50000", "zeros", "period7", "mixKR", "lowent", "skewed"]
+    blobs = [oracle.zstd_compress_chunk(CASES[n].tobytes(), level) for n in names]
+    outs, d = pc.run_detransform(emu, nat.COMPRESS, blobs, [int(CASES[n].size) for n in names])
+    for i, n in enumerate(names):
+        assert d["status"][i] == 0 and outs[i] == CASES[n].tobytes(), (n, level)
+
+
+def test_decoder_errors(emu, oracle):
+    good = oracle.zstd_compress_chunk(CASES["K70000"].tobytes())
+    bad_magic = b"\x00" + good[1:]
+    truncated = good[:len(good) // 2]
+    corrupt = bytearray(good); corrupt[len(good) // 2] ^= 0xFF; corrupt[len(good) // 2 + 1] ^= 0x55
+    no_size = b"\x28\xb5\x2f\xfd\x00\x58" + b"\x01\x00\x00"      # frame header without content size
+    outs, d = pc.run_detransform(emu, nat.COMPRESS, [good, bad_magic, truncated, no_size, good], [70000, 70000, 70000, 16, 100])
+    assert d["status"][0] == 0 and outs[0] == CASES["K70000"].tobytes()
+    assert d["status"][1] == nat.E_BAD_FRAME and d["status"][2] == nat.E_BAD_FRAME
+    assert d["status"][3] == nat.E_BAD_SIZE                      # reference: "Invalid decompressed size"
+    assert d["status"][4] == nat.E_DST_TOO_SMALL
+    _, d = pc.run_detransform(emu, nat.COMPRESS, [bytes(corrupt)], [70000])
+    assert d["status"][0] in (nat.E_BAD_FRAME, 0)                # a flipped byte either breaks the frame or decodes to other bytes
+    if d["status"][0] == 0:
+        assert _ is not None
+
+
+def test_compressed_frames_have_expected_structure(emu):
+    outs, _ = pc.run_transform(emu, nat.COMPRESS, [CASES["K200000"], CASES["R50000"]])
+    hdr, blocks, data = zi.parse_frame(outs[0])
+    assert hdr["single_segment"] and hdr["content_size"] == 200000 and not hdr["checksum"]
+    assert [b.btype for b in blocks] == ["compressed", "compressed"] and data == CASES["K200000"].tobytes()
+    hdr, blocks, _ = zi.parse_frame(outs[1])
+    assert [b.btype for b in blocks] == ["raw"] and len(outs[1]) == 50000 + 7 + 3

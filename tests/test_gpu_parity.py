@@ -110,3 +110,91 @@ def test_context_timing_reports_kernel_time(gpu):
     t = gpu.ctx_timing(ctx)
     assert t.crc_launches == 2 and 0 < t.crc_ms < 1000
     gpu.ctx_destroy(ctx)
+
+
+# ---- Zstandard stages -------------------------------------------------------------------------------------
+def _zcases():
+    rng = np.random.default_rng(7)
+    K = synth.gen_chunk("K", 5, 0, 0, 1 << 20); R = synth.gen_chunk("R", 5, 0, 0, 1 << 19)
+    return {
+        "golden15": np.frombuffer(bytes.fromhex("000000030000000A01000A0000001E"), np.uint8),
+        "empty": K[:0], "one": K[:1], "K7": K[:7], "K8": K[:8], "K64": K[:64], "K256": K[:256], "K1000": K[:1000], "K16385": K[:16385],
+        "K70000": K[:70000], "K131073": K[:131073], "K262145": K[:262145], "K1M": K, "R300000": R[:300000],
+        "zeros": np.zeros(500000, np.uint8), "period7": np.tile(np.frombuffer(b"abcdefg", np.uint8), 60000),
+        "mixKR": np.concatenate([K[:200000], R[:150000], K[200000:500000], np.zeros(70000, np.uint8), R[:50000], K[:300000]]),
+        "lowent": rng.integers(0, 4, 700000, dtype=np.uint8),
+        "skewed": np.minimum(rng.geometric(0.3, 800000), 255).astype(np.uint8),
+        "ramp": (np.arange(1000000) % 256).astype(np.uint8),
+        "far_repeat": np.concatenate([R[:100000], K[:1100000], R[:100000], K[:600000], R[:100000]]),
+    }
+
+
+def test_zstd_compressor_byte_identical_to_libzstd(gpu, oracle):
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    cases = _zcases(); names = list(cases)
+    outs, d = pc.run_transform(gpu, nat.COMPRESS, [cases[n] for n in names])
+    for i, n in enumerate(names):
+        assert d["status"][i] == 0, n
+        assert outs[i] == oracle.zstd_compress_chunk(cases[n].tobytes()), "%s: frame differs from libzstd %s" % (n, oracle.zstd_version())
+    # 1.5.6 profile (no pre-block splitter) against the serial restatement
+    outs, d = pc.run_transform(gpu, nat.COMPRESS, [cases["mixKR"], cases["K1M"]], profile=nat.ZSTD_PROFILE_1_5_6)
+    assert outs[0] == oracle.zstd_l3_compress(cases["mixKR"].tobytes(), 0) and outs[1] == oracle.zstd_l3_compress(cases["K1M"].tobytes(), 0)
+
+
+def test_zstd_full_size_chunks_and_full_chain(gpu, oracle):
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    chunks = [synth.gen_chunk("K", 1000, 0, 0), synth.gen_chunk("R", 1000, 0, 1), synth.gen_chunk("K", 1000, 0, 2, CHUNK - 5)]
+    outs, d = pc.check_transform_vs_oracle(gpu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
+    assert outs[0][:12] == synth.iv_for(0, 0) and d["dst_len"][1] == CHUNK + 106 + 28          # raw blocks: n + 10 + 3*32, + IV + tag
+    pc.check_roundtrip(gpu, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
+    pc.check_roundtrip(gpu, nat.COMPRESS, chunks)
+
+
+@pytest.mark.parametrize("level", [0, 1, 19])
+def test_zstd_decoder_accepts_libzstd_frames(gpu, oracle, level):
+    cases = _zcases(); names = list(cases)
+    blobs = [oracle.zstd_compress_chunk(cases[n].tobytes(), level) for n in names]
+    outs, d = pc.run_detransform(gpu, nat.COMPRESS, blobs, [int(cases[n].size) for n in names])
+    for i, n in enumerate(names):
+        assert d["status"][i] == 0 and outs[i] == cases[n].tobytes(), (n, level)
+
+
+def test_zstd_decoder_errors(gpu, oracle):
+    K = synth.gen_chunk("K", 5, 0, 0, 70000)
+    good = oracle.zstd_compress_chunk(K.tobytes())
+    no_size = b"\x28\xb5\x2f\xfd\x00\x58" + b"\x01\x00\x00"
+    outs, d = pc.run_detransform(gpu, nat.COMPRESS, [good, b"\x00" + good[1:], good[:len(good) // 2], no_size, good], [70000, 70000, 70000, 16, 100])
+    assert list(d["status"]) == [0, nat.E_BAD_FRAME, nat.E_BAD_FRAME, nat.E_BAD_SIZE, nat.E_DST_TOO_SMALL] and outs[0] == K.tobytes()
+
+
+def test_quarter_gib_full_chain_device_resident(gpu, oracle):
+    """64 x 4 MiB chunks through Zstd -> GCM -> CRC on the device; sampled chunks byte-exact vs libzstd + OpenSSL,
+    all chunks through the round trip and the CRC-of-restored property."""
+    import torch
+    n = 64
+    seg = _segment_on_gpu("K", 2, n)
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    slot = (gpu.transformed_bound(CHUNK, flags) + 63) // 64 * 64
+    out = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+    d = np.zeros(n, nat.DESC_DTYPE)
+    d["src_off"] = np.arange(n, dtype=np.uint64) * CHUNK; d["src_len"] = CHUNK
+    d["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d["dst_cap"] = slot
+    for c in range(n):
+        d["iv"][c] = np.frombuffer(synth.iv_for(2, c), np.uint8)
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    gpu.transform_batch(p, d, seg.data_ptr(), out.data_ptr(), out.numel(), nat.MEM_DEVICE)
+    assert (d["status"] == 0).all() and (d["dst_len"] < CHUNK // 2).all()
+    host = seg.cpu().numpy(); enc = out.cpu().numpy()
+    if oracle.zstd_version().startswith("1.5.7"):
+        for c in [0, 31, 63]:
+            exp, crc = oracle.transform_chunk(oracle.COMPRESS | oracle.ENCRYPT | oracle.CRC | oracle.OPENSSL, synth.KEY, synth.AAD, synth.iv_for(2, c),
+                                              host[c * CHUNK:(c + 1) * CHUNK].tobytes())
+            assert enc[c * slot:c * slot + d["dst_len"][c]].tobytes() == exp and d["crc32c"][c] == crc, c
+    back = torch.empty(n * CHUNK, dtype=torch.uint8, device="cuda")
+    d2 = np.zeros(n, nat.DESC_DTYPE)
+    d2["src_off"] = d["dst_off"]; d2["src_len"] = d["dst_len"]; d2["dst_off"] = d["src_off"]; d2["dst_cap"] = CHUNK
+    gpu.detransform_batch(p, d2, out.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE)
+    assert (d2["status"] == 0).all() and (d2["dst_len"] == CHUNK).all() and (d2["crc32c"] == d["crc32c"]).all()
+    assert torch.equal(back, seg)

@@ -4,3 +4,4 @@ Host-side mirror of the reference's transform/detransform interfaces over the C 
 """
 from . import _native  # noqa: F401
 from ._native import (COMPRESS, CRC, ENCRYPT, MEM_DEVICE, MEM_HOST, TsxError, get)  # noqa: F401
+HAVE_ZSTD = True  # Zstd level-3 compressor + frame decoder kernels are built into libtsxform

@@ -1,0 +1,487 @@
+// Zstandard frame decoder — gfx950, one 64-lane wavefront per chunk.
+//
+// Replaces zstd-jni's  Zstd.decompressedSize(chunk) / Zstd.decompress(chunk, size)
+//   core/src/main/java/io/aiven/kafka/tieredstorage/transform/DecompressionChunkEnumeration.java:39-46
+// and accepts any single Zstandard frame (RFC 8878) with a known content size and no dictionary — not only
+// the frames our own compressor writes: raw / RLE / compressed blocks, raw / RLE / Huffman (1 or 4 streams,
+// treeless) literals, predefined / RLE / FSE / repeat sequence tables, repeat offsets.
+// Errors are per chunk: TSX_E_BAD_SIZE when the frame declares no usable content size (the reference throws
+// "Invalid decompressed size"), TSX_E_DST_TOO_SMALL, TSX_E_BAD_FRAME for anything malformed.  A content
+// checksum, when present, is skipped, not verified (the reference's writer never emits one).
+//
+// Work split inside the wave: header parsing and table construction are scalar (lane 0, tables in LDS and
+// kept across blocks for the repeat modes); the four Huffman literal streams decode on four lanes at once;
+// the FSE sequence stream is a serial dependency chain (lane 0) that only produces (literal length, match
+// length, offset) triples; executing them — literal copies and match copies, the bulk of the bytes — uses all
+// 64 lanes, with a fence only when a match reads bytes written since the previous fence.
+#include "zstd_common.h"
+
+#define LANES 64
+#define DERR_FRAME TSX_E_BAD_FRAME
+
+__device__ static const uint32_t dLLbase[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
+__device__ static const uint8_t dLLbits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+__device__ static const uint32_t dMLbase[53] = {3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,131,259,515,1027,2051,4099,8195,16387,32771,65539};
+__device__ static const uint8_t dMLbits[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+__device__ static const short dLLnorm[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+__device__ static const short dOFnorm[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+__device__ static const short dMLnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+
+__device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+__device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
+struct DecLds {
+    uint16_t huf[4096];          // (nbBits << 8) | symbol
+    uint32_t hufLog; int hufValid;
+    FseD ll[512], of[256], ml[512];
+    FseD wt[64];                 // FSE table of the Huffman-weight stream (tableLog <= 6)
+    uint32_t llLog, ofLog, mlLog; int llValid, ofValid, mlValid;
+    uint8_t weights[256];
+    uint32_t rankCount[16], rankStart[16];
+    short norm[64];
+    uint16_t symNext[64];
+    uint32_t scal[16];
+    uint32_t streamOff[5];
+};
+
+// ---- backward bit reader (BIT_DStream) -----------------------------------------------------------------
+struct BitR { const uint8_t* start; const uint8_t* ptr; uint64_t c; uint32_t consumed; bool bad; };
+__device__ static void br_init(BitR& b, const uint8_t* src, uint32_t n) {
+    b.start = src; b.bad = false; b.consumed = 0; b.c = 0; b.ptr = src;
+    if (n == 0) { b.bad = true; return; }
+    const uint8_t last = src[n - 1];
+    if (last == 0) { b.bad = true; return; }
+    if (n >= 8) {
+        b.ptr = src + n - 8; b.c = dld64(b.ptr);
+        b.consumed = 8 - dhb32(last);
+    } else {
+        uint64_t c = 0;
+        for (uint32_t i = 0; i < n; i++) c |= (uint64_t)src[i] << (8 * i);
+        b.c = c;
+        b.consumed = 8 - dhb32(last) + (8 - n) * 8;
+    }
+}
+__device__ static inline uint64_t br_look(const BitR& b, uint32_t nb) {          // nb >= 1
+    return (b.c << (b.consumed & 63)) >> (64 - nb);
+}
+__device__ static inline uint64_t br_read(BitR& b, uint32_t nb) {
+    if (!nb) return 0;
+    const uint64_t v = br_look(b, nb);
+    b.consumed += nb;
+    return v;
+}
+// returns false once the stream is over-read
+__device__ static inline bool br_reload(BitR& b) {
+    if (b.consumed > 64) return false;
+    if (b.ptr >= b.start + 8) { b.ptr -= b.consumed >> 3; b.consumed &= 7; b.c = dld64(b.ptr); return true; }
+    if (b.ptr == b.start) return true;
+    uint32_t nbBytes = b.consumed >> 3;
+    if (b.ptr - nbBytes < b.start) nbBytes = (uint32_t)(b.ptr - b.start);
+    b.ptr -= nbBytes; b.consumed -= nbBytes * 8;
+    // fewer than 8 bytes may remain readable behind ptr only when the stream itself is shorter than 8 bytes
+    b.c = dld64(b.ptr);
+    return true;
+}
+__device__ static inline bool br_finished(const BitR& b) { return b.ptr == b.start && b.consumed == 64; }
+
+// ---- FSE table description + decoding table (lane 0) ---------------------------------------------------------
+// returns bytes consumed, 0 on error
+__device__ static uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint32_t* tableLogPtr, const uint8_t* src, uint32_t n, uint32_t maxLogAllowed) {
+    if (n < 1) return 0;
+    // bounded forward bit reader over at most n bytes
+    uint64_t bitpos = 0;
+    #define NC_PEEK(k) ({ uint32_t v_ = 0; for (int i_ = 0; i_ < 4; i_++) { uint64_t b_ = (bitpos >> 3) + i_; v_ |= (uint32_t)(b_ < n ? src[b_] : 0) << (8 * i_); } (v_ >> (bitpos & 7)) & ((1u << (k)) - 1); })
+    const uint32_t tableLog = NC_PEEK(4) + 5; bitpos += 4;
+    if (tableLog > maxLogAllowed) return 0;
+    int remaining = (1 << tableLog) + 1, threshold = 1 << tableLog, nbBits = (int)tableLog + 1;
+    uint32_t sym = 0; const uint32_t maxSym = *maxSymPtr;
+    bool prev0 = false;
+    while (remaining > 1 && sym <= maxSym) {
+        if (prev0) {
+            for (;;) {
+                const uint32_t r = NC_PEEK(2); bitpos += 2;
+                for (uint32_t k = 0; k < r; k++) { if (sym > maxSym) return 0; norm[sym++] = 0; }
+                if (r != 3) break;
+                if ((bitpos >> 3) > n + 4) return 0;
+            }
+            prev0 = false;
+            continue;
+        }
+        const int mx = (2 * threshold - 1) - remaining;
+        int count;
+        const uint32_t lo = NC_PEEK(nbBits - 1);
+        if ((int)lo < mx) { count = (int)lo; bitpos += nbBits - 1; }
+        else { count = (int)NC_PEEK(nbBits); if (count >= threshold) count -= mx; bitpos += nbBits; }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        if (sym > maxSym) return 0;
+        norm[sym++] = (short)count;
+        prev0 = count == 0;
+        while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        if ((bitpos >> 3) > n + 4) return 0;
+    }
+    #undef NC_PEEK
+    if (remaining != 1) return 0;
+    const uint32_t used = (uint32_t)((bitpos + 7) >> 3);
+    if (used > n) return 0;
+    *maxSymPtr = sym - 1; *tableLogPtr = tableLog;
+    return used;
+}
+
+__device__ static bool fse_buildDTable(FseD* dt, const short* norm, uint32_t maxSym, uint32_t tableLog, uint16_t* symNext) {
+    const uint32_t size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint32_t high = size - 1;
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        if (norm[s] == -1) { dt[high--].sym = (uint8_t)s; symNext[s] = 1; }
+        else symNext[s] = (uint16_t)norm[s];
+    }
+    uint32_t pos = 0;
+    for (uint32_t s = 0; s <= maxSym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            dt[pos].sym = (uint8_t)s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    if (pos != 0) return false;
+    for (uint32_t u = 0; u < size; u++) {
+        const uint8_t s = dt[u].sym;
+        const uint32_t ns = symNext[s]++;
+        const uint32_t nb = tableLog - dhb32(ns);
+        dt[u].nb = (uint8_t)nb; dt[u].base = (uint16_t)((ns << nb) - size);
+    }
+    return true;
+}
+
+// ---- Huffman table (lane 0): weights -> decoding table ------------------------------------------------------
+// returns bytes consumed by the tree description, 0 on error
+__device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t n) {
+    if (n < 1) return 0;
+    const uint32_t hb = src[0];
+    uint32_t nw = 0, used;
+    if (hb >= 128) {
+        nw = hb - 127; used = 1 + (nw + 1) / 2;
+        if (used > n) return 0;
+        for (uint32_t i = 0; i < nw; i++) { const uint8_t b = src[1 + i / 2]; L.weights[i] = (i & 1) ? (b & 15) : (b >> 4); }
+    } else {
+        used = 1 + hb;
+        if (hb < 2 || used > n) return 0;
+        uint32_t maxSym = 12, tl;
+        const uint32_t h = fse_readNCount(L.norm, &maxSym, &tl, src + 1, hb, 6);
+        if (!h) return 0;
+        if (!fse_buildDTable(L.wt, L.norm, maxSym, tl, L.symNext)) return 0;
+        BitR b; br_init(b, src + 1 + h, hb - h);
+        if (b.bad) return 0;
+        uint32_t s1 = (uint32_t)br_read(b, tl), s2 = (uint32_t)br_read(b, tl);
+        br_reload(b);
+        for (;;) {
+            if (nw > 253) return 0;
+            { const FseD e = L.wt[s1]; L.weights[nw++] = e.sym; s1 = e.base + (uint32_t)br_read(b, e.nb); }
+            if (!br_reload(b)) { L.weights[nw++] = L.wt[s2].sym; break; }
+            if (nw > 253) return 0;
+            { const FseD e = L.wt[s2]; L.weights[nw++] = e.sym; s2 = e.base + (uint32_t)br_read(b, e.nb); }
+            if (!br_reload(b)) { L.weights[nw++] = L.wt[s1].sym; break; }
+        }
+    }
+    // the last weight is implicit
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < 16; i++) L.rankCount[i] = 0;
+    for (uint32_t i = 0; i < nw; i++) { const uint32_t w = L.weights[i]; if (w > 12) return 0; L.rankCount[w]++; total += w ? (1u << (w - 1)) : 0; }
+    if (total == 0) return 0;
+    const uint32_t tableLog = dhb32(total) + 1;
+    if (tableLog > 12) return 0;
+    const uint32_t rest = (1u << tableLog) - total;
+    if (rest & (rest - 1)) return 0;
+    const uint32_t lastW = dhb32(rest) + 1;
+    L.weights[nw++] = (uint8_t)lastW; L.rankCount[lastW]++;
+    if (L.rankCount[1] < 2 || (L.rankCount[1] & 1)) return 0;
+    uint32_t next = 0;
+    for (uint32_t w = 1; w <= tableLog; w++) { L.rankStart[w] = next; next += L.rankCount[w] << (w - 1); }
+    for (uint32_t s = 0; s < nw; s++) {
+        const uint32_t w = L.weights[s];
+        if (!w) continue;
+        const uint32_t len = (1u << w) >> 1, nb = tableLog + 1 - w;
+        const uint16_t e = (uint16_t)((nb << 8) | s);
+        for (uint32_t i = L.rankStart[w]; i < L.rankStart[w] + len; i++) L.huf[i] = e;
+        L.rankStart[w] += len;
+    }
+    L.hufLog = tableLog; L.hufValid = 1;
+    return used;
+}
+
+// one Huffman stream -> exactly `count` symbols; false when the stream is malformed
+__device__ static bool huf_decodeStream(uint8_t* __restrict__ out, uint32_t count, const uint8_t* __restrict__ src, uint32_t n, const uint16_t* __restrict__ table, uint32_t tableLog) {
+    BitR b; br_init(b, src, n);
+    if (b.bad) return false;
+    for (uint32_t i = 0; i < count; i++) {
+        if ((i & 3) == 0 && !br_reload(b)) return false;       // 4 x 12 bits fit between reloads
+        const uint16_t e = table[br_look(b, tableLog)];
+        b.consumed += e >> 8;
+        out[i] = (uint8_t)e;
+    }
+    if (b.consumed > 64) return false;
+    br_reload(b);
+    return br_finished(b);
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------
+#define FAIL(code) do { err = (code); goto done; } while (0)
+
+__global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                                tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
+                                                                int32_t* __restrict__ status, uint8_t* __restrict__ work) {
+    __shared__ DecLds L;
+    const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
+    if (status[chunk] != TSX_OK) return;
+    const tsx_chunk_desc d = descs[chunk];
+    const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
+    const uint32_t srcSize = from_mid ? d.src_len - 28 : d.src_len;
+    uint8_t* __restrict__ out = dst_base + d.dst_off;
+    uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
+    zs_seq* const seqs = (zs_seq*)(ws + ZS_WS_HASHLONG);           // the decoder needs no hash tables: 768 KiB = 49152 sequences
+    uint8_t* const lit = ws + ZS_WS_LIT;
+    int32_t err = TSX_OK;
+    uint32_t opos = 0;
+    uint64_t contentSize = 0;
+    uint32_t p = 0;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    bool hasChecksum = false;
+    // ---- frame header ----
+    if (srcSize < 6) FAIL(DERR_FRAME);
+    if (src[0] != 0x28 || src[1] != 0xB5 || src[2] != 0x2F || src[3] != 0xFD) FAIL(DERR_FRAME);
+    {   const uint32_t fhd = src[4];
+        const uint32_t single = (fhd >> 5) & 1, dictFlag = fhd & 3, fcsFlag = fhd >> 6;
+        hasChecksum = (fhd >> 2) & 1;
+        if (fhd & 8) FAIL(DERR_FRAME);                                  // reserved bit
+        p = 5;
+        if (!single) { if (p >= srcSize) FAIL(DERR_FRAME); if ((src[p] >> 3) > 21) FAIL(DERR_FRAME); p++; }
+        const uint32_t dl = dictFlag == 0 ? 0 : dictFlag == 1 ? 1 : dictFlag == 2 ? 2 : 4;
+        if (p + dl > srcSize) FAIL(DERR_FRAME);
+        {   uint32_t dictId = 0; for (uint32_t i = 0; i < dl; i++) dictId |= (uint32_t)src[p + i] << (8 * i);
+            if (dictId) FAIL(DERR_FRAME); }                             // dictionaries are not supported (the reference uses none)
+        p += dl;
+        const uint32_t fl = fcsFlag == 0 ? single : fcsFlag == 1 ? 2 : fcsFlag == 2 ? 4 : 8;
+        if (fl == 0) FAIL(TSX_E_BAD_SIZE);                              // unknown content size: "Invalid decompressed size"
+        if (p + fl > srcSize) FAIL(DERR_FRAME);
+        for (uint32_t i = 0; i < fl; i++) contentSize |= (uint64_t)src[p + i] << (8 * i);
+        if (fl == 2) contentSize += 256;
+        p += fl;
+    }
+    if (contentSize > d.dst_cap) FAIL(TSX_E_DST_TOO_SMALL);
+    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; }
+    __syncthreads();
+    // ---- blocks ----
+    for (;;) {
+        if (p + 3 > srcSize) FAIL(DERR_FRAME);
+        const uint32_t bh = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+        p += 3;
+        const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 0) {                                               // raw
+            if (p + bsize > srcSize || opos + (uint64_t)bsize > contentSize) FAIL(DERR_FRAME);
+            for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = src[p + i];
+            p += bsize; opos += bsize;
+        } else if (btype == 1) {                                        // RLE
+            if (p + 1 > srcSize || opos + (uint64_t)bsize > contentSize) FAIL(DERR_FRAME);
+            const uint8_t b = src[p];
+            for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = b;
+            p += 1; opos += bsize;
+        } else if (btype == 2) {
+            if (bsize > ZS_BLOCK_MAX || p + bsize > srcSize || bsize < 2) FAIL(DERR_FRAME);
+            const uint8_t* const blk = src + p;
+            // ---- literals section ----
+            const uint32_t b0 = blk[0], ltype = b0 & 3, sf = (b0 >> 2) & 3;
+            uint32_t litSize = 0, q = 0;
+            const uint8_t* litPtr = lit;
+            if (ltype < 2) {
+                uint32_t hl;
+                if (sf == 0 || sf == 2) { litSize = b0 >> 3; hl = 1; }
+                else if (sf == 1) { if (bsize < 2) FAIL(DERR_FRAME); litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4); hl = 2; }
+                else { if (bsize < 3) FAIL(DERR_FRAME); litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4) + ((uint32_t)blk[2] << 12); hl = 3; }
+                if (litSize > ZS_BLOCK_MAX) FAIL(DERR_FRAME);
+                if (ltype == 0) { if (hl + litSize > bsize) FAIL(DERR_FRAME); litPtr = blk + hl; q = hl + litSize; }
+                else {
+                    if (hl + 1 > bsize) FAIL(DERR_FRAME);
+                    const uint8_t b = blk[hl];
+                    for (uint32_t i = lane; i < litSize; i += LANES) lit[i] = b;
+                    q = hl + 1;
+                }
+            } else {
+                uint32_t hl, bits, streams; uint64_t v = 0;
+                if (sf == 0) { hl = 3; bits = 10; streams = 1; }
+                else if (sf == 1) { hl = 3; bits = 10; streams = 4; }
+                else if (sf == 2) { hl = 4; bits = 14; streams = 4; }
+                else { hl = 5; bits = 18; streams = 4; }
+                if (hl > bsize) FAIL(DERR_FRAME);
+                for (uint32_t i = 0; i < hl; i++) v |= (uint64_t)blk[i] << (8 * i);
+                litSize = (uint32_t)(v >> 4) & ((1u << bits) - 1);
+                const uint32_t csize = (uint32_t)(v >> (4 + bits)) & ((1u << bits) - 1);
+                if (litSize > ZS_BLOCK_MAX || hl + csize > bsize || litSize == 0) FAIL(DERR_FRAME);
+                uint32_t t = hl;
+                if (ltype == 2) {
+                    if (lane == 0) L.scal[0] = huf_readTable(L, blk + hl, csize);
+                    __syncthreads();
+                    const uint32_t used = L.scal[0];
+                    __syncthreads();
+                    if (!used) FAIL(DERR_FRAME);
+                    t += used;
+                } else if (!L.hufValid) FAIL(DERR_FRAME);
+                const uint32_t payload = hl + csize - t;
+                // stream layout
+                uint32_t sOff[5], sCnt[4];
+                if (streams == 1) { sOff[0] = 0; sOff[1] = payload; sCnt[0] = litSize; }
+                else {
+                    if (payload < 10) FAIL(DERR_FRAME);
+                    const uint32_t s1 = blk[t] | (blk[t + 1] << 8), s2 = blk[t + 2] | (blk[t + 3] << 8), s3 = blk[t + 4] | (blk[t + 5] << 8);
+                    if (6 + (uint64_t)s1 + s2 + s3 >= payload) FAIL(DERR_FRAME);
+                    sOff[0] = 6; sOff[1] = 6 + s1; sOff[2] = sOff[1] + s2; sOff[3] = sOff[2] + s3; sOff[4] = payload;
+                    const uint32_t seg = (litSize + 3) / 4;
+                    if (3 * seg > litSize) FAIL(DERR_FRAME);
+                    sCnt[0] = sCnt[1] = sCnt[2] = seg; sCnt[3] = litSize - 3 * seg;
+                }
+                bool ok = true;
+                if (lane < streams) {
+                    uint32_t o = 0; for (uint32_t k = 0; k < lane; k++) o += sCnt[k];
+                    ok = huf_decodeStream(lit + o, sCnt[lane], blk + t + sOff[lane], sOff[lane + 1] - sOff[lane], L.huf, L.hufLog);
+                }
+                if (__any(!ok)) FAIL(DERR_FRAME);
+                q = hl + csize;
+            }
+            __threadfence_block();
+            __syncthreads();
+            // ---- sequences section ----
+            if (q >= bsize) FAIL(DERR_FRAME);
+            uint32_t nbSeq = blk[q];
+            if (nbSeq == 0) q += 1;
+            else if (nbSeq < 128) q += 1;
+            else if (nbSeq < 255) { if (q + 2 > bsize) FAIL(DERR_FRAME); nbSeq = ((nbSeq - 128) << 8) + blk[q + 1]; q += 2; }
+            else { if (q + 3 > bsize) FAIL(DERR_FRAME); nbSeq = blk[q + 1] + ((uint32_t)blk[q + 2] << 8) + 0x7F00; q += 3; }
+            if (nbSeq > ZS_WS_HASH_BYTES / sizeof(zs_seq)) FAIL(DERR_FRAME);     // 128 KiB / minMatch 3 = 43691 at most in a valid block
+            if (nbSeq) {
+                if (lane == 0) {                                        // tables + the serial FSE chain -> seqs[]
+                    uint32_t e = 0, t = q;
+                    do {
+                        if (t >= bsize) { e = 1; break; }
+                        const uint32_t modes = blk[t++];
+                        if (modes & 3) { e = 1; break; }
+                        const uint32_t m[3] = {(modes >> 6) & 3, (modes >> 4) & 3, (modes >> 2) & 3};
+                        for (int k = 0; k < 3 && !e; k++) {
+                            FseD* dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
+                            uint32_t* logp = k == 0 ? &L.llLog : k == 1 ? &L.ofLog : &L.mlLog;
+                            int* validp = k == 0 ? &L.llValid : k == 1 ? &L.ofValid : &L.mlValid;
+                            const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
+                            if (m[k] == 0) {
+                                const short* dn = k == 0 ? dLLnorm : k == 1 ? dOFnorm : dMLnorm;
+                                const uint32_t dmax = k == 0 ? 35 : k == 1 ? 28 : 52, dlog = k == 1 ? 5 : 6;
+                                for (uint32_t s = 0; s <= dmax; s++) L.norm[s] = dn[s];
+                                fse_buildDTable(dt, L.norm, dmax, dlog, L.symNext);
+                                *logp = dlog; *validp = 1;
+                            } else if (m[k] == 1) {
+                                if (t >= bsize) { e = 1; break; }
+                                const uint32_t s = blk[t++];
+                                if (s > maxSymK) { e = 1; break; }
+                                dt[0].sym = (uint8_t)s; dt[0].nb = 0; dt[0].base = 0;
+                                *logp = 0; *validp = 1;
+                            } else if (m[k] == 2) {
+                                uint32_t ms = maxSymK, tl;
+                                const uint32_t used = fse_readNCount(L.norm, &ms, &tl, blk + t, bsize - t, maxLogK);
+                                if (!used || !fse_buildDTable(dt, L.norm, ms, tl, L.symNext)) { e = 1; break; }
+                                t += used; *logp = tl; *validp = 1;
+                            } else if (!*validp) { e = 1; break; }
+                        }
+                        if (e) break;
+                        if (t >= bsize) { e = 1; break; }
+                        BitR b; br_init(b, blk + t, bsize - t);
+                        if (b.bad) { e = 1; break; }
+                        uint32_t sl = (uint32_t)br_read(b, L.llLog), so = (uint32_t)br_read(b, L.ofLog), sm = (uint32_t)br_read(b, L.mlLog);
+                        if (!br_reload(b)) { e = 1; break; }
+                        for (uint32_t i = 0; i < nbSeq; i++) {
+                            const FseD el = L.ll[sl], eo = L.of[so], em = L.ml[sm];
+                            const uint32_t oc = eo.sym, mc = em.sym, lc = el.sym;
+                            if (oc > 31 || mc > 52 || lc > 35) { e = 1; break; }
+                            uint32_t offBase;
+                            if (oc > 24) {                              // up to 31 extra bits: read in two parts around a reload
+                                const uint32_t hi = oc - 24;
+                                offBase = (1u << oc) + ((uint32_t)br_read(b, hi) << 24);
+                                if (!br_reload(b)) { e = 1; break; }
+                                offBase += (uint32_t)br_read(b, 24);
+                            } else offBase = (1u << oc) + (uint32_t)br_read(b, oc);
+                            const uint32_t ml = dMLbase[mc] + (uint32_t)br_read(b, dMLbits[mc]);
+                            if (!br_reload(b)) { e = 1; break; }
+                            const uint32_t ll = dLLbase[lc] + (uint32_t)br_read(b, dLLbits[lc]);
+                            zs_seq sq; sq.offBase = offBase; sq.litLength = ll; sq.mlBase = ml; sq.pad = 0;
+                            seqs[i] = sq;
+                            if (i + 1 < nbSeq) {
+                                sl = el.base + (uint32_t)br_read(b, el.nb);
+                                sm = em.base + (uint32_t)br_read(b, em.nb);
+                                if (!br_reload(b)) { e = 1; break; }
+                                so = eo.base + (uint32_t)br_read(b, eo.nb);
+                            }
+                            if (!br_reload(b)) { e = 1; break; }
+                        }
+                        if (!e && !br_finished(b)) e = 1;
+                    } while (0);
+                    L.scal[1] = e;
+                }
+                __threadfence_block();
+                __syncthreads();
+                if (L.scal[1]) FAIL(DERR_FRAME);
+            } else if (q != bsize) FAIL(DERR_FRAME);
+            // ---- execute the sequences: literal copy + match copy, all lanes ----
+            {
+                uint32_t lp = 0;
+                uint32_t dirtyFrom = opos;                              // output bytes at or beyond this may not be visible yet
+                for (uint32_t i = 0; i < nbSeq; i++) {
+                    const zs_seq sq = seqs[i];
+                    const uint32_t ll = sq.litLength, ml = sq.mlBase;
+                    if (lp + ll > litSize || (uint64_t)opos + ll + ml > contentSize) FAIL(DERR_FRAME);
+                    for (uint32_t k = lane; k < ll; k += LANES) out[opos + k] = litPtr[lp + k];
+                    lp += ll; opos += ll;
+                    uint32_t off;
+                    if (sq.offBase > 3) { off = sq.offBase - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                    else {
+                        const uint32_t idx = sq.offBase - 1 + (ll == 0);
+                        if (idx == 0) off = rep0;
+                        else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
+                        else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                        else { off = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                    }
+                    if (off == 0 || off > opos) FAIL(DERR_FRAME);
+                    const uint32_t from = opos - off;
+                    if (from + ml > dirtyFrom) { __threadfence_block(); dirtyFrom = opos; }
+                    if (off >= LANES || off >= ml) {
+                        for (uint32_t k = 0; k < ml; k += LANES) {
+                            // a 64-byte step may read bytes written by the previous step when off < ml
+                            if (k && off < ml && from + k + LANES > dirtyFrom) { __threadfence_block(); dirtyFrom = opos + k; }
+                            if (k + lane < ml) out[opos + k + lane] = out[from + k + lane];
+                        }
+                    } else {
+                        for (uint32_t k = lane; k < ml; k += LANES) out[opos + k] = out[from + (k % off)];   // periodic pattern
+                    }
+                    opos += ml;
+                }
+                const uint32_t tail = litSize - lp;
+                if ((uint64_t)opos + tail > contentSize) FAIL(DERR_FRAME);
+                for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
+                opos += tail;
+                __threadfence_block();
+            }
+            p += bsize;
+        } else FAIL(DERR_FRAME);
+        __syncthreads();
+        if (last) break;
+    }
+    if (hasChecksum) { if (p + 4 > srcSize) FAIL(DERR_FRAME); p += 4; }
+    if (p != srcSize || opos != contentSize) FAIL(DERR_FRAME);
+done:
+    if (lane == 0) {
+        if (err != TSX_OK) { status[chunk] = err; descs[chunk].dst_len = 0; }
+        else descs[chunk].dst_len = opos;
+    }
+}
+
+uint32_t tsx_launch_zstd_decompress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* frames, int from_mid, uint64_t mid_stride,
+                                    tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work);
+    return 1;
+}

@@ -1,0 +1,1095 @@
+// Zstandard level-3 frame compressor — gfx950, one 64-lane wavefront per chunk.
+//
+// Replaces zstd-jni's  new ZstdCompressCtx(); setPledgedSrcSize(n); setContentSize(true); compress(chunk)
+//   core/src/main/java/io/aiven/kafka/tieredstorage/transform/CompressionChunkEnumeration.java:50-63
+// and must emit, byte for byte, the frame libzstd emits for the same chunk (one-shot ZSTD_compress2, level 3:
+// strategy dfast, windowLog <= 21, 128 KiB blocks, Huffman literals + FSE sequences; profile 1.5.7 adds that
+// release's pre-block splitter).  The serial statement of the algorithm, pinned against the real library, is
+// oracle/zstd_l3.c; this file is its wave-parallel form:
+//
+//  * Match finding is an inherently serial greedy parse (every decision updates two hash tables and the
+//    repcode history), so parallelism inside a chunk is SPECULATION: the wave evaluates up to 63 consecutive
+//    search positions at once — each lane hashes its position, loads both table entries (global memory: 512 KiB
+//    + 256 KiB per chunk cannot live in LDS without changing the output), patches them with the insertions the
+//    EARLIER lanes of the same step would have made (exact, via lane broadcast), loads the candidate bytes and
+//    classifies repcode / long / short match.  A ballot picks the first lane with a match — everything before
+//    it is exactly what the serial loop would have done — its table inserts are committed and the match is
+//    extended with wave-wide 8-byte compares.  The speculation width adapts (16 -> 32 -> 63 lanes).
+//  * Chunks are independent (fresh context per chunk in the reference), so a batch runs one wave per chunk;
+//    a 1 GiB segment is 256 waves, eight segments fill the chip's 2048 wave slots at 2 waves/SIMD.
+//  * The entropy stage of each 128 KiB block (Huffman tree + FSE tables: a few thousand dependent scalar steps)
+//    runs on lane 0 with its work arrays in LDS; histograms, code conversion and the Huffman bit packing of the
+//    literals run on all 64 lanes.
+// This is byte-stream work: no MFMA.  Algorithmic traffic per chunk: N bytes read + frame bytes written; the
+// kernel is latency bound (dependent table -> candidate -> extension loads per sequence), see DESIGN.md.
+#include "zstd_common.h"
+
+#define LANES 64
+// cold, register-hungry scalar stages are kept out of line so the speculative match loop keeps its occupancy
+#define ZS_NOINLINE __attribute__((noinline))
+
+// ---- format tables ------------------------------------------------------------------------------------
+__device__ static const uint8_t kLLbits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
+__device__ static const uint8_t kMLbits[53] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16};
+__device__ static const short kLLdefaultNorm[36] = {4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1};
+__device__ static const short kOFdefaultNorm[29] = {1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1};
+__device__ static const short kMLdefaultNorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1};
+__device__ static const uint8_t kLLcode[64] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+    22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24};
+__device__ static const uint8_t kMLcode[128] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+    32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+    40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+    42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42};
+__device__ static const uint32_t kRtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+
+__device__ static inline uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
+__device__ static inline uint64_t ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ static inline uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ static inline uint32_t LLcode(uint32_t ll) { return ll > 63 ? hb32(ll) + 19 : kLLcode[ll]; }
+__device__ static inline uint32_t MLcode(uint32_t ml) { return ml > 127 ? hb32(ml) + 36 : kMLcode[ml]; }
+
+__device__ static inline uint32_t hash8(uint64_t u, uint32_t h) { return (uint32_t)((u * 0xCF1BBCDCB7A56463ULL) >> (64 - h)); }
+__device__ static inline uint32_t hashS(uint64_t u, uint32_t h, uint32_t mls) {
+    if (mls == 5) return (uint32_t)(((u << 24) * 889523592379ULL) >> (64 - h));
+    return ((uint32_t)u * 2654435761U) >> (32 - h);                       // mls == 4
+}
+
+// ---- LDS state of one chunk (one wave per workgroup) --------------------------------------------------------
+struct HufTable { uint16_t val[256]; uint8_t nb[256]; uint32_t tableLog, maxSym; };
+struct FseTable { uint16_t state[512]; uint32_t dnb[56]; int32_t dfs[56]; uint32_t tableLog; };
+struct NodeElt { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; };
+struct EncLds {
+    HufTable huf[2];            // [cur] = table of the previous compressed-literals block, [cur ^ 1] = candidate
+    int hufRepeat[2];           // 0 none, 1 check
+    FseTable ll, of, ml;
+    uint32_t hist[256];
+    uint32_t hist2[256];        // second histogram (pre-splitter / sampling)
+    uint32_t cnt[64];           // sequence-code histograms
+    NodeElt nodes[514];
+    uint16_t rankBase[192], rankCurr[192];
+    uint8_t tableSymbol[512];
+    uint32_t cumul[64];
+    short norm[64];
+    uint8_t weights[256];
+    uint32_t scal[16];          // lane-0 -> wave broadcast slots
+};
+
+// ---------------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------------
+// number of equal bytes of src[a..] and src[b..] (b < a), not reading a-side bytes at or beyond iend
+__device__ static uint32_t wave_count(const uint8_t* __restrict__ src, uint32_t a, uint32_t b, uint32_t iend, uint32_t lane) {
+    uint32_t total = 0, width = 8;
+    for (;;) {
+        const uint32_t off = total + 8 * lane;
+        const bool active = lane < width;
+        uint32_t n = 8;
+        if (active) {
+            const uint32_t avail = (a + off < iend) ? iend - (a + off) : 0;
+            if (avail >= 8) {
+                uint64_t x = ld64(src + a + off) ^ ld64(src + b + off);
+                n = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
+            } else {
+                n = 0;
+                while (n < avail && src[a + off + n] == src[b + off + n]) n++;
+            }
+        }
+        const unsigned long long m = __ballot(active && n < 8);
+        if (m) {
+            const int fl = __ffsll((long long)m) - 1;
+            return total + 8 * (uint32_t)fl + __builtin_amdgcn_readlane(n, fl);
+        }
+        total += 8 * width;
+        width = LANES;
+    }
+}
+
+// backward extension: while (ip > anchor && match > low && src[ip-1] == src[match-1])
+__device__ static uint32_t wave_count_back(const uint8_t* __restrict__ src, uint32_t ip, uint32_t match, uint32_t anchor, uint32_t low, uint32_t lane) {
+    uint32_t lim = ip - anchor;
+    if (match - low < lim) lim = match - low;
+    uint32_t done = 0;
+    for (;;) {
+        const uint32_t i = done + lane;
+        const bool ok = i < lim && src[ip - 1 - i] == src[match - 1 - i];
+        const unsigned long long m = __ballot(!ok);
+        if (m) return done + (uint32_t)(__ffsll((long long)m) - 1);
+        done += LANES;
+    }
+}
+
+struct MfState { uint32_t nbSeq, litSize; };
+
+__device__ static inline void store_seq(zs_seq* __restrict__ seqs, uint8_t* __restrict__ lit, const uint8_t* __restrict__ src, MfState& s,
+                                        uint32_t litLen, uint32_t litPos, uint32_t offBase, uint32_t mlen, uint32_t lane) {
+    for (uint32_t i = lane; i < litLen; i += LANES) lit[s.litSize + i] = src[litPos + i];
+    if (lane == 0) { zs_seq q; q.offBase = offBase; q.litLength = litLen; q.mlBase = mlen - 3; q.pad = 0; seqs[s.nbSeq] = q; }
+    s.litSize += litLen; s.nbSeq++;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// double-fast match finder for one block (ZSTD_compressBlock_doubleFast_noDict_generic, speculative form)
+// all "positions" are offsets within the chunk; table values are libzstd's indices = position + 2.
+// returns the size of the last literal run; rep[] updated as the serial code does.
+// ---------------------------------------------------------------------------------------------------
+__device__ ZS_NOINLINE static uint32_t match_block(const uint8_t* __restrict__ src, uint32_t blockStart, uint32_t blockSize, uint32_t* __restrict__ hashLong,
+                                       uint32_t* __restrict__ hashSmall, const zs_cparams cp, uint32_t plowIdx, uint32_t* rep,
+                                       zs_seq* __restrict__ seqs, uint8_t* __restrict__ lit, MfState& ms, uint32_t lane) {
+    const uint32_t iend = blockStart + blockSize;
+    const uint32_t hBitsL = cp.hashLog, hBitsS = cp.chainLog, mls = cp.minMatch;
+    uint32_t ip = blockStart, anchor = blockStart;
+    uint32_t off1 = rep[0], off2 = rep[1], sav1 = 0, sav2 = 0;
+    ms.nbSeq = 0; ms.litSize = 0;
+    if (ip + 2 == plowIdx) ip++;
+    {   const uint32_t maxRep = ip + 2 - plowIdx;
+        if (off2 > maxRep) { sav2 = off2; off2 = 0; }
+        if (off1 > maxRep) { sav1 = off1; off1 = 0; }
+    }
+    if (blockSize >= 8) {
+        const uint32_t ilimit = iend - 8;
+        bool dirty = true;
+        bool done = false;
+        while (!done) {                                               // one iteration per stored match
+            uint32_t step = 1, nextStep = ip + 256;
+            if (ip + step > ilimit) break;
+            uint32_t width = 16;
+            for (;;) {                                                // one iteration per speculative wave step
+                // K search positions ip + k*step (k < K) evaluated at once; lane K only provides the look-ahead
+                uint32_t K1 = 1;
+                if (nextStep > ip + step) K1 = (nextStep - ip - 1) / step + 1;      // first k with ip+(k+1)*step >= nextStep, plus one
+                uint32_t K = (ilimit - step - ip) / step + 1;
+                if (K1 < K) K = K1;
+                if (width < K) K = width;
+                const bool inRange = lane <= K;
+                const bool searching = lane < K;
+                const uint32_t pos = ip + lane * step;
+                const uint64_t d8 = inRange ? ld64(src + pos) : 0;
+                const uint32_t hl = hash8(d8, hBitsL), hs = hashS(d8, hBitsS, mls);
+                if (dirty) { __threadfence_block(); dirty = false; }
+                uint32_t cL = inRange ? hashLong[hl] : 0;
+                uint32_t cS = searching ? hashSmall[hs] : 0;
+                uint32_t nextL = LANES, nextS = LANES;               // first later searching lane with my hash
+                for (uint32_t i = 0; i < K; i++) {
+                    const uint32_t hli = __builtin_amdgcn_readlane(hl, i), hsi = __builtin_amdgcn_readlane(hs, i);
+                    const uint32_t idxi = ip + i * step + 2;
+                    if (hl == hli) { if (lane > i) cL = idxi; else if (lane < i && nextL == LANES) nextL = i; }
+                    if (hs == hsi) { if (lane > i) cS = idxi; else if (lane < i && nextS == LANES) nextS = i; }
+                }
+                const bool longOK = inRange && cL > plowIdx && ld64(src + cL - 2) == d8;
+                const bool shortOK = searching && cS > plowIdx && ld32(src + cS - 2) == (uint32_t)d8;
+                const bool repOK = searching && off1 > 0 && ld32(src + pos + 1 - off1) == (uint32_t)(d8 >> 8);
+                const uint32_t ev = !searching ? 0u : repOK ? 1u : longOK ? 2u : shortOK ? 3u : 0u;
+                const unsigned long long bm = __ballot(ev != 0);
+                const int f = bm ? __ffsll((long long)bm) - 1 : -1;
+                const uint32_t lastIns = f >= 0 ? (uint32_t)f : K - 1;
+                if (lane <= lastIns) {                                // the visited positions insert themselves
+                    if (nextL > lastIns) hashLong[hl] = pos + 2;
+                    if (nextS > lastIns) hashSmall[hs] = pos + 2;
+                }
+                dirty = true;
+                if (f < 0) {
+                    const bool inc = ip + K * step >= nextStep;
+                    ip += K * step;
+                    if (inc) { step++; nextStep += 256; }
+                    if (ip + step > ilimit) { done = true; break; }
+                    width = width >= 32 ? 63 : width * 2;
+                    continue;
+                }
+                const uint32_t evf = __builtin_amdgcn_readlane(ev, f);
+                const uint32_t posf = ip + (uint32_t)f * step;
+                uint32_t start, mlen;
+                if (evf == 1) {                                       // repcode at posf + 1
+                    start = posf + 1;
+                    mlen = 4 + wave_count(src, start + 4, start + 4 - off1, iend, lane);
+                    store_seq(seqs, lit, src, ms, start - anchor, anchor, 1, mlen, lane);
+                } else {
+                    uint32_t mpos;
+                    if (evf == 2) {                                   // long match at posf
+                        start = posf; mpos = __builtin_amdgcn_readlane(cL, f) - 2;
+                        mlen = 8 + wave_count(src, start + 8, mpos + 8, iend, lane);
+                    } else {                                          // short match; a strictly longer long match at +1 wins
+                        start = posf; mpos = __builtin_amdgcn_readlane(cS, f) - 2;
+                        mlen = 4 + wave_count(src, start + 4, mpos + 4, iend, lane);
+                        if (__builtin_amdgcn_readlane((uint32_t)longOK, f + 1)) {
+                            const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(cL, f + 1) - 2;
+                            const uint32_t l1 = 8 + wave_count(src, p1 + 8, m1 + 8, iend, lane);
+                            if (l1 > mlen) { start = p1; mpos = m1; mlen = l1; }
+                        }
+                    }
+                    const uint32_t back = wave_count_back(src, start, mpos, anchor, plowIdx - 2, lane);
+                    start -= back; mpos -= back; mlen += back;
+                    off2 = off1; off1 = start - mpos;
+                    if (step < 4 && lane == (uint32_t)f + 1) hashLong[hl] = pos + 2;     // hashLong[hl1] = ip1
+                    store_seq(seqs, lit, src, ms, start - anchor, anchor, off1 + 3, mlen, lane);
+                }
+                ip = start + mlen; anchor = ip;
+                if (ip <= ilimit) {
+                    {   // complementary insertion: long[curr+2], long[ip-2], small[curr+2], small[ip-1] (in that order)
+                        const uint32_t p = lane == 0 || lane == 2 ? posf + 2 : lane == 1 ? ip - 2 : ip - 1;
+                        const uint64_t d = lane < 4 ? ld64(src + p) : 0;
+                        const uint32_t h = lane < 2 ? hash8(d, hBitsL) : hashS(d, hBitsS, mls);
+                        const uint32_t hn = __shfl(h, lane + 1);
+                        const bool shadowed = (lane == 0 || lane == 2) && hn == h;      // the later write of the pair wins
+                        if (lane < 2 && !shadowed) hashLong[h] = p + 2;
+                        if ((lane == 2 || lane == 3) && !shadowed) hashSmall[h] = p + 2;
+                    }
+                    while (ip <= ilimit && off2 > 0 && ld32(src + ip) == ld32(src + ip - off2)) {   // immediate repcode
+                        const uint32_t rlen = 4 + wave_count(src, ip + 4, ip + 4 - off2, iend, lane);
+                        const uint32_t t = off2; off2 = off1; off1 = t;
+                        if (lane == 0) {
+                            const uint64_t d = ld64(src + ip);
+                            hashSmall[hashS(d, hBitsS, mls)] = ip + 2;
+                            hashLong[hash8(d, hBitsL)] = ip + 2;
+                        }
+                        store_seq(seqs, lit, src, ms, 0, ip, 1, rlen, lane);
+                        ip += rlen; anchor = ip;
+                    }
+                }
+                break;
+            }
+        }
+    }
+    sav2 = (sav1 != 0 && off1 != 0) ? sav1 : sav2;
+    rep[0] = off1 ? off1 : sav1;
+    rep[1] = off2 ? off2 : sav2;
+    const uint32_t lastLL = iend - anchor;
+    for (uint32_t i = lane; i < lastLL; i += LANES) lit[ms.litSize + i] = src[anchor + i];
+    ms.litSize += lastLL;
+    return lastLL;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// lane-0 serial pieces (FSE / Huffman table construction), work arrays in LDS
+// ---------------------------------------------------------------------------------------------------
+struct BitW { uint8_t* start; uint8_t* p; uint8_t* end; uint64_t acc; uint32_t n; bool overflow; };
+__device__ static inline void bw_init(BitW& b, uint8_t* dst, uint8_t* end) { b.start = b.p = dst; b.end = end; b.acc = 0; b.n = 0; b.overflow = false; }
+__device__ static inline void bw_add(BitW& b, uint64_t v, uint32_t nb) {
+    if (!nb) return;
+    b.acc |= (v & ((1ull << nb) - 1)) << b.n;
+    b.n += nb;
+    while (b.n >= 8) { if (b.p < b.end) *b.p++ = (uint8_t)b.acc; else b.overflow = true; b.acc >>= 8; b.n -= 8; }
+}
+__device__ static inline uint32_t bw_close(BitW& b) {
+    bw_add(b, 1, 1);
+    if (b.n) { if (b.p < b.end) *b.p++ = (uint8_t)b.acc; else b.overflow = true; b.n = 0; }
+    return (uint32_t)(b.p - b.start);
+}
+
+__device__ static uint32_t fse_minTableLog(uint32_t srcSize, uint32_t maxSym) {
+    uint32_t a = hb32(srcSize) + 1, b = hb32(maxSym) + 2;
+    return a < b ? a : b;
+}
+__device__ static uint32_t fse_optimalTableLog(uint32_t maxTableLog, uint32_t srcSize, uint32_t maxSym, uint32_t minus) {
+    uint32_t maxBitsSrc = hb32(srcSize - 1) - minus, tableLog = maxTableLog, minBits = fse_minTableLog(srcSize, maxSym);
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < 5) tableLog = 5;
+    if (tableLog > 12) tableLog = 12;
+    return tableLog;
+}
+
+__device__ ZS_NOINLINE static int fse_normalizeM2(short* norm, uint32_t tableLog, const uint32_t* cnt, uint32_t total, uint32_t maxSym, short lowProbCount) {
+    const short NOT_YET = -2;
+    uint32_t s, distributed = 0, toDist;
+    const uint32_t lowThreshold = total >> tableLog;
+    uint32_t lowOne = (uint32_t)(((uint64_t)total * 3) >> (tableLog + 1));
+    for (s = 0; s <= maxSym; s++) {
+        if (cnt[s] == 0) { norm[s] = 0; continue; }
+        if (cnt[s] <= lowThreshold) { norm[s] = lowProbCount; distributed++; total -= cnt[s]; continue; }
+        if (cnt[s] <= lowOne) { norm[s] = 1; distributed++; total -= cnt[s]; continue; }
+        norm[s] = NOT_YET;
+    }
+    toDist = (1u << tableLog) - distributed;
+    if (toDist == 0) return 0;
+    if ((total / toDist) > lowOne) {
+        lowOne = (uint32_t)(((uint64_t)total * 3) / (toDist * 2));
+        for (s = 0; s <= maxSym; s++)
+            if (norm[s] == NOT_YET && cnt[s] <= lowOne) { norm[s] = 1; distributed++; total -= cnt[s]; }
+        toDist = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSym + 1) {
+        uint32_t maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSym; s++) if (cnt[s] > maxC) { maxV = s; maxC = cnt[s]; }
+        norm[maxV] += (short)toDist;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; toDist > 0; s = (s + 1) % (maxSym + 1)) if (norm[s] > 0) { toDist--; norm[s]++; }
+        return 0;
+    }
+    {   const uint64_t vStepLog = 62 - tableLog, mid = (1ULL << (vStepLog - 1)) - 1;
+        const uint64_t rStep = ((((uint64_t)1 << vStepLog) * toDist) + mid) / total;
+        uint64_t tmpTotal = mid;
+        for (s = 0; s <= maxSym; s++) {
+            if (norm[s] == NOT_YET) {
+                const uint64_t end = tmpTotal + (cnt[s] * rStep);
+                const uint32_t weight = (uint32_t)(end >> vStepLog) - (uint32_t)(tmpTotal >> vStepLog);
+                if (weight < 1) return -1;
+                norm[s] = (short)weight;
+                tmpTotal = end;
+            }
+        }
+    }
+    return 0;
+}
+
+__device__ ZS_NOINLINE static int fse_normalizeCount(short* norm, uint32_t tableLog, const uint32_t* cnt, uint32_t total, uint32_t maxSym, bool useLowProb) {
+    const short lowProbCount = useLowProb ? -1 : 1;
+    const uint64_t scale = 62 - tableLog, step = ((uint64_t)1 << 62) / total, vStep = 1ULL << (scale - 20);
+    int still = 1 << tableLog;
+    uint32_t s, largest = 0; short largestP = 0;
+    const uint32_t lowThreshold = total >> tableLog;
+    if (tableLog < fse_minTableLog(total, maxSym)) return -1;
+    for (s = 0; s <= maxSym; s++) {
+        if (cnt[s] == total) return 0;
+        if (cnt[s] == 0) { norm[s] = 0; continue; }
+        if (cnt[s] <= lowThreshold) { norm[s] = lowProbCount; still--; }
+        else {
+            short proba = (short)((cnt[s] * step) >> scale);
+            if (proba < 8) { const uint64_t restToBeat = vStep * kRtb[proba]; proba += (cnt[s] * step) - ((uint64_t)proba << scale) > restToBeat; }
+            if (proba > largestP) { largestP = proba; largest = s; }
+            norm[s] = proba; still -= proba;
+        }
+    }
+    if (-still >= (norm[largest] >> 1)) { if (fse_normalizeM2(norm, tableLog, cnt, total, maxSym, lowProbCount) < 0) return -1; }
+    else norm[largest] += (short)still;
+    return (int)tableLog;
+}
+
+__device__ ZS_NOINLINE static uint32_t fse_writeNCount(uint8_t* out0, const short* norm, uint32_t maxSym, uint32_t tableLog) {
+    uint8_t* out = out0;
+    int nbBits, remaining, threshold; const int tableSize = 1 << tableLog;
+    uint32_t bitStream = 0; int bitCount = 0; uint32_t symbol = 0; const uint32_t alphabetSize = maxSym + 1; int previousIs0 = 0;
+    bitStream += (tableLog - 5) << bitCount; bitCount += 4;
+    remaining = tableSize + 1; threshold = tableSize; nbBits = (int)tableLog + 1;
+    while (symbol < alphabetSize && remaining > 1) {
+        if (previousIs0) {
+            uint32_t start = symbol;
+            while (symbol < alphabetSize && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) { start += 24; bitStream += 0xFFFFU << bitCount; out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16; }
+            while (symbol >= start + 3) { start += 3; bitStream += 3U << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) { out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+        }
+        {   int c = norm[symbol++];
+            const int mx = (2 * threshold - 1) - remaining;
+            remaining -= c < 0 ? -c : c;
+            c++;
+            if (c >= threshold) c += mx;
+            bitStream += (uint32_t)c << bitCount;
+            bitCount += nbBits;
+            bitCount -= (c < mx);
+            previousIs0 = (c == 1);
+            if (remaining < 1) return 0;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) { out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+    }
+    if (remaining != 1) return 0;
+    out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (uint32_t)(out - out0);
+}
+
+__device__ ZS_NOINLINE static void fse_buildCTable(FseTable& ct, const short* norm, uint32_t maxSym, uint32_t tableLog, uint32_t* cumul, uint8_t* tableSymbol) {
+    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    uint32_t highThreshold = tableSize - 1, u;
+    ct.tableLog = tableLog;
+    cumul[0] = 0;
+    for (u = 1; u <= maxSym + 1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (uint8_t)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (uint32_t)norm[u - 1];
+    }
+    cumul[maxSym + 1] = tableSize + 1;
+    {   uint32_t position = 0;
+        for (uint32_t symbol = 0; symbol <= maxSym; symbol++) {
+            const int freq = norm[symbol];
+            for (int n = 0; n < freq; n++) {
+                tableSymbol[position] = (uint8_t)symbol;
+                position = (position + step) & tableMask;
+                while (position > highThreshold) position = (position + step) & tableMask;
+            }
+        }
+    }
+    for (u = 0; u < tableSize; u++) { const uint8_t s = tableSymbol[u]; ct.state[cumul[s]++] = (uint16_t)(tableSize + u); }
+    {   uint32_t total = 0;
+        for (uint32_t s = 0; s <= maxSym; s++) {
+            const int nv = norm[s];
+            if (nv == 0) { ct.dnb[s] = ((tableLog + 1) << 16) - (1u << tableLog); ct.dfs[s] = 0; }
+            else if (nv == -1 || nv == 1) { ct.dnb[s] = (tableLog << 16) - (1u << tableLog); ct.dfs[s] = (int)(total - 1); total++; }
+            else {
+                const uint32_t maxBitsOut = tableLog - hb32((uint32_t)nv - 1), minStatePlus = (uint32_t)nv << maxBitsOut;
+                ct.dnb[s] = (maxBitsOut << 16) - minStatePlus; ct.dfs[s] = (int)(total - (uint32_t)nv); total += (uint32_t)nv;
+            }
+        }
+    }
+}
+__device__ static inline uint32_t fse_init2(const FseTable& ct, uint32_t symbol) {
+    const uint32_t dnb = ct.dnb[symbol];
+    const uint32_t nbBitsOut = (dnb + (1u << 15)) >> 16;
+    const uint32_t value = (nbBitsOut << 16) - dnb;
+    return ct.state[(value >> nbBitsOut) + ct.dfs[symbol]];
+}
+__device__ static inline void fse_encode(BitW& b, const FseTable& ct, uint32_t& value, uint32_t symbol) {
+    const uint32_t nbBitsOut = (value + ct.dnb[symbol]) >> 16;
+    bw_add(b, value, nbBitsOut);
+    value = ct.state[(value >> nbBitsOut) + ct.dfs[symbol]];
+}
+
+// ---- Huffman (lane 0) -----------------------------------------------------------------------------------
+#define RANK_TABLE 192
+#define RANK_LOG_BEGIN 158
+#define RANK_CUTOFF 165
+__device__ static inline uint32_t huf_getIndex(uint32_t c) { return c < RANK_CUTOFF ? c : hb32(c) + RANK_LOG_BEGIN; }
+__device__ static inline void huf_swap(NodeElt* a, NodeElt* b) { NodeElt t = *a; *a = *b; *b = t; }
+__device__ static void huf_insertionSort(NodeElt* h, int low, int high) {
+    const int size = high - low + 1;
+    h += low;
+    for (int i = 1; i < size; ++i) {
+        const NodeElt key = h[i]; int j = i - 1;
+        while (j >= 0 && h[j].count < key.count) { h[j + 1] = h[j]; j--; }
+        h[j + 1] = key;
+    }
+}
+__device__ static int huf_partition(NodeElt* arr, int low, int high) {
+    const uint32_t pivot = arr[high].count; int i = low - 1;
+    for (int j = low; j < high; j++) if (arr[j].count > pivot) { i++; huf_swap(&arr[i], &arr[j]); }
+    huf_swap(&arr[i + 1], &arr[high]);
+    return i + 1;
+}
+// HUF_simpleQuickSort with its recursion made explicit.  A CALL frame applies the insertion-sort threshold on
+// entry; a CONTinuation frame is the rest of the caller's `while (low < high)` loop, which partitions without
+// re-checking the threshold.  The two sides of a partition are disjoint, so their processing order is free.
+__device__ ZS_NOINLINE static void huf_quickSort(NodeElt* arr, int low0, int high0) {
+    int stLo[64], stHi[64]; bool stCall[64]; int sp = 0;
+    stLo[0] = low0; stHi[0] = high0; stCall[0] = true; sp = 1;
+    while (sp) {
+        --sp;
+        const int low = stLo[sp], high = stHi[sp]; const bool call = stCall[sp];
+        if (call && high - low < 8) { huf_insertionSort(arr, low, high); continue; }
+        if (!(low < high)) continue;
+        const int idx = huf_partition(arr, low, high);
+        if (idx - low < high - idx) {
+            stLo[sp] = idx + 1; stHi[sp] = high; stCall[sp] = false; sp++;
+            stLo[sp] = low; stHi[sp] = idx - 1; stCall[sp] = true; sp++;
+        } else {
+            stLo[sp] = low; stHi[sp] = idx - 1; stCall[sp] = false; sp++;
+            stLo[sp] = idx + 1; stHi[sp] = high; stCall[sp] = true; sp++;
+        }
+    }
+}
+
+__device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint32_t* cnt, uint32_t maxSym, uint32_t maxNbBits, EncLds& L) {
+    NodeElt* const huffNode0 = L.nodes; NodeElt* const huffNode = huffNode0 + 1;
+    for (int i = 0; i < 514; i++) { NodeElt z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
+    // HUF_sort
+    {   const uint32_t n1 = maxSym + 1;
+        for (int i = 0; i < RANK_TABLE; i++) { L.rankBase[i] = 0; L.rankCurr[i] = 0; }
+        for (uint32_t n = 0; n < n1; ++n) L.rankBase[huf_getIndex(cnt[n])]++;
+        for (int n = RANK_TABLE - 1; n > 0; --n) { L.rankBase[n - 1] += L.rankBase[n]; L.rankCurr[n - 1] = L.rankBase[n - 1]; }
+        for (uint32_t n = 0; n < n1; ++n) {
+            const uint32_t c = cnt[n], r = huf_getIndex(c) + 1, pos = L.rankCurr[r]++;
+            huffNode[pos].count = c; huffNode[pos].byte = (uint8_t)n;
+        }
+        for (int n = RANK_CUTOFF; n < RANK_TABLE - 1; ++n) {
+            const int bucketSize = L.rankCurr[n] - L.rankBase[n];
+            if (bucketSize > 1) huf_quickSort(huffNode + L.rankBase[n], 0, bucketSize - 1);
+        }
+    }
+    // HUF_buildTree
+    int nonNullRank = (int)maxSym;
+    {   const int STARTNODE = 256;
+        int lowS, lowN, nodeNb = STARTNODE, n, nodeRoot;
+        while (huffNode[nonNullRank].count == 0) nonNullRank--;
+        lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
+        huffNode[nodeNb].count = huffNode[lowS].count + huffNode[lowS - 1].count;
+        huffNode[lowS].parent = huffNode[lowS - 1].parent = (uint16_t)nodeNb;
+        nodeNb++; lowS -= 2;
+        for (n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = 1u << 30;
+        huffNode0[0].count = 1u << 31;
+        while (nodeNb <= nodeRoot) {
+            const int a = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+            const int b = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+            huffNode[nodeNb].count = huffNode[a].count + huffNode[b].count;
+            huffNode[a].parent = huffNode[b].parent = (uint16_t)nodeNb;
+            nodeNb++;
+        }
+        huffNode[nodeRoot].nbBits = 0;
+        for (n = nodeRoot - 1; n >= STARTNODE; n--) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+        for (n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+    }
+    // HUF_setMaxHeight
+    {   const uint32_t lastNonNull = (uint32_t)nonNullRank, targetNbBits = maxNbBits;
+        const uint32_t largestBits = huffNode[lastNonNull].nbBits;
+        if (largestBits <= targetNbBits) maxNbBits = largestBits;
+        else {
+            int totalCost = 0; const uint32_t baseCost = 1u << (largestBits - targetNbBits); int n = (int)lastNonNull;
+            while (huffNode[n].nbBits > targetNbBits) { totalCost += baseCost - (1 << (largestBits - huffNode[n].nbBits)); huffNode[n].nbBits = (uint8_t)targetNbBits; n--; }
+            while (huffNode[n].nbBits == targetNbBits) --n;
+            totalCost >>= (largestBits - targetNbBits);
+            {   const uint32_t noSymbol = 0xF0F0F0F0; uint32_t rankLast[ZS_HUF_TABLELOG_MAX + 2];
+                for (int i = 0; i < ZS_HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
+                {   uint32_t currentNbBits = targetNbBits;
+                    for (int pos = n; pos >= 0; pos--) {
+                        if (huffNode[pos].nbBits >= currentNbBits) continue;
+                        currentNbBits = huffNode[pos].nbBits;
+                        rankLast[targetNbBits - currentNbBits] = (uint32_t)pos;
+                    }
+                }
+                while (totalCost > 0) {
+                    uint32_t nBitsToDecrease = hb32((uint32_t)totalCost) + 1;
+                    for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+                        const uint32_t highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
+                        if (highPos == noSymbol) continue;
+                        if (lowPos == noSymbol) break;
+                        if (huffNode[highPos].count <= 2 * huffNode[lowPos].count) break;
+                    }
+                    while (nBitsToDecrease <= ZS_HUF_TABLELOG_MAX && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
+                    totalCost -= 1 << (nBitsToDecrease - 1);
+                    huffNode[rankLast[nBitsToDecrease]].nbBits++;
+                    if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+                    if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+                    else {
+                        rankLast[nBitsToDecrease]--;
+                        if (huffNode[rankLast[nBitsToDecrease]].nbBits != targetNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+                    }
+                }
+                while (totalCost < 0) {
+                    if (rankLast[1] == noSymbol) {
+                        while (huffNode[n].nbBits == targetNbBits) n--;
+                        huffNode[n + 1].nbBits--;
+                        rankLast[1] = (uint32_t)(n + 1);
+                        totalCost++;
+                        continue;
+                    }
+                    huffNode[rankLast[1] + 1].nbBits--;
+                    rankLast[1]++;
+                    totalCost++;
+                }
+            }
+            maxNbBits = targetNbBits;
+        }
+    }
+    // HUF_buildCTableFromTree
+    {   uint16_t nbPerRank[ZS_HUF_TABLELOG_MAX + 1], valPerRank[ZS_HUF_TABLELOG_MAX + 1];
+        const int alphabetSize = (int)(maxSym + 1);
+        for (int i = 0; i <= ZS_HUF_TABLELOG_MAX; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
+        for (int i = 0; i < 256; i++) { ct.val[i] = 0; ct.nb[i] = 0; }
+        for (int n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+        {   uint16_t mn = 0;
+            for (int n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
+        for (int n = 0; n < alphabetSize; n++) ct.nb[huffNode[n].byte] = huffNode[n].nbBits;
+        for (int n = 0; n < alphabetSize; n++) ct.val[n] = valPerRank[ct.nb[n]]++;
+        ct.tableLog = maxNbBits; ct.maxSym = maxSym;
+    }
+    return maxNbBits;
+}
+
+// HUF_compressWeights + HUF_writeCTable; returns header size, 0xFFFFFFFF when the table cannot be described
+__device__ ZS_NOINLINE static uint32_t huf_writeCTable(uint8_t* dst, const HufTable& ct, uint32_t maxSym, uint32_t huffLog, EncLds& L) {
+    uint8_t* const hw = L.weights;
+    for (uint32_t n = 0; n < maxSym; n++) { const uint32_t nb = ct.nb[n]; hw[n] = nb ? (uint8_t)(huffLog + 1 - nb) : 0; }
+    uint32_t hSize = 0;
+    {   // HUF_compressWeights(dst + 1, hw, maxSym)
+        uint8_t* op = dst + 1; const uint32_t wtSize = maxSym;
+        uint32_t maxSV = ZS_HUF_TABLELOG_MAX; uint32_t* cnt = L.cnt;
+        if (wtSize > 1) {
+            for (int i = 0; i <= ZS_HUF_TABLELOG_MAX; i++) cnt[i] = 0;
+            for (uint32_t i = 0; i < wtSize; i++) cnt[hw[i]]++;
+            while (!cnt[maxSV]) maxSV--;
+            uint32_t maxCount = 0;
+            for (uint32_t i = 0; i <= maxSV; i++) if (cnt[i] > maxCount) maxCount = cnt[i];
+            if (maxCount == wtSize) hSize = 1;
+            else if (maxCount == 1) hSize = 0;
+            else {
+                const uint32_t tableLog = fse_optimalTableLog(6, wtSize, maxSV, 2);
+                if (fse_normalizeCount(L.norm, tableLog, cnt, wtSize, maxSV, false) < 0) return 0xFFFFFFFFu;
+                op += fse_writeNCount(op, L.norm, maxSV, tableLog);
+                fse_buildCTable(L.ll, L.norm, maxSV, tableLog, L.cumul, L.tableSymbol);     // L.ll is free until the sequence stage
+                // FSE_compress_usingCTable: two interleaved states, from the last weight to the first
+                if (wtSize <= 2) hSize = 0;
+                else {
+                    BitW b; bw_init(b, op, op + 512);
+                    const uint8_t* ip = hw + wtSize; uint32_t s1, s2;
+                    if (wtSize & 1) { s1 = fse_init2(L.ll, *--ip); s2 = fse_init2(L.ll, *--ip); fse_encode(b, L.ll, s1, *--ip); }
+                    else { s2 = fse_init2(L.ll, *--ip); s1 = fse_init2(L.ll, *--ip); }
+                    while (ip > hw) { fse_encode(b, L.ll, s2, *--ip); if (ip > hw) fse_encode(b, L.ll, s1, *--ip); }
+                    bw_add(b, s2, tableLog); bw_add(b, s1, tableLog);
+                    op += bw_close(b);
+                    hSize = (uint32_t)(op - (dst + 1));
+                }
+            }
+        }
+    }
+    if ((hSize > 1) & (hSize < maxSym / 2)) { dst[0] = (uint8_t)hSize; return hSize + 1; }
+    if (maxSym > 128) return 0xFFFFFFFFu;
+    dst[0] = (uint8_t)(128 + (maxSym - 1));
+    hw[maxSym] = 0;
+    for (uint32_t n = 0; n < maxSym; n += 2) dst[(n / 2) + 1] = (uint8_t)((hw[n] << 4) + hw[n + 1]);
+    return ((maxSym + 1) / 2) + 1;
+}
+
+// ---- wave-parallel pieces ---------------------------------------------------------------------------------
+__device__ static inline uint32_t wave_sum(uint32_t v) { for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ static inline uint32_t wave_max(uint32_t v) { for (int o = 32; o; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; } return v; }
+__device__ static inline uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
+    uint32_t s = v;
+    for (int o = 1; o < LANES; o <<= 1) { uint32_t t = __shfl_up(s, o); if (lane >= (uint32_t)o) s += t; }
+    return s - v;
+}
+
+__device__ ZS_NOINLINE static void wave_histogram(uint32_t* hist, const uint8_t* __restrict__ p, uint32_t n, uint32_t lane) {
+    for (uint32_t i = lane; i < 256; i += LANES) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += LANES) atomicAdd(&hist[p[i]], 1u);
+    __syncthreads();
+}
+
+// One Huffman stream (HUF_compress1X_usingCTable): symbols are written from the LAST to the first, LSB-first,
+// closed by a 1 bit.  tmp is 4-byte aligned scratch; returns the stream size in bytes.
+__device__ ZS_NOINLINE static uint32_t wave_huf_encode(uint32_t* __restrict__ tmp, const uint8_t* __restrict__ src, uint32_t n, const HufTable& ct, uint32_t lane) {
+    const uint32_t per = (n + LANES - 1) / LANES;
+    const uint32_t r0 = lane * per < n ? lane * per : n, r1 = r0 + per < n ? r0 + per : n;     // reversed index range
+    uint32_t bits = 0;
+    for (uint32_t r = r0; r < r1; r++) bits += ct.nb[src[n - 1 - r]];
+    const uint32_t startBit = wave_excl_scan(bits, lane);
+    const uint32_t total = __shfl(startBit + bits, LANES - 1);
+    const uint32_t words = (total + 1 + 31) / 32;
+    for (uint32_t w = lane; w < words; w += LANES) tmp[w] = 0;
+    __threadfence_block();
+    __syncthreads();
+    {   uint64_t acc = 0; uint32_t word = startBit >> 5, nacc = startBit & 31;
+        for (uint32_t r = r0; r < r1; r++) {
+            const uint8_t s = src[n - 1 - r];
+            acc |= (uint64_t)ct.val[s] << nacc;
+            nacc += ct.nb[s];
+            if (nacc >= 32) { atomicOr(&tmp[word], (uint32_t)acc); acc >>= 32; nacc -= 32; word++; }
+        }
+        if (lane == LANES - 1) { acc |= 1ull << nacc; nacc++; }                                 // end mark
+        if (nacc) atomicOr(&tmp[word], (uint32_t)acc);
+        if (nacc > 32) atomicOr(&tmp[word + 1], (uint32_t)(acc >> 32));
+    }
+    __threadfence_block();
+    __syncthreads();
+    return (total + 1 + 7) / 8;
+}
+
+__device__ static inline void wave_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, uint32_t lane) {
+    for (uint32_t i = lane; i < n; i += LANES) dst[i] = src[i];
+}
+
+// HUF_compress1X / 4X_usingCTable + the compressibility check of HUF_compressCTable_internal.
+// Writes at op (inside blockout); returns the total size from ostart, 0 if not compressible.
+__device__ ZS_NOINLINE static uint32_t wave_huf_compress(uint8_t* ostart, uint8_t* op, const uint8_t* __restrict__ lit, uint32_t n, bool single, const HufTable& ct,
+                                             uint32_t* tmp, uint32_t lane) {
+    if (single) {
+        const uint32_t c = wave_huf_encode(tmp, lit, n, ct, lane);
+        wave_copy(op, (const uint8_t*)tmp, c, lane);
+        op += c;
+    } else {
+        if (n < 12) return 0;
+        const uint32_t seg = (n + 3) / 4;
+        uint8_t* const jump = op;
+        op += 6;
+        for (int i = 0; i < 4; i++) {
+            const uint32_t len = i < 3 ? seg : n - 3 * seg;
+            const uint32_t c = wave_huf_encode(tmp, lit + (uint32_t)i * seg, len, ct, lane);
+            if (c == 0 || c > 65535) return 0;
+            if (i < 3 && lane == 0) { jump[2 * i] = (uint8_t)c; jump[2 * i + 1] = (uint8_t)(c >> 8); }
+            wave_copy(op, (const uint8_t*)tmp, c, lane);
+            op += c;
+            __syncthreads();
+        }
+    }
+    const uint32_t tot = (uint32_t)(op - ostart);
+    if (tot >= n - 1) return 0;
+    return tot;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// literals section (ZSTD_compressLiterals).  Returns its size; updates L.huf / L.hufRepeat ("next" side).
+// cur = index of the confirmed (previous) Huffman state; the candidate state is written at cur ^ 1.
+// ---------------------------------------------------------------------------------------------------
+__device__ static uint32_t write_raw_literals(uint8_t* dst, const uint8_t* lit, uint32_t n, uint32_t lane) {
+    const uint32_t fl = 1 + (n > 31) + (n > 4095);
+    if (lane == 0) {
+        if (fl == 1) dst[0] = (uint8_t)(0 + (n << 3));
+        else if (fl == 2) { const uint32_t v = 0 + (1 << 2) + (n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); }
+        else { const uint32_t v = 0 + (3 << 2) + (n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); }
+    }
+    wave_copy(dst + fl, lit, n, lane);
+    return fl + n;
+}
+__device__ static uint32_t write_rle_literals(uint8_t* dst, const uint8_t* lit, uint32_t n, uint32_t lane) {
+    const uint32_t fl = 1 + (n > 31) + (n > 4095);
+    if (lane == 0) {
+        if (fl == 1) dst[0] = (uint8_t)(1 + (n << 3));
+        else if (fl == 2) { const uint32_t v = 1 + (1 << 2) + (n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); }
+        else { const uint32_t v = 1 + (3 << 2) + (n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); }
+        dst[fl] = lit[0];
+    }
+    return fl + 1;
+}
+
+__device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uint8_t* __restrict__ lit, uint32_t n, EncLds& L, int cur, bool suspectUncompressible,
+                                             uint32_t* tmp, uint32_t lane) {
+    const int nxt = cur ^ 1;
+    const uint32_t lhSize = 3 + (n >= 1024) + (n >= 16384);
+    bool single = n < 256;
+    // "next" starts as a copy of "prev" (nothing to copy: we only switch `cur` when a new table is adopted)
+    if (n < 64) return write_raw_literals(dst, lit, n, lane);              // ZSTD_minLiteralsToCompress (dfast, no valid repeat)
+    const int prevRepeat = L.hufRepeat[cur];
+    const bool preferRepeat = n <= 1024;                                   // strategy < lazy && srcSize <= 1024
+    uint8_t* const ostart = dst + lhSize;
+    // ---- HUF_compress_internal ----
+    uint32_t cLit = 0; bool usedOld = false, newTable = false;
+    bool decided = false;
+    if (suspectUncompressible && n >= 40960) {                             // sample the first and last 4 KiB
+        wave_histogram(L.hist2, lit, 4096, lane);
+        uint32_t m = 0; for (uint32_t i = lane; i < 256; i += LANES) m = L.hist2[i] > m ? L.hist2[i] : m;
+        uint32_t largestTotal = wave_max(m);
+        __syncthreads();
+        wave_histogram(L.hist2, lit + n - 4096, 4096, lane);
+        m = 0; for (uint32_t i = lane; i < 256; i += LANES) m = L.hist2[i] > m ? L.hist2[i] : m;
+        largestTotal += wave_max(m);
+        if (largestTotal <= ((2 * 4096) >> 7) + 4) { cLit = 0; decided = true; }
+    }
+    uint32_t maxSym = 255, largest = 0;
+    if (!decided) {
+        wave_histogram(L.hist, lit, n, lane);
+        uint32_t m = 0, top = 0;
+        for (uint32_t i = lane; i < 256; i += LANES) { const uint32_t c = L.hist[i]; if (c > m) m = c; if (c) top = i; }
+        largest = wave_max(m); maxSym = wave_max(top);
+        if (largest == n) { cLit = 1; decided = true; if (lane == 0) ostart[0] = lit[0]; }
+        else if (largest <= (n >> 7) + 4) { cLit = 0; decided = true; }
+    }
+    if (!decided) {
+        int repeat = prevRepeat;
+        if (repeat == 1) {                                                 // HUF_validateCTable
+            bool bad = L.huf[cur].maxSym < maxSym;
+            for (uint32_t i = lane; i <= maxSym; i += LANES) bad |= (L.hist[i] != 0) & (L.huf[cur].nb[i] == 0);
+            if (__any(bad)) repeat = 0;
+        }
+        if (preferRepeat && repeat != 0) {
+            cLit = wave_huf_compress(ostart, ostart, lit, n, single, L.huf[cur], tmp, lane);
+            usedOld = true;
+        } else {
+            // build the candidate table (lane 0), describe it, compare with reusing the old one
+            if (lane == 0) {
+                uint32_t huffLog = fse_optimalTableLog(ZS_LitHufLog, n, maxSym, 1);
+                huffLog = huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, L);
+                const uint32_t hSize = huf_writeCTable(ostart, L.huf[nxt], maxSym, huffLog, L);
+                uint32_t useOld = 0, fail = 0;
+                if (hSize == 0xFFFFFFFFu) fail = 1;
+                else {
+                    if (repeat != 0) {
+                        uint32_t oldBits = 0, newBits = 0;
+                        for (uint32_t s = 0; s <= maxSym; s++) { oldBits += L.huf[cur].nb[s] * L.hist[s]; newBits += L.huf[nxt].nb[s] * L.hist[s]; }
+                        if ((oldBits >> 3) <= hSize + (newBits >> 3) || hSize + 12 >= n) useOld = 1;
+                    }
+                    if (!useOld && hSize + 12 >= n) fail = 1;
+                }
+                L.scal[0] = hSize; L.scal[1] = useOld; L.scal[2] = fail;
+            }
+            __syncthreads();
+            const uint32_t hSize = L.scal[0]; const bool useOld = L.scal[1], fail = L.scal[2];
+            __syncthreads();
+            if (fail) cLit = 0;
+            else if (useOld) { cLit = wave_huf_compress(ostart, ostart, lit, n, single, L.huf[cur], tmp, lane); usedOld = true; }
+            else { cLit = wave_huf_compress(ostart, ostart + hSize, lit, n, single, L.huf[nxt], tmp, lane); newTable = true; }
+        }
+    }
+    // ---- back in ZSTD_compressLiterals ----
+    const uint32_t minGain = (n >> 6) + 2;
+    if (cLit == 0 || cLit >= n - minGain) return write_raw_literals(dst, lit, n, lane);
+    if (cLit == 1) return write_rle_literals(dst, lit, n, lane);           // n >= 64 here, so (srcSize >= 8) holds
+    const uint32_t hType = (usedOld && !newTable) ? 3u : 2u;                // set_repeat : set_compressed
+    if (newTable) L.scal[8] = 1;                                           // caller adopts huf[nxt] if the block is kept
+    if (lane == 0) {
+        if (lhSize == 3) { const uint32_t v = hType + ((uint32_t)(!single) << 2) + (n << 4) + (cLit << 14); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); }
+        else if (lhSize == 4) { const uint32_t v = hType + (2 << 2) + (n << 4) + (cLit << 18); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); dst[3] = (uint8_t)(v >> 24); }
+        else { const uint32_t v = hType + (3 << 2) + (n << 4) + (cLit << 22); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); dst[2] = (uint8_t)(v >> 16); dst[3] = (uint8_t)(v >> 24); dst[4] = (uint8_t)(cLit >> 10); }
+    }
+    return lhSize + cLit;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sequences section (ZSTD_buildSequencesStatistics + ZSTD_encodeSequences).  Returns bytes written at op,
+// 0xFFFFFFFF if the block must be emitted raw.
+// ---------------------------------------------------------------------------------------------------
+__device__ static int select_encoding(uint32_t mostFrequent, uint32_t nbSeq, uint32_t defaultNormLog, bool defaultAllowed) {
+    if (mostFrequent == nbSeq) return (defaultAllowed && nbSeq <= 2) ? 0 : 1;           // set_basic : set_rle
+    if (defaultAllowed) {
+        const uint32_t dynMin = ((1u << defaultNormLog) * 8u) >> 3;                      // mult = 10 - strategy(2)
+        if (nbSeq < dynMin || mostFrequent < (nbSeq >> (defaultNormLog - 1))) return 0;   // set_basic
+    }
+    return 2;                                                                            // set_compressed
+}
+
+// lane 0: one of LL / OF / ML.  Returns description size (0xFFFFFFFF on failure); *type receives the mode.
+__device__ ZS_NOINLINE static uint32_t build_seq_table(uint8_t* op, FseTable& ct, uint32_t FSELog, uint32_t* cnt, uint32_t maxSymStart, const uint8_t* codes, uint32_t nbSeq,
+                                           const short* defaultNorm, uint32_t defaultNormLog, uint32_t defaultMax, bool isOffsets, EncLds& L, uint32_t* type) {
+    uint32_t max = maxSymStart;
+    while (!cnt[max]) max--;
+    uint32_t mostFrequent = 0;
+    for (uint32_t s = 0; s <= max; s++) if (cnt[s] > mostFrequent) mostFrequent = cnt[s];
+    const bool defaultAllowed = isOffsets ? (max <= ZS_DefaultMaxOff) : true;
+    const int t = select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed);
+    *type = (uint32_t)t;
+    if (t == 1) {                                                          // rle
+        ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.dnb[max] = 0; ct.dfs[max] = 0;
+        *op = codes[0];
+        return 1;
+    }
+    if (t == 0) {
+        for (uint32_t s = 0; s <= defaultMax; s++) L.norm[s] = defaultNorm[s];
+        fse_buildCTable(ct, L.norm, defaultMax, defaultNormLog, L.cumul, L.tableSymbol);
+        return 0;
+    }
+    uint32_t nbSeq_1 = nbSeq;
+    const uint32_t tableLog = fse_optimalTableLog(FSELog, nbSeq, max, 2);
+    if (cnt[codes[nbSeq - 1]] > 1) { cnt[codes[nbSeq - 1]]--; nbSeq_1--; }
+    if (fse_normalizeCount(L.norm, tableLog, cnt, nbSeq_1, max, nbSeq_1 >= 2048) < 0) return 0xFFFFFFFFu;
+    const uint32_t sz = fse_writeNCount(op, L.norm, max, tableLog);
+    fse_buildCTable(ct, L.norm, max, tableLog, L.cumul, L.tableSymbol);
+    return sz;
+}
+
+__device__ ZS_NOINLINE static uint32_t compress_sequences(uint8_t* op0, uint8_t* oend, const zs_seq* __restrict__ seqs, uint32_t nbSeq, uint8_t* __restrict__ codes,
+                                              EncLds& L, uint32_t lane) {
+    uint8_t* op = op0;
+    uint8_t* const llC = codes; uint8_t* const ofC = codes + ZS_WS_CODE_STRIDE; uint8_t* const mlC = codes + 2 * ZS_WS_CODE_STRIDE;
+    if (lane == 0) {
+        if (nbSeq < 128) *op = (uint8_t)nbSeq;
+        else if (nbSeq < 0x7F00) { op[0] = (uint8_t)((nbSeq >> 8) + 0x80); op[1] = (uint8_t)nbSeq; }
+        else { op[0] = 0xFF; op[1] = (uint8_t)(nbSeq - 0x7F00); op[2] = (uint8_t)((nbSeq - 0x7F00) >> 8); }
+    }
+    op += nbSeq < 128 ? 1 : nbSeq < 0x7F00 ? 2 : 3;
+    if (nbSeq == 0) return (uint32_t)(op - op0);
+    // codes + the three histograms (all lanes); cnt layout: [0..35] LL, [64..95] OF, [128..180] ML inside hist2
+    uint32_t* const cLL = L.hist2; uint32_t* const cOF = L.hist2 + 64; uint32_t* const cML = L.hist2 + 128;
+    for (uint32_t i = lane; i < 192; i += LANES) L.hist2[i] = 0;
+    __syncthreads();
+    for (uint32_t u = lane; u < nbSeq; u += LANES) {
+        const zs_seq q = seqs[u];
+        const uint32_t a = LLcode(q.litLength), b = hb32(q.offBase), c = MLcode(q.mlBase);
+        llC[u] = (uint8_t)a; ofC[u] = (uint8_t)b; mlC[u] = (uint8_t)c;
+        atomicAdd(&cLL[a], 1u); atomicAdd(&cOF[b], 1u); atomicAdd(&cML[c], 1u);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) {
+        uint8_t* const seqHead = op; uint8_t* q = op + 1;
+        uint32_t tLL, tOF, tML, lastCountSize = 0, fail = 0;
+        uint32_t s1 = build_seq_table(q, L.ll, ZS_LLFSELog, cLL, ZS_MaxLL, llC, nbSeq, kLLdefaultNorm, 6, ZS_MaxLL, false, L, &tLL);
+        if (s1 == 0xFFFFFFFFu) fail = 1; else { if (tLL == 2) lastCountSize = s1; q += s1; }
+        uint32_t s2 = fail ? 0 : build_seq_table(q, L.of, ZS_OffFSELog, cOF, ZS_MaxOff, ofC, nbSeq, kOFdefaultNorm, 5, ZS_DefaultMaxOff, true, L, &tOF);
+        if (s2 == 0xFFFFFFFFu) fail = 1; else if (!fail) { if (tOF == 2) lastCountSize = s2; q += s2; }
+        uint32_t s3 = fail ? 0 : build_seq_table(q, L.ml, ZS_MLFSELog, cML, ZS_MaxML, mlC, nbSeq, kMLdefaultNorm, 6, ZS_MaxML, false, L, &tML);
+        if (s3 == 0xFFFFFFFFu) fail = 1; else if (!fail) { if (tML == 2) lastCountSize = s3; q += s3; }
+        uint32_t total = 0xFFFFFFFFu;
+        if (!fail) {
+            *seqHead = (uint8_t)((tLL << 6) + (tOF << 4) + (tML << 2));
+            BitW b; bw_init(b, q, oend);
+            uint32_t stML = fse_init2(L.ml, mlC[nbSeq - 1]), stOF = fse_init2(L.of, ofC[nbSeq - 1]), stLL = fse_init2(L.ll, llC[nbSeq - 1]);
+            {   const zs_seq s = seqs[nbSeq - 1];
+                bw_add(b, s.litLength, kLLbits[llC[nbSeq - 1]]);
+                bw_add(b, s.mlBase, kMLbits[mlC[nbSeq - 1]]);
+                bw_add(b, s.offBase, ofC[nbSeq - 1]); }
+            for (uint32_t n = nbSeq - 2; n < nbSeq; n--) {
+                const uint32_t lc = llC[n], oc = ofC[n], mc = mlC[n];
+                const zs_seq s = seqs[n];
+                fse_encode(b, L.of, stOF, oc);
+                fse_encode(b, L.ml, stML, mc);
+                fse_encode(b, L.ll, stLL, lc);
+                bw_add(b, s.litLength, kLLbits[lc]);
+                bw_add(b, s.mlBase, kMLbits[mc]);
+                bw_add(b, s.offBase, oc);
+            }
+            bw_add(b, stML, L.ml.tableLog); bw_add(b, stOF, L.of.tableLog); bw_add(b, stLL, L.ll.tableLog);
+            const uint32_t bitstreamSize = bw_close(b);
+            if (b.overflow) total = 0xFFFFFFFFu;
+            else if (lastCountSize && (lastCountSize + bitstreamSize) < 4) total = 0xFFFFFFFFu;
+            else total = (uint32_t)((q + bitstreamSize) - op0);
+        }
+        L.scal[3] = total;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t r = L.scal[3];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// libzstd 1.5.7 pre-block splitter (ZSTD_splitBlock_byChunks level 0): byte histogram of every 43rd byte of
+// each 8 KiB chunk, compared with the accumulated past.
+// ---------------------------------------------------------------------------------------------------
+__device__ ZS_NOINLINE static uint32_t split_block_1_5_7(const uint8_t* __restrict__ p, EncLds& L, uint32_t lane) {
+    uint32_t* past = L.hist; uint32_t* cur = L.hist2;
+    uint32_t pastN = 0; int penalty = 3;
+    for (uint32_t i = lane; i < 256; i += LANES) past[i] = 0;
+    __syncthreads();
+    for (uint32_t n = lane * 43; n < 8191; n += LANES * 43) atomicAdd(&past[p[n]], 1u);
+    pastN = 8191 / 43;
+    __syncthreads();
+    for (uint32_t pos = 8192; pos <= ZS_BLOCK_MAX - 8192; pos += 8192) {
+        for (uint32_t i = lane; i < 256; i += LANES) cur[i] = 0;
+        __syncthreads();
+        for (uint32_t n = lane * 43; n < 8191; n += LANES * 43) atomicAdd(&cur[p[pos + n]], 1u);
+        const uint32_t curN = 8191 / 43;
+        __syncthreads();
+        uint64_t dev = 0;
+        for (uint32_t i = lane; i < 256; i += LANES) {
+            const int64_t d = (int64_t)past[i] * (int64_t)curN - (int64_t)cur[i] * (int64_t)pastN;
+            dev += (uint64_t)(d < 0 ? -d : d);
+        }
+        for (int o = 32; o; o >>= 1) dev += __shfl_xor(dev, o);
+        const uint64_t p50 = (uint64_t)pastN * (uint64_t)curN;
+        const uint64_t threshold = p50 * (uint64_t)(14 + penalty) / 16;
+        if (dev >= threshold) return pos;
+        for (uint32_t i = lane; i < 256; i += LANES) past[i] += cur[i];
+        pastN += curN;
+        if (penalty > 0) penalty--;
+        __syncthreads();
+    }
+    return ZS_BLOCK_MAX;
+}
+
+__device__ static bool wave_is_rle(const uint8_t* __restrict__ p, uint32_t n, uint32_t lane) {
+    const uint8_t b0 = p[0];
+    bool bad = false;
+    for (uint32_t i = lane; i < n && !bad; i += LANES) bad = p[i] != b0;
+    return !__any(bad);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the kernel: one wave per chunk
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, const tsx_chunk_desc* __restrict__ descs,
+                                                              uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
+                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile) {
+    __shared__ EncLds L;
+    const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
+    const uint8_t* __restrict__ src = src_base + descs[chunk].src_off;
+    const uint32_t srcSize = descs[chunk].src_len;
+    uint8_t* const frame = mid + (uint64_t)chunk * mid_stride;
+    uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
+    uint32_t* const hashLong = (uint32_t*)(ws + ZS_WS_HASHLONG);
+    uint32_t* const hashSmall = (uint32_t*)(ws + ZS_WS_HASHSMALL);
+    zs_seq* const seqs = (zs_seq*)(ws + ZS_WS_SEQS);
+    uint8_t* const lit = ws + ZS_WS_LIT;
+    uint8_t* const codes = ws + ZS_WS_CODES;
+    uint8_t* const blockout = ws + ZS_WS_BLOCKOUT;
+    uint32_t* const huftmp = (uint32_t*)(blockout + (256u << 10));                  // 4-byte aligned stream scratch
+    if (status[chunk] != TSX_OK) { if (lane == 0) zlen[chunk] = 0; return; }
+
+    const zs_cparams cp = zs_level3_cparams(srcSize);
+    {   // fresh tables (ZSTD_reset_matchState): zero hashLong[1 << hashLog] and hashSmall[1 << chainLog]
+        uint4 z; z.x = z.y = z.z = z.w = 0;
+        uint4* a = (uint4*)hashLong; uint4* b = (uint4*)hashSmall;
+        for (uint32_t i = lane; i < (1u << cp.hashLog) / 4; i += LANES) a[i] = z;
+        for (uint32_t i = lane; i < (1u << cp.chainLog) / 4; i += LANES) b[i] = z;
+    }
+    // ---- frame header (ZSTD_writeFrameHeader: content size known, no checksum, no dictID) ----
+    uint32_t hdr = 0;
+    {   const uint32_t windowSize = 1u << cp.windowLog;
+        const uint32_t single = windowSize >= srcSize;
+        const uint32_t fcs = (srcSize >= 256) + (srcSize >= 65536 + 256);
+        uint8_t h[16]; uint32_t k = 0;
+        h[k++] = 0x28; h[k++] = 0xB5; h[k++] = 0x2F; h[k++] = 0xFD;
+        h[k++] = (uint8_t)((single << 5) + (fcs << 6));
+        if (!single) h[k++] = (uint8_t)((cp.windowLog - 10) << 3);
+        if (fcs == 0) { if (single) h[k++] = (uint8_t)srcSize; }
+        else if (fcs == 1) { h[k++] = (uint8_t)(srcSize - 256); h[k++] = (uint8_t)((srcSize - 256) >> 8); }
+        else { h[k++] = (uint8_t)srcSize; h[k++] = (uint8_t)(srcSize >> 8); h[k++] = (uint8_t)(srcSize >> 16); h[k++] = (uint8_t)(srcSize >> 24); }
+        hdr = k;
+        if (lane == 0) for (uint32_t i = 0; i < k; i++) frame[i] = h[i];
+    }
+    uint8_t* op = frame + hdr;
+    if (srcSize == 0) {
+        if (lane == 0) { op[0] = 1; op[1] = 0; op[2] = 0; zlen[chunk] = hdr + 3; }
+        return;
+    }
+    if (lane == 0) { L.hufRepeat[0] = 0; L.hufRepeat[1] = 0; L.huf[0].maxSym = 0; L.huf[1].maxSym = 0; }
+    __syncthreads();
+    uint32_t repc[3] = {1, 4, 8};                                       // confirmed repcode history
+    const uint32_t blockSizeMax = (1u << cp.windowLog) < ZS_BLOCK_MAX ? (1u << cp.windowLog) : ZS_BLOCK_MAX;
+    uint32_t ipos = 0, remaining = srcSize, dictLimit = 2;
+    int64_t savings = 0;
+    int cur = 0;                 // index of the confirmed Huffman table (L.huf[cur]); a candidate is built in L.huf[cur ^ 1]
+    bool first = true;
+    while (remaining) {
+        // ---- block size (ZSTD_optimalBlockSize) ----
+        uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
+        if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
+            blockSize = split_block_1_5_7(src + ipos, L, lane);
+        const uint32_t lastBlock = blockSize == remaining;
+        {   // ZSTD_window_enforceMaxDist
+            const uint32_t blockEndIdx = ipos + blockSize + 2, maxDist = 1u << cp.windowLog;
+            if (blockEndIdx > maxDist && dictLimit < blockEndIdx - maxDist) dictLimit = blockEndIdx - maxDist;
+        }
+        uint32_t cSize = 0;                                             // 0 -> raw block
+        if (blockSize >= 7) {
+            uint32_t rep[3] = {repc[0], repc[1], repc[2]};
+            MfState ms;
+            match_block(src, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, lit, ms, lane);
+            __threadfence_block();
+            __syncthreads();
+            // ---- ZSTD_entropyCompressSeqStore ----
+            if (lane == 0) L.scal[8] = 0;
+            __syncthreads();
+            const bool suspect = ms.nbSeq == 0 || (ms.litSize / ms.nbSeq >= 20);
+            uint32_t litBytes = compress_literals(blockout, lit, ms.litSize, L, cur, suspect, huftmp, lane);
+            __threadfence_block();
+            __syncthreads();
+            uint32_t seqBytes = compress_sequences(blockout + litBytes, blockout + (255u << 10), seqs, ms.nbSeq, codes, L, lane);
+            const bool newHuf = L.scal[8] != 0;
+            if (seqBytes != 0xFFFFFFFFu) {
+                cSize = litBytes + seqBytes;
+                const uint32_t maxCSize = blockSize - ((blockSize >> 6) + 2);
+                if (cSize >= maxCSize) cSize = 0;
+            }
+            if (!first && ms.nbSeq < 4 && ms.litSize < 10 && wave_is_rle(src + ipos, blockSize, lane)) cSize = 1;
+            if (cSize > 1) {                                            // confirm repcodes + entropy tables
+                repc[0] = rep[0]; repc[1] = rep[1]; repc[2] = rep[2];
+                if (newHuf) { cur ^= 1; if (lane == 0) L.hufRepeat[cur] = 1; }      // HUF_repeat_check for the next block
+                __syncthreads();
+            }
+        }
+        // ---- emit the block ----
+        if (cSize == 0) {
+            if (lane == 0) { const uint32_t h = lastBlock + (0u << 1) + (blockSize << 3); op[0] = (uint8_t)h; op[1] = (uint8_t)(h >> 8); op[2] = (uint8_t)(h >> 16); }
+            wave_copy(op + 3, src + ipos, blockSize, lane);
+            cSize = 3 + blockSize;
+        } else if (cSize == 1) {
+            if (lane == 0) { const uint32_t h = lastBlock + (1u << 1) + (blockSize << 3); op[0] = (uint8_t)h; op[1] = (uint8_t)(h >> 8); op[2] = (uint8_t)(h >> 16); op[3] = src[ipos]; }
+            cSize = 4;
+        } else {
+            if (lane == 0) { const uint32_t h = lastBlock + (2u << 1) + (cSize << 3); op[0] = (uint8_t)h; op[1] = (uint8_t)(h >> 8); op[2] = (uint8_t)(h >> 16); }
+            wave_copy(op + 3, blockout, cSize, lane);
+            cSize += 3;
+        }
+        savings += (int64_t)blockSize - (int64_t)cSize;
+        ipos += blockSize; remaining -= blockSize; op += cSize; first = false;
+        __syncthreads();
+    }
+    if (lane == 0) zlen[chunk] = (uint32_t)(op - frame);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+size_t tsx_zstd_consts_bytes(void) { return sizeof(tsx_zstd_consts); }
+void tsx_zstd_build_consts(tsx_zstd_consts* h) { h->abi = 1; h->pad[0] = h->pad[1] = h->pad[2] = 0; }
+size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size_t)n * ZS_WS_BYTES; }
+
+uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* src, const tsx_chunk_desc* d_descs, uint32_t n,
+                                  uint32_t /*max_len*/, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status, void* d_work,
+                                  uint32_t profile) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
+                       (uint8_t*)d_work, profile);
+    return 1;
+}
