@@ -2,7 +2,7 @@
 //
 // Replaces zstd-jni's  new ZstdCompressCtx(); setPledgedSrcSize(n); setContentSize(true); compress(chunk)
 //   core/src/main/java/io/aiven/kafka/tieredstorage/transform/CompressionChunkEnumeration.java:50-63
-// and must emit, byte for byte, the frame libzstd emits for the same chunk (one-shot ZSTD_compress2, level 3:
+// and must emit, byte for byte, the frame libzstd emits for the same chunk (one-shot compression call, level 3:
 // strategy dfast, windowLog <= 21, 128 KiB blocks, Huffman literals + FSE sequences; profile 1.5.7 adds that
 // release's pre-block splitter).  The serial statement of the algorithm, pinned against the real library, is
 // oracle/zstd_l3.c; this file is its wave-parallel form:
