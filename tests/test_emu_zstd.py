@@ -24,6 +24,10 @@ def _cases():
         "lowent": rng.integers(0, 4, 150000, dtype=np.uint8),
         "skewed": np.minimum(rng.geometric(0.3, 150000), 255).astype(np.uint8),
         "ramp": (np.arange(150000) % 256).astype(np.uint8),
+        # matches whose candidates lie far behind the parser's LDS source window (global path) next to near ones
+        "farmatch": np.concatenate([R[:20000], K[:50000], R[:20000], K[20000:30000], R[5000:15000]]),
+        # long matches: ip jumps past the window (ring restart), then sparse positions again
+        "jumps": np.concatenate([R[:3000], np.zeros(40000, np.uint8), R[:3000], R[100000:130000], np.tile(R[:999], 30)]),
     }
 
 

@@ -18,7 +18,7 @@
 
 struct tsx_zstd_consts { uint32_t abi; uint32_t pad[3]; };
 
-struct zs_seq { uint32_t offBase, litLength, mlBase, pad; };
+struct zs_seq { uint32_t offBase, litLength, mlBase, litPos; };   /* litPos: chunk offset of the literal run (encoder) */
 
 // ---- per-chunk workspace (global memory) --------------------------------------------------------------
 #define ZS_WS_HASHLONG 0u                                             /* u32[1 << 17]                       */
@@ -27,7 +27,8 @@ struct zs_seq { uint32_t offBase, litLength, mlBase, pad; };
 #define ZS_WS_LIT (ZS_WS_SEQS + 16u * (ZS_MAX_SEQ + 64))              /* literals of the current block      */
 #define ZS_WS_CODES (ZS_WS_LIT + ZS_BLOCK_MAX + 256)                  /* llCode | ofCode | mlCode           */
 #define ZS_WS_CODE_STRIDE (ZS_MAX_SEQ + 64)
-#define ZS_WS_BLOCKOUT (ZS_WS_CODES + 3u * ZS_WS_CODE_STRIDE)         /* compressed block being built       */
+#define ZS_WS_STBITS (ZS_WS_CODES + 3u * ZS_WS_CODE_STRIDE)           /* u16[3][stride]: FSE state bits per sequence (LL|OF|ML) */
+#define ZS_WS_BLOCKOUT (ZS_WS_STBITS + 6u * ZS_WS_CODE_STRIDE)        /* compressed block being built       */
 #define ZS_BLOCKOUT_CAP (384u << 10)
 #define ZS_WS_BYTES ((size_t)(ZS_WS_BLOCKOUT + ZS_BLOCKOUT_CAP + 256))
 #define ZS_WS_HASH_BYTES (ZS_WS_SEQS)                                 /* prefix that must be zero at start  */

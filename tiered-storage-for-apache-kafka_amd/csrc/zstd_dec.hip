@@ -408,7 +408,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                             const uint32_t ml = dMLbase[mc] + (uint32_t)br_read(b, dMLbits[mc]);
                             if (!br_reload(b)) { e = 1; break; }
                             const uint32_t ll = dLLbase[lc] + (uint32_t)br_read(b, dLLbits[lc]);
-                            zs_seq sq; sq.offBase = offBase; sq.litLength = ll; sq.mlBase = ml; sq.pad = 0;
+                            zs_seq sq; sq.offBase = offBase; sq.litLength = ll; sq.mlBase = ml; sq.litPos = 0;
                             seqs[i] = sq;
                             if (i + 1 < nbSeq) {
                                 sl = el.base + (uint32_t)br_read(b, el.nb);

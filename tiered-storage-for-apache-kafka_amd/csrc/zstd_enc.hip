@@ -25,8 +25,45 @@
 #include "zstd_common.h"
 
 #define LANES 64
+#define ZS_RING 8192u         /* LDS source window of the parser (bytes) */
+#define ZS_RWM (ZS_RING / 4 - 1)
+#define ZS_FILL 4096u         /* refill granule */
+#define ZS_SAFE 384u          /* the parser may touch [ip, ip + ZS_SAFE) between two refill checks */
+#define ZS_SCR 2048u          /* slots of the intra-step hash-collision detector (per table) */
 // cold, register-hungry scalar stages are kept out of line so the speculative match loop keeps its occupancy
 #define ZS_NOINLINE __attribute__((noinline))
+
+// ---- optional phase profile (make prof): lap timer, lane 0 attributes the cycles since the previous PT() to bucket k ----
+#ifdef TSX_PROF2
+// light-weight lap timers for the parser: scalar accumulators, no LDS traffic, no forced drains
+#define LT_DECL unsigned long long lt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long lt_last_ = (unsigned long long)clock64();
+#define LT(k) do { const unsigned long long n_ = (unsigned long long)clock64(); lt_[k] += n_ - lt_last_; lt_last_ = n_; } while (0)
+#define LT_USE(v) do { asm volatile("" :: "s"(__builtin_amdgcn_readfirstlane((uint32_t)(v))) : "memory"); } while (0)
+#define LT_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) g_prof[i_] += lt_[i_]; } while (0)
+#else
+#define LT_DECL
+#define LT(k) do {} while (0)
+#define LT_USE(v) do {} while (0)
+#define LT_FLUSH() do {} while (0)
+#endif
+#ifdef TSX_PROF
+__shared__ unsigned long long g_prof[24];
+#ifdef TSX_PROF2
+#define PT(k) do {} while (0)
+#define PCNT(k, v) do {} while (0)
+#define PTW(k) do {} while (0)
+#else
+#define PT(k) do { const unsigned long long now_ = (unsigned long long)clock64(); if (threadIdx.x == 0) { g_prof[k] += now_ - g_prof[23]; g_prof[23] = now_; } } while (0)
+#define PCNT(k, v) do { if (threadIdx.x == 0) g_prof[k] += (v); } while (0)
+#define PTW(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PT(k); } while (0)   /* drain, then lap: stage latency */
+#endif
+static unsigned long long* g_prof_out = nullptr;                      // device buffer: 24 u64 per chunk
+extern "C" void tsx_debug_set_prof(void* dev_ptr) { g_prof_out = (unsigned long long*)dev_ptr; }
+#else
+#define PT(k) do {} while (0)
+#define PCNT(k, v) do {} while (0)
+#define PTW(k) do {} while (0)
+#endif
 
 // ---- format tables ------------------------------------------------------------------------------------
 __device__ static const uint8_t kLLbits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
@@ -45,6 +82,7 @@ __device__ static const uint32_t kRtb[8] = {0, 473195, 504333, 520860, 550000, 7
 __device__ static inline uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
 __device__ static inline uint64_t ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ static inline uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ static inline uint4 ld128(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ static inline uint32_t LLcode(uint32_t ll) { return ll > 63 ? hb32(ll) + 19 : kLLcode[ll]; }
 __device__ static inline uint32_t MLcode(uint32_t ml) { return ml > 127 ? hb32(ml) + 36 : kMLcode[ml]; }
 
@@ -54,37 +92,137 @@ __device__ static inline uint32_t hashS(uint64_t u, uint32_t h, uint32_t mls) {
     return ((uint32_t)u * 2654435761U) >> (32 - h);                       // mls == 4
 }
 
+// ---- tagged table entries ------------------------------------------------------------------------------------
+// libzstd's tables hold indices only, so every probe costs a read of the candidate's bytes - here a random HBM line per
+// probe, nearly all of them for candidates that do not match.  The tables are private to the kernel, so an entry also
+// carries, in the bits above the index, a tag hashed from exactly the bytes the serial code compares (8 for the long
+// table, 4 for the short one): equal bytes imply equal tags, so a probe whose tag differs is rejected without touching
+// the candidate and the parse is unchanged.  idxBits = bits of (chunk size + 2); 9 tag bits for a 4 MiB chunk.
+__device__ static inline uint32_t tag8(uint64_t u, uint32_t hBitsL, uint32_t tagBits) {       // bits right below the long index
+    return tagBits ? (uint32_t)(((u * 0xCF1BBCDCB7A56463ULL) << hBitsL) >> (64 - tagBits)) : 0u;
+}
+__device__ static inline uint32_t tag4(uint32_t u, uint32_t tagBits) { return tagBits ? (u * 0x85EBCA6Bu) >> (32 - tagBits) : 0u; }
+
 // ---- LDS state of one chunk (one wave per workgroup) --------------------------------------------------------
 struct HufTable { uint16_t val[256]; uint8_t nb[256]; uint32_t tableLog, maxSym; };
 struct FseTable { uint16_t state[512]; uint32_t dnb[56]; int32_t dfs[56]; uint32_t tableLog; };
 struct NodeElt { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; };
+
 struct EncLds {
     HufTable huf[2];            // [cur] = table of the previous compressed-literals block, [cur ^ 1] = candidate
     int hufRepeat[2];           // 0 none, 1 check
-    FseTable ll, of, ml;
-    uint32_t hist[256];
-    uint32_t hist2[256];        // second histogram (pre-splitter / sampling)
-    uint32_t cnt[64];           // sequence-code histograms
-    NodeElt nodes[514];
-    uint16_t rankBase[192], rankCurr[192];
-    uint8_t tableSymbol[512];
-    uint32_t cumul[64];
-    short norm[64];
-    uint8_t weights[256];
     uint32_t scal[16];          // lane-0 -> wave broadcast slots
+    union alignas(16) {
+        struct {                // entropy stage of a block
+            FseTable ll, of, ml;
+            uint32_t hist[256];
+            uint32_t hist2[256];        // second histogram (pre-splitter / sampling)
+            uint32_t cnt[64];           // sequence-code histograms
+            NodeElt nodes[514];
+            uint16_t rankBase[192], rankCurr[192];
+            uint8_t tableSymbol[512];
+            uint32_t cumul[64];
+            short norm[64];
+            uint8_t weights[256];
+        };
+        struct {                // parse stage of a block (re-primed per block): source window + collision scoreboard
+            uint32_t ring[ZS_RING / 4 + 4];     // + 16-byte mirror of the first bytes
+            uint8_t scr[2 * ZS_SCR];
+            alignas(16) uint8_t fwbuf[96];      // two far windows of 48 bytes (winner, long candidate at +1)
+        } p;
+    };
 };
 
 // ---------------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------------
+// Cross-lane memory hand-off inside ONE wave (lane A's store observed by lane B's later load).  The hardware issues a
+// wave's vector-memory / LDS instructions in order and keeps same-address order, so nothing is needed there; the fiber
+// emulator (tests/emu) does not run lanes in lockstep and needs a rendezvous.
+#ifdef HIPEMU
+#define WAVE_MEM_SYNC() __threadfence_block()
+#define VM_DRAIN() do {} while (0)
+#define LOADED64(x) do {} while (0)
+#else
+#define WAVE_MEM_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)   /* compiler-level only */
+#define VM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// "this value is consumed here": pins the wait for a global load inside the branch that issued it, so that the join with
+// an LDS-sourced alternative does not inherit a vmcnt(0) (which would also drain every store still in flight).
+#define LOADED64(x) do { uint32_t lo_ = (uint32_t)(x), hi_ = (uint32_t)((x) >> 32); asm volatile("" : "+v"(lo_), "+v"(hi_)); (x) = ((uint64_t)hi_ << 32) | lo_; } while (0)
+#endif
+
+// ---- the source window ------------------------------------------------------------------------------------
+// Under 8 resident waves per CU every dependent global round trip costs a wave 800-2000 cycles (tools/ubench/lat.hip),
+// and the serial parse needs the bytes around ip at every step: position hashing, repcode checks, match extension,
+// complementary insertions.  So the parser keeps chunk bytes [lo, hi) (the last ~4 KiB and the next ~4 KiB) in an LDS
+// ring, refilled 4 KiB at a time with coalesced 16-byte loads; only the hash tables and candidates older than the ring
+// are read from global memory.  The ring aliases the entropy stage's scratch (EncLds) and is re-primed per block.
+struct Win { uint32_t lo, hi; };      // wave-uniform
+
+// The ring is ZS_RING bytes plus a 16-byte mirror of its first bytes, so an unaligned 8-byte read never has to wrap
+// (gfx950 LDS reads need no alignment: one ds_read_b64 / ds_read_b32 each).
+__device__ static inline uint64_t ring8(const uint32_t* ring, uint32_t p) {
+    uint64_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(ring) + (p & (ZS_RING - 1)), 8); return v;
+}
+__device__ static inline uint32_t ring4(const uint32_t* ring, uint32_t p) {
+    uint32_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(ring) + (p & (ZS_RING - 1)), 4); return v;
+}
+__device__ static inline uint32_t ring1(const uint32_t* ring, uint32_t p) { return reinterpret_cast<const uint8_t*>(ring)[p & (ZS_RING - 1)]; }
+
+// Append chunk bytes [w.hi, w.hi + ZS_FILL) to the ring (16-byte pieces; pieces that start beyond the chunk are skipped
+// by re-reading the last valid piece, so nothing outside the caller's buffer granule is touched).
+__device__ __forceinline__ static void win_append(const uint8_t* __restrict__ src, uint32_t lastPiece, uint32_t* ring, Win& w, uint32_t lane) {
+    uint4 v[ZS_FILL / 1024];
+    WAVE_MEM_SYNC();                                                  // (emulator) no lane may still be reading the slots replaced here
+#pragma unroll
+    for (uint32_t k = 0; k < ZS_FILL / 1024; k++) {
+        uint32_t pp = w.hi + k * 1024 + lane * 16;
+        if (pp > lastPiece) pp = lastPiece;
+        v[k] = *reinterpret_cast<const uint4*>(src + pp);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < ZS_FILL / 1024; k++)
+        *reinterpret_cast<uint4*>(&ring[((w.hi + k * 1024 + lane * 16) >> 2) & ZS_RWM]) = v[k];
+    if ((w.hi & (ZS_RING - 1)) == 0 && lane == 0) *reinterpret_cast<uint4*>(&ring[ZS_RING / 4]) = v[0];    // the mirror
+    w.hi += ZS_FILL;
+    if (w.hi - w.lo > ZS_RING) w.lo = w.hi - ZS_RING;
+    WAVE_MEM_SYNC();
+}
+// make [ip, ip + ZS_SAFE) resident (or everything up to the end of the chunk)
+__device__ __forceinline__ static void win_ensure(const uint8_t* __restrict__ src, uint32_t srcCeil, uint32_t lastPiece, uint32_t* ring, Win& w,
+                                                  uint32_t ip, uint32_t lane) {
+    if (ip < w.lo || ip > w.hi + ZS_RING / 2) {                      // far jump: restart the ring behind ip
+        WAVE_MEM_SYNC();
+        const uint32_t base = ip > ZS_FILL ? (ip - ZS_FILL) & ~(ZS_FILL - 1) : 0;
+        w.lo = w.hi = base;
+    }
+    while (ip + ZS_SAFE > w.hi && w.hi < srcCeil) win_append(src, lastPiece, ring, w, lane);
+}
+
+// A match candidate older than the ring costs one global round trip to verify; its extension (forward and backward) would
+// cost two more.  So a lane probing such a candidate loads 48 bytes around it at once ([p - 16, p + 32)); the winner parks
+// them in a small LDS "far window" and the extension compares ring bytes against it.
+struct FarWin { uint32_t lo, hi; const uint8_t* buf; };   // chunk bytes [lo, hi) at buf[0 ..); lo == hi: none (wave-uniform)
+__device__ static inline uint64_t far8(const FarWin fw, uint32_t p) { uint64_t v; __builtin_memcpy(&v, fw.buf + (p - fw.lo), 8); return v; }
+
 // number of equal bytes of src[a..] and src[b..] (b < a), not reading a-side bytes at or beyond iend
-__device__ static uint32_t wave_count(const uint8_t* __restrict__ src, uint32_t a, uint32_t b, uint32_t iend, uint32_t lane) {
+__device__ static uint32_t wave_count(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, const FarWin fw, uint32_t a, uint32_t b,
+                                      uint32_t iend, uint32_t lane) {
     uint32_t total = 0, width = 8;
+    if (b >= fw.lo && b + 8 <= fw.hi) width = (fw.hi - b) >> 3;      // first pass: what the far window holds
     for (;;) {
         const uint32_t off = total + 8 * lane;
         const bool active = lane < width;
         uint32_t n = 8;
-        if (active) {
+        if (a + total + 8 * width <= iend) {                         // every active lane compares 8 whole bytes
+            uint64_t x = 0;
+            const bool aRing = a + total >= w.lo && a + total + 8 * width <= w.hi;
+            const uint32_t o = active ? off : total;
+            if (aRing && b + total >= w.lo) x = ring8(ring, a + o) ^ ring8(ring, b + o);
+            else if (aRing && b + total >= fw.lo && b + total + 8 * width <= fw.hi) x = ring8(ring, a + o) ^ far8(fw, b + o);
+            else { PCNT(21, 1); if (active) x = ld64(src + a + off) ^ ld64(src + b + off); }
+            if (active) n = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
+        } else if (active) {
             const uint32_t avail = (a + off < iend) ? iend - (a + off) : 0;
             if (avail >= 8) {
                 uint64_t x = ld64(src + a + off) ^ ld64(src + b + off);
@@ -105,38 +243,57 @@ __device__ static uint32_t wave_count(const uint8_t* __restrict__ src, uint32_t 
 }
 
 // backward extension: while (ip > anchor && match > low && src[ip-1] == src[match-1])
-__device__ static uint32_t wave_count_back(const uint8_t* __restrict__ src, uint32_t ip, uint32_t match, uint32_t anchor, uint32_t low, uint32_t lane) {
+__device__ static uint32_t wave_count_back(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, const FarWin fw, uint32_t ip, uint32_t match,
+                                           uint32_t anchor, uint32_t low, uint32_t lane) {
     uint32_t lim = ip - anchor;
     if (match - low < lim) lim = match - low;
-    uint32_t done = 0;
+    if (lim == 0) return 0;
+    uint32_t done = 0, width = LANES;
+    if (match > fw.lo && match <= fw.hi) width = match - fw.lo;      // first pass: the bytes the far window holds below the match
     for (;;) {
         const uint32_t i = done + lane;
-        const bool ok = i < lim && src[ip - 1 - i] == src[match - 1 - i];
-        const unsigned long long m = __ballot(!ok);
+        const bool active = lane < width;
+        bool ok = i < lim;
+        const uint32_t j = (ok && active) ? i : done;
+        const bool aRing = ip <= w.hi && ip - done >= w.lo + width;
+        if (aRing && match - done >= w.lo + width) ok = ok && ring1(ring, ip - 1 - j) == ring1(ring, match - 1 - j);
+        else if (aRing && match - done <= fw.hi && match - done >= fw.lo + width) ok = ok && ring1(ring, ip - 1 - j) == fw.buf[match - 1 - j - fw.lo];
+        else if (active) ok = ok && src[ip - 1 - i] == src[match - 1 - i];
+        const unsigned long long m = __ballot(active && !ok);
         if (m) return done + (uint32_t)(__ffsll((long long)m) - 1);
-        done += LANES;
+        done += width;
+        width = LANES;
     }
 }
 
-struct MfState { uint32_t nbSeq, litSize; };
+struct MfState { uint32_t nbSeq, litSize, lastLL, anchor; };
 
-__device__ static inline void store_seq(zs_seq* __restrict__ seqs, uint8_t* __restrict__ lit, const uint8_t* __restrict__ src, MfState& s,
-                                        uint32_t litLen, uint32_t litPos, uint32_t offBase, uint32_t mlen, uint32_t lane) {
-    for (uint32_t i = lane; i < litLen; i += LANES) lit[s.litSize + i] = src[litPos + i];
-    if (lane == 0) { zs_seq q; q.offBase = offBase; q.litLength = litLen; q.mlBase = mlen - 3; q.pad = 0; seqs[s.nbSeq] = q; }
+// The parser keeps the literals where they are: a sequence records where its literal run starts in the chunk and the
+// entropy stage gathers them with all lanes (gather_literals) instead of copying on the serial critical path.
+__device__ static inline void store_seq(zs_seq* __restrict__ seqs, MfState& s, uint32_t litLen, uint32_t litPos, uint32_t offBase,
+                                        uint32_t mlen, uint32_t lane) {
+    if (lane == 0) { zs_seq q; q.offBase = offBase; q.litLength = litLen; q.mlBase = mlen - 3; q.litPos = litPos; seqs[s.nbSeq] = q; }
     s.litSize += litLen; s.nbSeq++;
 }
+
+#ifndef ZS_W0
+#define ZS_W0 8u              /* first speculation width of a search run */
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // double-fast match finder for one block (ZSTD_compressBlock_doubleFast_noDict_generic, speculative form)
 // all "positions" are offsets within the chunk; table values are libzstd's indices = position + 2.
-// returns the size of the last literal run; rep[] updated as the serial code does.
+// rep[] updated as the serial code does.  Everything that is the same for all lanes (ip, anchor, offsets, step...) is
+// derived from ballots / readlanes so it lives in SGPRs and the control flow is scalar.
 // ---------------------------------------------------------------------------------------------------
-__device__ ZS_NOINLINE static uint32_t match_block(const uint8_t* __restrict__ src, uint32_t blockStart, uint32_t blockSize, uint32_t* __restrict__ hashLong,
-                                       uint32_t* __restrict__ hashSmall, const zs_cparams cp, uint32_t plowIdx, uint32_t* rep,
-                                       zs_seq* __restrict__ seqs, uint8_t* __restrict__ lit, MfState& ms, uint32_t lane) {
+__device__ __forceinline__ static void match_block(const uint8_t* __restrict__ src, const uint32_t srcSize, const uint32_t blockStart,
+                                                   const uint32_t blockSize, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
+                                                   const zs_cparams cp, const uint32_t plowIdx, uint32_t* rep, zs_seq* __restrict__ seqs,
+                                                   MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane) {
     const uint32_t iend = blockStart + blockSize;
     const uint32_t hBitsL = cp.hashLog, hBitsS = cp.chainLog, mls = cp.minMatch;
+    const uint32_t srcCeil = (srcSize + ZS_FILL - 1) & ~(ZS_FILL - 1), lastPiece = (srcSize - 1) & ~15u;
+    const uint32_t idxBits = 32u - (uint32_t)__clz((int)(srcSize + 2)), tagBits = 32u - idxBits, idxMask = (uint32_t)((1ull << idxBits) - 1);
     uint32_t ip = blockStart, anchor = blockStart;
     uint32_t off1 = rep[0], off2 = rep[1], sav1 = 0, sav2 = 0;
     ms.nbSeq = 0; ms.litSize = 0;
@@ -145,48 +302,147 @@ __device__ ZS_NOINLINE static uint32_t match_block(const uint8_t* __restrict__ s
         if (off2 > maxRep) { sav2 = off2; off2 = 0; }
         if (off1 > maxRep) { sav1 = off1; off1 = 0; }
     }
+    Win w; w.lo = w.hi = 0;                                           // empty: the first win_ensure primes the ring
+    FarWin FW0; FW0.lo = FW0.hi = 0; FW0.buf = fwbuf;                 // "no far window"
+    LT_DECL
     if (blockSize >= 8) {
         const uint32_t ilimit = iend - 8;
-        bool dirty = true;
-        bool done = false;
-        while (!done) {                                               // one iteration per stored match
+        // The serial code checks an "immediate repcode" (offset_2 at the new ip) right after every stored match.  Its far
+        // read src[ip - off2] rides with the table loads of the next search step instead of costing a round trip of its own.
+        bool afterMatch = false;
+        for (;;) {                                                    // one iteration per stored match
             uint32_t step = 1, nextStep = ip + 256;
-            if (ip + step > ilimit) break;
-            uint32_t width = 16;
+            if (ip + step > ilimit) {
+                if (afterMatch && ip <= ilimit) {                     // ip == ilimit: no search step left, only the repcode check
+                    if (ip + ZS_SAFE > w.hi || ip < w.lo) win_ensure(src, srcCeil, lastPiece, ring, w, ip, lane);
+                    const uint64_t dr = ring8(ring, ip);
+                    if ((uint32_t)dr == ld32(src + ip - off2)) {
+                        const uint32_t rlen = 4 + wave_count(src, ring, w, FW0, ip + 4, ip + 4 - off2, iend, lane);
+                        const uint32_t t = off2; off2 = off1; off1 = t;
+                        store_seq(seqs, ms, 0, ip, 1, rlen, lane);    // (its table insertions can no longer be probed in this block... but later blocks can)
+                        if (lane == 0) {
+                            hashSmall[hashS(dr, hBitsS, mls)] = ((tag4((uint32_t)dr, tagBits) << 1) << (idxBits - 1)) | (ip + 2);
+                            hashLong[hash8(dr, hBitsL)] = ((tag8(dr, hBitsL, tagBits) << 1) << (idxBits - 1)) | (ip + 2);
+                        }
+                        ip += rlen; anchor = ip;
+                        PCNT(13, 1);
+                    }
+                }
+                break;
+            }
+            uint32_t width = ZS_W0;
+            bool done = false;
             for (;;) {                                                // one iteration per speculative wave step
                 // K search positions ip + k*step (k < K) evaluated at once; lane K only provides the look-ahead
-                uint32_t K1 = 1;
-                if (nextStep > ip + step) K1 = (nextStep - ip - 1) / step + 1;      // first k with ip+(k+1)*step >= nextStep, plus one
-                uint32_t K = (ilimit - step - ip) / step + 1;
-                if (K1 < K) K = K1;
+                uint32_t K;
+                if (step == 1) {
+                    K = ilimit - ip;                                  // positions p with p + 1 <= ilimit
+                    const uint32_t K1 = nextStep > ip + 1 ? nextStep - ip : 1;
+                    if (K1 < K) K = K1;
+                } else {
+                    uint32_t K1 = 1;
+                    if (nextStep > ip + step) K1 = (nextStep - ip - 1) / step + 1;
+                    K = (ilimit - step - ip) / step + 1;
+                    if (K1 < K) K = K1;
+                }
                 if (width < K) K = width;
+                LT(0);                                                // 0: everything between steps (post-match work, loop control)
+                if (ip + ZS_SAFE > w.hi || ip < w.lo) win_ensure(src, srcCeil, lastPiece, ring, w, ip, lane);
                 const bool inRange = lane <= K;
                 const bool searching = lane < K;
                 const uint32_t pos = ip + lane * step;
-                const uint64_t d8 = inRange ? ld64(src + pos) : 0;
+                const uint32_t spos = inRange ? pos : ip;            // an address every lane may read
+                const bool posWin = ip + K * step + 8 <= w.hi;        // all position reads hit the ring (ip >= w.lo holds)
+                uint64_t d8;
+                if (posWin) d8 = ring8(ring, spos); else { d8 = ld64(src + spos); LOADED64(d8); }
+                PTW(16);
+                LT_USE(d8); LT(1);                                    // 1: window upkeep + position bytes
                 const uint32_t hl = hash8(d8, hBitsL), hs = hashS(d8, hBitsS, mls);
-                if (dirty) { __threadfence_block(); dirty = false; }
-                uint32_t cL = inRange ? hashLong[hl] : 0;
-                uint32_t cS = searching ? hashSmall[hs] : 0;
-                uint32_t nextL = LANES, nextS = LANES;               // first later searching lane with my hash
-                for (uint32_t i = 0; i < K; i++) {
-                    const uint32_t hli = __builtin_amdgcn_readlane(hl, i), hsi = __builtin_amdgcn_readlane(hs, i);
-                    const uint32_t idxi = ip + i * step + 2;
-                    if (hl == hli) { if (lane > i) cL = idxi; else if (lane < i && nextL == LANES) nextL = i; }
-                    if (hs == hsi) { if (lane > i) cS = idxi; else if (lane < i && nextS == LANES) nextS = i; }
+                const uint32_t tL = tag8(d8, hBitsL, tagBits), tS = tag4((uint32_t)d8, tagBits);
+                const uint32_t eL = ((tL << 1) << (idxBits - 1)) | (pos + 2), eS = ((tS << 1) << (idxBits - 1)) | (pos + 2);   // what this position inserts
+                WAVE_MEM_SYNC();
+                uint32_t cL = hashLong[hl];                          // lanes beyond the step read (harmlessly) too: no branches
+                uint32_t cS = hashSmall[hs];
+                uint32_t r1;                                          // bytes at pos + 1 - off1 (repcode check)
+                {   const uint32_t ra = off1 > 0 ? spos + 1 - off1 : spos;
+                    if (posWin && ip + 1 >= w.lo + off1) r1 = ring4(ring, ra); else r1 = ld32(src + ra);
                 }
-                const bool longOK = inRange && cL > plowIdx && ld64(src + cL - 2) == d8;
-                const bool shortOK = searching && cS > plowIdx && ld32(src + cS - 2) == (uint32_t)d8;
-                const bool repOK = searching && off1 > 0 && ld32(src + pos + 1 - off1) == (uint32_t)(d8 >> 8);
+                if (afterMatch) {                                     // immediate repcode at ip (lane 0's position), wave-uniform
+                    afterMatch = false;
+                    const uint32_t r2 = (posWin && ip >= w.lo + off2) ? ring4(ring, ip - off2) : ld32(src + ip - off2);
+                    const uint32_t d0 = __builtin_amdgcn_readfirstlane((uint32_t)d8);
+                    if (__builtin_amdgcn_readfirstlane(r2) == d0) {
+                        const uint32_t rlen = 4 + wave_count(src, ring, w, FW0, ip + 4, ip + 4 - off2, iend, lane);
+                        const uint32_t t = off2; off2 = off1; off1 = t;
+                        if (lane == 0) { hashSmall[hs] = eS; hashLong[hl] = eL; }
+                        store_seq(seqs, ms, 0, ip, 1, rlen, lane);
+                        ip += rlen; anchor = ip;
+                        PCNT(13, 1);
+                        afterMatch = ip <= ilimit && off2 > 0;
+                        break;                                        // restart the search at the new ip (step = 1)
+                    }
+                }
+                uint32_t nextL = LANES, nextS = LANES;               // first later searching lane with my hash
+                PTW(17);
+                LT_USE(cL); LT_USE(cS); LT_USE(r1); LT(2);            // 2: hashing + table round trip (+ immediate repcode)
+                {   // Two lanes of one step with the same hash see each other's insertions.  Detect (conservatively) through
+                    // an LDS scoreboard: every lane posts its id under its hash, a lane that reads back another id collides.
+                    const uint32_t sl = hl & (ZS_SCR - 1), ss = ZS_SCR + (hs & (ZS_SCR - 1));
+                    if (inRange) scr[sl] = (uint8_t)lane;
+                    if (searching) scr[ss] = (uint8_t)lane;
+                    WAVE_MEM_SYNC();
+                    const bool coll = (inRange && scr[sl] != (uint8_t)lane) || (searching && scr[ss] != (uint8_t)lane);
+                    if (__any(coll)) {
+                        PCNT(19, 1);
+                        for (uint32_t i = 0; i < K; i++) {
+                            const uint32_t hli = __builtin_amdgcn_readlane(hl, i), hsi = __builtin_amdgcn_readlane(hs, i);
+                            const uint32_t eLi = __builtin_amdgcn_readlane(eL, i), eSi = __builtin_amdgcn_readlane(eS, i);
+                            if (hl == hli) { if (lane > i) cL = eLi; else if (lane < i && nextL == LANES) nextL = i; }
+                            if (hs == hsi) { if (lane > i) cS = eSi; else if (lane < i && nextS == LANES) nextS = i; }
+                        }
+                    }
+                }
+                PTW(18);
+                LT(3);                                                // 3: collision scoreboard
+                // candidates: from the ring when recent enough, else one global load each - all issued before any is used
+                const uint32_t iL = cL & idxMask, iS = cS & idxMask;
+                const bool vL = inRange && iL > plowIdx && ((cL ^ eL) & ~idxMask) == 0;      // in the window and same tag
+                const bool vS = searching && iS > plowIdx && ((cS ^ eS) & ~idxMask) == 0;
+                const uint32_t pL = vL ? iL - 2 : w.lo, pS = vS ? iS - 2 : w.lo;
+                const bool nL = pL >= w.lo && pL + 8 <= w.hi, nS = pS >= w.lo && pS + 4 <= w.hi;
+                // far candidates: 48 bytes around each in one go (verification + both extensions); the rare ones too close to the
+                // chunk's ends for that read just their 8 / 4 bytes
+                const bool wL = vL && !nL && pL >= 16 && pL + 32 <= srcSize, wS = vS && !nS && pS >= 16 && pS + 32 <= srcSize;
+                uint64_t gL = 0, kL = 0; uint32_t gS = 0, kS = 0;
+                uint4 L0, L1, L2, S0, S1, S2;
+                L0 = L1 = L2 = S0 = S1 = S2 = make_uint4(0, 0, 0, 0);
+                if (__any(wL || wS)) {                                // all six loads go out back to back (lanes without one re-read byte 0)
+                    const uint8_t* qL = src + (wL ? pL - 16 : 0); const uint8_t* qS = src + (wS ? pS - 16 : 0);
+                    L0 = ld128(qL); L1 = ld128(qL + 16); L2 = ld128(qL + 32);
+                    S0 = ld128(qS); S1 = ld128(qS + 16); S2 = ld128(qS + 32);
+                    PCNT(20, 1);
+                }
+                if (__any((vL && !nL && !wL) || (vS && !nS && !wS))) {
+                    gL = ld64(src + ((nL || wL) ? ip : pL));
+                    gS = ld32(src + ((nS || wS) ? ip : pS));
+                }
+                if (__any(vL && nL)) kL = ring8(ring, nL ? pL : w.lo);               // most steps have no live candidate of a kind:
+                if (__any(vS && nS)) kS = ring4(ring, nS ? pS : w.lo);               // skip the reads wave-uniformly
+                const uint64_t fL = wL ? (((uint64_t)L1.y << 32) | L1.x) : gL;
+                const uint32_t fS = wS ? S1.x : gS;
+                const bool longOK = vL && (nL ? kL : fL) == d8;
+                const bool shortOK = vS && (nS ? kS : fS) == (uint32_t)d8;
+                const bool repOK = searching && off1 > 0 && r1 == (uint32_t)(d8 >> 8);
                 const uint32_t ev = !searching ? 0u : repOK ? 1u : longOK ? 2u : shortOK ? 3u : 0u;
                 const unsigned long long bm = __ballot(ev != 0);
                 const int f = bm ? __ffsll((long long)bm) - 1 : -1;
+                PT(2); PCNT(12, 1); PCNT(15, K);
+                LT(4);                                                // 4: candidate fetch + verdict
                 const uint32_t lastIns = f >= 0 ? (uint32_t)f : K - 1;
                 if (lane <= lastIns) {                                // the visited positions insert themselves
-                    if (nextL > lastIns) hashLong[hl] = pos + 2;
-                    if (nextS > lastIns) hashSmall[hs] = pos + 2;
+                    if (nextL > lastIns) hashLong[hl] = eL;
+                    if (nextS > lastIns) hashSmall[hs] = eS;
                 }
-                dirty = true;
                 if (f < 0) {
                     const bool inc = ip + K * step >= nextStep;
                     ip += K * step;
@@ -198,64 +454,97 @@ __device__ ZS_NOINLINE static uint32_t match_block(const uint8_t* __restrict__ s
                 const uint32_t evf = __builtin_amdgcn_readlane(ev, f);
                 const uint32_t posf = ip + (uint32_t)f * step;
                 uint32_t start, mlen;
+                FarWin FW; FW.lo = FW.hi = 0; FW.buf = fwbuf;
+                FarWin FW1; FW1.lo = FW1.hi = 0; FW1.buf = fwbuf + 48;
                 if (evf == 1) {                                       // repcode at posf + 1
                     start = posf + 1;
-                    mlen = 4 + wave_count(src, start + 4, start + 4 - off1, iend, lane);
-                    store_seq(seqs, lit, src, ms, start - anchor, anchor, 1, mlen, lane);
+                    mlen = 4 + wave_count(src, ring, w, FW, start + 4, start + 4 - off1, iend, lane);
+                    store_seq(seqs, ms, start - anchor, anchor, 1, mlen, lane);
                 } else {
                     uint32_t mpos;
                     if (evf == 2) {                                   // long match at posf
-                        start = posf; mpos = __builtin_amdgcn_readlane(cL, f) - 2;
-                        mlen = 8 + wave_count(src, start + 8, mpos + 8, iend, lane);
+                        start = posf; mpos = __builtin_amdgcn_readlane(iL, f) - 2;
+                        if (__builtin_amdgcn_readlane((uint32_t)wL, f)) {
+                            if (lane == (uint32_t)f) { uint4* o = reinterpret_cast<uint4*>(fwbuf); o[0] = L0; o[1] = L1; o[2] = L2; }
+                            WAVE_MEM_SYNC();
+                            FW.lo = mpos - 16; FW.hi = mpos + 32;
+                        }
+                        mlen = 8 + wave_count(src, ring, w, FW, start + 8, mpos + 8, iend, lane);
                     } else {                                          // short match; a strictly longer long match at +1 wins
-                        start = posf; mpos = __builtin_amdgcn_readlane(cS, f) - 2;
-                        mlen = 4 + wave_count(src, start + 4, mpos + 4, iend, lane);
-                        if (__builtin_amdgcn_readlane((uint32_t)longOK, f + 1)) {
-                            const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(cL, f + 1) - 2;
-                            const uint32_t l1 = 8 + wave_count(src, p1 + 8, m1 + 8, iend, lane);
-                            if (l1 > mlen) { start = p1; mpos = m1; mlen = l1; }
+                        start = posf; mpos = __builtin_amdgcn_readlane(iS, f) - 2;
+                        const bool long1 = __builtin_amdgcn_readlane((uint32_t)longOK, f + 1) != 0;
+                        const bool far0 = __builtin_amdgcn_readlane((uint32_t)wS, f) != 0;
+                        const bool far1 = long1 && __builtin_amdgcn_readlane((uint32_t)wL, f + 1) != 0;
+                        if (far0 || far1) {
+                            if (far0 && lane == (uint32_t)f) { uint4* o = reinterpret_cast<uint4*>(fwbuf); o[0] = S0; o[1] = S1; o[2] = S2; }
+                            if (far1 && lane == (uint32_t)f + 1) { uint4* o = reinterpret_cast<uint4*>(fwbuf + 48); o[0] = L0; o[1] = L1; o[2] = L2; }
+                            WAVE_MEM_SYNC();
+                            if (far0) { FW.lo = mpos - 16; FW.hi = mpos + 32; }
+                        }
+                        mlen = 4 + wave_count(src, ring, w, FW, start + 4, mpos + 4, iend, lane);
+                        if (long1) {
+                            const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(iL, f + 1) - 2;
+                            if (far1) { FW1.lo = m1 - 16; FW1.hi = m1 + 32; }
+                            const uint32_t l1 = 8 + wave_count(src, ring, w, FW1, p1 + 8, m1 + 8, iend, lane);
+                            if (l1 > mlen) { start = p1; mpos = m1; mlen = l1; FW = FW1; }
                         }
                     }
-                    const uint32_t back = wave_count_back(src, start, mpos, anchor, plowIdx - 2, lane);
+                    const uint32_t back = wave_count_back(src, ring, w, FW, start, mpos, anchor, plowIdx - 2, lane);
                     start -= back; mpos -= back; mlen += back;
                     off2 = off1; off1 = start - mpos;
-                    if (step < 4 && lane == (uint32_t)f + 1) hashLong[hl] = pos + 2;     // hashLong[hl1] = ip1
-                    store_seq(seqs, lit, src, ms, start - anchor, anchor, off1 + 3, mlen, lane);
+                    if (step < 4 && lane == (uint32_t)f + 1) hashLong[hl] = eL;          // hashLong[hl1] = ip1
+                    store_seq(seqs, ms, start - anchor, anchor, off1 + 3, mlen, lane);
                 }
                 ip = start + mlen; anchor = ip;
+                PT(3); PCNT(13, 1);
+                LT_USE(ip); LT(5);                                    // 5: inserts + extension + sequence store
                 if (ip <= ilimit) {
+                    if (ip + ZS_SAFE > w.hi || ip < w.lo) win_ensure(src, srcCeil, lastPiece, ring, w, ip, lane);
                     {   // complementary insertion: long[curr+2], long[ip-2], small[curr+2], small[ip-1] (in that order)
                         const uint32_t p = lane == 0 || lane == 2 ? posf + 2 : lane == 1 ? ip - 2 : ip - 1;
-                        const uint64_t d = lane < 4 ? ld64(src + p) : 0;
+                        const uint32_t sp = lane < 4 ? p : ip;
+                        const uint64_t d = posf + 2 >= w.lo ? ring8(ring, sp) : ld64(src + sp);
                         const uint32_t h = lane < 2 ? hash8(d, hBitsL) : hashS(d, hBitsS, mls);
+                        const uint32_t t = lane < 2 ? tag8(d, hBitsL, tagBits) : tag4((uint32_t)d, tagBits);
+                        const uint32_t e = ((t << 1) << (idxBits - 1)) | (p + 2);
                         const uint32_t hn = __shfl(h, lane + 1);
                         const bool shadowed = (lane == 0 || lane == 2) && hn == h;      // the later write of the pair wins
-                        if (lane < 2 && !shadowed) hashLong[h] = p + 2;
-                        if ((lane == 2 || lane == 3) && !shadowed) hashSmall[h] = p + 2;
+                        if (lane < 2 && !shadowed) hashLong[h] = e;
+                        if ((lane == 2 || lane == 3) && !shadowed) hashSmall[h] = e;
                     }
-                    while (ip <= ilimit && off2 > 0 && ld32(src + ip) == ld32(src + ip - off2)) {   // immediate repcode
-                        const uint32_t rlen = 4 + wave_count(src, ip + 4, ip + 4 - off2, iend, lane);
-                        const uint32_t t = off2; off2 = off1; off1 = t;
-                        if (lane == 0) {
-                            const uint64_t d = ld64(src + ip);
-                            hashSmall[hashS(d, hBitsS, mls)] = ip + 2;
-                            hashLong[hash8(d, hBitsL)] = ip + 2;
-                        }
-                        store_seq(seqs, lit, src, ms, 0, ip, 1, rlen, lane);
-                        ip += rlen; anchor = ip;
-                    }
+                    afterMatch = off2 > 0;
                 }
+                PT(4);
                 break;
             }
+            if (done) break;
         }
     }
     sav2 = (sav1 != 0 && off1 != 0) ? sav1 : sav2;
     rep[0] = off1 ? off1 : sav1;
     rep[1] = off2 ? off2 : sav2;
-    const uint32_t lastLL = iend - anchor;
-    for (uint32_t i = lane; i < lastLL; i += LANES) lit[ms.litSize + i] = src[anchor + i];
-    ms.litSize += lastLL;
-    return lastLL;
+    ms.lastLL = iend - anchor; ms.anchor = anchor;
+    ms.litSize += ms.lastLL;
+    PT(4);
+    LT(0); LT_FLUSH();
+}
+
+// Literals of a parsed block, gathered by all lanes: sequence u's run is src[litPos, litPos + litLength) and lands at the
+// running sum of the earlier runs; the tail after the last match follows.
+__device__ ZS_NOINLINE static void gather_literals(uint8_t* __restrict__ lit, const uint8_t* __restrict__ src, const zs_seq* __restrict__ seqs,
+                                                   uint32_t nbSeq, uint32_t tailPos, uint32_t tailLen, uint32_t lane) {
+    uint32_t base = 0;
+    for (uint32_t g = 0; g < nbSeq; g += LANES) {
+        const uint32_t u = g + lane;
+        uint32_t ll = 0, lp = 0;
+        if (u < nbSeq) { const zs_seq q = seqs[u]; ll = q.litLength; lp = q.litPos; }
+        uint32_t incl = ll;
+        for (int o = 1; o < LANES; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
+        const uint32_t dst = base + incl - ll;
+        for (uint32_t i = 0; i < ll; i++) lit[dst + i] = src[lp + i];
+        base += __shfl(incl, LANES - 1);
+    }
+    for (uint32_t i = lane; i < tailLen; i += LANES) lit[base + i] = src[tailPos + i];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -757,6 +1046,7 @@ __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uin
     }
     uint32_t maxSym = 255, largest = 0;
     if (!decided) {
+        PT(5);
         wave_histogram(L.hist, lit, n, lane);
         uint32_t m = 0, top = 0;
         for (uint32_t i = lane; i < 256; i += LANES) { const uint32_t c = L.hist[i]; if (c > m) m = c; if (c) top = i; }
@@ -776,6 +1066,7 @@ __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uin
             usedOld = true;
         } else {
             // build the candidate table (lane 0), describe it, compare with reusing the old one
+            PT(5);
             if (lane == 0) {
                 uint32_t huffLog = fse_optimalTableLog(ZS_LitHufLog, n, maxSym, 1);
                 huffLog = huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, L);
@@ -795,12 +1086,14 @@ __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uin
             __syncthreads();
             const uint32_t hSize = L.scal[0]; const bool useOld = L.scal[1], fail = L.scal[2];
             __syncthreads();
+            PT(6);
             if (fail) cLit = 0;
             else if (useOld) { cLit = wave_huf_compress(ostart, ostart, lit, n, single, L.huf[cur], tmp, lane); usedOld = true; }
             else { cLit = wave_huf_compress(ostart, ostart + hSize, lit, n, single, L.huf[nxt], tmp, lane); newTable = true; }
         }
     }
     // ---- back in ZSTD_compressLiterals ----
+    PT(7);
     const uint32_t minGain = (n >> 6) + 2;
     if (cLit == 0 || cLit >= n - minGain) return write_raw_literals(dst, lit, n, lane);
     if (cLit == 1) return write_rle_literals(dst, lit, n, lane);           // n >= 64 here, so (srcSize >= 8) holds
@@ -857,7 +1150,7 @@ __device__ ZS_NOINLINE static uint32_t build_seq_table(uint8_t* op, FseTable& ct
 }
 
 __device__ ZS_NOINLINE static uint32_t compress_sequences(uint8_t* op0, uint8_t* oend, const zs_seq* __restrict__ seqs, uint32_t nbSeq, uint8_t* __restrict__ codes,
-                                              EncLds& L, uint32_t lane) {
+                                              EncLds& L, uint32_t* tmp, uint32_t tmpCap, uint32_t lane) {
     uint8_t* op = op0;
     uint8_t* const llC = codes; uint8_t* const ofC = codes + ZS_WS_CODE_STRIDE; uint8_t* const mlC = codes + 2 * ZS_WS_CODE_STRIDE;
     if (lane == 0) {
@@ -879,6 +1172,7 @@ __device__ ZS_NOINLINE static uint32_t compress_sequences(uint8_t* op0, uint8_t*
     }
     __threadfence_block();
     __syncthreads();
+    PT(8);
     if (lane == 0) {
         uint8_t* const seqHead = op; uint8_t* q = op + 1;
         uint32_t tLL, tOF, tML, lastCountSize = 0, fail = 0;
@@ -888,38 +1182,104 @@ __device__ ZS_NOINLINE static uint32_t compress_sequences(uint8_t* op0, uint8_t*
         if (s2 == 0xFFFFFFFFu) fail = 1; else if (!fail) { if (tOF == 2) lastCountSize = s2; q += s2; }
         uint32_t s3 = fail ? 0 : build_seq_table(q, L.ml, ZS_MLFSELog, cML, ZS_MaxML, mlC, nbSeq, kMLdefaultNorm, 6, ZS_MaxML, false, L, &tML);
         if (s3 == 0xFFFFFFFFu) fail = 1; else if (!fail) { if (tML == 2) lastCountSize = s3; q += s3; }
-        uint32_t total = 0xFFFFFFFFu;
-        if (!fail) {
-            *seqHead = (uint8_t)((tLL << 6) + (tOF << 4) + (tML << 2));
-            BitW b; bw_init(b, q, oend);
-            uint32_t stML = fse_init2(L.ml, mlC[nbSeq - 1]), stOF = fse_init2(L.of, ofC[nbSeq - 1]), stLL = fse_init2(L.ll, llC[nbSeq - 1]);
-            {   const zs_seq s = seqs[nbSeq - 1];
-                bw_add(b, s.litLength, kLLbits[llC[nbSeq - 1]]);
-                bw_add(b, s.mlBase, kMLbits[mlC[nbSeq - 1]]);
-                bw_add(b, s.offBase, ofC[nbSeq - 1]); }
-            for (uint32_t n = nbSeq - 2; n < nbSeq; n--) {
-                const uint32_t lc = llC[n], oc = ofC[n], mc = mlC[n];
-                const zs_seq s = seqs[n];
-                fse_encode(b, L.of, stOF, oc);
-                fse_encode(b, L.ml, stML, mc);
-                fse_encode(b, L.ll, stLL, lc);
-                bw_add(b, s.litLength, kLLbits[lc]);
-                bw_add(b, s.mlBase, kMLbits[mc]);
-                bw_add(b, s.offBase, oc);
-            }
-            bw_add(b, stML, L.ml.tableLog); bw_add(b, stOF, L.of.tableLog); bw_add(b, stLL, L.ll.tableLog);
-            const uint32_t bitstreamSize = bw_close(b);
-            if (b.overflow) total = 0xFFFFFFFFu;
-            else if (lastCountSize && (lastCountSize + bitstreamSize) < 4) total = 0xFFFFFFFFu;
-            else total = (uint32_t)((q + bitstreamSize) - op0);
-        }
-        L.scal[3] = total;
+        // lane 0 hands over: where the bit stream starts, the count size rule, failure
+        L.scal[3] = fail ? 0xFFFFFFFFu : (uint32_t)(q - op0);
+        L.scal[4] = lastCountSize;
+        if (!fail) *seqHead = (uint8_t)((tLL << 6) + (tOF << 4) + (tML << 2));
+        PT(9);
     }
     __threadfence_block();
     __syncthreads();
-    const uint32_t r = L.scal[3];
+    const uint32_t qoff = L.scal[3], lastCountSize = L.scal[4];
     __syncthreads();
-    return r;
+    if (qoff == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+    // ---- ZSTD_encodeSequences, wave-parallel ----
+    // (A) the three FSE state machines are independent chains: lanes 0 / 1 / 2 walk LL / OF / ML from the last sequence to
+    //     the first and record, per sequence, the bits each transition emits (value | nbBits << 12).
+    uint16_t* const stb = (uint16_t*)(codes + 3 * ZS_WS_CODE_STRIDE);
+    uint32_t finalState = 0, finalLog = 0;
+    if (lane < 3) {
+        const FseTable& ct = lane == 0 ? L.ll : lane == 1 ? L.of : L.ml;
+        const uint8_t* __restrict__ cd = codes + lane * ZS_WS_CODE_STRIDE;
+        uint16_t* __restrict__ o = stb + lane * ZS_WS_CODE_STRIDE;
+        uint32_t st = fse_init2(ct, cd[nbSeq - 1]);
+        o[nbSeq - 1] = 0;
+        if (nbSeq >= 2) {                                           // codes are read 8 at a time, one group ahead of their use
+            int32_t n = (int32_t)nbSeq - 2;
+            uint32_t g = (uint32_t)n & ~7u;
+            uint64_t cur = *reinterpret_cast<const uint64_t*>(cd + g);
+            for (;;) {
+                const uint64_t nxt = g >= 8 ? *reinterpret_cast<const uint64_t*>(cd + g - 8) : 0;
+                const int top = n & 7;
+#pragma unroll
+                for (int j = 7; j >= 0; j--) {
+                    if (j <= top) {
+                        const uint32_t sym = (uint32_t)(cur >> (8 * j)) & 0xFF;
+                        const uint32_t nb = (st + ct.dnb[sym]) >> 16;
+                        o[g + j] = (uint16_t)((st & ((1u << nb) - 1)) | (nb << 12));
+                        st = ct.state[(st >> nb) + ct.dfs[sym]];
+                    }
+                }
+                if (g == 0) break;
+                g -= 8; n = (int32_t)g + 7; cur = nxt;
+            }
+        }
+        finalState = st & ((1u << ct.tableLog) - 1); finalLog = ct.tableLog;
+    }
+    __threadfence_block();
+    __syncthreads();
+    PT(10);
+    // (B) every lane packs a contiguous run of sequences (in emission order: last sequence first)
+    const uint32_t fLL = __shfl(finalState, 0), fOF = __shfl(finalState, 1), fML = __shfl(finalState, 2);
+    const uint32_t gLL = __shfl(finalLog, 0), gOF = __shfl(finalLog, 1), gML = __shfl(finalLog, 2);
+    const uint32_t per = (nbSeq + LANES - 1) / LANES;
+    const uint32_t r0 = lane * per < nbSeq ? lane * per : nbSeq, r1 = r0 + per < nbSeq ? r0 + per : nbSeq;
+    uint32_t bits = 0;
+    for (uint32_t r = r0; r < r1; r++) {
+        const uint32_t n = nbSeq - 1 - r;
+        bits += (stb[n] >> 12) + (stb[ZS_WS_CODE_STRIDE + n] >> 12) + (stb[2 * ZS_WS_CODE_STRIDE + n] >> 12) + kLLbits[llC[n]] + kMLbits[mlC[n]] + ofC[n];
+    }
+    if (lane == LANES - 1) bits += gML + gOF + gLL + 1;             // final states + end mark
+    const uint32_t startBit = wave_excl_scan(bits, lane);
+    const uint32_t totalBits = __shfl(startBit + bits, LANES - 1);
+    const uint32_t bitstreamSize = (totalBits + 7) / 8;
+    uint8_t* const q = op0 + qoff;
+    if (q + bitstreamSize > oend || bitstreamSize > tmpCap) return 0xFFFFFFFFu;       // does not fit: the block goes out raw
+    {   const uint32_t words = (totalBits + 31) / 32 + 1;
+        for (uint32_t wd = lane; wd < words; wd += LANES) tmp[wd] = 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    {   uint64_t acc = 0; uint32_t word = startBit >> 5, nacc = startBit & 31;
+#define SEQ_PUT(v, nb) do { acc |= (uint64_t)(v) << nacc; nacc += (nb); if (nacc >= 32) { atomicOr(&tmp[word], (uint32_t)acc); acc >>= 32; nacc -= 32; word++; } } while (0)
+        for (uint32_t r = r0; r < r1; r++) {
+            const uint32_t n = nbSeq - 1 - r;
+            const zs_seq sq = seqs[n];
+            const uint32_t lc = llC[n], oc = ofC[n], mc = mlC[n];
+            const uint32_t sLL = stb[n], sOF = stb[ZS_WS_CODE_STRIDE + n], sML = stb[2 * ZS_WS_CODE_STRIDE + n];
+            const uint32_t nOF = sOF >> 12, nML = sML >> 12, nLL = sLL >> 12;
+            const uint32_t v1 = (sOF & 0xFFF) | ((sML & 0xFFF) << nOF) | ((sLL & 0xFFF) << (nOF + nML));
+            SEQ_PUT(v1, nOF + nML + nLL);
+            const uint32_t bl = kLLbits[lc], bm = kMLbits[mc];
+            const uint64_t v2 = (uint64_t)(sq.litLength & ((1u << bl) - 1)) | ((uint64_t)(sq.mlBase & ((1u << bm) - 1)) << bl);
+            SEQ_PUT(v2, bl + bm);
+            SEQ_PUT(sq.offBase & (uint32_t)((1ull << oc) - 1), oc);
+        }
+        if (lane == LANES - 1) {
+            SEQ_PUT(fML, gML); SEQ_PUT(fOF, gOF); SEQ_PUT(fLL, gLL);
+            SEQ_PUT(1u, 1u);
+        }
+#undef SEQ_PUT
+        if (nacc) atomicOr(&tmp[word], (uint32_t)acc);
+    }
+    __threadfence_block();
+    __syncthreads();
+    wave_copy(q, (const uint8_t*)tmp, bitstreamSize, lane);
+    __threadfence_block();
+    __syncthreads();
+    PT(10);
+    if (lastCountSize && (lastCountSize + bitstreamSize) < 4) return 0xFFFFFFFFu;
+    return qoff + bitstreamSize;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -969,9 +1329,17 @@ __device__ static bool wave_is_rle(const uint8_t* __restrict__ p, uint32_t n, ui
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, const tsx_chunk_desc* __restrict__ descs,
                                                               uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
-                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile) {
+                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile
+#ifdef TSX_PROF
+                                                              , unsigned long long* __restrict__ prof_out
+#endif
+                                                              ) {
     __shared__ EncLds L;
     const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
+#ifdef TSX_PROF
+    if (lane == 0) { for (int i = 0; i < 24; i++) g_prof[i] = 0; g_prof[22] = g_prof[23] = (unsigned long long)clock64(); }
+    __syncthreads();
+#endif
     const uint8_t* __restrict__ src = src_base + descs[chunk].src_off;
     const uint32_t srcSize = descs[chunk].src_len;
     uint8_t* const frame = mid + (uint64_t)chunk * mid_stride;
@@ -1014,6 +1382,7 @@ __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __r
     }
     if (lane == 0) { L.hufRepeat[0] = 0; L.hufRepeat[1] = 0; L.huf[0].maxSym = 0; L.huf[1].maxSym = 0; }
     __syncthreads();
+    PT(0);
     uint32_t repc[3] = {1, 4, 8};                                       // confirmed repcode history
     const uint32_t blockSizeMax = (1u << cp.windowLog) < ZS_BLOCK_MAX ? (1u << cp.windowLog) : ZS_BLOCK_MAX;
     uint32_t ipos = 0, remaining = srcSize, dictLimit = 2;
@@ -1025,6 +1394,7 @@ __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __r
         uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
         if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
             blockSize = split_block_1_5_7(src + ipos, L, lane);
+        PT(1);
         const uint32_t lastBlock = blockSize == remaining;
         {   // ZSTD_window_enforceMaxDist
             const uint32_t blockEndIdx = ipos + blockSize + 2, maxDist = 1u << cp.windowLog;
@@ -1034,9 +1404,16 @@ __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __r
         if (blockSize >= 7) {
             uint32_t rep[3] = {repc[0], repc[1], repc[2]};
             MfState ms;
-            match_block(src, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, lit, ms, lane);
+            match_block(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane);
             __threadfence_block();
             __syncthreads();
+#ifdef ZS_ABL_PARSE_ONLY
+            { cSize = 0; repc[0] = rep[0]; repc[1] = rep[1]; repc[2] = rep[2]; if (lane == 0) zlen[chunk] += ms.nbSeq; goto abl_next; }
+#endif
+            gather_literals(lit, src, seqs, ms.nbSeq, ms.anchor, ms.lastLL, lane);
+            __threadfence_block();
+            __syncthreads();
+            PT(5);
             // ---- ZSTD_entropyCompressSeqStore ----
             if (lane == 0) L.scal[8] = 0;
             __syncthreads();
@@ -1044,7 +1421,7 @@ __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __r
             uint32_t litBytes = compress_literals(blockout, lit, ms.litSize, L, cur, suspect, huftmp, lane);
             __threadfence_block();
             __syncthreads();
-            uint32_t seqBytes = compress_sequences(blockout + litBytes, blockout + (255u << 10), seqs, ms.nbSeq, codes, L, lane);
+            uint32_t seqBytes = compress_sequences(blockout + litBytes, blockout + (255u << 10), seqs, ms.nbSeq, codes, L, huftmp, (ZS_BLOCKOUT_CAP - (256u << 10)) - 64, lane);
             const bool newHuf = L.scal[8] != 0;
             if (seqBytes != 0xFFFFFFFFu) {
                 cSize = litBytes + seqBytes;
@@ -1071,11 +1448,18 @@ __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __r
             wave_copy(op + 3, blockout, cSize, lane);
             cSize += 3;
         }
+        PT(11);
+#ifdef ZS_ABL_PARSE_ONLY
+        abl_next:
+#endif
         savings += (int64_t)blockSize - (int64_t)cSize;
         ipos += blockSize; remaining -= blockSize; op += cSize; first = false;
         __syncthreads();
     }
     if (lane == 0) zlen[chunk] = (uint32_t)(op - frame);
+#ifdef TSX_PROF
+    if (lane == 0 && prof_out) { g_prof[14] = (unsigned long long)clock64() - g_prof[22]; for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i]; }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1090,6 +1474,10 @@ uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*
                                   uint32_t profile) {
     if (!n) return 0;
     hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
-                       (uint8_t*)d_work, profile);
+                       (uint8_t*)d_work, profile
+#ifdef TSX_PROF
+                       , g_prof_out
+#endif
+                       );
     return 1;
 }

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Phase profile of zstd_compress_kernel (libtsxform_prof.so, `make -C csrc prof`): s_memtime lap timers per chunk.
+Usage (GPU box): python tools/prof_zstd.py [--chunks 2048] [--dist K] -> JSON with mean cycles per bucket."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+NAMES = {0: "setup+table zero", 1: "split_block", 2: "match: search steps", 3: "match: extend+store", 4: "match: post (compl. insert, rep loop, tail)",
+         5: "lit: histogram/sample", 6: "lit: lane0 huffman build", 7: "lit: huffman encode", 8: "seq: codes+hist", 9: "seq: lane0 FSE tables",
+         10: "seq: lane0 encode", 11: "emit/copy + misc", 12: "#search steps", 13: "#sequences", 14: "total cycles", 15: "sum K (positions evaluated)",
+         16: "  step: src window load", 17: "  step: hash + table loads", 18: "  step: collision scoreboard", 19: "#steps with hash collision (slow path)", 20: "#steps with a far candidate (global)", 21: "#extension passes from global"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", type=int, default=2048)
+    ap.add_argument("--dist", default="K")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--data", default="", help=".npy cache of the 256 distinct chunks (made on first use): keeps generator kernels out of rocprofv3 runs")
+    ap.add_argument("--lib", default="libtsxform_prof.so", help="libtsxform_prof.so (lap timers) or libtsxform.so (plain, for rocprofv3 runs)")
+    args = ap.parse_args()
+    import torch
+    import tsxform
+    from tsxform import synth
+    nat = tsxform._native
+    N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), args.lib))
+    has_prof = "_prof" in args.lib
+    N.init(1, [0])
+    n, CH = args.chunks, synth.CHUNK
+    dev = torch.device("cuda", 0)
+    src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+    uniq = min(n, 256)                                   # one distinct segment, replicated (profiling only)
+    if args.data and os.path.exists(args.data):
+        src[:uniq * CH] = torch.from_numpy(np.load(args.data)[:uniq * CH]).to(dev)
+    else:
+        for i in range(uniq):
+            src[i * CH:(i + 1) * CH] = synth.gen_chunk(args.dist, 1000, 0, i, CH, device=dev)
+        if args.data:
+            np.save(args.data, src[:uniq * CH].cpu().numpy())
+    for i in range(uniq, n, uniq):
+        m = min(uniq, n - i)
+        src[i * CH:(i + m) * CH] = src[:m * CH]
+    flags = nat.COMPRESS
+    slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
+    dst = torch.empty(n * slot, dtype=torch.uint8, device=dev)
+    prof = torch.zeros(n * 24, dtype=torch.int64, device=dev)
+    if has_prof:
+        N.lib.tsx_debug_set_prof.restype = None
+        N.lib.tsx_debug_set_prof.argtypes = [C.c_void_p]
+        N.lib.tsx_debug_set_prof(prof.data_ptr())
+    d = np.zeros(n, nat.DESC_DTYPE)
+    d["src_off"] = np.arange(n, dtype=np.uint64) * CH
+    d["src_len"] = CH
+    d["dst_off"] = np.arange(n, dtype=np.uint64) * slot
+    d["dst_cap"] = slot
+    params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=nat.ZSTD_PROFILE_1_5_7)
+    ctx = N.ctx_create(0, n, CH)
+    res = {}
+    for it in range(2):
+        t0 = time.perf_counter()
+        N.transform_batch(params, d, src.data_ptr(), dst.data_ptr(), dst.numel(), nat.MEM_DEVICE, ctx=ctx)
+        torch.cuda.synchronize()
+        res["wall_ms_%d" % it] = (time.perf_counter() - t0) * 1e3
+        res["zstd_ms_%d" % it] = N.ctx_timing(ctx).zstd_ms
+    p = prof.cpu().numpy().reshape(n, 24)
+    mean = p.mean(axis=0)
+    res["chunks"] = n
+    res["mean_out"] = float(d["dst_len"].mean())
+    tot = max(mean[14], 1)
+    res["buckets"] = {NAMES[k]: {"mean": float(mean[k]), "frac_of_total": float(mean[k] / tot) if (k < 12 or 15 < k < 19) else None} for k in NAMES}
+    res["total_min_max"] = [int(p[:, 14].min()), int(p[:, 14].max())]
+    res["cycles_per_seq"] = float(tot / max(mean[13], 1))
+    s = json.dumps(res, indent=1)
+    print(s)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(s)
+
+
+if __name__ == "__main__":
+    main()
