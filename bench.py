@@ -67,8 +67,11 @@ def main():
 
     # ---- synthetic segments, generated directly in HBM; global segment id = rank * nseg + s ------------
     src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+    # weak scaling, segment-major (tsxform.shard): with world*nseg segments in the job, rank r owns segments r, r+world, ...
+    from tsxform import shard
+    my_segments = shard.segments_of_rank(world * nseg, rank, world)
     for s in range(nseg):
-        gs = rank * nseg + s
+        gs = my_segments[s]
         for c in range(cps):
             i = s * cps + c
             src[i * CH:(i + 1) * CH] = synth.gen_chunk(args.dist, 1000 + gs, gs, c, CH, device=dev)
@@ -81,7 +84,7 @@ def main():
     d["dst_cap"] = slot
     for s in range(nseg):
         for c in range(cps):
-            d["iv"][s * cps + c] = np.frombuffer(synth.iv_for(rank * nseg + s, c), np.uint8)
+            d["iv"][s * cps + c] = np.frombuffer(synth.iv_for(my_segments[s], c), np.uint8)
     profile = nat.ZSTD_PROFILE_1_5_7 if args.profile == "1.5.7" else nat.ZSTD_PROFILE_1_5_6
     params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=profile)
     ctx = N.ctx_create(0, n, CH)
@@ -147,9 +150,19 @@ def main():
     else:
         alg = n * (CH + (mean_out - 28 if flags & nat.ENCRYPT else mean_out)) # N read + frame written
     achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_zstd.sh -> profiles/pmc_traffic.json:
+    # FETCH_SIZE + WRITE_SIZE of the same kernel build and workload); null when no such measurement is recorded
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get("%s/%s/%d" % (workload, args.dist, n))
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {"bound": "hbm", "kernel": {"crc": "crc32c_partial_kernel", "gcm": "gcm_ctr_ghash_kernel", "zstd": "zstd_compress_kernel"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None, "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                "traffic": traffic, "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage.items()}}
 
     # ---- CPU baseline: the oracle port (libzstd + OpenSSL GCM + CRC32C), all host cores, bounded sample --

@@ -1,0 +1,114 @@
+/*
+ * Replaces DecryptionChunkEnumeration + DecompressionChunkEnumeration (DefaultChunkManager.java:58-67): verify tag +
+ * decrypt (DecryptionChunkEnumeration.java:54-62), Zstd.decompressedSize + Zstd.decompress
+ * (DecompressionChunkEnumeration.java:39-46), batched.  Failures surface like the reference's: RuntimeException carrying
+ * "Tag mismatch" (AEADBadTagException text) or "Invalid decompressed size: n", raised when the failed chunk is reached.
+ * C++ twin (tested): tiered-storage-for-apache-kafka_amd/host/tsxhost.cpp.
+ */
+package io.aiven.kafka.tieredstorage.gpu;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.util.ArrayDeque;
+import java.util.ArrayList;
+import java.util.List;
+import java.util.NoSuchElementException;
+import java.util.Objects;
+
+import io.aiven.kafka.tieredstorage.manifest.SegmentEncryptionMetadata;
+import io.aiven.kafka.tieredstorage.transform.DetransformChunkEnumeration;
+
+public class GpuDetransformChunkEnumeration implements DetransformChunkEnumeration {
+    private final DetransformChunkEnumeration inner;
+    private final boolean compressed;
+    private final SegmentEncryptionMetadata encryption;   // null: not encrypted
+    private final int maxOriginalChunkSize;
+    private final int batchChunks;
+    private final ArrayDeque<byte[]> ready = new ArrayDeque<>();
+    private RuntimeException failure;
+
+    public GpuDetransformChunkEnumeration(final DetransformChunkEnumeration inner, final boolean compressed,
+                                          final SegmentEncryptionMetadata encryption,
+                                          final int maxOriginalChunkSize, final int batchChunks) {
+        this.inner = Objects.requireNonNull(inner, "inner cannot be null");
+        this.compressed = compressed;
+        this.encryption = encryption;
+        this.maxOriginalChunkSize = maxOriginalChunkSize;
+        this.batchChunks = batchChunks;
+    }
+
+    @Override
+    public boolean hasMoreElements() {
+        fillBatchIfNeeded();
+        return !ready.isEmpty() || failure != null;
+    }
+
+    @Override
+    public byte[] nextElement() {
+        fillBatchIfNeeded();
+        if (!ready.isEmpty()) {
+            return ready.poll();
+        }
+        if (failure != null) {
+            throw failure;
+        }
+        throw new NoSuchElementException();
+    }
+
+    private static long align16(final long v) {
+        return (v + 15) & ~15L;
+    }
+
+    private void fillBatchIfNeeded() {
+        if (!ready.isEmpty() || failure != null) {
+            return;
+        }
+        final List<byte[]> in = new ArrayList<>();
+        while (in.size() < batchChunks && inner.hasMoreElements()) {
+            in.add(inner.nextElement());
+        }
+        if (in.isEmpty()) {
+            return;
+        }
+        final int flags = (compressed ? TsxNative.COMPRESS : 0) | (encryption != null ? TsxNative.ENCRYPT : 0);
+        final ByteBuffer descs = ByteBuffer.allocateDirect(in.size() * TsxNative.DESC_BYTES).order(ByteOrder.LITTLE_ENDIAN);
+        long srcSize = 0;
+        long dstSize = 0;
+        for (int i = 0; i < in.size(); i++) {
+            final int base = i * TsxNative.DESC_BYTES;
+            final int len = in.get(i).length;
+            final long cap = compressed ? maxOriginalChunkSize : Math.max(0, len - 28);
+            descs.putLong(base + TsxNative.DESC_SRC_OFF, srcSize);
+            descs.putLong(base + TsxNative.DESC_DST_OFF, dstSize);
+            descs.putInt(base + TsxNative.DESC_SRC_LEN, len);
+            descs.putInt(base + TsxNative.DESC_DST_CAP, (int) cap);
+            srcSize += align16(len) + 16;
+            dstSize += align16(cap) + 16;
+        }
+        final ByteBuffer src = ByteBuffer.allocateDirect((int) srcSize + 16);
+        final ByteBuffer dst = ByteBuffer.allocateDirect((int) dstSize + 16);
+        for (int i = 0; i < in.size(); i++) {
+            src.position((int) descs.getLong(i * TsxNative.DESC_BYTES + TsxNative.DESC_SRC_OFF));
+            src.put(in.get(i));
+        }
+        final int rc = TsxNative.detransformBatch(flags,
+            encryption != null ? encryption.dataKey().getEncoded() : null,
+            encryption != null ? encryption.aad() : null, descs, in.size(), src, dst);
+        if (rc != TsxNative.OK) {
+            throw new RuntimeException(TsxNative.strerror(rc));
+        }
+        for (int i = 0; i < in.size(); i++) {
+            final int base = i * TsxNative.DESC_BYTES;
+            final int status = descs.getInt(base + TsxNative.DESC_STATUS);
+            if (status != TsxNative.OK) {
+                failure = new RuntimeException(status == TsxNative.E_BAD_SIZE
+                    ? "Invalid decompressed size: -1" : TsxNative.strerror(status));
+                return;
+            }
+            final byte[] out = new byte[descs.getInt(base + TsxNative.DESC_DST_LEN)];
+            dst.position((int) descs.getLong(base + TsxNative.DESC_DST_OFF));
+            dst.get(out);
+            ready.add(out);
+        }
+    }
+}

@@ -1,0 +1,138 @@
+/*
+ * Replaces CompressionChunkEnumeration + EncryptionChunkEnumeration in RemoteStorageManager.transformation()
+ * (core/.../RemoteStorageManager.java:434-453) with one batched call into libtsxform.  Same contract as the two it
+ * replaces: one Zstd frame per chunk (CompressionChunkEnumeration.java:50-63), IV || ciphertext || tag per chunk with a
+ * fresh SecureRandom IV (EncryptionChunkEnumeration.java:66-84, AesEncryptionProvider.java:66-71),
+ * transformedChunkSize() == null when compressing, inner + 12 + 16 when only encrypting (:41-47, :82-84).
+ * The C++ twin with the same logic is tiered-storage-for-apache-kafka_amd/host/tsxhost.cpp (tested); this file is the
+ * JVM-side source a maintainer compiles - see INTEGRATION.md.
+ */
+package io.aiven.kafka.tieredstorage.gpu;
+
+import java.nio.ByteBuffer;
+import java.nio.ByteOrder;
+import java.security.SecureRandom;
+import java.util.ArrayDeque;
+import java.util.ArrayList;
+import java.util.List;
+import java.util.NoSuchElementException;
+import java.util.Objects;
+
+import io.aiven.kafka.tieredstorage.security.DataKeyAndAAD;
+import io.aiven.kafka.tieredstorage.transform.TransformChunkEnumeration;
+
+public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
+    static final int IV_SIZE = 12;
+    static final int TAG_SIZE = 16;
+
+    private final TransformChunkEnumeration inner;
+    private final boolean compress;
+    private final DataKeyAndAAD keyAndAad;   // null: no encryption
+    private final int batchChunks;
+    private final SecureRandom random;
+    private final Integer transformedChunkSize;
+    private final ArrayDeque<byte[]> ready = new ArrayDeque<>();
+
+    public GpuTransformChunkEnumeration(final TransformChunkEnumeration inner, final boolean compress,
+                                        final DataKeyAndAAD keyAndAad, final int batchChunks,
+                                        final SecureRandom random) {
+        this.inner = Objects.requireNonNull(inner, "inner cannot be null");
+        this.compress = compress;
+        this.keyAndAad = keyAndAad;
+        this.batchChunks = batchChunks;
+        this.random = random;
+        final Integer innerSize = inner.transformedChunkSize();
+        if (compress || innerSize == null) {
+            this.transformedChunkSize = null;
+        } else {
+            this.transformedChunkSize = keyAndAad != null ? innerSize + IV_SIZE + TAG_SIZE : innerSize;
+        }
+    }
+
+    @Override
+    public int originalChunkSize() {
+        return inner.originalChunkSize();
+    }
+
+    @Override
+    public Integer transformedChunkSize() {
+        return transformedChunkSize;
+    }
+
+    @Override
+    public boolean hasMoreElements() {
+        fillBatchIfNeeded();
+        return !ready.isEmpty();
+    }
+
+    @Override
+    public byte[] nextElement() {
+        fillBatchIfNeeded();
+        if (ready.isEmpty()) {
+            throw new NoSuchElementException();
+        }
+        return ready.poll();
+    }
+
+    private static long align16(final long v) {
+        return (v + 15) & ~15L;
+    }
+
+    private void fillBatchIfNeeded() {
+        if (!ready.isEmpty()) {
+            return;
+        }
+        final List<byte[]> in = new ArrayList<>();
+        while (in.size() < batchChunks && inner.hasMoreElements()) {
+            in.add(inner.nextElement());
+        }
+        if (in.isEmpty()) {
+            return;
+        }
+        final int flags = (compress ? TsxNative.COMPRESS : 0) | (keyAndAad != null ? TsxNative.ENCRYPT : 0);
+        final ByteBuffer descs = ByteBuffer.allocateDirect(in.size() * TsxNative.DESC_BYTES).order(ByteOrder.LITTLE_ENDIAN);
+        long srcSize = 0;
+        long dstSize = 0;
+        final byte[] iv = new byte[IV_SIZE];
+        for (int i = 0; i < in.size(); i++) {
+            final int base = i * TsxNative.DESC_BYTES;
+            final long cap = TsxNative.transformedBound(in.get(i).length, flags);
+            descs.putLong(base + TsxNative.DESC_SRC_OFF, srcSize);
+            descs.putLong(base + TsxNative.DESC_DST_OFF, dstSize);
+            descs.putInt(base + TsxNative.DESC_SRC_LEN, in.get(i).length);
+            descs.putInt(base + TsxNative.DESC_DST_CAP, (int) cap);
+            if (keyAndAad != null) {
+                random.nextBytes(iv);                      // the IV never comes from the device
+                for (int k = 0; k < IV_SIZE; k++) {
+                    descs.put(base + TsxNative.DESC_IV + k, iv[k]);
+                }
+            }
+            srcSize += align16(in.get(i).length) + 16;
+            dstSize += align16(cap) + 16;
+        }
+        final ByteBuffer src = ByteBuffer.allocateDirect((int) srcSize + 16);
+        final ByteBuffer dst = ByteBuffer.allocateDirect((int) dstSize + 16);
+        for (int i = 0; i < in.size(); i++) {
+            src.position((int) descs.getLong(i * TsxNative.DESC_BYTES + TsxNative.DESC_SRC_OFF));
+            src.put(in.get(i));
+        }
+        final int rc = TsxNative.transformBatch(flags,
+            keyAndAad != null ? keyAndAad.dataKey.getEncoded() : null,
+            keyAndAad != null ? keyAndAad.aad : null,
+            0 /* TSX_ZSTD_PROFILE_1_5_6: the libzstd inside zstd-jni 1.5.6-9 */, descs, in.size(), src, dst);
+        if (rc != TsxNative.OK) {
+            throw new RuntimeException(TsxNative.strerror(rc));
+        }
+        for (int i = 0; i < in.size(); i++) {
+            final int base = i * TsxNative.DESC_BYTES;
+            final int status = descs.getInt(base + TsxNative.DESC_STATUS);
+            if (status != TsxNative.OK) {
+                throw new RuntimeException(TsxNative.strerror(status));   // as EncryptionChunkEnumeration.java:76-78
+            }
+            final byte[] out = new byte[descs.getInt(base + TsxNative.DESC_DST_LEN)];   // fresh array per chunk, owned by the caller
+            dst.position((int) descs.getLong(base + TsxNative.DESC_DST_OFF));
+            dst.get(out);
+            ready.add(out);
+        }
+    }
+}

@@ -1,0 +1,62 @@
+/*
+ * JNI binding of libtsxform's C ABI (include/tsxform.h).  One native method per entry point the hot path needs;
+ * java/jni/tsx_jni.c is the shim.  NOT compiled in this repository's CI (no JDK in the build image) - see INTEGRATION.md.
+ */
+package io.aiven.kafka.tieredstorage.gpu;
+
+import java.nio.ByteBuffer;
+
+public final class TsxNative {
+    public static final int COMPRESS = 0x1;
+    public static final int ENCRYPT = 0x2;
+    public static final int CRC = 0x4;
+
+    public static final int OK = 0;
+    public static final int E_TAG_MISMATCH = -5;
+    public static final int E_BAD_FRAME = -6;
+    public static final int E_BAD_SIZE = -7;
+
+    /** Size of one tsx_chunk_desc (include/tsxform.h), written/read through a direct little-endian ByteBuffer. */
+    public static final int DESC_BYTES = 48;
+    public static final int DESC_SRC_OFF = 0;
+    public static final int DESC_DST_OFF = 8;
+    public static final int DESC_SRC_LEN = 16;
+    public static final int DESC_DST_CAP = 20;
+    public static final int DESC_DST_LEN = 24;
+    public static final int DESC_CRC32C = 28;
+    public static final int DESC_STATUS = 32;
+    public static final int DESC_IV = 36;
+
+    static {
+        System.loadLibrary("tsxform_jni");   // links libtsxform.so
+        final int devices = init();
+        if (devices <= 0) {
+            // there is no CPU implementation behind this binding
+            throw new UnsatisfiedLinkError("tsxform: no usable gfx950 device: " + strerror(devices));
+        }
+    }
+
+    private TsxNative() {
+    }
+
+    /** tsx_init(0, NULL): all visible devices. */
+    private static native int init();
+
+    public static native String strerror(int code);
+
+    /** tsx_transformed_bound. */
+    public static native long transformedBound(long n, int flags);
+
+    /**
+     * tsx_transform_batch / tsx_detransform_batch over direct buffers (host memory, TSX_MEM_HOST) with a pooled context.
+     *
+     * @param descs n * DESC_BYTES, little-endian, in/out
+     * @param key   32-byte AES key or null; zeroised in native memory before returning
+     * @return batch-level status (0 or a negative TSX_E_* code); per-chunk status is in descs
+     */
+    public static native int transformBatch(int flags, byte[] key, byte[] aad, int zstdProfile,
+                                            ByteBuffer descs, int n, ByteBuffer src, ByteBuffer dst);
+
+    public static native int detransformBatch(int flags, byte[] key, byte[] aad,
+                                              ByteBuffer descs, int n, ByteBuffer src, ByteBuffer dst);
+}

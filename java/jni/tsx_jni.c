@@ -1,0 +1,73 @@
+/*
+ * JNI shim between io.aiven.kafka.tieredstorage.gpu.TsxNative and the C ABI of libtsxform.so (include/tsxform.h).
+ * Build (needs a JDK, which this repository's build image does not have):
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include tsx_jni.c \
+ *       -L../../tiered-storage-for-apache-kafka_amd -ltsxform -o libtsxform_jni.so
+ * Nothing here computes: it only moves pointers across the boundary and never throws from native code.
+ */
+#include <jni.h>
+#include <string.h>
+
+#include "tsxform.h"
+
+JNIEXPORT jint JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_init(JNIEnv* env, jclass cls) {
+    (void)env; (void)cls;
+    return tsx_init(0, NULL);
+}
+
+JNIEXPORT jstring JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_strerror(JNIEnv* env, jclass cls, jint code) {
+    (void)cls;
+    return (*env)->NewStringUTF(env, tsx_strerror(code));
+}
+
+JNIEXPORT jlong JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_transformedBound(JNIEnv* env, jclass cls, jlong n, jint flags) {
+    (void)env; (void)cls;
+    return (jlong)tsx_transformed_bound((size_t)n, (uint32_t)flags);
+}
+
+static int fill_params(JNIEnv* env, tsx_batch_params* p, jint flags, jbyteArray key, jbyteArray aad, jint profile) {
+    memset(p, 0, sizeof *p);
+    p->flags = (uint32_t)flags;
+    p->zstd_level = 0;                    /* library default = 3: CompressionChunkEnumeration.java:52 never sets a level */
+    p->zstd_profile = (uint32_t)profile;
+    if (flags & TSX_ENCRYPT) {
+        if (!key || (*env)->GetArrayLength(env, key) != 32) return TSX_E_INVAL;
+        (*env)->GetByteArrayRegion(env, key, 0, 32, (jbyte*)p->key);
+        if (aad) {
+            const jsize n = (*env)->GetArrayLength(env, aad);
+            if (n > (jsize)sizeof p->aad) return TSX_E_INVAL;
+            (*env)->GetByteArrayRegion(env, aad, 0, n, (jbyte*)p->aad);
+            p->aad_len = (uint32_t)n;
+        }
+    }
+    return TSX_OK;
+}
+
+static jint run(JNIEnv* env, int detransform, jint flags, jbyteArray key, jbyteArray aad, jint profile,
+                jobject descs, jint n, jobject src, jobject dst) {
+    tsx_batch_params p;
+    int rc = fill_params(env, &p, flags, key, aad, profile);
+    if (rc == TSX_OK) {
+        tsx_chunk_desc* d = (tsx_chunk_desc*)(*env)->GetDirectBufferAddress(env, descs);
+        const void* s = (*env)->GetDirectBufferAddress(env, src);
+        void* o = (*env)->GetDirectBufferAddress(env, dst);
+        const jlong cap = (*env)->GetDirectBufferCapacity(env, dst);
+        if (!d || !s || !o || (*env)->GetDirectBufferCapacity(env, descs) < (jlong)n * (jlong)sizeof(tsx_chunk_desc)) rc = TSX_E_INVAL;
+        else rc = detransform ? tsx_detransform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, TSX_MEM_HOST)
+                              : tsx_transform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, TSX_MEM_HOST);
+    }
+    memset(&p, 0, sizeof p);              /* the key does not outlive the call (ownership) */
+    return rc;
+}
+
+JNIEXPORT jint JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_transformBatch(
+    JNIEnv* env, jclass cls, jint flags, jbyteArray key, jbyteArray aad, jint profile, jobject descs, jint n, jobject src, jobject dst) {
+    (void)cls;
+    return run(env, 0, flags, key, aad, profile, descs, n, src, dst);
+}
+
+JNIEXPORT jint JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_detransformBatch(
+    JNIEnv* env, jclass cls, jint flags, jbyteArray key, jbyteArray aad, jobject descs, jint n, jobject src, jobject dst) {
+    (void)cls;
+    return run(env, 1, flags, key, aad, 1, descs, n, src, dst);
+}

@@ -1,0 +1,344 @@
+// Host-side tests of the chunk-transform path (tsxhost over libtsxform's C ABI), written to read like the reference's own
+// JUnit tests — each TEST names the reference test it restates (CT/ = core/src/test/java/io/aiven/kafka/tieredstorage/).
+// Run by tests/test_host.py:  host_tests cpu            (pure host logic, no device library)
+//                             host_tests backend <lib>  (chain through a libtsxform build: the emulated one on CPU, the real one -m gpu)
+// The oracle (oracle/_build/liboracle.so) is linked here as the checker only.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+
+#include "../../tiered-storage-for-apache-kafka_amd/host/tsxhost.hpp"
+
+extern "C" {
+size_t orc_transform_chunk(unsigned flags, const uint8_t key[32], const uint8_t* aad, size_t aad_len, const uint8_t iv[12], const uint8_t* src, size_t n,
+                           uint8_t* dst, size_t cap, uint8_t* scratch, uint32_t* crc_out);
+size_t orc_chain_bound(size_t n, unsigned flags);
+const char* orc_zstd_version(void);
+}
+
+using namespace tsx;
+static int g_failed = 0, g_run = 0;
+static std::string g_lib;
+#define CHECK(c) do { if (!(c)) { printf("    FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); throw std::runtime_error("check failed"); } } while (0)
+template <class E, class F> static void expectThrows(F f, const char* msg) {
+    try { f(); } catch (const E& e) { if (msg && std::string(e.what()) != msg) { printf("    wrong message: '%s' (expected '%s')\n", e.what(), msg); throw std::runtime_error("check failed"); } return; }
+    printf("    expected exception '%s' was not thrown\n", msg ? msg : "");
+    throw std::runtime_error("check failed");
+}
+static void run(const char* name, const std::function<void()>& f) {
+    g_run++;
+    try { f(); printf("  ok   %s\n", name); } catch (const std::exception& e) { g_failed++; printf("  FAIL %s: %s\n", name, e.what()); }
+}
+static Bytes randomBytes(size_t n, uint32_t seed) { std::mt19937 r(seed); Bytes b(n); for (auto& x : b) x = (uint8_t)r(); return b; }
+static Bytes textBytes(size_t n, uint32_t seed) {       // compressible, record-like
+    std::mt19937 r(seed); Bytes b; b.reserve(n + 128); int id = 0;
+    while (b.size() < n) {
+        char rec[160];
+        int len = snprintf(rec, sizeof rec, "{\"id\":%010d,\"user\":\"u%05u\",\"event\":\"%s\",\"payload\":\"", id++, (unsigned)(r() % 1000), (r() & 1) ? "click" : "views");
+        b.insert(b.end(), rec, rec + len);
+        for (unsigned k = 8 + r() % 40; k; k--) b.push_back((uint8_t)('a' + r() % 26));
+        b.push_back('"'); b.push_back('}'); b.push_back('\n');
+    }
+    b.resize(n);
+    return b;
+}
+static std::shared_ptr<InputStream> stream(const Bytes& b) { return std::make_shared<ByteArrayInputStream>(b); }
+
+// ---------------------------------------------------------------------------------------------------------
+static void cpuTests() {
+    // CT/transform/BaseTransformChunkEnumerationTest.java:45-94
+    run("BaseTransformChunkEnumerationTest.negativeChunkSize", [] {
+        expectThrows<std::invalid_argument>([] { BaseTransformChunkEnumeration e(stream({}), -1); }, "originalChunkSize must be non-negative, -1 given");
+    });
+    run("BaseTransformChunkEnumerationTest.emptyInputStream", [] {
+        BaseTransformChunkEnumeration e(stream({}), 1);
+        CHECK(!e.hasMoreElements());
+        expectThrows<std::out_of_range>([&] { e.nextElement(); }, nullptr);
+    });
+    run("BaseTransformChunkEnumerationTest.inAllCases (10 bytes @3 -> 3,3,3,1; chunk > file; chunk == 0)", [] {
+        const Bytes data = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+        BaseTransformChunkEnumeration e(stream(data), 3);
+        CHECK(e.originalChunkSize() == 3 && *e.transformedChunkSize() == 3);
+        std::vector<size_t> sizes; Bytes all;
+        while (e.hasMoreElements()) { Bytes c = e.nextElement(); sizes.push_back(c.size()); all.insert(all.end(), c.begin(), c.end()); }
+        CHECK((sizes == std::vector<size_t>{3, 3, 3, 1}) && all == data);
+        BaseTransformChunkEnumeration big(stream(data), 100);
+        CHECK(big.nextElement() == data && !big.hasMoreElements());
+        BaseTransformChunkEnumeration none(stream(data), 0);           // chunking disabled: readAllBytes
+        CHECK(none.nextElement() == data && !none.hasMoreElements());
+    });
+    // CT/manifest/index/ChunkIndexBuilderCommonTest.java:37-127 for both builders
+    for (int kind = 0; kind < 2; kind++) {
+        auto normal = [kind]() -> std::unique_ptr<AbstractChunkIndexBuilder> {
+            if (kind == 0) return std::make_unique<FixedSizeChunkIndexBuilder>(100, 250, 113);
+            return std::make_unique<VariableSizeChunkIndexBuilder>(100, 250);
+        };
+        auto emptyFile = [kind]() -> std::unique_ptr<AbstractChunkIndexBuilder> {
+            if (kind == 0) return std::make_unique<FixedSizeChunkIndexBuilder>(100, 0, 113);
+            return std::make_unique<VariableSizeChunkIndexBuilder>(100, 0);
+        };
+        const std::string pre = kind == 0 ? "FixedSizeChunkIndexBuilderTest." : "VariableSizeChunkIndexBuilderTest.";
+        run((pre + "addChunkToAlreadyFinishedIndex").c_str(), [&] {
+            auto b = normal(); b->addChunk(113); b->addChunk(113); b->finish(113);
+            expectThrows<std::logic_error>([&] { b->addChunk(113); }, "Cannot add chunk to already finished index");
+        });
+        run((pre + "addNonPositiveSizedChunk").c_str(), [&] {
+            auto b = normal();
+            expectThrows<std::invalid_argument>([&] { b->addChunk(-1); }, "Transformed chunk size must be non-negative, -1 given");
+        });
+        run((pre + "addSupposedToBeFinalChunkAsNonFinal").c_str(), [&] {
+            auto b = normal(); b->addChunk(113); b->addChunk(113);
+            expectThrows<std::logic_error>([&] { b->addChunk(113); }, "This must be final chunk. Call `finish` instead.");
+        });
+        run((pre + "finishedAlreadyFinishedIndex").c_str(), [&] {
+            auto b = normal(); b->addChunk(113); b->addChunk(113); b->finish(113);
+            expectThrows<std::logic_error>([&] { b->finish(113); }, "Cannot finish already finished index");
+        });
+        run((pre + "finishWithNegativeSizedChunk").c_str(), [&] {
+            auto b = normal(); b->addChunk(113); b->addChunk(113);
+            expectThrows<std::invalid_argument>([&] { b->finish(-1); }, "Transformed chunk size must be non-negative, -1 given");
+        });
+        run((pre + "finishWithNonFinalChunk").c_str(), [&] {
+            auto b = normal(); b->addChunk(113);
+            expectThrows<std::logic_error>([&] { b->finish(113); }, "This cannot be final chunk: not enough chunks to cover original file. Call `addChunk` instead.");
+        });
+        run((pre + "findForNegativeOffset / findForEmptyFile / findBeyondFileBorder").c_str(), [&] {
+            auto b = normal(); b->addChunk(113); b->addChunk(113); auto index = b->finish(113);
+            expectThrows<std::invalid_argument>([&] { index->findChunkForOriginalOffset(-1); }, "Offset must be non-negative, -1 given");
+            CHECK(!index->findChunkForOriginalOffset(250) && !index->findChunkForOriginalOffset(251));
+            auto e = emptyFile()->finish(0);
+            CHECK(!e->findChunkForOriginalOffset(0) && !e->findChunkForOriginalOffset(1));
+            CHECK(e->chunks().size() == 1 && e->chunks()[0] == (Chunk{0, 0, 0, 0, 0}));
+        });
+    }
+    // CT/manifest/index/FixedSizeChunkIndexBuilderTest.java:48-88
+    run("FixedSizeChunkIndexBuilderTest.addInvalidNonFinalTransformedChunkSize", [] {
+        FixedSizeChunkIndexBuilder b(100, 250, 113);
+        expectThrows<std::invalid_argument>([&] { b.addChunk(12); }, "Non-final chunk must be of size 113, but 12 given");
+    });
+    run("FixedSizeChunkIndexBuilderTest.threeChunks", [] {
+        FixedSizeChunkIndexBuilder b(101, 253, 111); b.addChunk(111); b.addChunk(111); auto index = b.finish(81);
+        const Chunk c1{0, 0, 101, 0, 111}, c2{1, 101, 101, 111, 111}, c3{2, 202, 51, 222, 81};
+        CHECK((index->chunks() == std::vector<Chunk>{c1, c2, c3}));
+        for (int i = 0; i < 101; i++) CHECK(*index->findChunkForOriginalOffset(i) == c1);
+        for (int i = 101; i < 202; i++) CHECK(*index->findChunkForOriginalOffset(i) == c2);
+        for (int i = 202; i < 253; i++) CHECK(*index->findChunkForOriginalOffset(i) == c3);
+        CHECK(!index->findChunkForOriginalOffset(253) && !index->findChunkForOriginalOffset(254));
+    });
+    // CT/manifest/index/VariableSizeChunkIndexBuilderTest.java:39-81
+    run("VariableSizeChunkIndexBuilderTest.invalidSizes + threeChunks", [] {
+        expectThrows<std::invalid_argument>([] { VariableSizeChunkIndexBuilder b(100, -1); }, "Original file size must be non-negative, -1 given");
+        VariableSizeChunkIndexBuilder b(101, 253); b.addChunk(33); b.addChunk(22); auto index = b.finish(5);
+        const Chunk c1{0, 0, 101, 0, 33}, c2{1, 101, 101, 33, 22}, c3{2, 202, 51, 55, 5};
+        CHECK((index->chunks() == std::vector<Chunk>{c1, c2, c3}));
+        for (int i = 0; i < 253; i++) CHECK(*index->findChunkForOriginalOffset(i) == (i < 101 ? c1 : i < 202 ? c2 : c3));
+        CHECK(!index->findChunkForOriginalOffset(253));
+    });
+    // CT/manifest/index/serde/ChunkSizesBinaryCodecTest.java:36-113
+    run("ChunkSizesBinaryCodecTest.empty / singleValue / multipleValues / negativeValues", [] {
+        CHECK(ChunkSizesBinaryCodec::encode({}).size() == 4 && ChunkSizesBinaryCodec::decode(ChunkSizesBinaryCodec::encode({})).empty());
+        for (int v : {0, 1, 0x7FFFFFFF}) { const Bytes e = ChunkSizesBinaryCodec::encode({v}); CHECK(e.size() == 8 && ChunkSizesBinaryCodec::decode(e) == std::vector<int>{v}); }
+        const int MAX = 0x7FFFFFFF;
+        struct Case { std::vector<int> v; int bpv; };
+        std::vector<int> longList; for (long long i = 0; i < (long long)MAX - 2000; i += 1000) longList.push_back((int)i);
+        std::vector<int> rev(longList.rbegin(), longList.rend());
+        const std::vector<Case> cases = {{{0, 1000, 2, 44002, 369}, 2}, {{MAX, MAX - 1, MAX - 2, 10}, 1}, {{MAX / 2, MAX / 2 - 1, MAX / 2 - 2, 10}, 1}, {longList, 4}, {rev, 4},
+                                         {{1, 2, 3, MAX}, 1}, {{1, 0xFF + 10, 0xFF + 20, 0xFF + 30, MAX}, 2}, {{1, 0xFFFF + 10, 0xFFFF + 20, 0xFFFF + 30, MAX}, 3},
+                                         {{1, 0xFFFFFF + 10, 0xFFFFFF + 20, 0xFFFFFF + 30, MAX}, 4}};
+        for (const auto& c : cases) {
+            const Bytes e = ChunkSizesBinaryCodec::encode(c.v);
+            CHECK(e.size() == 4 + 4 + 1 + (c.v.size() - 1) * (size_t)c.bpv + 4);
+            CHECK((((uint32_t)e[0] << 24) | ((uint32_t)e[1] << 16) | ((uint32_t)e[2] << 8) | e[3]) == c.v.size() && e[8] == c.bpv);
+            CHECK(ChunkSizesBinaryCodec::decode(e) == c.v);
+        }
+        expectThrows<std::invalid_argument>([] { ChunkSizesBinaryCodec::encode({-1}); }, "Values cannot be negative");
+        expectThrows<std::invalid_argument>([] { ChunkSizesBinaryCodec::encode({1, -1, 1}); }, "Values cannot be negative");
+        expectThrows<std::invalid_argument>([] { ChunkSizesBinaryCodec::encode({1, 1, -1}); }, "Values cannot be negative");
+    });
+    // CT/transform/TransformFinisherTest.java:46-125 (the parts that need no transform)
+    run("TransformFinisherTest.getIndexBeforeUsing / nullInnerEnumeration / negativeOriginalFileSize", [] {
+        struct Fake : TransformChunkEnumeration {              // a non-base enumeration with a fixed transformed size
+            std::shared_ptr<BaseTransformChunkEnumeration> b; Fake(std::shared_ptr<BaseTransformChunkEnumeration> x) : b(std::move(x)) {}
+            int originalChunkSize() const override { return b->originalChunkSize(); }
+            std::optional<int> transformedChunkSize() const override { return b->transformedChunkSize(); }
+            bool hasMoreElements() override { return b->hasMoreElements(); }
+            Bytes nextElement() override { return b->nextElement(); }
+        };
+        auto base = std::make_shared<BaseTransformChunkEnumeration>(stream({1, 2, 3, 4, 5, 6, 7}), 3);
+        TransformFinisher f(std::make_shared<Fake>(base), 7);
+        expectThrows<std::logic_error>([&] { f.chunkIndex(); }, "Chunk index was not built, was finisher used?");
+        expectThrows<std::invalid_argument>([] { TransformFinisher f2(nullptr, 7); }, "inner cannot be null");
+        expectThrows<std::invalid_argument>([&] { TransformFinisher f3(base, -1); }, "originalFileSize must be non-negative, -1 given");
+    });
+    run("TransformFinisherTest.buildIndexWhenInnerEnumerationHasFixedSize (7 bytes @3, base transform)", [] {
+        auto base = std::make_shared<BaseTransformChunkEnumeration>(stream({1, 2, 3, 4, 5, 6, 7}), 3);
+        TransformFinisher f(base, 7);
+        const Bytes all = f.toBytes();
+        CHECK(all == (Bytes{1, 2, 3, 4, 5, 6, 7}));
+        auto idx = f.chunkIndex();
+        CHECK(idx->isFixed());
+        CHECK((idx->chunks() == std::vector<Chunk>{{0, 0, 3, 0, 3}, {1, 3, 3, 3, 3}, {2, 6, 1, 6, 1}}));
+        // the arithmetic path (index asked without consuming a base transform, TransformFinisher.java:124-132)
+        TransformFinisher g(std::make_shared<BaseTransformChunkEnumeration>(stream({1, 2, 3, 4, 5, 6, 7}), 3), 7);
+        CHECK(g.chunkIndex()->chunks() == idx->chunks());
+    });
+    // CT/transform/BaseDetransformChunkEnumerationTest.java:47-117
+    run("BaseDetransformChunkEnumerationTest.*", [] {
+        BaseDetransformChunkEnumeration empty(stream({}), {Chunk{0, 0, 0, 0, 0}});
+        CHECK(!empty.hasMoreElements());
+        const Bytes data = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+        auto in = std::make_shared<ByteArrayInputStream>(data);
+        BaseDetransformChunkEnumeration e(in, {Chunk{0, 0, 3, 0, 3}, Chunk{1, 3, 3, 3, 3}, Chunk{2, 6, 3, 6, 3}});       // extra bytes are ignored
+        CHECK(e.nextElement() == (Bytes{0, 1, 2}) && e.nextElement() == (Bytes{3, 4, 5}) && e.nextElement() == (Bytes{6, 7, 8}));
+        CHECK(!e.hasMoreElements() && in->closed());
+        expectThrows<std::out_of_range>([&] { e.nextElement(); }, nullptr);
+        BaseDetransformChunkEnumeration shortStream(stream({0, 1, 2, 3}), {Chunk{0, 0, 3, 0, 3}, Chunk{1, 3, 3, 3, 3}});
+        CHECK(shortStream.nextElement() == (Bytes{0, 1, 2}));
+        expectThrows<std::runtime_error>([&] { shortStream.hasMoreElements(); }, "Stream has fewer bytes than expected");
+        BaseDetransformChunkEnumeration noChunks(stream(data));                // empty chunk list: everything at once
+        CHECK(noChunks.nextElement() == data && !noChunks.hasMoreElements());
+        BaseDetransformChunkEnumeration raw(stream(data));                     // DetransformFinisherTest.java:28-49: base -> the raw stream
+        CHECK(DetransformFinisher(std::make_shared<BaseDetransformChunkEnumeration>(stream(data))).toBytes() == data);
+    });
+    run("base64 (java.util.Base64 basic alphabet, padding)", [] {
+        CHECK(base64Encode({}) == "" && base64Encode({'f'}) == "Zg==" && base64Encode({'f', 'o'}) == "Zm8=" && base64Encode({'f', 'o', 'o', 'b', 'a', 'r'}) == "Zm9vYmFy");
+        CHECK(base64Decode("Zm9vYmE=") == (Bytes{'f', 'o', 'o', 'b', 'a'}));
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static const Bytes KEY = [] { Bytes k(32); for (int i = 0; i < 32; i++) k[(size_t)i] = (uint8_t)i; return k; }();
+static const Bytes AAD = [] { Bytes k(32); for (int i = 0; i < 32; i++) k[(size_t)i] = (uint8_t)(32 + i); return k; }();
+static IvSupplier countingIv() { auto n = std::make_shared<uint64_t>(0); return [n](uint8_t iv[12]) { memset(iv, 0, 12); uint64_t v = (*n)++; for (int i = 0; i < 8; i++) iv[11 - i] = (uint8_t)(v >> (8 * i)); }; }
+
+struct MemFetcher : ObjectFetcher {
+    Bytes object; int fetches = 0;
+    std::shared_ptr<InputStream> fetch(const std::string&, BytesRange r) override {
+        fetches++;
+        return std::make_shared<ByteArrayInputStream>(Bytes(object.begin() + r.from, object.begin() + r.to + 1));
+    }
+};
+
+static void backendTests(bool full) {
+    auto be = std::make_shared<Backend>(g_lib);
+    printf("  backend: %s\n", be->version().c_str());
+    const int ORIGINAL_SIZE = full ? 1812004 : 70000;
+    const Bytes original = randomBytes((size_t)ORIGINAL_SIZE, 1), text = textBytes((size_t)ORIGINAL_SIZE, 2);
+
+    // CT/transform/TransformsEndToEndTest.java:44-108 — same chunk sizes, all four chains, transform then detransform
+    auto endToEnd = [&](const Bytes& data, int chunkSize, bool compression, bool encryption) {
+        std::shared_ptr<TransformChunkEnumeration> t = std::make_shared<BaseTransformChunkEnumeration>(stream(data), chunkSize);
+        if (compression || encryption)
+            t = std::make_shared<GpuTransformChunkEnumeration>(be, t, compression, encryption ? std::optional<DataKeyAndAAD>(DataKeyAndAAD{KEY, AAD}) : std::nullopt, countingIv(), 16);
+        TransformFinisher tf(t, (int)data.size(), chunkSize != 0);
+        const Bytes uploaded = tf.toBytes();
+        auto index = tf.chunkIndex();
+        CHECK(index->isFixed() == !compression);                                     // TransformFinisherTest.java:97-125: variable iff transformedChunkSize() is null
+        if (encryption && !compression && chunkSize != 0) CHECK(index->chunks()[0].transformedSize == std::min(chunkSize, (int)data.size()) + 28);
+        std::shared_ptr<DetransformChunkEnumeration> d = std::make_shared<BaseDetransformChunkEnumeration>(stream(uploaded), index->chunks());
+        if (compression || encryption)
+            d = std::make_shared<GpuDetransformChunkEnumeration>(be, d, compression, encryption ? std::optional<SegmentEncryptionMetadata>(SegmentEncryptionMetadata{KEY, AAD, IV_SIZE}) : std::nullopt,
+                                                                 chunkSize == 0 ? (int)data.size() : chunkSize, 16);
+        CHECK(DetransformFinisher(d).toBytes() == data);
+    };
+    const int S = ORIGINAL_SIZE;
+    run("TransformsEndToEndTest.plaintext", [&] { for (int c : {0, 1024, 1024 * 2, 1024 * 5 + 3, S - 1, S * 2}) endToEnd(original, c, false, false); });
+    run("TransformsEndToEndTest.encryption", [&] { for (int c : {0, 1024 * 5 + 3, 16384 + 2, S - 1, S * 2}) endToEnd(original, c, false, true); });
+    run("TransformsEndToEndTest.compression", [&] { for (int c : {1024 * 5 + 3, 16384, S - 1, S * 2}) { endToEnd(original, c, true, false); endToEnd(text, c, true, false); } });
+    run("TransformsEndToEndTest.compressionAndEncryption", [&] { for (int c : {1024 * 5 + 3, 16384, S - 1, S * 2}) { endToEnd(original, c, true, true); endToEnd(text, c, true, true); } });
+
+    // CT/transform/EncryptionChunkEnumerationTest.java:79-110, DecryptionChunkEnumerationTest.java:81-95
+    run("EncryptionChunkEnumerationTest.transformedChunkSizePropagation + layout IV||C||TAG", [&] {
+        auto base = std::make_shared<BaseTransformChunkEnumeration>(stream(text), 4096);
+        GpuTransformChunkEnumeration enc(be, base, false, DataKeyAndAAD{KEY, AAD}, countingIv(), 4);
+        CHECK(enc.originalChunkSize() == 4096 && *enc.transformedChunkSize() == 4096 + 12 + 16);
+        GpuTransformChunkEnumeration comp(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), 4096), true, DataKeyAndAAD{KEY, AAD}, countingIv(), 4);
+        CHECK(!comp.transformedChunkSize());                                                         // CompressionChunkEnumeration.java:39-42
+        const Bytes c0 = enc.nextElement(), c1 = enc.nextElement();
+        CHECK(c0.size() == 4096 + 28 && c0[11] == 0 && c1[11] == 1);                                // the IVs of the supplier, in order, in front
+        Bytes exp(orc_chain_bound(4096, 2)); uint32_t crc; uint8_t iv0[12] = {0};
+        Bytes scratch(orc_chain_bound(4096, 1) + 64);
+        const size_t m = orc_transform_chunk(2 /*encrypt*/, KEY.data(), AAD.data(), AAD.size(), iv0, text.data(), 4096, exp.data(), exp.size(), scratch.data(), &crc);
+        exp.resize(m);
+        CHECK(c0 == exp);                                                                            // ciphertext + tag bit-exact vs the oracle
+    });
+    run("full chain bytes == oracle chain (Zstd frame + GCM) for the supplier's IVs", [&] {
+        if (std::string(orc_zstd_version()).rfind("1.5.7", 0) != 0) { printf("    (skipped: libzstd 1.5.7 not available)\n"); return; }
+        const int cs = full ? 1 << 20 : 20000;
+        GpuTransformChunkEnumeration e(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), cs), true, DataKeyAndAAD{KEY, AAD}, countingIv(), 3, true);
+        size_t pos = 0; uint64_t n = 0;
+        while (e.hasMoreElements()) {
+            const Bytes got = e.nextElement();
+            const size_t len = std::min((size_t)cs, text.size() - pos);
+            Bytes exp(orc_chain_bound(len, 7)); uint32_t crc; uint8_t iv[12] = {0}; for (int i = 0; i < 8; i++) iv[11 - i] = (uint8_t)(n >> (8 * i));
+            Bytes scratch(orc_chain_bound(len, 1) + 64);
+            exp.resize(orc_transform_chunk(7 /*compress|encrypt|crc*/, KEY.data(), AAD.data(), AAD.size(), iv, text.data() + pos, len, exp.data(), exp.size(), scratch.data(), &crc));
+            CHECK(got == exp);
+            CHECK(e.crc32cOfOriginalChunks()[n] == crc);
+            pos += len; n++;
+        }
+        CHECK(pos == text.size());
+    });
+    run("DecryptionChunkEnumerationTest: wrong AAD / flipped byte -> \"Tag mismatch\"; earlier chunks still delivered", [&] {
+        GpuTransformChunkEnumeration enc(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), 8192), false, DataKeyAndAAD{KEY, AAD}, countingIv(), 8);
+        TransformFinisher tf(std::shared_ptr<TransformChunkEnumeration>(&enc, [](TransformChunkEnumeration*) {}), (int)text.size());
+        Bytes up = tf.toBytes(); auto index = tf.chunkIndex();
+        up[(size_t)index->chunks()[2].transformedPosition + 100] ^= 1;                              // corrupt chunk 2
+        GpuDetransformChunkEnumeration d(be, std::make_shared<BaseDetransformChunkEnumeration>(stream(up), index->chunks()), false, SegmentEncryptionMetadata{KEY, AAD, 12}, 8192, 8);
+        CHECK(d.nextElement() == Bytes(text.begin(), text.begin() + 8192));
+        CHECK(d.nextElement() == Bytes(text.begin() + 8192, text.begin() + 16384));
+        expectThrows<std::runtime_error>([&] { d.nextElement(); }, "Tag mismatch");
+        Bytes badAad = AAD; badAad[0] ^= 1;
+        GpuDetransformChunkEnumeration d2(be, std::make_shared<BaseDetransformChunkEnumeration>(stream(tf.chunkIndex() ? up : up), index->chunks()), false, SegmentEncryptionMetadata{KEY, badAad, 12}, 8192, 8);
+        expectThrows<std::runtime_error>([&] { d2.nextElement(); }, "Tag mismatch");
+    });
+    run("DecompressionChunkEnumeration: frame without content size -> \"Invalid decompressed size: -1\"", [&] {
+        const Bytes noSize = {0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58, 0x01, 0x00, 0x00};
+        GpuDetransformChunkEnumeration d(be, std::make_shared<BaseDetransformChunkEnumeration>(stream(noSize), std::vector<Chunk>{Chunk{0, 0, 16, 0, 9}}), true, std::nullopt, 16, 1);
+        expectThrows<std::runtime_error>([&] { d.nextElement(); }, "Invalid decompressed size: -1");
+    });
+    // CT/manifest/index/ChunkIndexSerializationTest.java:39-123 — the reference's only golden Zstd frame
+    run("ChunkIndexSerializationTest: ENCODED_CHUNKS + JSON of both index kinds", [&] {
+        CHECK(serializeTransformedChunks(*be, {10, 20, 30}) == "KLUv/SAPeQAAAAAAAwAAAAoBAAoAAAAe");
+        CHECK((deserializeTransformedChunks(*be, "KLUv/SAPeQAAAAAAAwAAAAoBAAoAAAAe") == std::vector<int>{10, 20, 30}));
+        FixedSizeChunkIndex fixed(100, 250, 110, 30);
+        CHECK(chunkIndexToJson(*be, fixed) == "{\"type\":\"fixed\",\"originalChunkSize\":100,\"originalFileSize\":250,\"transformedChunkSize\":110,\"finalTransformedChunkSize\":30}");
+        VariableSizeChunkIndex var(100, 250, {10, 20, 30});
+        const std::string vj = "{\"type\":\"variable\",\"originalChunkSize\":100,\"originalFileSize\":250,\"transformedChunks\":\"KLUv/SAPeQAAAAAAAwAAAAoBAAoAAAAe\"}";
+        CHECK(chunkIndexToJson(*be, var) == vj);
+        CHECK((chunkIndexFromJson(*be, vj)->chunks() == std::vector<Chunk>{{0, 0, 100, 0, 10}, {1, 100, 100, 10, 20}, {2, 200, 50, 30, 30}}));
+        CHECK((chunkIndexFromJson(*be, chunkIndexToJson(*be, fixed))->chunks() == std::vector<Chunk>{{0, 0, 100, 0, 110}, {1, 100, 100, 110, 110}, {2, 200, 50, 220, 30}}));
+        std::vector<int> many; std::mt19937 r(5); for (int i = 0; i < 2000; i++) many.push_back(1000000 + (int)(r() % 300));      // README.md:162-170 sized index
+        CHECK(deserializeTransformedChunks(*be, serializeTransformedChunks(*be, many)) == many);
+    });
+    // C/fetch/DefaultChunkManager.java:50-70 — every chunk by id through GpuChunkManager, and a prefetch window in one batch
+    run("ChunkManager.getChunk / getChunks over an uploaded object", [&] {
+        const int cs = 16384;
+        GpuTransformChunkEnumeration t(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), cs), true, DataKeyAndAAD{KEY, AAD}, countingIv(), 32);
+        TransformFinisher tf(std::shared_ptr<TransformChunkEnumeration>(&t, [](TransformChunkEnumeration*) {}), (int)text.size());
+        auto fetcher = std::make_shared<MemFetcher>(); fetcher->object = tf.toBytes();
+        SegmentManifest m; m.chunkIndex = tf.chunkIndex(); m.compression = true; m.encryption = SegmentEncryptionMetadata{KEY, AAD, 12};
+        GpuChunkManager cm(be, fetcher);
+        const auto& chunks = m.chunkIndex->chunks();
+        for (int id : {0, 1, (int)chunks.size() / 2, (int)chunks.size() - 1}) {
+            const Chunk& c = chunks[(size_t)id];
+            CHECK(cm.getChunk("k.log", m, id) == Bytes(text.begin() + c.originalPosition, text.begin() + c.originalPosition + c.originalSize));
+        }
+        fetcher->fetches = 0;
+        const auto win = cm.getChunks("k.log", m, 1, 4);                                              // 4-chunk prefetch window: one ranged fetch, one batch
+        CHECK(fetcher->fetches == 1 && win.size() == 4);
+        for (int k = 0; k < 4; k++) { const Chunk& c = chunks[(size_t)(1 + k)]; CHECK(win[(size_t)k] == Bytes(text.begin() + c.originalPosition, text.begin() + c.originalPosition + c.originalSize)); }
+    });
+}
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    if (argc < 2) { printf("usage: host_tests cpu | backend <libtsxform path> [full]\n"); return 2; }
+    if (std::string(argv[1]) == "cpu") cpuTests();
+    else { if (argc < 3) return 2; g_lib = argv[2]; try { backendTests(argc > 3 && std::string(argv[3]) == "full"); } catch (const std::exception& e) { printf("  FAIL backend: %s\n", e.what()); g_failed++; } }
+    printf("%d run, %d failed\n", g_run, g_failed);
+    return g_failed ? 1 : 0;
+}

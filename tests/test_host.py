@@ -1,0 +1,43 @@
+"""Host layer above the C ABI (tiered-storage-for-apache-kafka_amd/host, C++ mirror of the reference's Java interfaces):
+tests/host/host_tests.cpp restates the reference's JUnit tests; this module builds and runs it.
+  cpu     : chunking, chunk-index builders, binary codec, finishers - no device library
+  backend : Transform/Detransform enumerations, index serde (golden frame), ChunkManager through a libtsxform build -
+            the emulated kernels here (CPU), the real library under -m gpu."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_DIR = os.path.join(ROOT, "tests", "host")
+BIN = os.path.join(HOST_DIR, "_build", "host_tests")
+
+
+@pytest.fixture(scope="module")
+def host_tests(oracle):
+    subprocess.check_call(["make", "-s", "-C", HOST_DIR])
+    return BIN
+
+
+def _run(args, env=None):
+    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=1500)
+    assert p.returncode == 0 and " 0 failed" in p.stdout, p.stdout[-4000:]
+    return p.stdout
+
+
+def test_host_logic_matches_reference_tests(host_tests):
+    out = _run([host_tests, "cpu"])
+    assert "FixedSizeChunkIndexBuilderTest.threeChunks" in out and "ChunkSizesBinaryCodecTest" in out
+
+
+def test_host_chain_over_emulated_kernels(host_tests, emu):
+    from tests.emu import emu_native
+    out = _run([host_tests, "backend", emu_native.EMU_LIB], env=dict(os.environ, TSX_ALLOW_ANY_ARCH="1"))
+    assert "ChunkIndexSerializationTest" in out and "TransformsEndToEndTest.compressionAndEncryption" in out
+
+
+@pytest.mark.gpu
+def test_host_chain_on_gpu(host_tests):
+    import tsxform
+    out = _run([host_tests, "backend", tsxform._native.LIB_PATH, "full"])
+    assert "gfx950" in out and "ChunkManager.getChunk" in out

@@ -1,0 +1,590 @@
+// tsxhost — see tsxhost.hpp.  Host logic only: every byte of compression / encryption / checksum is computed by
+// libtsxform.so on the GPU (there is no CPU fallback here either: a missing library or device throws).
+#include "tsxhost.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace tsx {
+
+// =====================================================================================================
+// chunk index (manifest/index/*.java)
+// =====================================================================================================
+static void checkSizeNonNegative(int size, const char* name) {
+    if (size < 0) throw std::invalid_argument(std::string(name) + " must be non-negative, " + std::to_string(size) + " given");
+}
+static void checkSizePositive(int size, const char* name) {
+    if (size <= 0) throw std::invalid_argument(std::string(name) + " must be positive, " + std::to_string(size) + " given");
+}
+
+ChunkIndex::ChunkIndex(int originalChunkSize, int originalFileSize, int finalTransformedChunkSize, int chunkCount)
+    : originalChunkSize_(originalChunkSize), originalFileSize_(originalFileSize), finalTransformedChunkSize_(finalTransformedChunkSize),
+      chunkCount_(chunkCount) {
+    checkSizePositive(originalChunkSize, "Original chunk size");
+    checkSizeNonNegative(originalFileSize, "Original file size");
+    checkSizeNonNegative(finalTransformedChunkSize, "Final transformed chunk size");
+}
+
+int ChunkIndex::originalChunkSizeOf(int chunkI) const {
+    const bool isFinalChunk = chunkI == chunkCount_ - 1;
+    return isFinalChunk ? (originalFileSize_ - (chunkCount_ - 1) * originalChunkSize_) : originalChunkSize_;
+}
+
+void ChunkIndex::materializeChunks() {                       // AbstractChunkIndex.java:52-72
+    chunks_.clear();
+    int originalPosition = 0, transformedPosition = 0;
+    if (chunkCount_ == 0) {
+        chunks_.push_back(Chunk{0, 0, 0, 0, 0});
+        return;
+    }
+    for (int chunkI = 0; chunkI < chunkCount_; chunkI++) {
+        const int originalSize = originalChunkSizeOf(chunkI), transformedSize = transformedChunkSize(chunkI);
+        chunks_.push_back(Chunk{chunkI, originalPosition, originalSize, transformedPosition, transformedSize});
+        originalPosition += originalSize;
+        transformedPosition += transformedSize;
+    }
+}
+
+std::optional<Chunk> ChunkIndex::findChunkForOriginalOffset(int offset) const {      // AbstractChunkIndex.java:75-110
+    if (offset < 0) throw std::invalid_argument("Offset must be non-negative, " + std::to_string(offset) + " given");
+    if (offset >= originalFileSize_) return std::nullopt;
+    int chunkI = 0, curOriginalChunkPosition = 0, curTransformedChunkPosition = 0;
+    for (; chunkI < chunkCount_; chunkI++) {
+        const int firstOffsetBeyondCurOriginalChunk = (chunkI + 1) * originalChunkSize_;
+        if (offset < firstOffsetBeyondCurOriginalChunk) break;
+        curOriginalChunkPosition += originalChunkSizeOf(chunkI);
+        curTransformedChunkPosition += transformedChunkSize(chunkI);
+    }
+    return Chunk{chunkI, curOriginalChunkPosition, originalChunkSizeOf(chunkI), curTransformedChunkPosition, transformedChunkSize(chunkI)};
+}
+
+std::vector<Chunk> ChunkIndex::chunksForRange(BytesRange r) const {                  // AbstractChunkIndex.java:113-123
+    std::vector<Chunk> result;
+    for (int i = r.from; i <= r.to && i < originalFileSize_;) {
+        const Chunk c = *findChunkForOriginalOffset(i);
+        result.push_back(c);
+        i += c.originalSize;
+    }
+    return result;
+}
+
+static int fixedChunkCount(int originalChunkSize, int originalFileSize) {
+    checkSizePositive(originalChunkSize, "Original chunk size");
+    return originalFileSize % originalChunkSize == 0 ? originalFileSize / originalChunkSize : originalFileSize / originalChunkSize + 1;
+}
+
+FixedSizeChunkIndex::FixedSizeChunkIndex(int originalChunkSize, int originalFileSize, int transformedChunkSize, int finalTransformedChunkSize)
+    : ChunkIndex(originalChunkSize, originalFileSize, finalTransformedChunkSize, fixedChunkCount(originalChunkSize, originalFileSize)),
+      transformedChunkSize_(transformedChunkSize) {
+    checkSizeNonNegative(transformedChunkSize, "Transformed chunk size");
+    materializeChunks();
+}
+
+VariableSizeChunkIndex::VariableSizeChunkIndex(int originalChunkSize, int originalFileSize, std::vector<int> transformedChunks)
+    : ChunkIndex(originalChunkSize, originalFileSize, transformedChunks.empty() ? 0 : transformedChunks.back(), (int)transformedChunks.size()),
+      transformedChunks_(std::move(transformedChunks)) {
+    materializeChunks();
+}
+
+AbstractChunkIndexBuilder::AbstractChunkIndexBuilder(int originalChunkSize, int originalFileSize) {
+    checkSize(originalChunkSize, "Original chunk size");
+    originalChunkSize_ = originalChunkSize;
+    checkSize(originalFileSize, "Original file size");
+    originalFileSize_ = originalFileSize;
+}
+void AbstractChunkIndexBuilder::checkSize(int size, const char* name) { checkSizeNonNegative(size, name); }
+
+void AbstractChunkIndexBuilder::addChunk(int transformedChunkSize) {                 // AbstractChunkIndexBuilder.java:39-55
+    if (finished_) throw std::logic_error("Cannot add chunk to already finished index");
+    checkSize(transformedChunkSize, "Transformed chunk size");
+    if (remainOfOriginalFileSize() <= originalChunkSize_) throw std::logic_error("This must be final chunk. Call `finish` instead.");
+    addChunk0(transformedChunkSize);
+    chunksAdded_ += 1;
+}
+
+std::shared_ptr<ChunkIndex> AbstractChunkIndexBuilder::finish(int finalTransformedChunkSize) {     // :63-83
+    if (finished_) throw std::logic_error("Cannot finish already finished index");
+    checkSize(finalTransformedChunkSize, "Transformed chunk size");
+    if (remainOfOriginalFileSize() > originalChunkSize_)
+        throw std::logic_error("This cannot be final chunk: not enough chunks to cover original file. Call `addChunk` instead.");
+    auto result = finish0(finalTransformedChunkSize);
+    chunksAdded_ += 1;
+    finished_ = true;
+    return result;
+}
+
+FixedSizeChunkIndexBuilder::FixedSizeChunkIndexBuilder(int originalChunkSize, int originalFileSize, int transformedChunkSize)
+    : AbstractChunkIndexBuilder(originalChunkSize, originalFileSize) {
+    checkSize(transformedChunkSize, "Transformed chunk size");
+    transformedChunkSize_ = transformedChunkSize;
+}
+void FixedSizeChunkIndexBuilder::addChunk0(int transformedChunkSize) {               // FixedSizeChunkIndexBuilder.java:31-38
+    if (transformedChunkSize != transformedChunkSize_)
+        throw std::invalid_argument("Non-final chunk must be of size " + std::to_string(transformedChunkSize_) + ", but " +
+                                    std::to_string(transformedChunkSize) + " given");
+}
+std::shared_ptr<ChunkIndex> FixedSizeChunkIndexBuilder::finish0(int finalTransformedChunkSize) {
+    return std::make_shared<FixedSizeChunkIndex>(originalChunkSize_, originalFileSize_, transformedChunkSize_, finalTransformedChunkSize);
+}
+std::shared_ptr<ChunkIndex> VariableSizeChunkIndexBuilder::finish0(int finalTransformedChunkSize) {
+    transformedChunks_.push_back(finalTransformedChunkSize);
+    return std::make_shared<VariableSizeChunkIndex>(originalChunkSize_, originalFileSize_, transformedChunks_);
+}
+
+// ---- ChunkSizesBinaryCodec.java:104-202 (big-endian) ------------------------------------------------------
+static void putInt(Bytes& b, uint32_t v) { for (int s = 24; s >= 0; s -= 8) b.push_back((uint8_t)(v >> s)); }
+static uint32_t getInt(const Bytes& b, size_t& pos) {
+    if (pos + 4 > b.size()) throw std::runtime_error("BufferUnderflowException");
+    uint32_t v = ((uint32_t)b[pos] << 24) | ((uint32_t)b[pos + 1] << 16) | ((uint32_t)b[pos + 2] << 8) | b[pos + 3];
+    pos += 4;
+    return v;
+}
+static int bytesNeeded(int v) { return v <= 0xFF ? 1 : v <= 0xFFFF ? 2 : v <= 0xFFFFFF ? 3 : 4; }
+
+Bytes ChunkSizesBinaryCodec::encode(const std::vector<int>& values) {
+    Bytes out;
+    const int count = (int)values.size();
+    putInt(out, (uint32_t)count);
+    if (count == 0) return out;
+    const int lastValue = values.back();
+    if (count == 1) {
+        if (lastValue < 0) throw std::invalid_argument("Values cannot be negative");
+        putInt(out, (uint32_t)lastValue);
+        return out;
+    }
+    const int min = *std::min_element(values.begin(), values.end() - 1);
+    if (min < 0 || lastValue < 0) throw std::invalid_argument("Values cannot be negative");
+    const int base = min;
+    int bytesPerValue = 0;
+    for (int i = 0; i < count - 1; i++) bytesPerValue = std::max(bytesPerValue, bytesNeeded(values[(size_t)i] - base));
+    putInt(out, (uint32_t)base);
+    out.push_back((uint8_t)bytesPerValue);
+    for (int i = 0; i < count - 1; i++) {
+        const uint32_t onBase = (uint32_t)(values[(size_t)i] - base);
+        for (int s = 8 * (bytesPerValue - 1); s >= 0; s -= 8) out.push_back((uint8_t)(onBase >> s));
+    }
+    putInt(out, (uint32_t)lastValue);
+    return out;
+}
+
+std::vector<int> ChunkSizesBinaryCodec::decode(const Bytes& a) {
+    size_t pos = 0;
+    const int count = (int)getInt(a, pos);
+    if (count == 0) return {};
+    if (count == 1) return {(int)getInt(a, pos)};
+    std::vector<int> result;
+    const int base = (int)getInt(a, pos);
+    if (pos >= a.size()) throw std::runtime_error("BufferUnderflowException");
+    const int bytesPerValue = a[pos++];
+    for (int i = 0; i < count - 1; i++) {
+        if (pos + (size_t)bytesPerValue > a.size()) throw std::runtime_error("BufferUnderflowException");
+        uint32_t v = 0;
+        for (int k = 0; k < bytesPerValue; k++) v = (v << 8) | a[pos++];
+        result.push_back((int)v + base);
+    }
+    result.push_back((int)getInt(a, pos));
+    return result;
+}
+
+static const char kB64[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+std::string base64Encode(const Bytes& b) {
+    std::string s;
+    size_t i = 0;
+    for (; i + 2 < b.size(); i += 3) {
+        const uint32_t v = ((uint32_t)b[i] << 16) | ((uint32_t)b[i + 1] << 8) | b[i + 2];
+        s += kB64[v >> 18]; s += kB64[(v >> 12) & 63]; s += kB64[(v >> 6) & 63]; s += kB64[v & 63];
+    }
+    if (i + 1 == b.size()) { const uint32_t v = (uint32_t)b[i] << 16; s += kB64[v >> 18]; s += kB64[(v >> 12) & 63]; s += "=="; }
+    else if (i + 2 == b.size()) { const uint32_t v = ((uint32_t)b[i] << 16) | ((uint32_t)b[i + 1] << 8); s += kB64[v >> 18]; s += kB64[(v >> 12) & 63]; s += kB64[(v >> 6) & 63]; s += '='; }
+    return s;
+}
+Bytes base64Decode(const std::string& s) {
+    Bytes out; uint32_t acc = 0; int bits = 0;
+    for (char c : s) {
+        if (c == '=') break;
+        const char* p = strchr(kB64, c);
+        if (!p || !c) throw std::invalid_argument("Illegal base64 character");
+        acc = (acc << 6) | (uint32_t)(p - kB64); bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+    }
+    return out;
+}
+
+// =====================================================================================================
+// Backend: libtsxform.so through its C ABI
+// =====================================================================================================
+struct Backend::Fns {
+    decltype(&tsx_init) init; decltype(&tsx_ctx_create) ctx_create; decltype(&tsx_ctx_destroy) ctx_destroy;
+    decltype(&tsx_transform_batch) transform; decltype(&tsx_detransform_batch) detransform;
+    decltype(&tsx_transformed_bound) bound; decltype(&tsx_strerror) strerr; decltype(&tsx_version) version; decltype(&tsx_abi_version) abi;
+};
+
+Backend::Backend(const std::string& libPath, int deviceIndex) : f_(new Fns) {
+    handle_ = dlopen(libPath.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!handle_) throw std::runtime_error("tsxhost: cannot load " + libPath + ": " + dlerror() + " (there is no CPU fallback)");
+    auto sym = [&](const char* n) { void* p = dlsym(handle_, n); if (!p) throw std::runtime_error(std::string("tsxhost: missing symbol ") + n); return p; };
+    f_->init = (decltype(f_->init))sym("tsx_init"); f_->ctx_create = (decltype(f_->ctx_create))sym("tsx_ctx_create");
+    f_->ctx_destroy = (decltype(f_->ctx_destroy))sym("tsx_ctx_destroy"); f_->transform = (decltype(f_->transform))sym("tsx_transform_batch");
+    f_->detransform = (decltype(f_->detransform))sym("tsx_detransform_batch"); f_->bound = (decltype(f_->bound))sym("tsx_transformed_bound");
+    f_->strerr = (decltype(f_->strerr))sym("tsx_strerror"); f_->version = (decltype(f_->version))sym("tsx_version");
+    f_->abi = (decltype(f_->abi))sym("tsx_abi_version");
+    if (f_->abi() != TSX_ABI_VERSION) throw std::runtime_error("tsxhost: ABI version mismatch");
+    const int n = f_->init(0, nullptr);
+    if (n <= 0) throw std::runtime_error(std::string("tsxhost: tsx_init failed: ") + f_->strerr(n));
+    const int rc = f_->ctx_create(deviceIndex, 0, 0, &ctx_);
+    if (rc) throw std::runtime_error(std::string("tsxhost: tsx_ctx_create failed: ") + f_->strerr(rc));
+}
+Backend::~Backend() {
+    if (ctx_) f_->ctx_destroy(ctx_);
+    // the library stays loaded: other Backends of the process share its device state
+}
+void Backend::transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
+    const int rc = f_->transform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
+    if (rc) throw std::runtime_error(std::string("tsx_transform_batch: ") + f_->strerr(rc));
+}
+void Backend::detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
+    const int rc = f_->detransform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
+    if (rc) throw std::runtime_error(std::string("tsx_detransform_batch: ") + f_->strerr(rc));
+}
+size_t Backend::transformedBound(size_t n, uint32_t flags) const { return f_->bound(n, flags); }
+std::string Backend::strerror(int code) const { return f_->strerr(code); }
+std::string Backend::version() const { return f_->version(); }
+
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+static tsx_batch_params makeParams(uint32_t flags, const Bytes* key, const Bytes* aad, uint32_t profile) {
+    tsx_batch_params p;
+    memset(&p, 0, sizeof p);
+    p.flags = flags;
+    p.zstd_level = 0;
+    p.zstd_profile = profile;
+    if (flags & TSX_ENCRYPT) {
+        if (!key || key->size() != 32) throw std::invalid_argument("AES-256 data key must be 32 bytes");
+        if (aad && aad->size() > sizeof p.aad) throw std::invalid_argument("AAD longer than 64 bytes");
+        memcpy(p.key, key->data(), 32);
+        if (aad) { memcpy(p.aad, aad->data(), aad->size()); p.aad_len = (uint32_t)aad->size(); }
+    }
+    return p;
+}
+
+// Zstd frame header (RFC 8878 3.1.1.1): content size, -1 unknown / not a frame  (Zstd.decompressedSize)
+static long long zstdFrameContentSize(const Bytes& f) {
+    if (f.size() < 5 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD) return -1;
+    const uint8_t fhd = f[4];
+    const int fcsFlag = fhd >> 6, single = (fhd >> 5) & 1, dictFlag = fhd & 3;
+    size_t pos = 5 + (single ? 0 : 1) + (dictFlag == 0 ? 0 : dictFlag == 1 ? 1 : dictFlag == 2 ? 2 : 4);
+    const int fcsBytes = fcsFlag == 0 ? (single ? 1 : 0) : fcsFlag == 1 ? 2 : fcsFlag == 2 ? 4 : 8;
+    if (fcsBytes == 0 || pos + (size_t)fcsBytes > f.size()) return -1;
+    unsigned long long v = 0;
+    for (int i = 0; i < fcsBytes; i++) v |= (unsigned long long)f[pos + (size_t)i] << (8 * i);
+    if (fcsBytes == 2) v += 256;
+    return (long long)v;
+}
+
+std::string serializeTransformedChunks(Backend& be, const std::vector<int>& values, uint32_t profile) {
+    const Bytes bin = ChunkSizesBinaryCodec::encode(values);
+    if (bin.size() > 10u * 1024 * 1024) throw std::invalid_argument("Encoded index is too big (" + std::to_string(bin.size()) + "), cannot serialize");
+    Bytes src(align16(bin.size()) + 16);
+    memcpy(src.data(), bin.data(), bin.size());
+    const size_t cap = be.transformedBound(bin.size(), TSX_COMPRESS);
+    Bytes dst(align16(cap) + 16);
+    std::vector<tsx_chunk_desc> d(1);
+    memset(d.data(), 0, sizeof(tsx_chunk_desc));
+    d[0].src_len = (uint32_t)bin.size(); d[0].dst_cap = (uint32_t)cap;
+    const tsx_batch_params p = makeParams(TSX_COMPRESS, nullptr, nullptr, profile);
+    be.transformBatch(p, d, src.data(), dst.data(), dst.size());
+    if (d[0].status != TSX_OK) throw std::runtime_error("index compression failed: " + be.strerror(d[0].status));
+    dst.resize(d[0].dst_len);
+    return base64Encode(dst);
+}
+
+std::vector<int> deserializeTransformedChunks(Backend& be, const std::string& base64) {
+    const Bytes frame = base64Decode(base64);
+    const long long size = zstdFrameContentSize(frame);
+    if (size < 0 || size > 10ll * 1024 * 1024) throw std::runtime_error("Invalid decompressed size: " + std::to_string(size));
+    Bytes src(align16(frame.size()) + 16);
+    memcpy(src.data(), frame.data(), frame.size());
+    Bytes dst(align16((size_t)size) + 16);
+    std::vector<tsx_chunk_desc> d(1);
+    memset(d.data(), 0, sizeof(tsx_chunk_desc));
+    d[0].src_len = (uint32_t)frame.size(); d[0].dst_cap = (uint32_t)size;
+    const tsx_batch_params p = makeParams(TSX_COMPRESS, nullptr, nullptr, TSX_ZSTD_PROFILE_1_5_7);
+    be.detransformBatch(p, d, src.data(), dst.data(), dst.size());
+    if (d[0].status != TSX_OK) throw std::runtime_error("index decompression failed: " + be.strerror(d[0].status));
+    dst.resize(d[0].dst_len);
+    return ChunkSizesBinaryCodec::decode(dst);
+}
+
+std::string chunkIndexToJson(Backend& be, const ChunkIndex& index) {
+    std::string j = "{\"type\":\"";
+    j += index.isFixed() ? "fixed" : "variable";
+    j += "\",\"originalChunkSize\":" + std::to_string(index.originalChunkSize()) + ",\"originalFileSize\":" + std::to_string(index.originalFileSize());
+    if (index.isFixed()) {
+        const auto& f = static_cast<const FixedSizeChunkIndex&>(index);
+        j += ",\"transformedChunkSize\":" + std::to_string(f.transformedChunkSize()) + ",\"finalTransformedChunkSize\":" + std::to_string(f.finalTransformedChunkSize());
+    } else {
+        j += ",\"transformedChunks\":\"" + serializeTransformedChunks(be, static_cast<const VariableSizeChunkIndex&>(index).transformedChunks()) + "\"";
+    }
+    return j + "}";
+}
+
+static std::string jsonField(const std::string& json, const std::string& name) {      // flat object, no escapes in the values we read
+    const std::string key = "\"" + name + "\":";
+    const size_t k = json.find(key);
+    if (k == std::string::npos) throw std::invalid_argument("Missing required creator property '" + name + "'");
+    size_t b = k + key.size(), e;
+    if (json[b] == '"') { b++; e = json.find('"', b); }
+    else e = json.find_first_of(",}", b);
+    if (e == std::string::npos) throw std::invalid_argument("malformed JSON");
+    return json.substr(b, e - b);
+}
+
+std::shared_ptr<ChunkIndex> chunkIndexFromJson(Backend& be, const std::string& json) {
+    const std::string type = jsonField(json, "type");
+    const int ocs = std::stoi(jsonField(json, "originalChunkSize")), ofs = std::stoi(jsonField(json, "originalFileSize"));
+    if (type == "fixed")
+        return std::make_shared<FixedSizeChunkIndex>(ocs, ofs, std::stoi(jsonField(json, "transformedChunkSize")), std::stoi(jsonField(json, "finalTransformedChunkSize")));
+    if (type == "variable") return std::make_shared<VariableSizeChunkIndex>(ocs, ofs, deserializeTransformedChunks(be, jsonField(json, "transformedChunks")));
+    throw std::invalid_argument("Could not resolve type id '" + type + "'");
+}
+
+// =====================================================================================================
+// streams, IVs
+// =====================================================================================================
+Bytes ByteArrayInputStream::readNBytes(size_t n) {
+    const size_t m = std::min(n, data_.size() - pos_);
+    Bytes out(data_.begin() + (long)pos_, data_.begin() + (long)(pos_ + m));
+    pos_ += m;
+    return out;
+}
+Bytes ByteArrayInputStream::readAllBytes() { return readNBytes(data_.size() - pos_); }
+
+IvSupplier secureRandomIvSupplier() {
+    return [](uint8_t iv[IV_SIZE]) {
+        FILE* f = fopen("/dev/urandom", "rb");
+        if (!f || fread(iv, 1, IV_SIZE, f) != IV_SIZE) { if (f) fclose(f); throw std::runtime_error("cannot read /dev/urandom"); }
+        fclose(f);
+    };
+}
+
+// =====================================================================================================
+// upload side
+// =====================================================================================================
+BaseTransformChunkEnumeration::BaseTransformChunkEnumeration(std::shared_ptr<InputStream> in, int originalChunkSize) : in_(std::move(in)) {
+    if (!in_) throw std::invalid_argument("inputStream cannot be null");
+    if (originalChunkSize < 0) throw std::invalid_argument("originalChunkSize must be non-negative, " + std::to_string(originalChunkSize) + " given");
+    originalChunkSize_ = originalChunkSize;
+}
+void BaseTransformChunkEnumeration::fillChunkIfNeeded() {                            // BaseTransformChunkEnumeration.java:79-93
+    if (chunk_) return;
+    chunk_ = originalChunkSize_ != 0 ? in_->readNBytes((size_t)originalChunkSize_) : in_->readAllBytes();
+}
+bool BaseTransformChunkEnumeration::hasMoreElements() { fillChunkIfNeeded(); return !chunk_->empty(); }
+Bytes BaseTransformChunkEnumeration::nextElement() {
+    fillChunkIfNeeded();
+    if (chunk_->empty()) throw std::out_of_range("NoSuchElementException");
+    Bytes r = std::move(*chunk_);
+    chunk_.reset();
+    return r;
+}
+
+GpuTransformChunkEnumeration::GpuTransformChunkEnumeration(std::shared_ptr<Backend> be, std::shared_ptr<TransformChunkEnumeration> inner, bool compress,
+                                                           std::optional<DataKeyAndAAD> enc, IvSupplier iv, int batchChunks, bool withCrc, uint32_t profile)
+    : be_(std::move(be)), inner_(std::move(inner)), compress_(compress), enc_(std::move(enc)), iv_(std::move(iv)), batch_(batchChunks), withCrc_(withCrc),
+      profile_(profile) {
+    if (!inner_) throw std::invalid_argument("inner cannot be null");
+    if (batch_ < 1) throw std::invalid_argument("batchChunks must be positive");
+    if (enc_ && enc_->dataKey.size() != 32) throw std::invalid_argument("AES-256 data key must be 32 bytes");
+    // CompressionChunkEnumeration.java:39-42 (null) then EncryptionChunkEnumeration.java:41-47 (inner + ivSize + getOutputSize)
+    const std::optional<int> innerSize = inner_->transformedChunkSize();
+    if (compress_ || !innerSize) transformedChunkSize_ = std::nullopt;
+    else transformedChunkSize_ = enc_ ? *innerSize + IV_SIZE + GCM_TAG_BYTES : *innerSize;
+}
+
+void GpuTransformChunkEnumeration::fillBatchIfNeeded() {
+    if (next_ < ready_.size()) return;
+    ready_.clear(); next_ = 0;
+    std::vector<Bytes> in;
+    while ((int)in.size() < batch_ && inner_->hasMoreElements()) in.push_back(inner_->nextElement());
+    if (in.empty()) return;
+    const uint32_t flags = (compress_ ? TSX_COMPRESS : 0u) | (enc_ ? TSX_ENCRYPT : 0u) | (withCrc_ ? TSX_CRC : 0u);
+    if ((flags & (TSX_COMPRESS | TSX_ENCRYPT)) == 0 && !withCrc_) { ready_ = std::move(in); return; }     // pure base: nothing to do
+    std::vector<tsx_chunk_desc> d(in.size());
+    size_t so = 0, dofs = 0;
+    for (size_t i = 0; i < in.size(); i++) {
+        memset(&d[i], 0, sizeof d[i]);
+        d[i].src_off = so; d[i].src_len = (uint32_t)in[i].size(); so += align16(in[i].size()) + 16;
+        const size_t cap = be_->transformedBound(in[i].size(), flags);
+        d[i].dst_off = dofs; d[i].dst_cap = (uint32_t)cap; dofs += align16(cap) + 16;
+        if (enc_) iv_(d[i].iv);
+    }
+    Bytes src(so + 16), dst(dofs + 16);
+    for (size_t i = 0; i < in.size(); i++) memcpy(src.data() + d[i].src_off, in[i].data(), in[i].size());
+    const tsx_batch_params p = makeParams(flags, enc_ ? &enc_->dataKey : nullptr, enc_ ? &enc_->aad : nullptr, profile_);
+    be_->transformBatch(p, d, src.data(), dst.data(), dst.size());
+    for (size_t i = 0; i < in.size(); i++) {
+        if (d[i].status != TSX_OK) throw std::runtime_error(be_->strerror(d[i].status));        // the reference wraps crypto failures in RuntimeException
+        if (withCrc_) crcs_.push_back(d[i].crc32c);
+        ready_.emplace_back(dst.begin() + (long)d[i].dst_off, dst.begin() + (long)(d[i].dst_off + d[i].dst_len));
+    }
+}
+bool GpuTransformChunkEnumeration::hasMoreElements() { fillBatchIfNeeded(); return next_ < ready_.size(); }
+Bytes GpuTransformChunkEnumeration::nextElement() {
+    fillBatchIfNeeded();
+    if (next_ >= ready_.size()) throw std::out_of_range("NoSuchElementException");
+    return std::move(ready_[next_++]);
+}
+
+TransformFinisher::TransformFinisher(std::shared_ptr<TransformChunkEnumeration> inner, int originalFileSize, bool chunkingEnabled)
+    : inner_(std::move(inner)), originalFileSize_(originalFileSize) {
+    if (!inner_) throw std::invalid_argument("inner cannot be null");
+    if (originalFileSize < 0) throw std::invalid_argument("originalFileSize must be non-negative, " + std::to_string(originalFileSize) + " given");
+    const int originalChunkSize = chunkingEnabled ? inner_->originalChunkSize() : originalFileSize;      // TransformFinisher.java:68
+    const std::optional<int> t = inner_->transformedChunkSize();                                          // :75-93
+    if (!t) builder_.reset(new VariableSizeChunkIndexBuilder(originalChunkSize, originalFileSize));
+    else builder_.reset(new FixedSizeChunkIndexBuilder(originalChunkSize, originalFileSize, *t));
+}
+bool TransformFinisher::isBaseTransform() const { return dynamic_cast<BaseTransformChunkEnumeration*>(inner_.get()) != nullptr; }
+Bytes TransformFinisher::nextElement() {                                              // TransformFinisher.java:101-110
+    Bytes chunk = inner_->nextElement();
+    if (hasMoreElements()) builder_->addChunk((int)chunk.size());
+    else chunkIndex_ = builder_->finish((int)chunk.size());
+    return chunk;
+}
+std::shared_ptr<ChunkIndex> TransformFinisher::chunkIndex() {                          // :112-132
+    if (!chunkIndex_) {
+        if (!isBaseTransform()) throw std::logic_error("Chunk index was not built, was finisher used?");
+        const int chunkSize = *inner_->transformedChunkSize();
+        int size = originalFileSize_;
+        while (size > chunkSize) { builder_->addChunk(chunkSize); size -= chunkSize; }
+        chunkIndex_ = builder_->finish(size);
+    }
+    return chunkIndex_;
+}
+Bytes TransformFinisher::toBytes() {
+    Bytes out;
+    while (hasMoreElements()) { const Bytes c = nextElement(); out.insert(out.end(), c.begin(), c.end()); }
+    return out;
+}
+
+// =====================================================================================================
+// fetch side
+// =====================================================================================================
+BaseDetransformChunkEnumeration::BaseDetransformChunkEnumeration(std::shared_ptr<InputStream> in) : in_(std::move(in)), isEmpty_(true) {
+    if (!in_) throw std::invalid_argument("inputStream cannot be null");
+}
+BaseDetransformChunkEnumeration::BaseDetransformChunkEnumeration(std::shared_ptr<InputStream> in, std::vector<Chunk> chunks)
+    : in_(std::move(in)), chunks_(std::move(chunks)), isEmpty_(chunks_.empty()) {
+    if (!in_) throw std::invalid_argument("inputStream cannot be null");
+}
+void BaseDetransformChunkEnumeration::fillChunkIfNeeded() {                            // BaseDetransformChunkEnumeration.java:78-115
+    if (chunk_) return;
+    if (iter_ >= chunks_.size() && !isEmpty_) {
+        chunk_ = Bytes{};
+        if (!inputStreamClosed_) { in_->close(); inputStreamClosed_ = true; }
+        return;
+    }
+    if (inputStreamClosed_) throw std::runtime_error("Input stream already closed");
+    if (!isEmpty_) {
+        const int expected = chunks_[iter_++].transformedSize;
+        chunk_ = in_->readNBytes((size_t)expected);
+        if ((int)chunk_->size() < expected) throw std::runtime_error("Stream has fewer bytes than expected");
+    } else {
+        chunk_ = in_->readAllBytes();
+    }
+}
+bool BaseDetransformChunkEnumeration::hasMoreElements() { fillChunkIfNeeded(); return !chunk_->empty(); }
+Bytes BaseDetransformChunkEnumeration::nextElement() {
+    fillChunkIfNeeded();
+    if (chunk_->empty()) throw std::out_of_range("NoSuchElementException");
+    Bytes r = std::move(*chunk_);
+    chunk_.reset();
+    return r;
+}
+
+GpuDetransformChunkEnumeration::GpuDetransformChunkEnumeration(std::shared_ptr<Backend> be, std::shared_ptr<DetransformChunkEnumeration> inner, bool compressed,
+                                                               std::optional<SegmentEncryptionMetadata> enc, int maxOriginalChunkSize, int batchChunks)
+    : be_(std::move(be)), inner_(std::move(inner)), compressed_(compressed), enc_(std::move(enc)), maxOriginal_(maxOriginalChunkSize), batch_(batchChunks) {
+    if (!inner_) throw std::invalid_argument("inner cannot be null");
+    if (batch_ < 1) throw std::invalid_argument("batchChunks must be positive");
+}
+
+void GpuDetransformChunkEnumeration::fillBatchIfNeeded() {
+    if (next_ < ready_.size()) return;
+    ready_.clear(); next_ = 0;
+    std::vector<Bytes> in;
+    while ((int)in.size() < batch_ && inner_->hasMoreElements()) in.push_back(inner_->nextElement());
+    if (in.empty()) return;
+    const uint32_t flags = (compressed_ ? TSX_COMPRESS : 0u) | (enc_ ? TSX_ENCRYPT : 0u);
+    if (flags == 0) { ready_ = std::move(in); return; }
+    std::vector<tsx_chunk_desc> d(in.size());
+    size_t so = 0, dofs = 0;
+    for (size_t i = 0; i < in.size(); i++) {
+        memset(&d[i], 0, sizeof d[i]);
+        d[i].src_off = so; d[i].src_len = (uint32_t)in[i].size(); so += align16(in[i].size()) + 16;
+        size_t cap;
+        if (compressed_) {
+            // the frame states its content size (the reference asks Zstd.decompressedSize first); an encrypted frame is not
+            // readable on the host, so the slot is the original chunk size, which bounds every chunk of the segment
+            cap = (size_t)maxOriginal_;
+            if (!enc_) { const long long n = zstdFrameContentSize(in[i]); if (n >= 0) cap = (size_t)n; }
+        } else {
+            cap = in[i].size() >= (size_t)(IV_SIZE + GCM_TAG_BYTES) ? in[i].size() - IV_SIZE - GCM_TAG_BYTES : 0;
+        }
+        d[i].dst_off = dofs; d[i].dst_cap = (uint32_t)cap; dofs += align16(cap) + 16;
+    }
+    Bytes src(so + 16), dst(dofs + 16);
+    for (size_t i = 0; i < in.size(); i++) memcpy(src.data() + d[i].src_off, in[i].data(), in[i].size());
+    const tsx_batch_params p = makeParams(flags, enc_ ? &enc_->dataKey : nullptr, enc_ ? &enc_->aad : nullptr, TSX_ZSTD_PROFILE_1_5_7);
+    be_->detransformBatch(p, d, src.data(), dst.data(), dst.size());
+    for (size_t i = 0; i < in.size(); i++) {
+        if (d[i].status != TSX_OK) {
+            // the failure belongs to chunk i: everything before it is still handed out, the exception surfaces when i is reached
+            std::string msg = be_->strerror(d[i].status);
+            if (d[i].status == TSX_E_BAD_SIZE) msg = "Invalid decompressed size: " + std::to_string(zstdFrameContentSize(in[i]));
+            failMsg_ = msg;
+            return;
+        }
+        ready_.emplace_back(dst.begin() + (long)d[i].dst_off, dst.begin() + (long)(d[i].dst_off + d[i].dst_len));
+    }
+}
+bool GpuDetransformChunkEnumeration::hasMoreElements() {
+    if (next_ >= ready_.size() && !failMsg_) fillBatchIfNeeded();
+    return next_ < ready_.size() || failMsg_.has_value();
+}
+Bytes GpuDetransformChunkEnumeration::nextElement() {
+    if (next_ >= ready_.size() && !failMsg_) fillBatchIfNeeded();
+    if (next_ < ready_.size()) return std::move(ready_[next_++]);
+    if (failMsg_) throw std::runtime_error(*failMsg_);
+    throw std::out_of_range("NoSuchElementException");
+}
+
+Bytes DetransformFinisher::toBytes() {                                                // DetransformFinisher.java:48-54
+    if (auto* base = dynamic_cast<BaseDetransformChunkEnumeration*>(inner_.get())) return base->inputStream()->readAllBytes();
+    Bytes out;
+    while (inner_->hasMoreElements()) { const Bytes c = inner_->nextElement(); out.insert(out.end(), c.begin(), c.end()); }
+    return out;
+}
+
+Bytes GpuChunkManager::getChunk(const std::string& objectKey, const SegmentManifest& manifest, int chunkId) {      // DefaultChunkManager.java:50-70
+    return getChunks(objectKey, manifest, chunkId, 1)[0];
+}
+
+std::vector<Bytes> GpuChunkManager::getChunks(const std::string& objectKey, const SegmentManifest& manifest, int firstChunkId, int count) {
+    const std::vector<Chunk>& all = manifest.chunkIndex->chunks();
+    if (firstChunkId < 0 || count < 1 || (size_t)(firstChunkId + count) > all.size()) throw std::out_of_range("chunk id out of range");
+    std::vector<Chunk> wanted(all.begin() + firstChunkId, all.begin() + firstChunkId + count);
+    const BytesRange range{wanted.front().transformedPosition, wanted.back().transformedPosition + wanted.back().transformedSize - 1};
+    std::shared_ptr<InputStream> content = fetcher_->fetch(objectKey, range);
+    std::shared_ptr<DetransformChunkEnumeration> e = std::make_shared<BaseDetransformChunkEnumeration>(content, wanted);
+    if (manifest.encryption || manifest.compression)
+        e = std::make_shared<GpuDetransformChunkEnumeration>(be_, e, manifest.compression, manifest.encryption, manifest.chunkIndex->originalChunkSize(), count);
+    std::vector<Bytes> out;
+    while (e->hasMoreElements()) out.push_back(e->nextElement());
+    return out;
+}
+
+}  // namespace tsx

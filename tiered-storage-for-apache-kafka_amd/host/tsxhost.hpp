@@ -1,0 +1,367 @@
+// tsxhost — host side of the chunk-transform path, above the C ABI of libtsxform.so (include/tsxform.h).
+//
+// The reference's host code is Java; no JDK exists in this image, so the same interfaces are provided here in C++ with
+// the reference's names, argument meaning and error behaviour (java/ holds the Java classes + JNI shim a maintainer would
+// compile, INTEGRATION.md shows where they plug in).  Mirrored reference types (core/src/main/java/io/aiven/kafka/tieredstorage/):
+//   Chunk.java:21-66                                   -> tsx::Chunk
+//   manifest/index/AbstractChunkIndex.java:30-128      -> tsx::ChunkIndex (+ FixedSizeChunkIndex.java:30-91, VariableSizeChunkIndex.java:30-87)
+//   manifest/index/AbstractChunkIndexBuilder.java:25-96, FixedSizeChunkIndexBuilder.java:25-44, VariableSizeChunkIndexBuilder.java:25-42
+//   manifest/index/serde/ChunkSizesBinaryCodec.java:104-202, TransformedChunksSerializer.java:28-53, TransformedChunksDeserializer.java:27-48
+//   transform/TransformChunkEnumeration.java:28-42, BaseTransformChunkEnumeration.java:30-97, TransformFinisher.java:40-151
+//   transform/DetransformChunkEnumeration.java:28, BaseDetransformChunkEnumeration.java:39-115, DetransformFinisher.java:30-54
+//   transform/CompressionChunkEnumeration.java + EncryptionChunkEnumeration.java  -> fused tsx::GpuTransformChunkEnumeration
+//   transform/DecryptionChunkEnumeration.java + DecompressionChunkEnumeration.java -> fused tsx::GpuDetransformChunkEnumeration
+//   fetch/ChunkManager.java:26-31, fetch/DefaultChunkManager.java:36-70               -> tsx::ChunkManager, tsx::GpuChunkManager
+// Java exceptions map to: IllegalArgumentException -> std::invalid_argument, IllegalStateException -> std::logic_error,
+// NoSuchElementException -> std::out_of_range, RuntimeException -> std::runtime_error (same messages).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tsxform.h"
+
+namespace tsx {
+
+using Bytes = std::vector<uint8_t>;
+
+// ---- storage/BytesRange + Chunk ------------------------------------------------------------------------
+struct BytesRange {                       // inclusive [from, to]
+    int from, to;
+    static BytesRange ofFromPositionAndSize(int position, int size) { return BytesRange{position, position + size - 1}; }
+    int size() const { return to - from + 1; }
+};
+
+struct Chunk {
+    int id, originalPosition, originalSize, transformedPosition, transformedSize;
+    BytesRange range() const { return BytesRange::ofFromPositionAndSize(transformedPosition, transformedSize); }
+    bool operator==(const Chunk& o) const {
+        return id == o.id && originalPosition == o.originalPosition && originalSize == o.originalSize &&
+               transformedPosition == o.transformedPosition && transformedSize == o.transformedSize;
+    }
+};
+
+// ---- chunk index ---------------------------------------------------------------------------------------
+class ChunkIndex {
+public:
+    virtual ~ChunkIndex() = default;
+    const std::vector<Chunk>& chunks() const { return chunks_; }
+    // nullopt at / after the end of the original file; throws std::invalid_argument on a negative offset
+    std::optional<Chunk> findChunkForOriginalOffset(int offset) const;
+    std::vector<Chunk> chunksForRange(BytesRange range) const;
+    int originalChunkSize() const { return originalChunkSize_; }
+    int originalFileSize() const { return originalFileSize_; }
+    virtual bool isFixed() const = 0;
+    virtual int transformedChunkSize(int chunkI) const = 0;
+
+protected:
+    ChunkIndex(int originalChunkSize, int originalFileSize, int finalTransformedChunkSize, int chunkCount);
+    void materializeChunks();
+    int originalChunkSizeOf(int chunkI) const;
+    int originalChunkSize_, originalFileSize_, finalTransformedChunkSize_, chunkCount_;
+    std::vector<Chunk> chunks_;
+};
+
+class FixedSizeChunkIndex : public ChunkIndex {
+public:
+    FixedSizeChunkIndex(int originalChunkSize, int originalFileSize, int transformedChunkSize, int finalTransformedChunkSize);
+    bool isFixed() const override { return true; }
+    int transformedChunkSize(int chunkI) const override { return chunkI == chunkCount_ - 1 ? finalTransformedChunkSize_ : transformedChunkSize_; }
+    int transformedChunkSize() const { return transformedChunkSize_; }
+    int finalTransformedChunkSize() const { return finalTransformedChunkSize_; }
+
+private:
+    int transformedChunkSize_;
+};
+
+class VariableSizeChunkIndex : public ChunkIndex {
+public:
+    VariableSizeChunkIndex(int originalChunkSize, int originalFileSize, std::vector<int> transformedChunks);
+    bool isFixed() const override { return false; }
+    int transformedChunkSize(int chunkI) const override { return transformedChunks_[(size_t)chunkI]; }
+    const std::vector<int>& transformedChunks() const { return transformedChunks_; }
+
+private:
+    std::vector<int> transformedChunks_;
+};
+
+class AbstractChunkIndexBuilder {
+public:
+    virtual ~AbstractChunkIndexBuilder() = default;
+    void addChunk(int transformedChunkSize);                          // every chunk but the last
+    std::shared_ptr<ChunkIndex> finish(int finalTransformedChunkSize);   // the last chunk
+
+protected:
+    AbstractChunkIndexBuilder(int originalChunkSize, int originalFileSize);
+    virtual void addChunk0(int transformedChunkSize) = 0;
+    virtual std::shared_ptr<ChunkIndex> finish0(int finalTransformedChunkSize) = 0;
+    static void checkSize(int size, const char* name);
+    int remainOfOriginalFileSize() const { return originalFileSize_ - chunksAdded_ * originalChunkSize_; }
+    int originalChunkSize_, originalFileSize_, chunksAdded_ = 0;
+    bool finished_ = false;
+};
+
+class FixedSizeChunkIndexBuilder : public AbstractChunkIndexBuilder {
+public:
+    FixedSizeChunkIndexBuilder(int originalChunkSize, int originalFileSize, int transformedChunkSize);
+
+protected:
+    void addChunk0(int transformedChunkSize) override;
+    std::shared_ptr<ChunkIndex> finish0(int finalTransformedChunkSize) override;
+
+private:
+    int transformedChunkSize_;
+};
+
+class VariableSizeChunkIndexBuilder : public AbstractChunkIndexBuilder {
+public:
+    VariableSizeChunkIndexBuilder(int originalChunkSize, int originalFileSize) : AbstractChunkIndexBuilder(originalChunkSize, originalFileSize) {}
+
+protected:
+    void addChunk0(int transformedChunkSize) override { transformedChunks_.push_back(transformedChunkSize); }
+    std::shared_ptr<ChunkIndex> finish0(int finalTransformedChunkSize) override;
+
+private:
+    std::vector<int> transformedChunks_;
+};
+
+struct ChunkSizesBinaryCodec {
+    static Bytes encode(const std::vector<int>& values);
+    static std::vector<int> decode(const Bytes& array);
+};
+
+std::string base64Encode(const Bytes& b);
+Bytes base64Decode(const std::string& s);
+
+// ---- the device library ---------------------------------------------------------------------------------
+// libtsxform.so loaded by path (dlopen) so that tests can point the same host code at the emulated build.
+class Backend {
+public:
+    explicit Backend(const std::string& libPath, int deviceIndex = 0);
+    ~Backend();
+    Backend(const Backend&) = delete;
+    Backend& operator=(const Backend&) = delete;
+    // one batch over host buffers; throws std::runtime_error on a batch-level failure, per-chunk status stays in descs
+    void transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
+    void detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
+    size_t transformedBound(size_t n, uint32_t flags) const;
+    std::string strerror(int code) const;
+    std::string version() const;
+
+private:
+    struct Fns;
+    void* handle_ = nullptr;
+    std::unique_ptr<Fns> f_;
+    tsx_ctx* ctx_ = nullptr;
+};
+
+// TransformedChunksSerializer / Deserializer: codec -> one Zstd frame (GPU compressor: same bytes as the reference's
+// ZstdCompressCtx for this input) -> Base64, and back ("Invalid decompressed size: n" above 10 MiB).
+std::string serializeTransformedChunks(Backend& be, const std::vector<int>& values, uint32_t zstdProfile = TSX_ZSTD_PROFILE_1_5_7);
+std::vector<int> deserializeTransformedChunks(Backend& be, const std::string& base64);
+// The chunk index as it appears in the segment manifest (Jackson layout of FixedSizeChunkIndex / VariableSizeChunkIndex,
+// pinned by CT/manifest/index/ChunkIndexSerializationTest.java:63-123)
+std::string chunkIndexToJson(Backend& be, const ChunkIndex& index);
+std::shared_ptr<ChunkIndex> chunkIndexFromJson(Backend& be, const std::string& json);
+
+// ---- streams (java.io.InputStream as far as the path needs it) --------------------------------------------
+class InputStream {
+public:
+    virtual ~InputStream() = default;
+    virtual Bytes readNBytes(size_t n) = 0;      // up to n bytes, fewer only at end of stream
+    virtual Bytes readAllBytes() = 0;
+    virtual void close() {}
+};
+class ByteArrayInputStream : public InputStream {
+public:
+    explicit ByteArrayInputStream(Bytes data) : data_(std::move(data)) {}
+    Bytes readNBytes(size_t n) override;
+    Bytes readAllBytes() override;
+    void close() override { closed_ = true; }
+    bool closed() const { return closed_; }
+
+private:
+    Bytes data_;
+    size_t pos_ = 0;
+    bool closed_ = false;
+};
+
+// ---- security/DataKeyAndAAD ------------------------------------------------------------------------------
+struct DataKeyAndAAD {
+    Bytes dataKey;   // 32 bytes (AES-256, AesEncryptionProvider.java:36)
+    Bytes aad;       // reference: 32 bytes
+};
+constexpr int IV_SIZE = 12;            // SegmentEncryptionMetadataV1.java:30
+constexpr int GCM_TAG_BYTES = 16;      // AesEncryptionProvider.java:39 (128 bits)
+// IV source; the default reads /dev/urandom (the reference: SecureRandom.getInstanceStrong(), AesEncryptionProvider.java:66-71)
+using IvSupplier = std::function<void(uint8_t iv[IV_SIZE])>;
+IvSupplier secureRandomIvSupplier();
+
+// ---- upload side -------------------------------------------------------------------------------------------
+class TransformChunkEnumeration {
+public:
+    virtual ~TransformChunkEnumeration() = default;
+    virtual int originalChunkSize() const = 0;
+    virtual std::optional<int> transformedChunkSize() const = 0;      // nullopt: unknown (variable)
+    virtual bool hasMoreElements() = 0;
+    virtual Bytes nextElement() = 0;                                  // throws std::out_of_range when exhausted
+};
+
+class BaseTransformChunkEnumeration : public TransformChunkEnumeration {
+public:
+    BaseTransformChunkEnumeration(std::shared_ptr<InputStream> inputStream, int originalChunkSize);   // 0 disables chunking
+    int originalChunkSize() const override { return originalChunkSize_; }
+    std::optional<int> transformedChunkSize() const override { return originalChunkSize_; }
+    bool hasMoreElements() override;
+    Bytes nextElement() override;
+
+private:
+    void fillChunkIfNeeded();
+    std::shared_ptr<InputStream> in_;
+    int originalChunkSize_;
+    std::optional<Bytes> chunk_;
+};
+
+// Replaces CompressionChunkEnumeration + EncryptionChunkEnumeration (RemoteStorageManager.java:443-451) with one batched
+// device call: reads ahead up to `batchChunks` chunks from `inner`, draws their IVs, transforms them together and hands
+// them out in order.  transformedChunkSize(): unknown when compressing, else inner + 28 when encrypting.
+class GpuTransformChunkEnumeration : public TransformChunkEnumeration {
+public:
+    GpuTransformChunkEnumeration(std::shared_ptr<Backend> backend, std::shared_ptr<TransformChunkEnumeration> inner, bool compress,
+                                 std::optional<DataKeyAndAAD> encryption, IvSupplier ivSupplier = secureRandomIvSupplier(),
+                                 int batchChunks = 64, bool withCrc = false, uint32_t zstdProfile = TSX_ZSTD_PROFILE_1_5_7);
+    int originalChunkSize() const override { return inner_->originalChunkSize(); }
+    std::optional<int> transformedChunkSize() const override { return transformedChunkSize_; }
+    bool hasMoreElements() override;
+    Bytes nextElement() override;
+    const std::vector<uint32_t>& crc32cOfOriginalChunks() const { return crcs_; }   // out of band, filled when withCrc
+
+private:
+    void fillBatchIfNeeded();
+    std::shared_ptr<Backend> be_;
+    std::shared_ptr<TransformChunkEnumeration> inner_;
+    bool compress_;
+    std::optional<DataKeyAndAAD> enc_;
+    IvSupplier iv_;
+    int batch_;
+    bool withCrc_;
+    uint32_t profile_;
+    std::optional<int> transformedChunkSize_;
+    std::vector<Bytes> ready_;
+    size_t next_ = 0;
+    std::vector<uint32_t> crcs_;
+};
+
+class TransformFinisher {
+public:
+    // chunkingEnabled == false: TransformFinisher.Builder.withChunkingDisabled()
+    TransformFinisher(std::shared_ptr<TransformChunkEnumeration> inner, int originalFileSize, bool chunkingEnabled = true);
+    bool hasMoreElements() { return inner_->hasMoreElements(); }
+    Bytes nextElement();                                  // the reference wraps it in a ByteArrayInputStream
+    std::shared_ptr<ChunkIndex> chunkIndex();             // "Chunk index was not built, was finisher used?"
+    Bytes toBytes();                                      // SequenceInputStream(this) drained: the transformed .log object
+
+private:
+    bool isBaseTransform() const;
+    std::shared_ptr<TransformChunkEnumeration> inner_;
+    std::unique_ptr<AbstractChunkIndexBuilder> builder_;
+    int originalFileSize_;
+    std::shared_ptr<ChunkIndex> chunkIndex_;
+};
+
+// ---- fetch side --------------------------------------------------------------------------------------------
+class DetransformChunkEnumeration {
+public:
+    virtual ~DetransformChunkEnumeration() = default;
+    virtual bool hasMoreElements() = 0;
+    virtual Bytes nextElement() = 0;
+};
+
+class BaseDetransformChunkEnumeration : public DetransformChunkEnumeration {
+public:
+    explicit BaseDetransformChunkEnumeration(std::shared_ptr<InputStream> inputStream);                       // no chunking: everything at once
+    BaseDetransformChunkEnumeration(std::shared_ptr<InputStream> inputStream, std::vector<Chunk> chunks);
+    bool hasMoreElements() override;
+    Bytes nextElement() override;
+    std::shared_ptr<InputStream> inputStream() const { return in_; }
+
+private:
+    void fillChunkIfNeeded();
+    std::shared_ptr<InputStream> in_;
+    bool inputStreamClosed_ = false;
+    std::vector<Chunk> chunks_;
+    size_t iter_ = 0;
+    bool isEmpty_;
+    std::optional<Bytes> chunk_;
+};
+
+struct SegmentEncryptionMetadata { Bytes dataKey; Bytes aad; int ivSize = IV_SIZE; };
+
+// Replaces DecryptionChunkEnumeration + DecompressionChunkEnumeration (DefaultChunkManager.java:58-67).
+// Failures surface as the reference's do: std::runtime_error("Tag mismatch") (javax.crypto.AEADBadTagException wrapped),
+// std::runtime_error("Invalid decompressed size: n"), std::runtime_error(corrupt frame).
+class GpuDetransformChunkEnumeration : public DetransformChunkEnumeration {
+public:
+    GpuDetransformChunkEnumeration(std::shared_ptr<Backend> backend, std::shared_ptr<DetransformChunkEnumeration> inner, bool compressed,
+                                   std::optional<SegmentEncryptionMetadata> encryption, int maxOriginalChunkSize, int batchChunks = 64);
+    bool hasMoreElements() override;
+    Bytes nextElement() override;
+
+private:
+    void fillBatchIfNeeded();
+    std::shared_ptr<Backend> be_;
+    std::shared_ptr<DetransformChunkEnumeration> inner_;
+    bool compressed_;
+    std::optional<SegmentEncryptionMetadata> enc_;
+    int maxOriginal_, batch_;
+    std::vector<Bytes> ready_;
+    size_t next_ = 0;
+    std::optional<std::string> failMsg_;      // failure of the chunk that follows ready_
+};
+
+class DetransformFinisher {
+public:
+    explicit DetransformFinisher(std::shared_ptr<DetransformChunkEnumeration> inner) : inner_(std::move(inner)) {}
+    Bytes toBytes();      // toInputStream() drained; a pure base enumeration hands back the raw stream's bytes
+
+private:
+    std::shared_ptr<DetransformChunkEnumeration> inner_;
+};
+
+// storage/ObjectFetcher.java:27-35 as far as the path needs it
+class ObjectFetcher {
+public:
+    virtual ~ObjectFetcher() = default;
+    virtual std::shared_ptr<InputStream> fetch(const std::string& objectKey, BytesRange range) = 0;
+};
+
+struct SegmentManifest {                 // manifest/SegmentManifestV1 as far as the path needs it
+    std::shared_ptr<ChunkIndex> chunkIndex;
+    bool compression = false;
+    std::optional<SegmentEncryptionMetadata> encryption;
+};
+
+class ChunkManager {
+public:
+    virtual ~ChunkManager() = default;
+    virtual Bytes getChunk(const std::string& objectKey, const SegmentManifest& manifest, int chunkId) = 0;
+};
+
+class GpuChunkManager : public ChunkManager {
+public:
+    GpuChunkManager(std::shared_ptr<Backend> backend, std::shared_ptr<ObjectFetcher> fetcher) : be_(std::move(backend)), fetcher_(std::move(fetcher)) {}
+    Bytes getChunk(const std::string& objectKey, const SegmentManifest& manifest, int chunkId) override;
+    // a prefetch window of consecutive chunks in ONE ranged fetch and ONE device batch
+    std::vector<Bytes> getChunks(const std::string& objectKey, const SegmentManifest& manifest, int firstChunkId, int count);
+
+private:
+    std::shared_ptr<Backend> be_;
+    std::shared_ptr<ObjectFetcher> fetcher_;
+};
+
+}  // namespace tsx

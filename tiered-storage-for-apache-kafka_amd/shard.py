@@ -1,0 +1,51 @@
+"""Multi-GPU partitioning of the chunk-transform path - one process per GPU under torch.distributed.
+
+Chunks are independent by construction (fresh Zstd context and fresh cipher per chunk:
+core/.../transform/CompressionChunkEnumeration.java:52, EncryptionChunkEnumeration.java:67), so:
+
+* segment-major (segments >= ranks): segment s belongs to rank s % world.  No data-path collective at all.
+* chunk-range (one segment split over ranks): rank g takes the contiguous chunks [g*n/G, (g+1)*n/G).  The only
+  cross-rank state is the running sum of transformed sizes (the chunk index, AbstractChunkIndex.java:52-72), so the ranks
+  all-gather their int32 transformed sizes (1 KiB per 256-chunk segment) and each exclusive-scans its
+  transformedPosition base.  RCCL ("nccl" on ROCm) on GPUs, gloo in the CPU tests.
+"""
+import numpy as np
+
+
+def segment_owner(segment: int, world: int) -> int:
+    return segment % world
+
+
+def segments_of_rank(n_segments: int, rank: int, world: int):
+    return [s for s in range(n_segments) if segment_owner(s, world) == rank]
+
+
+def chunk_range_of_rank(n_chunks: int, rank: int, world: int):
+    """Contiguous chunk ids [lo, hi) of `rank`; every rank's output is then a contiguous slice of the .log object."""
+    return (n_chunks * rank) // world, (n_chunks * (rank + 1)) // world
+
+
+def exchange_transformed_sizes(local_sizes, n_chunks: int, rank: int, world: int, dist=None, device="cpu"):
+    """All-gather the transformed chunk sizes of a segment split by chunk_range_of_rank.
+
+    Returns (sizes[n_chunks] int64, positions[n_chunks] int64, my_base): the full size list in chunk order, every chunk's
+    transformedPosition, and the offset at which this rank's slice starts in the transformed object."""
+    lo, hi = chunk_range_of_rank(n_chunks, rank, world)
+    local = np.asarray(local_sizes, dtype=np.int32)
+    assert local.shape == (hi - lo,)
+    if world == 1:
+        sizes = local.astype(np.int64)
+    else:
+        import torch
+        per = max(chunk_range_of_rank(n_chunks, r, world)[1] - chunk_range_of_rank(n_chunks, r, world)[0] for r in range(world))
+        buf = torch.zeros(per, dtype=torch.int32, device=device)
+        buf[:hi - lo] = torch.from_numpy(local).to(device)
+        out = [torch.zeros(per, dtype=torch.int32, device=device) for _ in range(world)]
+        dist.all_gather(out, buf)
+        parts = []
+        for r in range(world):
+            a, b = chunk_range_of_rank(n_chunks, r, world)
+            parts.append(out[r][:b - a].cpu().numpy())
+        sizes = np.concatenate(parts).astype(np.int64)
+    positions = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    return sizes, positions, int(positions[lo]) if hi > lo else int(sizes.sum())
