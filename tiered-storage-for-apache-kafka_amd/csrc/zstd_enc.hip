@@ -25,11 +25,17 @@
 #include "zstd_common.h"
 
 #define LANES 64
-#define ZS_RING 8192u         /* LDS source window of the parser (bytes) */
+// "this value is the same in every lane": results of out-of-line calls and LDS broadcasts are divergent to the compiler;
+// pinning the parser's state to SGPRs turns its control flow into scalar branches instead of exec-mask juggling.
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
+#define ZS_RING 4096u         /* LDS source window of the parser (bytes) */
 #define ZS_RWM (ZS_RING / 4 - 1)
-#define ZS_FILL 4096u         /* refill granule */
+#define ZS_FILL 2048u         /* refill granule */
 #define ZS_SAFE 384u          /* the parser may touch [ip, ip + ZS_SAFE) between two refill checks */
-#define ZS_SCR 2048u          /* slots of the intra-step hash-collision detector (per table) */
+#ifndef ZS_WAVES_PER_SIMD
+#define ZS_WAVES_PER_SIMD 5   /* occupancy target: 96 VGPRs, <= 8 KiB LDS -> 20 chunks per CU */
+#endif
+#define ZS_SCR 1024u          /* slots of the intra-step hash-collision detector (per table) */
 // cold, register-hungry scalar stages are kept out of line so the speculative match loop keeps its occupancy
 #define ZS_NOINLINE __attribute__((noinline))
 
@@ -108,20 +114,24 @@ struct HufTable { uint16_t val[256]; uint8_t nb[256]; uint32_t tableLog, maxSym;
 struct FseTable { uint16_t state[512]; uint32_t dnb[56]; int32_t dfs[56]; uint32_t tableLog; };
 struct NodeElt { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; };
 
+// Work arrays of the (lane-0, once per block) Huffman tree construction.  They live in the chunk's global workspace, not
+// in LDS: LDS per wave is what bounds how many chunks a CU can hold, and occupancy is this kernel's only latency cover.
+struct HufScratch { NodeElt nodes[514]; uint16_t rankBase[192], rankCurr[192]; };
 struct EncLds {
     HufTable huf[2];            // [cur] = table of the previous compressed-literals block, [cur ^ 1] = candidate
     int hufRepeat[2];           // 0 none, 1 check
     uint32_t scal[16];          // lane-0 -> wave broadcast slots
     union alignas(16) {
         struct {                // entropy stage of a block
-            FseTable ll, of, ml;
-            uint32_t hist[256];
-            uint32_t hist2[256];        // second histogram (pre-splitter / sampling)
-            uint32_t cnt[64];           // sequence-code histograms
-            NodeElt nodes[514];
-            uint16_t rankBase[192], rankCurr[192];
+            FseTable ll, of;
+            union {
+                FseTable ml;            // sequence stage
+                uint32_t hist[256];     // literal stage (and the pre-splitter): byte histogram, dead before ml is built
+            };
+            uint32_t hist2[256];        // second histogram (pre-splitter / sampling); sequence-code histograms
+            uint32_t cnt[16];           // histogram of Huffman weights
             uint8_t tableSymbol[512];
-            uint32_t cumul[64];
+            uint16_t cumul[64];
             short norm[64];
             uint8_t weights[256];
         };
@@ -288,14 +298,14 @@ __device__ static inline void store_seq(zs_seq* __restrict__ seqs, MfState& s, u
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ src, const uint32_t srcSize, const uint32_t blockStart,
                                                    const uint32_t blockSize, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
-                                                   const zs_cparams cp, const uint32_t plowIdx, uint32_t* rep, zs_seq* __restrict__ seqs,
+                                                   const zs_cparams cp, const uint32_t plowIdxIn, uint32_t* rep, zs_seq* __restrict__ seqs,
                                                    MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane) {
-    const uint32_t iend = blockStart + blockSize;
-    const uint32_t hBitsL = cp.hashLog, hBitsS = cp.chainLog, mls = cp.minMatch;
+    const uint32_t iend = UNI(blockStart + blockSize), plowIdx = UNI(plowIdxIn);
+    const uint32_t hBitsL = UNI(cp.hashLog), hBitsS = UNI(cp.chainLog), mls = UNI(cp.minMatch);
     const uint32_t srcCeil = (srcSize + ZS_FILL - 1) & ~(ZS_FILL - 1), lastPiece = (srcSize - 1) & ~15u;
     const uint32_t idxBits = 32u - (uint32_t)__clz((int)(srcSize + 2)), tagBits = 32u - idxBits, idxMask = (uint32_t)((1ull << idxBits) - 1);
-    uint32_t ip = blockStart, anchor = blockStart;
-    uint32_t off1 = rep[0], off2 = rep[1], sav1 = 0, sav2 = 0;
+    uint32_t ip = UNI(blockStart), anchor = ip;
+    uint32_t off1 = UNI(rep[0]), off2 = UNI(rep[1]), sav1 = 0, sav2 = 0;
     ms.nbSeq = 0; ms.litSize = 0;
     if (ip + 2 == plowIdx) ip++;
     {   const uint32_t maxRep = ip + 2 - plowIdx;
@@ -495,7 +505,8 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
                     if (step < 4 && lane == (uint32_t)f + 1) hashLong[hl] = eL;          // hashLong[hl1] = ip1
                     store_seq(seqs, ms, start - anchor, anchor, off1 + 3, mlen, lane);
                 }
-                ip = start + mlen; anchor = ip;
+                ip = UNI(start + mlen); anchor = ip;
+                off1 = UNI(off1); off2 = UNI(off2);
                 PT(3); PCNT(13, 1);
                 LT_USE(ip); LT(5);                                    // 5: inserts + extension + sequence store
                 if (ip <= ilimit) {
@@ -681,16 +692,16 @@ __device__ ZS_NOINLINE static uint32_t fse_writeNCount(uint8_t* out0, const shor
     return (uint32_t)(out - out0);
 }
 
-__device__ ZS_NOINLINE static void fse_buildCTable(FseTable& ct, const short* norm, uint32_t maxSym, uint32_t tableLog, uint32_t* cumul, uint8_t* tableSymbol) {
+__device__ ZS_NOINLINE static void fse_buildCTable(FseTable& ct, const short* norm, uint32_t maxSym, uint32_t tableLog, uint16_t* cumul, uint8_t* tableSymbol) {
     const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
     uint32_t highThreshold = tableSize - 1, u;
     ct.tableLog = tableLog;
     cumul[0] = 0;
     for (u = 1; u <= maxSym + 1; u++) {
-        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (uint8_t)(u - 1); }
-        else cumul[u] = cumul[u - 1] + (uint32_t)norm[u - 1];
+        if (norm[u - 1] == -1) { cumul[u] = (uint16_t)(cumul[u - 1] + 1); tableSymbol[highThreshold--] = (uint8_t)(u - 1); }
+        else cumul[u] = (uint16_t)(cumul[u - 1] + (uint32_t)norm[u - 1]);
     }
-    cumul[maxSym + 1] = tableSize + 1;
+    cumul[maxSym + 1] = (uint16_t)(tableSize + 1);
     {   uint32_t position = 0;
         for (uint32_t symbol = 0; symbol <= maxSym; symbol++) {
             const int freq = norm[symbol];
@@ -769,7 +780,7 @@ __device__ ZS_NOINLINE static void huf_quickSort(NodeElt* arr, int low0, int hig
     }
 }
 
-__device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint32_t* cnt, uint32_t maxSym, uint32_t maxNbBits, EncLds& L) {
+__device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint32_t* cnt, uint32_t maxSym, uint32_t maxNbBits, HufScratch& L) {
     NodeElt* const huffNode0 = L.nodes; NodeElt* const huffNode = huffNode0 + 1;
     for (int i = 0; i < 514; i++) { NodeElt z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
     // HUF_sort
@@ -1022,7 +1033,7 @@ __device__ static uint32_t write_rle_literals(uint8_t* dst, const uint8_t* lit, 
 }
 
 __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uint8_t* __restrict__ lit, uint32_t n, EncLds& L, int cur, bool suspectUncompressible,
-                                             uint32_t* tmp, uint32_t lane) {
+                                             uint32_t* tmp, HufScratch* hufScratch, uint32_t lane) {
     const int nxt = cur ^ 1;
     const uint32_t lhSize = 3 + (n >= 1024) + (n >= 16384);
     bool single = n < 256;
@@ -1069,7 +1080,7 @@ __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uin
             PT(5);
             if (lane == 0) {
                 uint32_t huffLog = fse_optimalTableLog(ZS_LitHufLog, n, maxSym, 1);
-                huffLog = huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, L);
+                huffLog = huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, *hufScratch);
                 const uint32_t hSize = huf_writeCTable(ostart, L.huf[nxt], maxSym, huffLog, L);
                 uint32_t useOld = 0, fail = 0;
                 if (hSize == 0xFFFFFFFFu) fail = 1;
@@ -1327,7 +1338,7 @@ __device__ static bool wave_is_rle(const uint8_t* __restrict__ p, uint32_t n, ui
 // ---------------------------------------------------------------------------------------------------
 // the kernel: one wave per chunk
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, const tsx_chunk_desc* __restrict__ descs,
+__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, const tsx_chunk_desc* __restrict__ descs,
                                                               uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
                                                               int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile
 #ifdef TSX_PROF
@@ -1393,7 +1404,7 @@ __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __r
         // ---- block size (ZSTD_optimalBlockSize) ----
         uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
         if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
-            blockSize = split_block_1_5_7(src + ipos, L, lane);
+            blockSize = UNI(split_block_1_5_7(src + ipos, L, lane));
         PT(1);
         const uint32_t lastBlock = blockSize == remaining;
         {   // ZSTD_window_enforceMaxDist
@@ -1418,11 +1429,11 @@ __global__ __launch_bounds__(LANES) void zstd_compress_kernel(const uint8_t* __r
             if (lane == 0) L.scal[8] = 0;
             __syncthreads();
             const bool suspect = ms.nbSeq == 0 || (ms.litSize / ms.nbSeq >= 20);
-            uint32_t litBytes = compress_literals(blockout, lit, ms.litSize, L, cur, suspect, huftmp, lane);
+            uint32_t litBytes = UNI(compress_literals(blockout, lit, ms.litSize, L, cur, suspect, huftmp, (HufScratch*)(codes + 3 * ZS_WS_CODE_STRIDE), lane));
             __threadfence_block();
             __syncthreads();
-            uint32_t seqBytes = compress_sequences(blockout + litBytes, blockout + (255u << 10), seqs, ms.nbSeq, codes, L, huftmp, (ZS_BLOCKOUT_CAP - (256u << 10)) - 64, lane);
-            const bool newHuf = L.scal[8] != 0;
+            uint32_t seqBytes = UNI(compress_sequences(blockout + litBytes, blockout + (255u << 10), seqs, ms.nbSeq, codes, L, huftmp, (ZS_BLOCKOUT_CAP - (256u << 10)) - 64, lane));
+            const bool newHuf = UNI(L.scal[8]) != 0;
             if (seqBytes != 0xFFFFFFFFu) {
                 cSize = litBytes + seqBytes;
                 const uint32_t maxCSize = blockSize - ((blockSize >> 6) + 2);
