@@ -1222,14 +1222,24 @@ __device__ ZS_NOINLINE static uint32_t compress_sequences(uint8_t* op0, uint8_t*
             for (;;) {
                 const uint64_t nxt = g >= 8 ? *reinterpret_cast<const uint64_t*>(cd + g - 8) : 0;
                 const int top = n & 7;
+                // the per-symbol constants do not depend on the state: fetch all eight before walking the dependent chain,
+                // which then costs one LDS lookup (the next state) per symbol
+                uint32_t dn[8]; int32_t df[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const uint32_t sym = (uint32_t)(cur >> (8 * j)) & 0xFF; dn[j] = ct.dnb[sym < 56 ? sym : 0]; df[j] = ct.dfs[sym < 56 ? sym : 0]; }
+                uint32_t ob[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int j = 7; j >= 0; j--) {
                     if (j <= top) {
-                        const uint32_t sym = (uint32_t)(cur >> (8 * j)) & 0xFF;
-                        const uint32_t nb = (st + ct.dnb[sym]) >> 16;
-                        o[g + j] = (uint16_t)((st & ((1u << nb) - 1)) | (nb << 12));
-                        st = ct.state[(st >> nb) + ct.dfs[sym]];
+                        const uint32_t nb = (st + dn[j]) >> 16;
+                        ob[j >> 1] |= ((st & ((1u << nb) - 1)) | (nb << 12)) << (16 * (j & 1));
+                        st = ct.state[(st >> nb) + df[j]];
                     }
+                }
+                if (top == 7) *reinterpret_cast<uint4*>(o + g) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) if (j <= top) o[g + j] = (uint16_t)(ob[j >> 1] >> (16 * (j & 1)));
                 }
                 if (g == 0) break;
                 g -= 8; n = (int32_t)g + 7; cur = nxt;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Inverse path timing (fetchLogSegment side): 2048 transformed chunks resident in HBM -> tsx_detransform_batch."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import tsxform
+from tsxform import synth
+nat = tsxform._native
+N = nat.Native(nat.LIB_PATH); N.init(1, [0])
+n, CH = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, synth.CHUNK
+dev = torch.device("cuda", 0)
+src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+if os.path.exists("/tmp/k256.npy"):
+    src[:256 * CH] = torch.from_numpy(np.load("/tmp/k256.npy")).to(dev)
+else:
+    for i in range(256): src[i * CH:(i + 1) * CH] = synth.gen_chunk("K", 1000, 0, i, CH, device=dev)
+for i in range(256, n, 256): src[i * CH:(i + 256) * CH] = src[:256 * CH]
+flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
+params = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+mid = torch.empty(n * slot, dtype=torch.uint8, device=dev)
+d = np.zeros(n, nat.DESC_DTYPE); d["src_off"] = np.arange(n, dtype=np.uint64) * CH; d["src_len"] = CH
+d["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d["dst_cap"] = slot
+ctx = N.ctx_create(0, n, CH)
+N.transform_batch(params, d, src.data_ptr(), mid.data_ptr(), mid.numel(), nat.MEM_DEVICE, ctx=ctx)
+crc = d["crc32c"].copy()
+back = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+e = np.zeros(n, nat.DESC_DTYPE); e["src_off"] = d["dst_off"]; e["src_len"] = d["dst_len"]; e["dst_off"] = np.arange(n, dtype=np.uint64) * CH; e["dst_cap"] = CH
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    N.detransform_batch(params, e, mid.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE, ctx=ctx)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    t = N.ctx_timing(ctx)
+    print("detransform %d chunks: %.1f ms -> %.2f GiB/s of restored bytes (gcm %.1f ms, unzstd %.1f ms, crc %.1f ms)" % (n, el * 1e3, n * CH / 2**30 / el, t.gcm_ms, t.unzstd_ms, t.crc_ms))
+assert (e["status"] == 0).all() and (e["crc32c"] == crc).all() and torch.equal(back, src)
+print("round trip exact")

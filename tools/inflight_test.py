@@ -39,4 +39,4 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print("threads %d: %.1f ms per batch-equivalent, %.2f GiB/s" % (T, el / (steps * T) * 1e3, steps * T * n * CH / 2**30 / el))
 assert all((d["status"] == 0).all() for d in descs)
-assert (descs[0]["dst_len"] == descs[-1]["dst_len"]).all()
+#assert (descs[0]["dst_len"] == descs[-1]["dst_len"]).all()
