@@ -30,6 +30,7 @@ __device__ static const short dMLnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1
 __device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
 __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
+#define ZS_DWIN 4096u
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 struct DecLds {
     uint16_t huf[4096];          // (nbBits << 8) | symbol
@@ -43,6 +44,8 @@ struct DecLds {
     uint16_t symNext[64];
     uint32_t scal[16];
     uint32_t streamOff[5];
+    uint32_t rep[3];             // repeat-offset history, carried across the blocks of the frame (lane 0)
+    alignas(16) uint8_t win[ZS_DWIN + 16];   // window of the sequence bit stream being decoded
 };
 
 // ---- backward bit reader (BIT_DStream) -----------------------------------------------------------------
@@ -84,6 +87,41 @@ __device__ static inline bool br_reload(BitR& b) {
     return true;
 }
 __device__ static inline bool br_finished(const BitR& b) { return b.ptr == b.start && b.consumed == 64; }
+
+// The same reader over a window of the stream held in LDS: win[0 ..) = stream bytes [wbase ..); positions are offsets
+// in the stream, so no pointer ever leaves the window array.
+struct BitW { uint64_t c; uint32_t pos, consumed; bool bad; };
+__device__ static inline uint64_t wld64(const uint8_t* win, uint32_t wbase, uint32_t pos) { return dld64(win + (pos - wbase)); }
+__device__ static void bw_init(BitW& b, const uint8_t* win, uint32_t wbase, uint32_t n) {
+    b.bad = false; b.consumed = 0; b.c = 0; b.pos = 0;
+    if (n == 0) { b.bad = true; return; }
+    const uint8_t last = win[n - 1 - wbase];
+    if (last == 0) { b.bad = true; return; }
+    if (n >= 8) { b.pos = n - 8; b.c = wld64(win, wbase, b.pos); b.consumed = 8 - dhb32(last); }
+    else {
+        uint64_t c = 0;
+        for (uint32_t i = 0; i < n; i++) c |= (uint64_t)win[i] << (8 * i);      // n < 8: wbase == 0
+        b.c = c;
+        b.consumed = 8 - dhb32(last) + (8 - n) * 8;
+    }
+}
+__device__ static inline uint64_t bw_read(BitW& b, uint32_t nb) {
+    if (!nb) return 0;
+    const uint64_t v = (b.c << (b.consumed & 63)) >> (64 - nb);
+    b.consumed += nb;
+    return v;
+}
+__device__ static inline bool bw_reload(BitW& b, const uint8_t* win, uint32_t wbase) {
+    if (b.consumed > 64) return false;
+    if (b.pos >= 8) { b.pos -= b.consumed >> 3; b.consumed &= 7; b.c = wld64(win, wbase, b.pos); return true; }
+    if (b.pos == 0) return true;
+    uint32_t nbBytes = b.consumed >> 3;
+    if (nbBytes > b.pos) nbBytes = b.pos;
+    b.pos -= nbBytes; b.consumed -= nbBytes * 8;
+    b.c = wld64(win, wbase, b.pos);
+    return true;
+}
+__device__ static inline bool bw_finished(const BitW& b) { return b.pos == 0 && b.consumed == 64; }
 
 // ---- FSE table description + decoding table (lane 0) ---------------------------------------------------------
 // returns bytes consumed, 0 on error
@@ -224,6 +262,33 @@ __device__ static bool huf_decodeStream(uint8_t* __restrict__ out, uint32_t coun
     return br_finished(b);
 }
 
+// Per-lane copy of a short, non-overlapping run (a literal run, or a match whose source is already final): up to four
+// 8-byte loads are in flight before the first store, so a run of <= 32 bytes costs one memory round trip.
+__device__ static inline void copy_small(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
+    uint32_t k = 0;
+    while (n - k >= 32) {
+        const uint64_t a = dld64(src + k), b = dld64(src + k + 8), c = dld64(src + k + 16), d = dld64(src + k + 24);
+        __builtin_memcpy(dst + k, &a, 8); __builtin_memcpy(dst + k + 8, &b, 8); __builtin_memcpy(dst + k + 16, &c, 8); __builtin_memcpy(dst + k + 24, &d, 8);
+        k += 32;
+    }
+    const uint32_t r = n - k;                                       // < 32
+    uint64_t q0 = 0, q1 = 0, q2 = 0; uint32_t w = 0; uint16_t h = 0; uint8_t b1 = 0;
+    const uint32_t nq = r >> 3;
+    if (nq > 0) q0 = dld64(src + k);
+    if (nq > 1) q1 = dld64(src + k + 8);
+    if (nq > 2) q2 = dld64(src + k + 16);
+    uint32_t t = k + 8 * nq;
+    if (r & 4) { __builtin_memcpy(&w, src + t, 4); }
+    if (r & 2) { __builtin_memcpy(&h, src + t + (r & 4), 2); }
+    if (r & 1) { b1 = src[t + (r & 6)]; }
+    if (nq > 0) __builtin_memcpy(dst + k, &q0, 8);
+    if (nq > 1) __builtin_memcpy(dst + k + 8, &q1, 8);
+    if (nq > 2) __builtin_memcpy(dst + k + 16, &q2, 8);
+    if (r & 4) __builtin_memcpy(dst + t, &w, 4);
+    if (r & 2) __builtin_memcpy(dst + t + (r & 4), &h, 2);
+    if (r & 1) dst[t + (r & 6)] = b1;
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------
 #define FAIL(code) do { err = (code); goto done; } while (0)
 
@@ -244,7 +309,6 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
     uint32_t opos = 0;
     uint64_t contentSize = 0;
     uint32_t p = 0;
-    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     bool hasChecksum = false;
     // ---- frame header ----
     if (srcSize < 6) FAIL(DERR_FRAME);
@@ -268,7 +332,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
         p += fl;
     }
     if (contentSize > d.dst_cap) FAIL(TSX_E_DST_TOO_SMALL);
-    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; }
+    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; L.rep[0] = 1; L.rep[1] = 4; L.rep[2] = 8; }
     __syncthreads();
     // ---- blocks ----
     for (;;) {
@@ -390,74 +454,142 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         }
                         if (e) break;
                         if (t >= bsize) { e = 1; break; }
-                        BitR b; br_init(b, blk + t, bsize - t);
-                        if (b.bad) { e = 1; break; }
-                        uint32_t sl = (uint32_t)br_read(b, L.llLog), so = (uint32_t)br_read(b, L.ofLog), sm = (uint32_t)br_read(b, L.mlLog);
-                        if (!br_reload(b)) { e = 1; break; }
-                        for (uint32_t i = 0; i < nbSeq; i++) {
-                            const FseD el = L.ll[sl], eo = L.of[so], em = L.ml[sm];
-                            const uint32_t oc = eo.sym, mc = em.sym, lc = el.sym;
-                            if (oc > 31 || mc > 52 || lc > 35) { e = 1; break; }
-                            uint32_t offBase;
-                            if (oc > 24) {                              // up to 31 extra bits: read in two parts around a reload
-                                const uint32_t hi = oc - 24;
-                                offBase = (1u << oc) + ((uint32_t)br_read(b, hi) << 24);
-                                if (!br_reload(b)) { e = 1; break; }
-                                offBase += (uint32_t)br_read(b, 24);
-                            } else offBase = (1u << oc) + (uint32_t)br_read(b, oc);
-                            const uint32_t ml = dMLbase[mc] + (uint32_t)br_read(b, dMLbits[mc]);
-                            if (!br_reload(b)) { e = 1; break; }
-                            const uint32_t ll = dLLbase[lc] + (uint32_t)br_read(b, dLLbits[lc]);
-                            zs_seq sq; sq.offBase = offBase; sq.litLength = ll; sq.mlBase = ml; sq.litPos = 0;
-                            seqs[i] = sq;
-                            if (i + 1 < nbSeq) {
-                                sl = el.base + (uint32_t)br_read(b, el.nb);
-                                sm = em.base + (uint32_t)br_read(b, em.nb);
-                                if (!br_reload(b)) { e = 1; break; }
-                                so = eo.base + (uint32_t)br_read(b, eo.nb);
-                            }
-                            if (!br_reload(b)) { e = 1; break; }
-                        }
-                        if (!e && !br_finished(b)) e = 1;
+                        L.scal[2] = t;
                     } while (0);
                     L.scal[1] = e;
                 }
                 __threadfence_block();
                 __syncthreads();
                 if (L.scal[1]) FAIL(DERR_FRAME);
+                // The sequence bit stream is one serial chain (lane 0), read backwards with up to four reloads per sequence.
+                // From global memory every reload is a dependent round trip; so the wave stages the stream through an LDS
+                // window (all lanes copy, lane 0 decodes until it gets close to the window's lower edge, repeat).
+                {
+                    const uint32_t t = L.scal[2], n = bsize - t;
+                    const uint8_t* const stream = blk + t;
+                    BitW b; b.bad = false; b.c = 0; b.consumed = 0; b.pos = 0;
+                    uint32_t pos = n >= 8 ? n - 8 : 0;                      // byte offset of the reader's 8-byte word in the stream
+                    uint32_t i = 0, sl = 0, so = 0, sm = 0, rep0 = 0, rep1 = 0, rep2 = 0;
+                    bool started = false;
+                    for (;;) {
+                        const uint32_t top = pos + 8 < n ? pos + 8 : n;
+                        const uint32_t wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
+                        for (uint32_t k = lane * 16; wbase + k < top; k += LANES * 16) {
+                            uint4 v;
+                            if (wbase + k + 16 <= n) __builtin_memcpy(&v, stream + wbase + k, 16);
+                            else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wbase + k + j < n ? stream[wbase + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
+                            *reinterpret_cast<uint4*>(&L.win[k]) = v;
+                        }
+                        __threadfence_block();
+                        __syncthreads();
+                        if (lane == 0) {
+                            uint32_t e = 0;
+                            const uint8_t* const win = L.win;
+                            do {
+                                if (!started) {
+                                    bw_init(b, win, wbase, n);               // reads the last bytes of the stream: resident
+                                    if (b.bad) { e = 1; break; }
+                                    sl = (uint32_t)bw_read(b, L.llLog); so = (uint32_t)bw_read(b, L.ofLog); sm = (uint32_t)bw_read(b, L.mlLog);
+                                    if (!bw_reload(b, win, wbase)) { e = 1; break; }
+                                    rep0 = L.rep[0]; rep1 = L.rep[1]; rep2 = L.rep[2];
+                                    started = true;
+                                }
+                                // one sequence moves the reader down by at most 12 bytes
+                                while (i < nbSeq && (wbase == 0 || b.pos >= wbase + 16)) {
+                                    const FseD el = L.ll[sl], eo = L.of[so], em = L.ml[sm];
+                                    const uint32_t oc = eo.sym, mc = em.sym, lc = el.sym;
+                                    if (oc > 31 || mc > 52 || lc > 35) { e = 1; break; }
+                                    uint32_t offBase;
+                                    if (oc > 24) {                              // up to 31 extra bits: read in two parts around a reload
+                                        const uint32_t hi = oc - 24;
+                                        offBase = (1u << oc) + ((uint32_t)bw_read(b, hi) << 24);
+                                        if (!bw_reload(b, win, wbase)) { e = 1; break; }
+                                        offBase += (uint32_t)bw_read(b, 24);
+                                    } else offBase = (1u << oc) + (uint32_t)bw_read(b, oc);
+                                    const uint32_t ml = dMLbase[mc] + (uint32_t)bw_read(b, dMLbits[mc]);
+                                    if (!bw_reload(b, win, wbase)) { e = 1; break; }
+                                    const uint32_t ll = dLLbase[lc] + (uint32_t)bw_read(b, dLLbits[lc]);
+                                    uint32_t off;                               // resolve the repeat codes here: the execution is order-free then
+                                    if (offBase > 3) { off = offBase - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                                    else {
+                                        const uint32_t idx = offBase - 1 + (ll == 0);
+                                        if (idx == 0) off = rep0;
+                                        else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
+                                        else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                                        else { off = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                                    }
+                                    zs_seq sq; sq.offBase = off; sq.litLength = ll; sq.mlBase = ml; sq.litPos = 0;
+                                    seqs[i] = sq;
+                                    if (i + 1 < nbSeq) {
+                                        sl = el.base + (uint32_t)bw_read(b, el.nb);
+                                        sm = em.base + (uint32_t)bw_read(b, em.nb);
+                                        if (!bw_reload(b, win, wbase)) { e = 1; break; }
+                                        so = eo.base + (uint32_t)bw_read(b, eo.nb);
+                                    }
+                                    if (!bw_reload(b, win, wbase)) { e = 1; break; }
+                                    i++;
+                                }
+                                if (e) break;
+                                pos = b.pos;
+                                if (i >= nbSeq) {
+                                    if (!bw_finished(b)) e = 1;
+                                    L.rep[0] = rep0; L.rep[1] = rep1; L.rep[2] = rep2;
+                                }
+                            } while (0);
+                            L.scal[1] = e; L.scal[3] = i; L.scal[4] = pos;
+                        }
+                        __threadfence_block();
+                        __syncthreads();
+                        const uint32_t e = L.scal[1], di = L.scal[3];
+                        pos = L.scal[4];
+                        __syncthreads();
+                        if (e || di >= nbSeq) break;
+                    }
+                }
+                if (L.scal[1]) FAIL(DERR_FRAME);
             } else if (q != bsize) FAIL(DERR_FRAME);
-            // ---- execute the sequences: literal copy + match copy, all lanes ----
+            // ---- execute the sequences, 64 at a time (one per lane) ----
+            // Positions come from prefix sums, so literal runs and every match whose source lies before the group's first
+            // output byte are copied by their own lane, all at once; only matches that read bytes produced inside the same
+            // group (short offsets) are replayed in order with wave-wide copies.
             {
                 uint32_t lp = 0;
-                uint32_t dirtyFrom = opos;                              // output bytes at or beyond this may not be visible yet
-                for (uint32_t i = 0; i < nbSeq; i++) {
-                    const zs_seq sq = seqs[i];
-                    const uint32_t ll = sq.litLength, ml = sq.mlBase;
-                    if (lp + ll > litSize || (uint64_t)opos + ll + ml > contentSize) FAIL(DERR_FRAME);
-                    for (uint32_t k = lane; k < ll; k += LANES) out[opos + k] = litPtr[lp + k];
-                    lp += ll; opos += ll;
-                    uint32_t off;
-                    if (sq.offBase > 3) { off = sq.offBase - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                    else {
-                        const uint32_t idx = sq.offBase - 1 + (ll == 0);
-                        if (idx == 0) off = rep0;
-                        else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
-                        else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                        else { off = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                for (uint32_t g = 0; g < nbSeq; g += LANES) {
+                    const uint32_t u = g + lane;
+                    const bool valid = u < nbSeq;
+                    zs_seq sq; sq.offBase = 1; sq.litLength = 0; sq.mlBase = 0; sq.litPos = 0;
+                    if (valid) sq = seqs[u];
+                    const uint32_t ll = sq.litLength, ml = sq.mlBase, off = sq.offBase;
+                    uint32_t litIncl = ll, totIncl = ll + ml;
+                    for (int o = 1; o < LANES; o <<= 1) {
+                        const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
+                        if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
                     }
-                    if (off == 0 || off > opos) FAIL(DERR_FRAME);
-                    const uint32_t from = opos - off;
-                    if (from + ml > dirtyFrom) { __threadfence_block(); dirtyFrom = opos; }
-                    if (off >= LANES || off >= ml) {
-                        for (uint32_t k = 0; k < ml; k += LANES) {
-                            // a 64-byte step may read bytes written by the previous step when off < ml
-                            if (k && off < ml && from + k + LANES > dirtyFrom) { __threadfence_block(); dirtyFrom = opos + k; }
-                            if (k + lane < ml) out[opos + k + lane] = out[from + k + lane];
+                    const uint32_t groupLit = __shfl(litIncl, LANES - 1), groupTot = __shfl(totIncl, LANES - 1);
+                    if (lp + groupLit > litSize || (uint64_t)opos + groupTot > contentSize) FAIL(DERR_FRAME);
+                    const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
+                    if (__any(valid && ml && (off == 0 || off > mOut))) FAIL(DERR_FRAME);
+                    copy_small(out + myOut, litPtr + myLit, ll);
+                    const bool early = valid && ml && mOut - off + ml <= opos;
+                    if (early) copy_small(out + mOut, out + mOut - off, ml);
+                    unsigned long long late = __ballot(valid && ml && !early);
+                    __threadfence_block();
+                    while (late) {
+                        const int i = __ffsll((long long)late) - 1;
+                        late &= late - 1;
+                        const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
+                        const uint32_t from = dpos - o_;
+                        if (o_ >= LANES || o_ >= m_) {
+                            for (uint32_t k = 0; k < m_; k += LANES) {
+                                if (k && o_ < m_) __threadfence_block();          // a 64-byte step may read bytes written by the previous step
+                                if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
+                            }
+                        } else {
+                            for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];   // periodic pattern
                         }
-                    } else {
-                        for (uint32_t k = lane; k < ml; k += LANES) out[opos + k] = out[from + (k % off)];   // periodic pattern
+                        __threadfence_block();
                     }
-                    opos += ml;
+                    lp += groupLit; opos += groupTot;
                 }
                 const uint32_t tail = litSize - lp;
                 if ((uint64_t)opos + tail > contentSize) FAIL(DERR_FRAME);
