@@ -18,6 +18,13 @@
 
 #define LANES 64
 #define DERR_FRAME TSX_E_BAD_FRAME
+#ifdef TSX_PROF2
+static unsigned long long* g_dprof_out = nullptr;                     // 8 u64 per chunk: phase laps of the decoder
+extern "C" void tsx_debug_set_dprof(void* dev_ptr) { g_dprof_out = (unsigned long long*)dev_ptr; }
+#define DLT(k) do { const unsigned long long n_ = (unsigned long long)clock64(); dlt_[k] += n_ - dlast_; dlast_ = n_; } while (0)
+#else
+#define DLT(k) do {} while (0)
+#endif
 
 __device__ static const uint32_t dLLbase[36] = {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,128,256,512,1024,2048,4096,8192,16384,32768,65536};
 __device__ static const uint8_t dLLbits[36] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16};
@@ -30,12 +37,22 @@ __device__ static const short dMLnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1
 __device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
 __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
-#define ZS_DWIN 4096u
+#define ZS_DWIN 2048u
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
+// sequence decoding entry: everything one state transition needs in one 8-byte LDS read (next-state base + bits, and the
+// symbol's own base value + number of extra bits, looked up once when the table is built instead of once per sequence)
+struct alignas(8) SeqD { uint16_t base; uint8_t nb; uint8_t ebits; uint32_t bval; };
+__device__ static inline SeqD seqd_load(const SeqD* p) {               // one ds_read_b64
+    uint64_t raw; __builtin_memcpy(&raw, p, 8);
+    SeqD e; e.base = (uint16_t)raw; e.nb = (uint8_t)(raw >> 16); e.ebits = (uint8_t)(raw >> 24); e.bval = (uint32_t)(raw >> 32);
+    return e;
+}
 struct DecLds {
-    uint16_t huf[4096];          // (nbBits << 8) | symbol
+    uint16_t huf[2048];          // (nbBits << 8) | symbol; Max_Number_of_Bits of a literals tree is 11 (RFC 8878 4.2.1)
     uint32_t hufLog; int hufValid;
-    FseD ll[512], of[256], ml[512];
+    SeqD ll[512], of[256], ml[512];
+    uint8_t cellSym[512];        // table construction scratch: symbol of each cell
+    uint32_t cLLbase[36], cMLbase[53]; uint8_t cLLbits[36], cMLbits[53];   // LDS copies of the length code tables
     FseD wt[64];                 // FSE table of the Huffman-weight stream (tableLog <= 6)
     uint32_t llLog, ofLog, mlLog; int llValid, ofValid, mlValid;
     uint8_t weights[256];
@@ -167,32 +184,38 @@ __device__ static uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint
     return used;
 }
 
-__device__ static bool fse_buildDTable(FseD* dt, const short* norm, uint32_t maxSym, uint32_t tableLog, uint16_t* symNext) {
+template <class E, class Fill>
+__device__ static bool fse_buildDTable(E* dt, uint8_t* cellSym, const short* norm, uint32_t maxSym, uint32_t tableLog, uint16_t* symNext, Fill fill) {
     const uint32_t size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
     uint32_t high = size - 1;
     for (uint32_t s = 0; s <= maxSym; s++) {
-        if (norm[s] == -1) { dt[high--].sym = (uint8_t)s; symNext[s] = 1; }
+        if (norm[s] == -1) { cellSym[high--] = (uint8_t)s; symNext[s] = 1; }
         else symNext[s] = (uint16_t)norm[s];
     }
     uint32_t pos = 0;
     for (uint32_t s = 0; s <= maxSym; s++)
         for (int i = 0; i < norm[s]; i++) {
-            dt[pos].sym = (uint8_t)s;
+            cellSym[pos] = (uint8_t)s;
             pos = (pos + step) & mask;
             while (pos > high) pos = (pos + step) & mask;
         }
     if (pos != 0) return false;
     for (uint32_t u = 0; u < size; u++) {
-        const uint8_t s = dt[u].sym;
+        const uint8_t s = cellSym[u];
         const uint32_t ns = symNext[s]++;
         const uint32_t nb = tableLog - dhb32(ns);
-        dt[u].nb = (uint8_t)nb; dt[u].base = (uint16_t)((ns << nb) - size);
+        E e; e.nb = (uint8_t)nb; e.base = (uint16_t)((ns << nb) - size);
+        fill(e, s);
+        dt[u] = e;
     }
     return true;
 }
-
-// ---- Huffman table (lane 0): weights -> decoding table ------------------------------------------------------
-// returns bytes consumed by the tree description, 0 on error
+// kind 0 = literal lengths, 1 = offsets, 2 = match lengths
+__device__ static inline void seq_fill(const DecLds& L, SeqD& e, uint32_t sym, int kind) {
+    if (kind == 0) { e.ebits = L.cLLbits[sym]; e.bval = L.cLLbase[sym]; }
+    else if (kind == 1) { e.ebits = (uint8_t)sym; e.bval = 1u << sym; }
+    else { e.ebits = L.cMLbits[sym]; e.bval = L.cMLbase[sym]; }
+}
 __device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t n) {
     if (n < 1) return 0;
     const uint32_t hb = src[0];
@@ -207,7 +230,7 @@ __device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t
         uint32_t maxSym = 12, tl;
         const uint32_t h = fse_readNCount(L.norm, &maxSym, &tl, src + 1, hb, 6);
         if (!h) return 0;
-        if (!fse_buildDTable(L.wt, L.norm, maxSym, tl, L.symNext)) return 0;
+        if (!fse_buildDTable(L.wt, L.cellSym, L.norm, maxSym, tl, L.symNext, [](FseD& e, uint32_t sym) { e.sym = (uint8_t)sym; })) return 0;
         BitR b; br_init(b, src + 1 + h, hb - h);
         if (b.bad) return 0;
         uint32_t s1 = (uint32_t)br_read(b, tl), s2 = (uint32_t)br_read(b, tl);
@@ -227,7 +250,7 @@ __device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t
     for (uint32_t i = 0; i < nw; i++) { const uint32_t w = L.weights[i]; if (w > 12) return 0; L.rankCount[w]++; total += w ? (1u << (w - 1)) : 0; }
     if (total == 0) return 0;
     const uint32_t tableLog = dhb32(total) + 1;
-    if (tableLog > 12) return 0;
+    if (tableLog > 11) return 0;
     const uint32_t rest = (1u << tableLog) - total;
     if (rest & (rest - 1)) return 0;
     const uint32_t lastW = dhb32(rest) + 1;
@@ -294,7 +317,11 @@ __device__ static inline void copy_small(uint8_t* __restrict__ dst, const uint8_
 
 __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
                                                                 tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
-                                                                int32_t* __restrict__ status, uint8_t* __restrict__ work) {
+                                                                int32_t* __restrict__ status, uint8_t* __restrict__ work
+#ifdef TSX_PROF2
+                                                                , unsigned long long* __restrict__ dprof
+#endif
+                                                                ) {
     __shared__ DecLds L;
     const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
     if (status[chunk] != TSX_OK) return;
@@ -306,6 +333,9 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
     zs_seq* const seqs = (zs_seq*)(ws + ZS_WS_HASHLONG);           // the decoder needs no hash tables: 768 KiB = 49152 sequences
     uint8_t* const lit = ws + ZS_WS_LIT;
     int32_t err = TSX_OK;
+#ifdef TSX_PROF2
+    unsigned long long dlt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast_ = (unsigned long long)clock64();
+#endif
     uint32_t opos = 0;
     uint64_t contentSize = 0;
     uint32_t p = 0;
@@ -333,6 +363,8 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
     }
     if (contentSize > d.dst_cap) FAIL(TSX_E_DST_TOO_SMALL);
     if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; L.rep[0] = 1; L.rep[1] = 4; L.rep[2] = 8; }
+    if (lane < 36) { L.cLLbase[lane] = dLLbase[lane]; L.cLLbits[lane] = dLLbits[lane]; }
+    if (lane < 53) { L.cMLbase[lane] = dMLbase[lane]; L.cMLbits[lane] = dMLbits[lane]; }
     __syncthreads();
     // ---- blocks ----
     for (;;) {
@@ -412,6 +444,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
             }
             __threadfence_block();
             __syncthreads();
+            DLT(0);                                                     // 0: block header + literals section
             // ---- sequences section ----
             if (q >= bsize) FAIL(DERR_FRAME);
             uint32_t nbSeq = blk[q];
@@ -429,7 +462,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         if (modes & 3) { e = 1; break; }
                         const uint32_t m[3] = {(modes >> 6) & 3, (modes >> 4) & 3, (modes >> 2) & 3};
                         for (int k = 0; k < 3 && !e; k++) {
-                            FseD* dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
+                            SeqD* dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
                             uint32_t* logp = k == 0 ? &L.llLog : k == 1 ? &L.ofLog : &L.mlLog;
                             int* validp = k == 0 ? &L.llValid : k == 1 ? &L.ofValid : &L.mlValid;
                             const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
@@ -437,18 +470,18 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                                 const short* dn = k == 0 ? dLLnorm : k == 1 ? dOFnorm : dMLnorm;
                                 const uint32_t dmax = k == 0 ? 35 : k == 1 ? 28 : 52, dlog = k == 1 ? 5 : 6;
                                 for (uint32_t s = 0; s <= dmax; s++) L.norm[s] = dn[s];
-                                fse_buildDTable(dt, L.norm, dmax, dlog, L.symNext);
+                                fse_buildDTable(dt, L.cellSym, L.norm, dmax, dlog, L.symNext, [k](SeqD& e, uint32_t sym) { seq_fill(L, e, sym, k); });
                                 *logp = dlog; *validp = 1;
                             } else if (m[k] == 1) {
                                 if (t >= bsize) { e = 1; break; }
                                 const uint32_t s = blk[t++];
                                 if (s > maxSymK) { e = 1; break; }
-                                dt[0].sym = (uint8_t)s; dt[0].nb = 0; dt[0].base = 0;
+                                dt[0].nb = 0; dt[0].base = 0; seq_fill(L, dt[0], s, k);
                                 *logp = 0; *validp = 1;
                             } else if (m[k] == 2) {
                                 uint32_t ms = maxSymK, tl;
                                 const uint32_t used = fse_readNCount(L.norm, &ms, &tl, blk + t, bsize - t, maxLogK);
-                                if (!used || !fse_buildDTable(dt, L.norm, ms, tl, L.symNext)) { e = 1; break; }
+                                if (!used || !fse_buildDTable(dt, L.cellSym, L.norm, ms, tl, L.symNext, [k](SeqD& e, uint32_t sym) { seq_fill(L, e, sym, k); })) { e = 1; break; }
                                 t += used; *logp = tl; *validp = 1;
                             } else if (!*validp) { e = 1; break; }
                         }
@@ -461,6 +494,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                 __threadfence_block();
                 __syncthreads();
                 if (L.scal[1]) FAIL(DERR_FRAME);
+                DLT(1);                                                 // 1: sequence tables
                 // The sequence bit stream is one serial chain (lane 0), read backwards with up to four reloads per sequence.
                 // From global memory every reload is a dependent round trip; so the wave stages the stream through an LDS
                 // window (all lanes copy, lane 0 decodes until it gets close to the window's lower edge, repeat).
@@ -496,19 +530,18 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                                 }
                                 // one sequence moves the reader down by at most 12 bytes
                                 while (i < nbSeq && (wbase == 0 || b.pos >= wbase + 16)) {
-                                    const FseD el = L.ll[sl], eo = L.of[so], em = L.ml[sm];
-                                    const uint32_t oc = eo.sym, mc = em.sym, lc = el.sym;
-                                    if (oc > 31 || mc > 52 || lc > 35) { e = 1; break; }
+                                    const SeqD el = seqd_load(&L.ll[sl]), eo = seqd_load(&L.of[so]), em = seqd_load(&L.ml[sm]);
+                                    const uint32_t oc = eo.ebits;
                                     uint32_t offBase;
                                     if (oc > 24) {                              // up to 31 extra bits: read in two parts around a reload
                                         const uint32_t hi = oc - 24;
-                                        offBase = (1u << oc) + ((uint32_t)bw_read(b, hi) << 24);
+                                        offBase = eo.bval + ((uint32_t)bw_read(b, hi) << 24);
                                         if (!bw_reload(b, win, wbase)) { e = 1; break; }
                                         offBase += (uint32_t)bw_read(b, 24);
-                                    } else offBase = (1u << oc) + (uint32_t)bw_read(b, oc);
-                                    const uint32_t ml = dMLbase[mc] + (uint32_t)bw_read(b, dMLbits[mc]);
+                                    } else offBase = eo.bval + (uint32_t)bw_read(b, oc);
+                                    const uint32_t ml = em.bval + (uint32_t)bw_read(b, em.ebits);
                                     if (!bw_reload(b, win, wbase)) { e = 1; break; }
-                                    const uint32_t ll = dLLbase[lc] + (uint32_t)bw_read(b, dLLbits[lc]);
+                                    const uint32_t ll = el.bval + (uint32_t)bw_read(b, el.ebits);
                                     uint32_t off;                               // resolve the repeat codes here: the execution is order-free then
                                     if (offBase > 3) { off = offBase - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
                                     else {
@@ -548,6 +581,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                 }
                 if (L.scal[1]) FAIL(DERR_FRAME);
             } else if (q != bsize) FAIL(DERR_FRAME);
+            DLT(2);                                                     // 2: FSE sequence decode
             // ---- execute the sequences, 64 at a time (one per lane) ----
             // Positions come from prefix sums, so literal runs and every match whose source lies before the group's first
             // output byte are copied by their own lane, all at once; only matches that read bytes produced inside the same
@@ -597,6 +631,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                 opos += tail;
                 __threadfence_block();
             }
+            DLT(3);                                                     // 3: execution
             p += bsize;
         } else FAIL(DERR_FRAME);
         __syncthreads();
@@ -605,6 +640,10 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
     if (hasChecksum) { if (p + 4 > srcSize) FAIL(DERR_FRAME); p += 4; }
     if (p != srcSize || opos != contentSize) FAIL(DERR_FRAME);
 done:
+#ifdef TSX_PROF2
+    DLT(4);
+    if (lane == 0 && dprof) for (int i_ = 0; i_ < 8; i_++) dprof[(size_t)chunk * 8 + i_] = dlt_[i_];
+#endif
     if (lane == 0) {
         if (err != TSX_OK) { status[chunk] = err; descs[chunk].dst_len = 0; }
         else descs[chunk].dst_len = opos;
@@ -614,6 +653,10 @@ done:
 uint32_t tsx_launch_zstd_decompress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* frames, int from_mid, uint64_t mid_stride,
                                     tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work) {
     if (!n) return 0;
-    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work);
+    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work
+#ifdef TSX_PROF2
+                       , g_dprof_out
+#endif
+                       );
     return 1;
 }

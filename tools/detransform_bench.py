@@ -8,7 +8,8 @@ import torch
 import tsxform
 from tsxform import synth
 nat = tsxform._native
-N = nat.Native(nat.LIB_PATH); N.init(1, [0])
+LIBNAME = sys.argv[2] if len(sys.argv) > 2 else "libtsxform.so"
+N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), LIBNAME)); N.init(1, [0])
 n, CH = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, synth.CHUNK
 dev = torch.device("cuda", 0)
 src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
@@ -28,6 +29,12 @@ N.transform_batch(params, d, src.data_ptr(), mid.data_ptr(), mid.numel(), nat.ME
 crc = d["crc32c"].copy()
 back = torch.empty(n * CH, dtype=torch.uint8, device=dev)
 e = np.zeros(n, nat.DESC_DTYPE); e["src_off"] = d["dst_off"]; e["src_len"] = d["dst_len"]; e["dst_off"] = np.arange(n, dtype=np.uint64) * CH; e["dst_cap"] = CH
+dprof = None
+if "prof2" in LIBNAME:
+    import ctypes as C
+    dprof = torch.zeros(n * 8, dtype=torch.int64, device=dev)
+    N.lib.tsx_debug_set_dprof.restype = None; N.lib.tsx_debug_set_dprof.argtypes = [C.c_void_p]
+    N.lib.tsx_debug_set_dprof(dprof.data_ptr())
 for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     N.detransform_batch(params, e, mid.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE, ctx=ctx)
@@ -36,3 +43,7 @@ for it in range(3):
     print("detransform %d chunks: %.1f ms -> %.2f GiB/s of restored bytes (gcm %.1f ms, unzstd %.1f ms, crc %.1f ms)" % (n, el * 1e3, n * CH / 2**30 / el, t.gcm_ms, t.unzstd_ms, t.crc_ms))
 assert (e["status"] == 0).all() and (e["crc32c"] == crc).all() and torch.equal(back, src)
 print("round trip exact")
+if dprof is not None:
+    m = dprof.cpu().numpy().reshape(n, 8).mean(axis=0)
+    for k, name in enumerate(["block header + literals", "sequence tables", "FSE sequence decode", "execution", "rest"]):
+        print("  %-26s %12.0f cycles (%.1f%%)" % (name, m[k], 100 * m[k] / m[:5].sum()))
