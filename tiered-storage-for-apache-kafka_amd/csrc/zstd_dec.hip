@@ -38,6 +38,8 @@ __device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__c
 __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
 #define ZS_DWIN 2048u
+#define ZS_HWIN 1024u
+static_assert(4 * (ZS_HWIN + 16) >= ZS_DWIN + 16, "the sequence window shares the Huffman windows' LDS");
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 // sequence decoding entry: everything one state transition needs in one 8-byte LDS read (next-state base + bits, and the
 // symbol's own base value + number of extra bits, looked up once when the table is built instead of once per sequence)
@@ -62,7 +64,7 @@ struct DecLds {
     uint32_t scal[16];
     uint32_t streamOff[5];
     uint32_t rep[3];             // repeat-offset history, carried across the blocks of the frame (lane 0)
-    alignas(16) uint8_t win[ZS_DWIN + 16];   // window of the sequence bit stream being decoded
+    alignas(16) uint8_t win[4 * (ZS_HWIN + 16)];   // literal stage: one window per Huffman stream; sequence stage: one window (ZS_DWIN)
 };
 
 // ---- backward bit reader (BIT_DStream) -----------------------------------------------------------------
@@ -434,10 +436,58 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                     if (3 * seg > litSize) FAIL(DERR_FRAME);
                     sCnt[0] = sCnt[1] = sCnt[2] = seg; sCnt[3] = litSize - 3 * seg;
                 }
+                // The (1 or 4) Huffman streams decode on lanes 0..3, each through its own LDS window of the stream, refilled by
+                // the whole wave whenever a lane gets close to its window's lower edge (a reload from global memory would be a
+                // dependent round trip every four symbols).
                 bool ok = true;
-                if (lane < streams) {
-                    uint32_t o = 0; for (uint32_t k = 0; k < lane; k++) o += sCnt[k];
-                    ok = huf_decodeStream(lit + o, sCnt[lane], blk + t + sOff[lane], sOff[lane + 1] - sOff[lane], L.huf, L.hufLog);
+                {
+                    const bool mine = lane < streams;
+                    uint32_t o = 0; for (uint32_t k = 0; k < lane && k < 4; k++) o += mine ? sCnt[k] : 0;
+                    const uint32_t cnt = mine ? sCnt[lane] : 0, sn = mine ? sOff[lane + 1] - sOff[lane] : 0, sbeg = mine ? t + sOff[lane] : 0;
+                    uint8_t* const outp = lit + o;
+                    BitW hb; hb.bad = false; hb.c = 0; hb.consumed = 0; hb.pos = sn >= 8 ? sn - 8 : 0;
+                    uint32_t hi = 0; bool started = false, hdone = !mine;
+                    if (mine && sn == 0) { ok = false; hdone = true; }
+                    const uint32_t tableLog = L.hufLog;
+                    for (;;) {
+                        const uint32_t myTop = hdone ? 0 : (hb.pos + 8 < sn ? hb.pos + 8 : sn);
+                        const uint32_t myWb = myTop > ZS_HWIN ? (myTop - ZS_HWIN + 15) & ~15u : 0;     // top - wb <= ZS_HWIN = one 16-byte piece per lane
+                        for (uint32_t s_ = 0; s_ < streams; s_++) {
+                            const uint32_t top = __shfl(myTop, s_), wb = __shfl(myWb, s_), beg = __shfl(sbeg, s_), n_ = __shfl(sn, s_);
+                            const uint32_t k = lane * 16;
+                            if (wb + k < top) {
+                                uint4 v;
+                                if (wb + k + 16 <= n_) __builtin_memcpy(&v, blk + beg + wb + k, 16);
+                                else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wb + k + j < n_ ? blk[beg + wb + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
+                                *reinterpret_cast<uint4*>(&L.win[s_ * (ZS_HWIN + 16) + k]) = v;
+                            }
+                        }
+                        __threadfence_block();
+                        __syncthreads();
+                        if (!hdone) {
+                            const uint8_t* const win = &L.win[lane * (ZS_HWIN + 16)];
+                            if (!started) { bw_init(hb, win, myWb, sn); started = true; if (hb.bad) { ok = false; hdone = true; } }
+                            while (!hdone && hi < cnt && (myWb == 0 || hb.pos >= myWb + 8)) {       // four symbols (<= 44 bits) per reload
+                                if (!bw_reload(hb, win, myWb)) { ok = false; hdone = true; break; }
+                                uint32_t packed = 0; const uint32_t m = cnt - hi < 4 ? cnt - hi : 4;
+                                for (uint32_t j = 0; j < m; j++) {
+                                    const uint16_t e = L.huf[(hb.c << (hb.consumed & 63)) >> (64 - tableLog)];
+                                    hb.consumed += e >> 8;
+                                    packed |= (uint32_t)(e & 0xFF) << (8 * j);
+                                }
+                                if (m == 4) __builtin_memcpy(outp + hi, &packed, 4);
+                                else for (uint32_t j = 0; j < m; j++) outp[hi + j] = (uint8_t)(packed >> (8 * j));
+                                hi += m;
+                            }
+                            if (!hdone && hi >= cnt) {
+                                if (hb.consumed > 64) ok = false;
+                                else { bw_reload(hb, win, myWb); if (!bw_finished(hb)) ok = false; }
+                                hdone = true;
+                            }
+                        }
+                        __syncthreads();
+                        if (__all(hdone)) break;
+                    }
                 }
                 if (__any(!ok)) FAIL(DERR_FRAME);
                 q = hl + csize;
