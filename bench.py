@@ -212,7 +212,7 @@ def main():
             "value": round(value, 4), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": {"full": "8x1GiB segments/GPU, 4 MiB chunks, Zstd(L3)+AES-256-GCM+CRC32C (BASELINE configs[3])",
+            "config": {"workload": {"full": "%dx1GiB segments/GPU, 4 MiB chunks, Zstd(L3)+AES-256-GCM+CRC32C (BASELINE configs[3])" % nseg,
                                     "gcm_crc": "1 GiB segment, 4 MiB chunks, AES-256-GCM+CRC32C (BASELINE configs[2])",
                                     "crc": "1 GiB segment, 4 MiB chunks, CRC32C only (BASELINE configs[1])"}[workload],
                        "stages": workload, "segments_per_gpu": nseg, "chunks_per_gpu": n, "chunk_bytes": CH, "content": args.dist,
