@@ -540,6 +540,32 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
     LT(0); LT_FLUSH();
 }
 
+// Per-lane copy of a short run with up to 32 bytes of loads in flight before the first store (a byte loop would pay one
+// memory round trip per byte).
+__device__ static inline void copy_run(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
+    uint32_t k = 0;
+    while (n - k >= 32) {
+        const uint64_t a = ld64(src + k), b = ld64(src + k + 8), c = ld64(src + k + 16), d = ld64(src + k + 24);
+        __builtin_memcpy(dst + k, &a, 8); __builtin_memcpy(dst + k + 8, &b, 8); __builtin_memcpy(dst + k + 16, &c, 8); __builtin_memcpy(dst + k + 24, &d, 8);
+        k += 32;
+    }
+    const uint32_t r = n - k, nq = r >> 3;
+    uint64_t q0 = 0, q1 = 0, q2 = 0; uint32_t w = 0; uint16_t h = 0; uint8_t b1 = 0;
+    if (nq > 0) q0 = ld64(src + k);
+    if (nq > 1) q1 = ld64(src + k + 8);
+    if (nq > 2) q2 = ld64(src + k + 16);
+    const uint32_t t = k + 8 * nq;
+    if (r & 4) __builtin_memcpy(&w, src + t, 4);
+    if (r & 2) __builtin_memcpy(&h, src + t + (r & 4), 2);
+    if (r & 1) b1 = src[t + (r & 6)];
+    if (nq > 0) __builtin_memcpy(dst + k, &q0, 8);
+    if (nq > 1) __builtin_memcpy(dst + k + 8, &q1, 8);
+    if (nq > 2) __builtin_memcpy(dst + k + 16, &q2, 8);
+    if (r & 4) __builtin_memcpy(dst + t, &w, 4);
+    if (r & 2) __builtin_memcpy(dst + t + (r & 4), &h, 2);
+    if (r & 1) dst[t + (r & 6)] = b1;
+}
+
 // Literals of a parsed block, gathered by all lanes: sequence u's run is src[litPos, litPos + litLength) and lands at the
 // running sum of the earlier runs; the tail after the last match follows.
 __device__ ZS_NOINLINE static void gather_literals(uint8_t* __restrict__ lit, const uint8_t* __restrict__ src, const zs_seq* __restrict__ seqs,
@@ -552,7 +578,7 @@ __device__ ZS_NOINLINE static void gather_literals(uint8_t* __restrict__ lit, co
         uint32_t incl = ll;
         for (int o = 1; o < LANES; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += t; }
         const uint32_t dst = base + incl - ll;
-        for (uint32_t i = 0; i < ll; i++) lit[dst + i] = src[lp + i];
+        copy_run(lit + dst, src + lp, ll);
         base += __shfl(incl, LANES - 1);
     }
     for (uint32_t i = lane; i < tailLen; i += LANES) lit[base + i] = src[tailPos + i];
