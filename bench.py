@@ -196,7 +196,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as o
         cores = os.cpu_count() or 1
-        sample = {"full": 48, "gcm_crc": 256, "crc": 256}[workload]
+        # every host core gets work: 4 chunks per thread for the full chain (about 10-30 s of CPU work), one segment otherwise
+        sample = {"full": max(48, 4 * cores), "gcm_crc": 256, "crc": 256}[workload]
         sample = min(sample, n)
         host = src[:sample * CH].cpu().numpy()
         ivs = np.ascontiguousarray(d["iv"][:sample]).reshape(-1)

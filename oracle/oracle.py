@@ -194,6 +194,7 @@ def chain_run_threads(flags, key, aad, src: np.ndarray, chunk: int, ivs: np.ndar
     n = src.size // chunk
     stride = lib().orc_chain_bound(chunk, flags)
     dst = np.empty(n * stride, np.uint8)
+    dst[::4096] = 0                                     # pre-fault the output pages: the baseline times the chain, not the kernel's page faults
     sizes = np.zeros(n, np.uint32); crcs = np.zeros(n, np.uint32)
     k, kp = _buf(key); a, ap = _buf(aad)
     secs = lib().orc_chain_run_threads(flags, kp, ap, a.size, src.ctypes.data, chunk, n, ivs.ctypes.data,
