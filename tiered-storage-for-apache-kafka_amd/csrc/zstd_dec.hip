@@ -43,7 +43,10 @@ static_assert(4 * (ZS_HWIN + 16) >= ZS_DWIN + 16, "the sequence window shares th
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 // sequence decoding entry: everything one state transition needs in one 8-byte LDS read (next-state base + bits, and the
 // symbol's own base value + number of extra bits, looked up once when the table is built instead of once per sequence)
+#define DUNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
+__device__ static inline uint64_t duni64(uint64_t v) { return ((uint64_t)DUNI(v >> 32) << 32) | DUNI(v); }
 struct alignas(8) SeqD { uint16_t base; uint8_t nb; uint8_t ebits; uint32_t bval; };
+__device__ static inline uint64_t seqd_raw(const SeqD* p) { uint64_t raw; __builtin_memcpy(&raw, p, 8); return raw; }   // base | nb << 16 | ebits << 24 | bval << 32
 __device__ static inline SeqD seqd_load(const SeqD* p) {               // one ds_read_b64
     uint64_t raw; __builtin_memcpy(&raw, p, 8);
     SeqD e; e.base = (uint16_t)raw; e.nb = (uint8_t)(raw >> 16); e.ebits = (uint8_t)(raw >> 24); e.bval = (uint32_t)(raw >> 32);
@@ -545,16 +548,28 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                 __syncthreads();
                 if (L.scal[1]) FAIL(DERR_FRAME);
                 DLT(1);                                                 // 1: sequence tables
-                // The sequence bit stream is one serial chain (lane 0), read backwards with up to four reloads per sequence.
-                // From global memory every reload is a dependent round trip; so the wave stages the stream through an LDS
-                // window (all lanes copy, lane 0 decodes until it gets close to the window's lower edge, repeat).
+                // The sequence bit stream is one serial chain, read backwards with up to four reloads per sequence.  From global
+                // memory every reload is a dependent round trip, so the wave stages the stream through an LDS window (all lanes
+                // copy, then decode until the reader gets close to the window's lower edge, repeat).  The chain itself is computed
+                // by EVERY lane on wave-uniform values (LDS reads broadcast, results pinned to SGPRs): scalar ALU and scalar
+                // branches instead of one active lane dragging exec masks through ~20 branches per sequence.
                 {
-                    const uint32_t t = L.scal[2], n = bsize - t;
+                    const uint32_t t = DUNI(L.scal[2]), n = DUNI(bsize - t);
                     const uint8_t* const stream = blk + t;
-                    BitW b; b.bad = false; b.c = 0; b.consumed = 0; b.pos = 0;
+                    const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog), nseq = DUNI(nbSeq);
+                    uint64_t c = 0; uint32_t consumed = 0;
                     uint32_t pos = n >= 8 ? n - 8 : 0;                      // byte offset of the reader's 8-byte word in the stream
-                    uint32_t i = 0, sl = 0, so = 0, sm = 0, rep0 = 0, rep1 = 0, rep2 = 0;
+                    uint32_t i = 0, sl = 0, so = 0, sm = 0;
+                    uint32_t rep0 = DUNI(L.rep[0]), rep1 = DUNI(L.rep[1]), rep2 = DUNI(L.rep[2]);
+                    uint32_t e = 0;
                     bool started = false;
+                    const uint8_t* const win = L.win;
+#define SQ_READ(nb_) ((nb_) ? (uint32_t)((c << (consumed & 63)) >> (64 - (nb_))) : 0u)
+#define SQ_RELOAD() do {                                                                                                  \
+        if (consumed > 64) { e = 1; }                                                                                      \
+        else if (pos >= 8) { pos -= consumed >> 3; consumed &= 7; c = duni64(wld64(win, wbase, pos)); }                      \
+        else if (pos != 0) { uint32_t nbB = consumed >> 3; if (nbB > pos) nbB = pos; pos -= nbB; consumed -= nbB * 8; c = duni64(wld64(win, wbase, pos)); } \
+    } while (0)
                     for (;;) {
                         const uint32_t top = pos + 8 < n ? pos + 8 : n;
                         const uint32_t wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
@@ -566,68 +581,70 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         }
                         __threadfence_block();
                         __syncthreads();
-                        if (lane == 0) {
-                            uint32_t e = 0;
-                            const uint8_t* const win = L.win;
-                            do {
-                                if (!started) {
-                                    bw_init(b, win, wbase, n);               // reads the last bytes of the stream: resident
-                                    if (b.bad) { e = 1; break; }
-                                    sl = (uint32_t)bw_read(b, L.llLog); so = (uint32_t)bw_read(b, L.ofLog); sm = (uint32_t)bw_read(b, L.mlLog);
-                                    if (!bw_reload(b, win, wbase)) { e = 1; break; }
-                                    rep0 = L.rep[0]; rep1 = L.rep[1]; rep2 = L.rep[2];
-                                    started = true;
+                        if (!started) {                                     // BIT_initDStream: the last byte carries the end mark
+                            started = true;
+                            if (n == 0) e = 1;
+                            else {
+                                const uint32_t last = DUNI(win[n - 1 - wbase]);
+                                if (last == 0) e = 1;
+                                else if (n >= 8) { c = duni64(wld64(win, wbase, pos)); consumed = 8 - dhb32(last); }
+                                else {
+                                    uint64_t cc = 0;
+                                    for (uint32_t k = 0; k < n; k++) cc |= (uint64_t)DUNI(win[k]) << (8 * k);
+                                    c = cc; consumed = 8 - dhb32(last) + (8 - n) * 8;
                                 }
-                                // one sequence moves the reader down by at most 12 bytes
-                                while (i < nbSeq && (wbase == 0 || b.pos >= wbase + 16)) {
-                                    const SeqD el = seqd_load(&L.ll[sl]), eo = seqd_load(&L.of[so]), em = seqd_load(&L.ml[sm]);
-                                    const uint32_t oc = eo.ebits;
-                                    uint32_t offBase;
-                                    if (oc > 24) {                              // up to 31 extra bits: read in two parts around a reload
-                                        const uint32_t hi = oc - 24;
-                                        offBase = eo.bval + ((uint32_t)bw_read(b, hi) << 24);
-                                        if (!bw_reload(b, win, wbase)) { e = 1; break; }
-                                        offBase += (uint32_t)bw_read(b, 24);
-                                    } else offBase = eo.bval + (uint32_t)bw_read(b, oc);
-                                    const uint32_t ml = em.bval + (uint32_t)bw_read(b, em.ebits);
-                                    if (!bw_reload(b, win, wbase)) { e = 1; break; }
-                                    const uint32_t ll = el.bval + (uint32_t)bw_read(b, el.ebits);
-                                    uint32_t off;                               // resolve the repeat codes here: the execution is order-free then
-                                    if (offBase > 3) { off = offBase - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                                    else {
-                                        const uint32_t idx = offBase - 1 + (ll == 0);
-                                        if (idx == 0) off = rep0;
-                                        else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
-                                        else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                                        else { off = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                                    }
-                                    zs_seq sq; sq.offBase = off; sq.litLength = ll; sq.mlBase = ml; sq.litPos = 0;
-                                    seqs[i] = sq;
-                                    if (i + 1 < nbSeq) {
-                                        sl = el.base + (uint32_t)bw_read(b, el.nb);
-                                        sm = em.base + (uint32_t)bw_read(b, em.nb);
-                                        if (!bw_reload(b, win, wbase)) { e = 1; break; }
-                                        so = eo.base + (uint32_t)bw_read(b, eo.nb);
-                                    }
-                                    if (!bw_reload(b, win, wbase)) { e = 1; break; }
-                                    i++;
-                                }
-                                if (e) break;
-                                pos = b.pos;
-                                if (i >= nbSeq) {
-                                    if (!bw_finished(b)) e = 1;
-                                    L.rep[0] = rep0; L.rep[1] = rep1; L.rep[2] = rep2;
-                                }
-                            } while (0);
-                            L.scal[1] = e; L.scal[3] = i; L.scal[4] = pos;
+                            }
+                            if (!e) {
+                                sl = SQ_READ(llLog); consumed += llLog; so = SQ_READ(ofLog); consumed += ofLog; sm = SQ_READ(mlLog); consumed += mlLog;
+                                SQ_RELOAD();
+                            }
                         }
-                        __threadfence_block();
-                        __syncthreads();
-                        const uint32_t e = L.scal[1], di = L.scal[3];
-                        pos = L.scal[4];
-                        __syncthreads();
-                        if (e || di >= nbSeq) break;
+                        // One reload at the head of a sequence leaves >= 57 bits in the container (a sequence needs ~40 on
+                        // average, 89 at most), so the other reads reload only on demand: refilling is transparent to the bits
+                        // read, it only has to happen before the container runs dry.  One sequence moves the reader <= 12 bytes.
+#define SQ_NEED(nb_) do { if (consumed + (nb_) > 64) { SQ_RELOAD(); if (consumed + (nb_) > 64) e = 1; } } while (0)
+                        while (!e && i < nseq && (wbase == 0 || pos >= wbase + 24)) {
+                            SQ_RELOAD();
+                            const uint64_t rl = duni64(seqd_raw(&L.ll[sl])), ro = duni64(seqd_raw(&L.of[so])), rm = duni64(seqd_raw(&L.ml[sm]));
+                            const uint32_t oc = (uint32_t)(ro >> 24) & 0xFF, mbits = (uint32_t)(rm >> 24) & 0xFF, lbits = (uint32_t)(rl >> 24) & 0xFF;
+                            uint32_t offBase = (uint32_t)(ro >> 32);
+                            if (oc > 24) {                                  // up to 31 extra bits: read in two parts
+                                const uint32_t hi = oc - 24;
+                                SQ_NEED(hi); offBase += SQ_READ(hi) << 24; consumed += hi;
+                                SQ_NEED(24u); offBase += SQ_READ(24u); consumed += 24;
+                            } else { SQ_NEED(oc); offBase += SQ_READ(oc); consumed += oc; }
+                            SQ_NEED(mbits); const uint32_t ml = (uint32_t)(rm >> 32) + SQ_READ(mbits); consumed += mbits;
+                            SQ_NEED(lbits); const uint32_t ll = (uint32_t)(rl >> 32) + SQ_READ(lbits); consumed += lbits;
+                            uint32_t off;                                   // resolve the repeat codes here: the execution is order-free then
+                            if (offBase > 3) { off = offBase - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                            else {
+                                const uint32_t idx = offBase - 1 + (ll == 0);
+                                if (idx == 0) off = rep0;
+                                else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
+                                else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                                else { off = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = off; }
+                            }
+                            if (lane == 0) { zs_seq sq; sq.offBase = off; sq.litLength = ll; sq.mlBase = ml; sq.litPos = 0; seqs[i] = sq; }
+                            if (i + 1 < nseq) {
+                                const uint32_t nbl = (uint32_t)(rl >> 16) & 0xFF, nbm = (uint32_t)(rm >> 16) & 0xFF, nbo = (uint32_t)(ro >> 16) & 0xFF;
+                                SQ_NEED(nbl + nbm + nbo);                   // <= 26 bits
+                                sl = ((uint32_t)rl & 0xFFFF) + SQ_READ(nbl); consumed += nbl;
+                                sm = ((uint32_t)rm & 0xFFFF) + SQ_READ(nbm); consumed += nbm;
+                                so = ((uint32_t)ro & 0xFFFF) + SQ_READ(nbo); consumed += nbo;
+                            }
+                            i++;
+                        }
+                        if (!e && i >= nseq) SQ_RELOAD();                   // normalise for the end-of-stream check
+#undef SQ_NEED
+                        __syncthreads();                                    // everyone is done with this window
+                        if (e || i >= nseq) break;
                     }
+#undef SQ_READ
+#undef SQ_RELOAD
+                    if (!e && !(pos == 0 && consumed == 64)) e = 1;        // BIT_endOfDStream
+                    if (lane == 0) { L.rep[0] = rep0; L.rep[1] = rep1; L.rep[2] = rep2; L.scal[1] = e; }
+                    __threadfence_block();
+                    __syncthreads();
                 }
                 if (L.scal[1]) FAIL(DERR_FRAME);
             } else if (q != bsize) FAIL(DERR_FRAME);
