@@ -139,6 +139,15 @@ def main():
     elapsed = time.perf_counter() - t0
     for t in range(1, T):
         assert (ds[t]["status"] == 0).all() and (ds[t]["dst_len"] == d["dst_len"]).all() and (ds[t]["crc32c"] == d["crc32c"]).all()
+    # for the record (outside the timed region): the same batch strictly one at a time
+    single = None
+    if T > 1:
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step(0)
+        fence()
+        single = float(n) * CH * 2 / GiB / (time.perf_counter() - t1)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -220,7 +229,7 @@ def main():
                        "zstd_profile": args.profile if flags & nat.COMPRESS else None,
                        "mean_transformed_chunk_bytes": round(mean_out, 1), "residency": "device (HBM) in/out",
                        "parallelism": "segment-major shard, %d rank(s), no data-path collective" % world,
-                       "batches_in_flight": T,
+                       "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
                        "verified_chunks_vs_oracle": verified},
             "roofline": roofline, "cpu_baseline": cpu,
         }
