@@ -13,6 +13,8 @@
 #include "../../tiered-storage-for-apache-kafka_amd/host/tsxhost.hpp"
 
 extern "C" {
+uint32_t orc_crc32c(const uint8_t* p, size_t n);
+long orc_gcm_decrypt_chunk(const uint8_t key[32], const uint8_t* aad, size_t aad_len, const uint8_t* chunk, size_t len, uint8_t* out);
 size_t orc_transform_chunk(unsigned flags, const uint8_t key[32], const uint8_t* aad, size_t aad_len, const uint8_t iv[12], const uint8_t* src, size_t n,
                            uint8_t* dst, size_t cap, uint8_t* scratch, uint32_t* crc_out);
 size_t orc_chain_bound(size_t n, unsigned flags);
@@ -313,6 +315,32 @@ static void backendTests(bool full) {
         CHECK((chunkIndexFromJson(*be, chunkIndexToJson(*be, fixed))->chunks() == std::vector<Chunk>{{0, 0, 100, 0, 110}, {1, 100, 100, 110, 110}, {2, 200, 50, 220, 30}}));
         std::vector<int> many; std::mt19937 r(5); for (int i = 0; i < 2000; i++) many.push_back(1000000 + (int)(r() % 300));      // README.md:162-170 sized index
         CHECK(deserializeTransformedChunks(*be, serializeTransformedChunks(*be, many)) == many);
+    });
+    // C/SegmentCompressionChecker.java:37-53 (+ Kafka DefaultRecordBatch.ensureValid) and C/RemoteStorageManager.java:455-490
+    run("SegmentCompressionChecker.check + transformIndex", [&] {
+        auto batch = [&](uint16_t attributes, size_t payload) {
+            Bytes b(61 + payload, 0x5A);
+            const uint32_t batchLength = (uint32_t)(b.size() - 12);
+            for (int i = 0; i < 8; i++) b[(size_t)i] = 0;                              // baseOffset
+            b[8] = (uint8_t)(batchLength >> 24); b[9] = (uint8_t)(batchLength >> 16); b[10] = (uint8_t)(batchLength >> 8); b[11] = (uint8_t)batchLength;
+            b[16] = 2; b[21] = (uint8_t)(attributes >> 8); b[22] = (uint8_t)attributes;
+            const uint32_t crc = orc_crc32c(b.data() + 21, b.size() - 21);
+            b[17] = (uint8_t)(crc >> 24); b[18] = (uint8_t)(crc >> 16); b[19] = (uint8_t)(crc >> 8); b[20] = (uint8_t)crc;
+            return b;
+        };
+        Bytes plain = batch(0, 5000), zstdBatch = batch(4, 333);
+        plain.insert(plain.end(), 100, 0x11);                                          // more batches may follow in the segment
+        CHECK(!segmentIsCompressed(*be, plain) && segmentIsCompressed(*be, zstdBatch));
+        Bytes corrupt = plain; corrupt[100] ^= 1;
+        try { segmentIsCompressed(*be, corrupt); CHECK(false); } catch (const InvalidRecordBatchException& e) { CHECK(std::string(e.what()).rfind("Record is corrupt (stored crc = ", 0) == 0); }
+        try { segmentIsCompressed(*be, Bytes(plain.begin(), plain.begin() + 40)); CHECK(false); } catch (const InvalidRecordBatchException&) {}
+        // index files: one chunk, encrypted only (CIT RemoteStorageManagerTest.java:472-596: size recorded = transformed size)
+        const Bytes index = randomBytes(10 * 1024 + 7, 9);
+        CHECK(transformIndex(be, index, std::nullopt) == index && transformIndex(be, {}, DataKeyAndAAD{KEY, AAD}).empty());
+        const Bytes enc = transformIndex(be, index, DataKeyAndAAD{KEY, AAD}, countingIv());
+        CHECK(enc.size() == index.size() + 28);
+        Bytes dec(index.size());
+        CHECK(orc_gcm_decrypt_chunk(KEY.data(), AAD.data(), AAD.size(), enc.data(), enc.size(), dec.data()) == (long)index.size() && dec == index);
     });
     // C/fetch/DefaultChunkManager.java:50-70 — every chunk by id through GpuChunkManager, and a prefetch window in one batch
     run("ChunkManager.getChunk / getChunks over an uploaded object", [&] {

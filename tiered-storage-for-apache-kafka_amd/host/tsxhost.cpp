@@ -219,7 +219,7 @@ Bytes base64Decode(const std::string& s) {
 struct Backend::Fns {
     decltype(&tsx_init) init; decltype(&tsx_ctx_create) ctx_create; decltype(&tsx_ctx_destroy) ctx_destroy;
     decltype(&tsx_transform_batch) transform; decltype(&tsx_detransform_batch) detransform;
-    decltype(&tsx_transformed_bound) bound; decltype(&tsx_strerror) strerr; decltype(&tsx_version) version; decltype(&tsx_abi_version) abi;
+    decltype(&tsx_crc32c_batch) crc; decltype(&tsx_transformed_bound) bound; decltype(&tsx_strerror) strerr; decltype(&tsx_version) version; decltype(&tsx_abi_version) abi;
 };
 
 Backend::Backend(const std::string& libPath, int deviceIndex) : f_(new Fns) {
@@ -229,6 +229,7 @@ Backend::Backend(const std::string& libPath, int deviceIndex) : f_(new Fns) {
     f_->init = (decltype(f_->init))sym("tsx_init"); f_->ctx_create = (decltype(f_->ctx_create))sym("tsx_ctx_create");
     f_->ctx_destroy = (decltype(f_->ctx_destroy))sym("tsx_ctx_destroy"); f_->transform = (decltype(f_->transform))sym("tsx_transform_batch");
     f_->detransform = (decltype(f_->detransform))sym("tsx_detransform_batch"); f_->bound = (decltype(f_->bound))sym("tsx_transformed_bound");
+    f_->crc = (decltype(f_->crc))sym("tsx_crc32c_batch");
     f_->strerr = (decltype(f_->strerr))sym("tsx_strerror"); f_->version = (decltype(f_->version))sym("tsx_version");
     f_->abi = (decltype(f_->abi))sym("tsx_abi_version");
     if (f_->abi() != TSX_ABI_VERSION) throw std::runtime_error("tsxhost: ABI version mismatch");
@@ -248,6 +249,16 @@ void Backend::transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_de
 void Backend::detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
     const int rc = f_->detransform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
     if (rc) throw std::runtime_error(std::string("tsx_detransform_batch: ") + f_->strerr(rc));
+}
+uint32_t Backend::crc32c(const uint8_t* data, size_t n) {
+    Bytes buf(((n + 15) & ~(size_t)15) + 16);                       // the ABI wants a 16-byte aligned chunk start
+    if (n) memcpy(buf.data(), data, n);
+    tsx_chunk_desc d;
+    memset(&d, 0, sizeof d);
+    d.src_len = (uint32_t)n;
+    const int rc = f_->crc(ctx_, &d, 1, buf.data(), TSX_MEM_HOST);
+    if (rc || d.status != TSX_OK) throw std::runtime_error(std::string("tsx_crc32c_batch: ") + f_->strerr(rc ? rc : d.status));
+    return d.crc32c;
 }
 size_t Backend::transformedBound(size_t n, uint32_t flags) const { return f_->bound(n, flags); }
 std::string Backend::strerror(int code) const { return f_->strerr(code); }
@@ -584,6 +595,41 @@ std::vector<Bytes> GpuChunkManager::getChunks(const std::string& objectKey, cons
         e = std::make_shared<GpuDetransformChunkEnumeration>(be_, e, manifest.compression, manifest.encryption, manifest.chunkIndex->originalChunkSize(), count);
     std::vector<Bytes> out;
     while (e->hasMoreElements()) out.push_back(e->nextElement());
+    return out;
+}
+
+// =====================================================================================================
+// neighbours of the path
+// =====================================================================================================
+bool segmentIsCompressed(Backend& be, const Bytes& seg) {
+    // Kafka record batch v2 header: baseOffset 8 | batchLength 4 | partitionLeaderEpoch 4 | magic 1 | crc 4 | attributes 2 | ... (61 bytes)
+    constexpr size_t LOG_OVERHEAD = 12, RECORD_BATCH_OVERHEAD = 61, MAGIC_OFFSET = 16, CRC_OFFSET = 17, ATTRIBUTES_OFFSET = 21;
+    if (seg.size() < LOG_OVERHEAD + 5) throw InvalidRecordBatchException("Record batch is null");
+    auto be32 = [&](size_t o) { return ((uint32_t)seg[o] << 24) | ((uint32_t)seg[o + 1] << 16) | ((uint32_t)seg[o + 2] << 8) | seg[o + 3]; };
+    const uint32_t batchLength = be32(8);
+    const size_t sizeInBytes = LOG_OVERHEAD + (size_t)batchLength;
+    if (seg[MAGIC_OFFSET] != 2) throw InvalidRecordBatchException("Failed to read and validate first batch: unsupported magic " + std::to_string(seg[MAGIC_OFFSET]));
+    if (sizeInBytes < RECORD_BATCH_OVERHEAD)
+        throw InvalidRecordBatchException("Record batch is corrupt (the size " + std::to_string(sizeInBytes) + " is smaller than the minimum allowed overhead " +
+                                          std::to_string(RECORD_BATCH_OVERHEAD) + ")");
+    if (sizeInBytes > seg.size()) throw InvalidRecordBatchException("Record batch is null");                    // FileRecords.firstBatch(): incomplete batch
+    const uint32_t stored = be32(CRC_OFFSET);
+    const uint32_t computed = be.crc32c(seg.data() + ATTRIBUTES_OFFSET, sizeInBytes - ATTRIBUTES_OFFSET);
+    if (stored != computed)
+        throw InvalidRecordBatchException("Record is corrupt (stored crc = " + std::to_string(stored) + ", computed crc = " + std::to_string(computed) + ")");
+    const uint32_t attributes = ((uint32_t)seg[ATTRIBUTES_OFFSET] << 8) | seg[ATTRIBUTES_OFFSET + 1];
+    return (attributes & 0x07) != 0;                                                                             // CompressionType.NONE has id 0
+}
+
+Bytes transformIndex(std::shared_ptr<Backend> be, const Bytes& index, const std::optional<DataKeyAndAAD>& key, IvSupplier iv) {
+    if (index.empty()) return {};
+    std::shared_ptr<TransformChunkEnumeration> e = std::make_shared<BaseTransformChunkEnumeration>(std::make_shared<ByteArrayInputStream>(index), (int)index.size());
+    if (key) e = std::make_shared<GpuTransformChunkEnumeration>(be, e, false, key, std::move(iv), 1);
+    TransformFinisher f(e, (int)index.size(), false);                 // withChunkingDisabled()
+    Bytes out = f.nextElement();
+    const auto chunkIndex = f.chunkIndex();
+    if (chunkIndex->chunks().size() != 1) throw std::logic_error("Number of chunks different than 1, single chunk is expected");
+    if ((size_t)chunkIndex->chunks()[0].range().size() != out.size()) throw std::logic_error("chunk index and transformed index disagree");
     return out;
 }
 

@@ -149,6 +149,7 @@ public:
     // one batch over host buffers; throws std::runtime_error on a batch-level failure, per-chunk status stays in descs
     void transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
     void detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
+    uint32_t crc32c(const uint8_t* data, size_t n);              // java.util.zip.CRC32C of one byte range (tsx_crc32c_batch)
     size_t transformedBound(size_t n, uint32_t flags) const;
     std::string strerror(int code) const;
     std::string version() const;
@@ -363,5 +364,16 @@ private:
     std::shared_ptr<Backend> be_;
     std::shared_ptr<ObjectFetcher> fetcher_;
 };
+
+// ---- neighbours of the path ------------------------------------------------------------------
+// SegmentCompressionChecker.check (core/.../SegmentCompressionChecker.java:37-53): is the segment's first record batch
+// compressed?  Kafka's RecordBatch.ensureValid() for magic v2 = size sanity + CRC32C over [attributes .. end of batch];
+// the CRC runs on the device.  Throws InvalidRecordBatchException (std::runtime_error) like the reference.
+struct InvalidRecordBatchException : std::runtime_error { using std::runtime_error::runtime_error; };
+bool segmentIsCompressed(Backend& be, const Bytes& segmentHead);
+
+// RemoteStorageManager.transformIndex (core/.../RemoteStorageManager.java:455-490): an index file is ONE chunk, never
+// compressed, encrypted when encryption is on; returns the transformed bytes (size 0 -> empty, recorded as size 0).
+Bytes transformIndex(std::shared_ptr<Backend> be, const Bytes& index, const std::optional<DataKeyAndAAD>& key, IvSupplier iv = secureRandomIvSupplier());
 
 }  // namespace tsx
