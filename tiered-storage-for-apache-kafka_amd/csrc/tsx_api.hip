@@ -431,7 +431,20 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     if (mode != 1) hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_descs, (const int32_t*)c->d_status, n);
     HIPCHK(hipEventRecord(c->ev[5], st));
     HIPCHK(hipMemcpyAsync(descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
-    if (host && mode != 2) HIPCHK(hipMemcpyAsync(dst, c->d_out, dst_size, hipMemcpyDeviceToHost, st));
+    if (host && mode != 2) {
+        // only the bytes each chunk produced travel back (a compressed chunk fills ~1/3 of its slot): the descriptors
+        // first, then one copy per run of chunks whose outputs are adjacent in dst
+        HIPCHK(hipStreamSynchronize(st));
+        uint32_t i = 0;
+        while (i < n) {
+            if (descs[i].status != TSX_OK || descs[i].dst_len == 0) { i++; continue; }
+            size_t lo = descs[i].dst_off, hi = lo + descs[i].dst_len;
+            uint32_t j = i + 1;
+            while (j < n && descs[j].status == TSX_OK && descs[j].dst_off >= hi && descs[j].dst_off - hi <= 4096) { hi = descs[j].dst_off + descs[j].dst_len; j++; }
+            HIPCHK(hipMemcpyAsync((uint8_t*)dst + lo, c->d_out + lo, hi - lo, hipMemcpyDeviceToHost, st));
+            i = j;
+        }
+    }
     HIPCHK(hipEventRecord(c->ev[6], st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
