@@ -1,43 +1,60 @@
 /*
- * Drop-in for DefaultChunkManager (core/.../fetch/DefaultChunkManager.java:36-70): same constructor shape, same
- * getChunk() contract (ranged fetch of chunk.range(), plain-text InputStream out), so ChunkManagerFactory and the
- * ChunkCache subclasses (which take a ChunkManager, ChunkManagerFactory.java:41-45) work unchanged.
+ * ChunkManager whose detransform step (tag check + decrypt, Zstd decode) runs on the GPU through libtsxform.
+ * Takes the place of the reference's default chunk manager behind ChunkManagerFactory; ChunkCache subclasses wrap it
+ * through their (ChunkManager) constructor as before.  Contract kept from ChunkManager.getChunk(): plain-text bytes of
+ * exactly one chunk, fetched with one ranged request of the chunk's transformed range.
+ *
+ * Beyond the single-chunk call it offers getChunks(): a window of consecutive chunks (a ChunkCache prefetch) with ONE
+ * ranged fetch and ONE device batch - the form in which the GPU path pays off on the fetch side (SURVEY.md 8 f2).
+ * C++ twin with tests: tiered-storage-for-apache-kafka_amd/host/tsxhost.cpp (tsx::GpuChunkManager).
  */
 package io.aiven.kafka.tieredstorage.gpu;
 
+import java.io.ByteArrayInputStream;
 import java.io.InputStream;
+import java.util.ArrayList;
 import java.util.List;
-import java.util.Optional;
 
 import io.aiven.kafka.tieredstorage.Chunk;
 import io.aiven.kafka.tieredstorage.fetch.ChunkManager;
-import io.aiven.kafka.tieredstorage.manifest.SegmentEncryptionMetadata;
 import io.aiven.kafka.tieredstorage.manifest.SegmentManifest;
+import io.aiven.kafka.tieredstorage.storage.BytesRange;
 import io.aiven.kafka.tieredstorage.storage.ObjectFetcher;
 import io.aiven.kafka.tieredstorage.storage.ObjectKey;
 import io.aiven.kafka.tieredstorage.storage.StorageBackendException;
 import io.aiven.kafka.tieredstorage.transform.BaseDetransformChunkEnumeration;
 import io.aiven.kafka.tieredstorage.transform.DetransformChunkEnumeration;
-import io.aiven.kafka.tieredstorage.transform.DetransformFinisher;
 
 public class GpuChunkManager implements ChunkManager {
-    private final ObjectFetcher fetcher;
+    private final ObjectFetcher objects;
 
-    public GpuChunkManager(final ObjectFetcher fetcher) {
-        this.fetcher = fetcher;
+    public GpuChunkManager(final ObjectFetcher objects) {
+        this.objects = objects;
     }
 
     @Override
-    public InputStream getChunk(final ObjectKey objectKey, final SegmentManifest manifest,
-                                final int chunkId) throws StorageBackendException {
-        final Chunk chunk = manifest.chunkIndex().chunks().get(chunkId);
-        final InputStream chunkContent = fetcher.fetch(objectKey, chunk.range());
-        DetransformChunkEnumeration detransformEnum = new BaseDetransformChunkEnumeration(chunkContent, List.of(chunk));
-        final Optional<SegmentEncryptionMetadata> encryptionMetadata = manifest.encryption();
-        if (encryptionMetadata.isPresent() || manifest.compression()) {
-            detransformEnum = new GpuDetransformChunkEnumeration(detransformEnum, manifest.compression(),
-                encryptionMetadata.orElse(null), chunk.originalSize, 1);
+    public InputStream getChunk(final ObjectKey key, final SegmentManifest manifest, final int chunkId)
+        throws StorageBackendException {
+        return new ByteArrayInputStream(getChunks(key, manifest, chunkId, 1).get(0));
+    }
+
+    /** Plain-text content of chunks [firstChunkId, firstChunkId + count), one fetch, one device batch. */
+    public List<byte[]> getChunks(final ObjectKey key, final SegmentManifest manifest,
+                                  final int firstChunkId, final int count) throws StorageBackendException {
+        final List<Chunk> window = manifest.chunkIndex().chunks().subList(firstChunkId, firstChunkId + count);
+        final Chunk head = window.get(0);
+        final Chunk tail = window.get(count - 1);
+        final BytesRange span = BytesRange.of(head.transformedPosition, tail.transformedPosition + tail.transformedSize - 1);
+        DetransformChunkEnumeration chunks = new BaseDetransformChunkEnumeration(objects.fetch(key, span), window);
+        final boolean encrypted = manifest.encryption().isPresent();
+        if (encrypted || manifest.compression()) {
+            chunks = new GpuDetransformChunkEnumeration(chunks, manifest.compression(),
+                manifest.encryption().orElse(null), manifest.chunkIndex().chunks().get(0).originalSize, count);
         }
-        return new DetransformFinisher(detransformEnum).toInputStream();
+        final List<byte[]> plain = new ArrayList<>(count);
+        while (chunks.hasMoreElements()) {
+            plain.add(chunks.nextElement());
+        }
+        return plain;
     }
 }

@@ -103,3 +103,37 @@ def test_compressed_frames_have_expected_structure(emu):
     assert [b.btype for b in blocks] == ["compressed", "compressed"] and data == CASES["K200000"].tobytes()
     hdr, blocks, _ = zi.parse_frame(outs[1])
     assert [b.btype for b in blocks] == ["raw"] and len(outs[1]) == 50000 + 7 + 3
+
+
+def _fuzzed_frames(oracle, n_variants, seed):
+    rng = np.random.default_rng(seed)
+    base = [oracle.zstd_compress_chunk(CASES[n].tobytes(), lvl) for n, lvl in (("K70000", 0), ("lowent", 1), ("mixKR", 0), ("K1000", 19))]
+    blobs, sizes = [], []
+    for v in range(n_variants):
+        f = bytearray(base[v % len(base)])
+        kind = v % 5
+        if kind == 0:
+            for _ in range(1 + v % 7): f[int(rng.integers(4, len(f)))] ^= 1 << int(rng.integers(0, 8))       # bit flips
+        elif kind == 1:
+            p = int(rng.integers(4, len(f) - 8)); f[p:p + 8] = rng.integers(0, 256, 8, dtype=np.uint8).tobytes()   # garbage run
+        elif kind == 2:
+            f = f[:int(rng.integers(5, len(f)))]                                                         # truncation
+        elif kind == 3:
+            p = int(rng.integers(6, len(f))); f = f[:p] + bytes(rng.integers(0, 256, 16, dtype=np.uint8)) + f[p:]   # insertion
+        else:
+            f[int(rng.integers(4, min(len(f), 40)))] = int(rng.integers(0, 256))                              # header damage
+        blobs.append(bytes(f)); sizes.append(len(CASES[("K70000", "lowent", "mixKR", "K1000")[v % 4]]))
+    return blobs, sizes
+
+
+@pytest.mark.timeout(900)
+def test_decoder_survives_corrupt_frames(emu, oracle):
+    """A damaged object in tiered storage must come back as a per-chunk error (or as bytes that fail the GCM tag one stage
+    earlier), never as a hang or a crash: every loop of the decoder is bounded by sizes read from the frame."""
+    blobs, sizes = _fuzzed_frames(oracle, 40, 11)
+    outs, d = pc.run_detransform(emu, nat.COMPRESS, blobs, sizes)
+    assert set(int(x) for x in d["status"]) <= {0, nat.E_BAD_FRAME, nat.E_BAD_SIZE, nat.E_DST_TOO_SMALL}
+    assert (d["status"] != 0).sum() >= 10                    # most damage is detected structurally
+    for i in range(len(blobs)):
+        if d["status"][i] == 0:
+            assert len(outs[i]) <= sizes[i]

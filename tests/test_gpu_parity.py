@@ -198,3 +198,16 @@ def test_quarter_gib_full_chain_device_resident(gpu, oracle):
     gpu.detransform_batch(p, d2, out.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE)
     assert (d2["status"] == 0).all() and (d2["dst_len"] == CHUNK).all() and (d2["crc32c"] == d["crc32c"]).all()
     assert torch.equal(back, seg)
+
+
+@pytest.mark.timeout(600)
+def test_zstd_decoder_survives_corrupt_frames(gpu, oracle):
+    """Same fuzz as the emulated run, 600 variants on the device: per-chunk errors, no hang, no fault."""
+    from tests.test_emu_zstd import _fuzzed_frames
+    blobs, sizes = _fuzzed_frames(oracle, 600, 23)
+    outs, d = pc.run_detransform(gpu, nat.COMPRESS, blobs, sizes)
+    assert set(int(x) for x in d["status"]) <= {0, nat.E_BAD_FRAME, nat.E_BAD_SIZE, nat.E_DST_TOO_SMALL}
+    assert (d["status"] != 0).sum() >= 200
+    good = oracle.zstd_compress_chunk(np.arange(5000, dtype=np.uint8).tobytes())       # the device still works afterwards
+    outs, d = pc.run_detransform(gpu, nat.COMPRESS, [good], [5000])
+    assert d["status"][0] == 0 and outs[0] == np.arange(5000, dtype=np.uint8).tobytes()
