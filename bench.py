@@ -42,6 +42,24 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity, capped by the container's CPU quota (cgroup v2
+    cpu.max / v1 cfs quota) - oversubscribing a throttled container makes a CPU baseline look slower than it is."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -204,9 +222,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as o
-        cores = os.cpu_count() or 1
-        # every host core gets work: 4 chunks per thread for the full chain (about 10-30 s of CPU work), one segment otherwise
-        sample = {"full": max(48, 4 * cores), "gcm_crc": 256, "crc": 256}[workload]
+        cores = usable_cores()
+        # every usable host core gets work: 16 chunks per thread for the full chain (about 10 s of CPU work), one segment otherwise
+        sample = {"full": max(48, 16 * cores), "gcm_crc": 256, "crc": 256}[workload]
         sample = min(sample, n)
         host = src[:sample * CH].cpu().numpy()
         ivs = np.ascontiguousarray(d["iv"][:sample]).reshape(-1)
