@@ -1,27 +1,30 @@
-// Zstandard level-3 frame compressor — gfx950, one 64-lane wavefront per chunk.
+// Zstandard level-3 frame compressor — gfx950, one 64-lane wavefront per chunk, up to 20 chunks resident per CU.
 //
 // Replaces zstd-jni's  new ZstdCompressCtx(); setPledgedSrcSize(n); setContentSize(true); compress(chunk)
 //   core/src/main/java/io/aiven/kafka/tieredstorage/transform/CompressionChunkEnumeration.java:50-63
 // and must emit, byte for byte, the frame libzstd emits for the same chunk (one-shot compression call, level 3:
 // strategy dfast, windowLog <= 21, 128 KiB blocks, Huffman literals + FSE sequences; profile 1.5.7 adds that
 // release's pre-block splitter).  The serial statement of the algorithm, pinned against the real library, is
-// oracle/zstd_l3.c; this file is its wave-parallel form:
+// oracle/zstd_l3.c; this file is its wave-parallel form (DESIGN.md §5 has the measurements behind each choice):
 //
-//  * Match finding is an inherently serial greedy parse (every decision updates two hash tables and the
-//    repcode history), so parallelism inside a chunk is SPECULATION: the wave evaluates up to 63 consecutive
-//    search positions at once — each lane hashes its position, loads both table entries (global memory: 512 KiB
-//    + 256 KiB per chunk cannot live in LDS without changing the output), patches them with the insertions the
-//    EARLIER lanes of the same step would have made (exact, via lane broadcast), loads the candidate bytes and
-//    classifies repcode / long / short match.  A ballot picks the first lane with a match — everything before
-//    it is exactly what the serial loop would have done — its table inserts are committed and the match is
-//    extended with wave-wide 8-byte compares.  The speculation width adapts (16 -> 32 -> 63 lanes).
-//  * Chunks are independent (fresh context per chunk in the reference), so a batch runs one wave per chunk;
-//    a 1 GiB segment is 256 waves, eight segments fill the chip's 2048 wave slots at 2 waves/SIMD.
-//  * The entropy stage of each 128 KiB block (Huffman tree + FSE tables: a few thousand dependent scalar steps)
-//    runs on lane 0 with its work arrays in LDS; histograms, code conversion and the Huffman bit packing of the
-//    literals run on all 64 lanes.
-// This is byte-stream work: no MFMA.  Algorithmic traffic per chunk: N bytes read + frame bytes written; the
-// kernel is latency bound (dependent table -> candidate -> extension loads per sequence), see DESIGN.md.
+//  * Match finding is an inherently serial greedy parse (every decision updates two hash tables and the repcode
+//    history), so parallelism inside a chunk is SPECULATION: the wave evaluates K consecutive search positions at once
+//    (K = 8, doubling to 63 while nothing matches) — each lane hashes its position, probes both tables (global memory:
+//    512 KiB + 256 KiB per chunk cannot shrink into LDS without changing the output), sees the insertions EARLIER lanes
+//    of the same step would have made (LDS scoreboard detects shared buckets, lane broadcasts resolve them), checks its
+//    candidates and classifies repcode / long / short match.  A ballot picks the first lane with a match — everything
+//    before it is exactly what the serial loop would have done — its table inserts are committed and the match is
+//    extended with wave-wide 8-byte compares.
+//  * A dependent global round trip costs a wave 1300-2000 cycles here, so the parser never reads global memory for bytes
+//    near ip (LDS ring of the chunk around ip), never reads a candidate that cannot match (tags in the table entries),
+//    fetches a far candidate together with the 48 bytes both extensions need, and keeps its state in SGPRs.
+//  * Chunks are independent (fresh context per chunk in the reference); the kernel is latency bound per chunk and
+//    HBM-random-access bound in aggregate, so it is shaped for residency: 96 VGPRs, 8 KiB LDS (parse-stage and
+//    entropy-stage LDS alias), and callers keep several batches in flight.
+//  * The entropy stage of each block: histograms, Huffman bit packing, literal gathering and the FSE sequence bit stream
+//    run on all lanes (the three FSE state machines on three lanes, then prefix-summed bit packing); only the table
+//    constructions (Huffman tree, FSE normalisation: a few thousand dependent steps per block) stay on lane 0.
+// This is byte-stream work: no MFMA.  Algorithmic traffic per chunk: N bytes read + frame bytes written.
 #include "zstd_common.h"
 
 #define LANES 64
