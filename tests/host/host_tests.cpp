@@ -3,6 +3,7 @@
 // Run by tests/test_host.py:  host_tests cpu            (pure host logic, no device library)
 //                             host_tests backend <lib>  (chain through a libtsxform build: the emulated one on CPU, the real one -m gpu)
 // The oracle (oracle/_build/liboracle.so) is linked here as the checker only.
+#include <time.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -315,6 +316,42 @@ static void backendTests(bool full) {
         CHECK((chunkIndexFromJson(*be, chunkIndexToJson(*be, fixed))->chunks() == std::vector<Chunk>{{0, 0, 100, 0, 110}, {1, 100, 100, 110, 110}, {2, 200, 50, 220, 30}}));
         std::vector<int> many; std::mt19937 r(5); for (int i = 0; i < 2000; i++) many.push_back(1000000 + (int)(r() % 300));      // README.md:162-170 sized index
         CHECK(deserializeTransformedChunks(*be, serializeTransformedChunks(*be, many)) == many);
+    });
+    // upload sink: TransformFinisher.toInputStream() -> ObjectUploader.upload (RemoteStorageManager.java:410-420,
+    // FileSystemStorage.java:51-60), then every chunk back through GpuChunkManager from the stored object
+    run("upload .log object to FileSystemStorage through the chain, fetch chunks back", [&] {
+        char tmpl[] = "/tmp/tsxhost_fs_XXXXXX";
+        CHECK(mkdtemp(tmpl) != nullptr);
+        auto fs = std::make_shared<FileSystemStorage>(tmpl);
+        expectThrows<std::invalid_argument>([] { FileSystemStorage bad("/nonexistent/dir"); }, "/nonexistent/dir must be a writable directory");
+        const int cs = 32768;
+        auto t = std::make_shared<GpuTransformChunkEnumeration>(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), cs), true, DataKeyAndAAD{KEY, AAD}, countingIv(), 8);
+        TransformFinisher tf(t, (int)text.size());
+        const long bytes = fs->upload(*tf.toInputStream(), "topic-abc/7/00000000000000000023-segment.log");
+        SegmentManifest m; m.chunkIndex = tf.chunkIndex(); m.compression = true; m.encryption = SegmentEncryptionMetadata{KEY, AAD, 12};
+        const auto& chunks = m.chunkIndex->chunks();
+        CHECK(bytes == chunks.back().transformedPosition + chunks.back().transformedSize);
+        GpuChunkManager cm(be, fs);
+        Bytes all;
+        for (size_t id = 0; id < chunks.size(); id += 3) {
+            const auto part = cm.getChunks("topic-abc/7/00000000000000000023-segment.log", m, (int)id, (int)std::min<size_t>(3, chunks.size() - id));
+            for (const auto& c : part) all.insert(all.end(), c.begin(), c.end());
+        }
+        CHECK(all == text);
+    });
+    run("RateLimitedInputStream: bucket of `rate` tokens, refilled greedily (RateLimitedInputStream.java:46-84)", [&] {
+        const Bytes data = randomBytes(40 * 1024, 3);
+        auto bucket = std::make_shared<TokenBucket>(16384);
+        RateLimitedInputStream in(stream(data), bucket);
+        timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
+        const Bytes got = in.readAllBytes();                              // 40 KiB at 16 KiB/s with a full 16 KiB bucket: >= 1.4 s
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        const double el = (double)(b.tv_sec - a.tv_sec) + (double)(b.tv_nsec - a.tv_nsec) * 1e-9;
+        CHECK(got == data);
+        CHECK(el > 1.2 && el < 3.0);
+        TokenBucket minRate(1);                                           // below MIN_RATE the bucket is built with MIN_RATE
+        timespec c; clock_gettime(CLOCK_MONOTONIC, &a); minRate.consume(8192); clock_gettime(CLOCK_MONOTONIC, &c);
+        CHECK((double)(c.tv_sec - a.tv_sec) + (double)(c.tv_nsec - a.tv_nsec) * 1e-9 < 0.2);
     });
     // C/SegmentCompressionChecker.java:37-53 (+ Kafka DefaultRecordBatch.ensureValid) and C/RemoteStorageManager.java:455-490
     run("SegmentCompressionChecker.check + transformIndex", [&] {

@@ -3,6 +3,9 @@
 #include "tsxhost.hpp"
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -365,6 +368,30 @@ std::shared_ptr<ChunkIndex> chunkIndexFromJson(Backend& be, const std::string& j
 // =====================================================================================================
 // streams, IVs
 // =====================================================================================================
+Bytes InputStream::readNBytes(size_t n) {                              // InputStream.readNBytes: loops over read() until n or end
+    Bytes out(n);
+    size_t got = 0;
+    while (got < n) {
+        const long r = read(out.data() + got, std::min<size_t>(n - got, 8192));
+        if (r <= 0) break;
+        got += (size_t)r;
+    }
+    out.resize(got);
+    return out;
+}
+Bytes InputStream::readAllBytes() {
+    Bytes out;
+    uint8_t buf[8192];
+    for (;;) { const long r = read(buf, sizeof buf); if (r <= 0) break; out.insert(out.end(), buf, buf + r); }
+    return out;
+}
+long ByteArrayInputStream::read(uint8_t* b, size_t len) {
+    if (pos_ >= data_.size()) return -1;
+    const size_t m = std::min(len, data_.size() - pos_);
+    memcpy(b, data_.data() + pos_, m);
+    pos_ += m;
+    return (long)m;
+}
 Bytes ByteArrayInputStream::readNBytes(size_t n) {
     const size_t m = std::min(n, data_.size() - pos_);
     Bytes out(data_.begin() + (long)pos_, data_.begin() + (long)(pos_ + m));
@@ -596,6 +623,94 @@ std::vector<Bytes> GpuChunkManager::getChunks(const std::string& objectKey, cons
     std::vector<Bytes> out;
     while (e->hasMoreElements()) out.push_back(e->nextElement());
     return out;
+}
+
+// =====================================================================================================
+// upload sink
+// =====================================================================================================
+namespace {
+class FinisherInputStream : public InputStream {        // new SequenceInputStream(transformFinisher)
+public:
+    explicit FinisherInputStream(TransformFinisher* f) : f_(f) {}
+    long read(uint8_t* b, size_t len) override {
+        while (pos_ >= cur_.size()) {
+            if (!f_->hasMoreElements()) return -1;
+            cur_ = f_->nextElement(); pos_ = 0;
+        }
+        const size_t m = std::min(len, cur_.size() - pos_);
+        memcpy(b, cur_.data() + pos_, m);
+        pos_ += m;
+        return (long)m;
+    }
+
+private:
+    TransformFinisher* f_;
+    Bytes cur_;
+    size_t pos_ = 0;
+};
+long long nowNs() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (long long)t.tv_sec * 1000000000ll + t.tv_nsec; }
+}  // namespace
+
+std::shared_ptr<InputStream> TransformFinisher::toInputStream(std::shared_ptr<TokenBucket> bucket) {
+    std::shared_ptr<InputStream> s = std::make_shared<FinisherInputStream>(this);
+    if (bucket) s = std::make_shared<RateLimitedInputStream>(s, std::move(bucket));
+    return s;
+}
+
+TokenBucket::TokenBucket(int uploadRate) : rate_((double)std::max(uploadRate, MIN_RATE)), lastNs_(nowNs()) { tokens_ = rate_; }
+void TokenBucket::refill() {
+    const long long n = nowNs();
+    tokens_ = std::min(rate_, tokens_ + (double)(n - lastNs_) * 1e-9 * rate_);
+    lastNs_ = n;
+}
+void TokenBucket::consume(long tokens) {
+    refill();
+    tokens_ -= (double)tokens;                                     // may go negative: the debt is slept off, like a blocking consume
+    if (tokens_ < 0) {
+        const double wait = -tokens_ / rate_;
+        timespec t; t.tv_sec = (time_t)wait; t.tv_nsec = (long)((wait - (double)t.tv_sec) * 1e9);
+        nanosleep(&t, nullptr);
+    }
+}
+void TokenBucket::forceAddTokens(long tokens) { tokens_ += (double)tokens; }
+
+long RateLimitedInputStream::read(uint8_t* b, size_t len) {           // RateLimitedInputStream.java:56-84
+    if (len > 0) bucket_->consume((long)len);
+    const long r = in_->read(b, len);
+    if (r > -1) { if ((long)len > r) bucket_->forceAddTokens((long)len - r); }
+    else if (len > 0) bucket_->forceAddTokens((long)len);
+    return r;
+}
+
+FileSystemStorage::FileSystemStorage(std::string root) : root_(std::move(root)) {
+    struct stat st;
+    if (stat(root_.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || access(root_.c_str(), W_OK) != 0) throw std::invalid_argument(root_ + " must be a writable directory");
+}
+long FileSystemStorage::upload(InputStream& in, const std::string& key) {
+    const std::string path = root_ + "/" + key;
+    for (size_t p = root_.size() + 1; (p = path.find('/', p)) != std::string::npos; p++) mkdir(path.substr(0, p).c_str(), 0777);   // Files.createDirectories
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("Failed to upload " + key);
+    uint8_t buf[8192];                                               // InputStream.transferTo's buffer (Files.copy)
+    long total = 0;
+    for (;;) {
+        const long r = in.read(buf, sizeof buf);
+        if (r <= 0) break;
+        if (fwrite(buf, 1, (size_t)r, f) != (size_t)r) { fclose(f); throw std::runtime_error("Failed to upload " + key); }
+        total += r;
+    }
+    fclose(f);
+    return total;
+}
+std::shared_ptr<InputStream> FileSystemStorage::fetch(const std::string& key, BytesRange range) {
+    FILE* f = fopen((root_ + "/" + key).c_str(), "rb");
+    if (!f) throw std::runtime_error("Key " + key + " does not exists in storage");          // KeyNotFoundException
+    Bytes data((size_t)range.size());
+    fseek(f, range.from, SEEK_SET);
+    const size_t got = fread(data.data(), 1, data.size(), f);
+    fclose(f);
+    data.resize(got);
+    return std::make_shared<ByteArrayInputStream>(std::move(data));
 }
 
 // =====================================================================================================

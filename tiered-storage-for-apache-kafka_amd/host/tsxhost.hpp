@@ -174,13 +174,15 @@ std::shared_ptr<ChunkIndex> chunkIndexFromJson(Backend& be, const std::string& j
 class InputStream {
 public:
     virtual ~InputStream() = default;
-    virtual Bytes readNBytes(size_t n) = 0;      // up to n bytes, fewer only at end of stream
-    virtual Bytes readAllBytes() = 0;
+    virtual long read(uint8_t* b, size_t len) = 0;   // InputStream.read(b, off, len): bytes read (> 0), -1 at end of stream
+    virtual Bytes readNBytes(size_t n);               // up to n bytes, fewer only at end of stream
+    virtual Bytes readAllBytes();
     virtual void close() {}
 };
 class ByteArrayInputStream : public InputStream {
 public:
     explicit ByteArrayInputStream(Bytes data) : data_(std::move(data)) {}
+    long read(uint8_t* b, size_t len) override;
     Bytes readNBytes(size_t n) override;
     Bytes readAllBytes() override;
     void close() override { closed_ = true; }
@@ -266,6 +268,9 @@ public:
     Bytes nextElement();                                  // the reference wraps it in a ByteArrayInputStream
     std::shared_ptr<ChunkIndex> chunkIndex();             // "Chunk index was not built, was finisher used?"
     Bytes toBytes();                                      // SequenceInputStream(this) drained: the transformed .log object
+    // TransformFinisher.toInputStream(): chunks are pulled (and transformed, batch-wise) only as the consumer reads;
+    // with a bucket the stream is rate limited (TransformFinisher.java:146-151)
+    std::shared_ptr<InputStream> toInputStream(std::shared_ptr<class TokenBucket> rateLimitingBucket = nullptr);
 
 private:
     bool isBaseTransform() const;
@@ -363,6 +368,47 @@ public:
 private:
     std::shared_ptr<Backend> be_;
     std::shared_ptr<ObjectFetcher> fetcher_;
+};
+
+// ---- upload sink --------------------------------------------------------------------------
+// io.github.bucket4j.Bucket as RateLimitedInputStream.rateLimitBucket builds it (RateLimitedInputStream.java:46-55):
+// capacity = rate tokens, greedy refill of `rate` tokens per second, starts full.
+class TokenBucket {
+public:
+    explicit TokenBucket(int uploadRate);                 // rate = max(uploadRate, MIN_RATE)
+    void consume(long tokens);                            // asBlocking().consume: sleeps until the tokens are there
+    void forceAddTokens(long tokens);
+    static constexpr int MIN_RATE = 8192;                 // InputStream.DEFAULT_BUFFER_SIZE before JDK 21
+
+private:
+    void refill();
+    double tokens_, rate_;
+    long long lastNs_;
+};
+class RateLimitedInputStream : public InputStream {      // RateLimitedInputStream.java:56-84: only read(b, off, len) is limited
+public:
+    RateLimitedInputStream(std::shared_ptr<InputStream> delegated, std::shared_ptr<TokenBucket> bucket) : in_(std::move(delegated)), bucket_(std::move(bucket)) {}
+    long read(uint8_t* b, size_t len) override;
+    void close() override { in_->close(); }
+
+private:
+    std::shared_ptr<InputStream> in_;
+    std::shared_ptr<TokenBucket> bucket_;
+};
+class ObjectUploader {                                   // storage/ObjectUploader.java:27
+public:
+    virtual ~ObjectUploader() = default;
+    virtual long upload(InputStream& inputStream, const std::string& objectKey) = 0;     // returns the object's size
+};
+// storage/filesystem/FileSystemStorage.java:41-90: objects are files under a root directory
+class FileSystemStorage : public ObjectUploader, public ObjectFetcher {
+public:
+    explicit FileSystemStorage(std::string root);        // "<root> must be a writable directory"
+    long upload(InputStream& inputStream, const std::string& objectKey) override;
+    std::shared_ptr<InputStream> fetch(const std::string& objectKey, BytesRange range) override;
+
+private:
+    std::string root_;
 };
 
 // ---- neighbours of the path ------------------------------------------------------------------
