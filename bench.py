@@ -200,7 +200,9 @@ def main():
         m = mean_out - 28 if workload != "crc" else CH                        # GCM input = frame (or chunk)
         alg = n * (m + m + 28.0)                                               # m read + m + 28 written
     else:
-        alg = n * (CH + (mean_out - 28 if flags & nat.ENCRYPT else mean_out)) # N read + frame written
+        # the whole chain of a chunk runs in its compressor wave (CRC head, GCM tail): N bytes read, the transformed chunk
+        # (frame, + IV and tag when encrypting) written
+        alg = n * (CH + mean_out)
     achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_zstd.sh -> profiles/pmc_traffic.json:
     # FETCH_SIZE + WRITE_SIZE of the same kernel build and workload); null when no such measurement is recorded

@@ -28,10 +28,13 @@ def make_descs(sizes, soff, doff, caps, segment=0):
     return d
 
 
-def run_transform(N, flags, chunks, key=synth.KEY, aad=synth.AAD, mem=None, profile=nat.ZSTD_PROFILE_1_5_7):
-    """chunks: list of numpy uint8 arrays.  Returns (list of transformed bytes, descs)."""
+def run_transform(N, flags, chunks, key=synth.KEY, aad=synth.AAD, mem=None, profile=nat.ZSTD_PROFILE_1_5_7, dst_caps=None):
+    """chunks: list of numpy uint8 arrays.  Returns (list of transformed bytes, descs).  dst_caps: per-chunk override of the
+    slot capacity handed to the library (None = the library's own bound)."""
     sizes = [int(c.size) for c in chunks]
     soff, doff, caps, st, dt = layout(sizes, flags, N)
+    if dst_caps:
+        caps = [c if o_ is None else o_ for c, o_ in zip(caps, dst_caps)]
     src = np.zeros(max(st, 16), np.uint8)
     for c, o_ in zip(chunks, soff):
         src[o_:o_ + c.size] = c
@@ -67,6 +70,11 @@ def run_detransform(N, flags, blobs, out_sizes, key=synth.KEY, aad=synth.AAD):
     N.detransform_batch(p, d, src, dst, dst.size)
     outs = [dst[doff[i]:doff[i] + d["dst_len"][i]].tobytes() for i in range(len(sizes))]
     return outs, d
+
+
+def oracle_transform(o, flags, chunk, i, segment=0):
+    oflags = (o.COMPRESS if flags & nat.COMPRESS else 0) | (o.ENCRYPT if flags & nat.ENCRYPT else 0) | (o.CRC if flags & nat.CRC else 0)
+    return o.transform_chunk(oflags, synth.KEY, synth.AAD, synth.iv_for(segment, i), chunk.tobytes())[0]
 
 
 def check_transform_vs_oracle(N, o, flags, chunks, **kw):

@@ -62,12 +62,23 @@ def test_profile_1_5_6_matches_restatement_and_decodes(emu, oracle):
         assert oracle.zstd_decompress_chunk(outs[i]) == CASES[n].tobytes()
 
 
-def test_full_chain_vs_oracle(emu, oracle):
+@pytest.mark.parametrize("gcm", ["in_compressor_wave", "separate_kernels"])
+def test_full_chain_vs_oracle(emu, oracle, gcm, monkeypatch):
+    """With compression, each compressor wave also checksums its source chunk (crc32c_wave) and encrypts its own frame
+    (gcm_encrypt_wave); TSX_STAGES_SEPARATE=1 keeps one launch per stage.  Both must give the oracle's bytes and CRCs."""
     _need157(oracle)
-    chunks = [CASES[n] for n in ("K70000", "R50000", "K1000", "empty")]
+    if gcm == "separate_kernels":
+        monkeypatch.setenv("TSX_STAGES_SEPARATE", "1")
+    else:
+        monkeypatch.delenv("TSX_STAGES_SEPARATE", raising=False)
+    chunks = [CASES[n] for n in ("K70000", "R50000", "K1000", "empty", "one")]
     pc.check_transform_vs_oracle(emu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
     pc.check_roundtrip(emu, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
     pc.check_roundtrip(emu, nat.COMPRESS, chunks)
+    # a slot that cannot hold IV || frame || TAG fails that chunk only (TSX_E_DST_TOO_SMALL), neighbours unaffected
+    outs, d = pc.run_transform(emu, nat.COMPRESS | nat.ENCRYPT, [CASES["R50000"], CASES["K1000"]], dst_caps=[50000, None])
+    assert d["status"][0] == nat.E_DST_TOO_SMALL and d["dst_len"][0] == 0 and d["status"][1] == 0
+    assert outs[1] == pc.oracle_transform(oracle, nat.COMPRESS | nat.ENCRYPT, CASES["K1000"], 1)
 
 
 @pytest.mark.parametrize("level", [0, 1, 19])

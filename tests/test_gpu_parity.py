@@ -142,9 +142,21 @@ def test_zstd_compressor_byte_identical_to_libzstd(gpu, oracle):
     assert outs[0] == oracle.zstd_l3_compress(cases["mixKR"].tobytes(), 0) and outs[1] == oracle.zstd_l3_compress(cases["K1M"].tobytes(), 0)
 
 
-def test_zstd_full_size_chunks_and_full_chain(gpu, oracle):
+@pytest.mark.parametrize("gcm", ["in_compressor_wave", "separate_kernels"])
+def test_zstd_full_size_chunks_and_full_chain(gpu, oracle, gcm, monkeypatch):
+    """With compression each compressor wave also checksums its chunk and encrypts its frame, unless TSX_STAGES_SEPARATE=1
+    (one launch per stage)."""
     if not oracle.zstd_version().startswith("1.5.7"):
         pytest.skip("libzstd 1.5.7 not available")
+    if gcm == "separate_kernels":
+        monkeypatch.setenv("TSX_STAGES_SEPARATE", "1")
+    else:
+        monkeypatch.delenv("TSX_STAGES_SEPARATE", raising=False)
+    small = [synth.gen_chunk("K", 7, 1, i, s) for i, s in enumerate([0, 1, 15, 16, 17, 1000, 65536, 70001, 300007])]
+    pc.check_transform_vs_oracle(gpu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, small)
+    outs, d = pc.run_transform(gpu, nat.COMPRESS | nat.ENCRYPT, [synth.gen_chunk("R", 7, 1, 0, 50000), small[5]], dst_caps=[50000, None])
+    assert d["status"][0] == nat.E_DST_TOO_SMALL and d["dst_len"][0] == 0 and d["status"][1] == 0
+    assert outs[1] == pc.oracle_transform(oracle, nat.COMPRESS | nat.ENCRYPT, small[5], 1)
     chunks = [synth.gen_chunk("K", 1000, 0, 0), synth.gen_chunk("R", 1000, 0, 1), synth.gen_chunk("K", 1000, 0, 2, CHUNK - 5)]
     outs, d = pc.check_transform_vs_oracle(gpu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
     assert outs[0][:12] == synth.iv_for(0, 0) and d["dst_len"][1] == CHUNK + 106 + 28          # raw blocks: n + 10 + 3*32, + IV + tag

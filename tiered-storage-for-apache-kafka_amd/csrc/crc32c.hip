@@ -14,21 +14,7 @@
 // x^(128 * pieces-to-the-end-of-the-sub-block) (bit-serial GF(2) multiply, once per sub-block), the
 // workgroup XOR-reduces with wave shuffles, and a tiny second kernel stitches the sub-blocks and the
 // <16-byte tail together.  Algorithmic traffic: N bytes read + 4 bytes written per chunk.
-#include "tsx_internal.h"
-
-#define POLY 0x82F63B78u
-
-// ---- GF(2)[x]/P helpers (reflected representation: bit 31 = x^0, shifting right multiplies by x) ----
-__host__ __device__ static inline uint32_t crc_mulx(uint32_t v) { return (v >> 1) ^ (POLY & (0u - (v & 1u))); }
-
-__host__ __device__ static inline uint32_t crc_mulmod(uint32_t a, uint32_t b) {
-    uint32_t acc = 0;
-    for (int i = 0; i < 32; i++) {
-        acc ^= b & (0u - ((a >> (31 - i)) & 1u));
-        b = crc_mulx(b);
-    }
-    return acc;
-}
+#include "crc_dev.h"
 
 void tsx_crc_build_tables(tsx_crc_tables* t) {
     static uint32_t all[TSX_CRC_ROW_BYTES][256];   // slicing tables 0..4095 (4 MiB scratch, built once)
@@ -51,14 +37,6 @@ void tsx_crc_build_tables(tsx_crc_tables* t) {
     for (int d = 1; d < 512; d++) t->piece_pow[d] = crc_mulmod(t->piece_pow[d - 1], x128);
     t->pow2[0] = x128;
     for (int k = 1; k < 32; k++) t->pow2[k] = crc_mulmod(t->pow2[k - 1], t->pow2[k - 1]);
-}
-
-// x^(128*e) mod P by square-and-multiply over the pow2 table.
-__device__ static inline uint32_t crc_pow_pieces(const tsx_crc_tables* tab, uint32_t e) {
-    uint32_t r = 0x80000000u;
-    for (int k = 0; e; k++, e >>= 1)
-        if (e & 1u) r = crc_mulmod(r, tab->pow2[k]);
-    return r;
 }
 
 __device__ static inline void crc_chunk_span(const tsx_chunk_desc* d, int use_dst_side, uint64_t* off, uint32_t* len) {

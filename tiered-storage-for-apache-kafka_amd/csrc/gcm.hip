@@ -47,82 +47,7 @@ void tsx_aes_build_tables(tsx_aes_tables* t) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------------------
-__device__ static inline uint32_t bswap32(uint32_t v) { return __byte_perm(v, 0, 0x0123); }
-__device__ static inline uint32_t rotl32(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
-
-// AES-256 encryption of one block given as four little-endian column words.  `T0(x)` returns T0[x].
-template <class Lookup>
-__device__ static inline void aes256_encrypt(const uint32_t* __restrict__ rk, Lookup T0, uint32_t& w0, uint32_t& w1,
-                                             uint32_t& w2, uint32_t& w3) {
-    uint32_t s0 = w0 ^ rk[0], s1 = w1 ^ rk[1], s2 = w2 ^ rk[2], s3 = w3 ^ rk[3];
-#pragma unroll
-    for (int r = 1; r < 14; r++) {
-        uint32_t t0 = T0(s0 & 0xFF) ^ rotl32(T0((s1 >> 8) & 0xFF), 8) ^ rotl32(T0((s2 >> 16) & 0xFF), 16) ^ rotl32(T0(s3 >> 24), 24) ^ rk[4 * r + 0];
-        uint32_t t1 = T0(s1 & 0xFF) ^ rotl32(T0((s2 >> 8) & 0xFF), 8) ^ rotl32(T0((s3 >> 16) & 0xFF), 16) ^ rotl32(T0(s0 >> 24), 24) ^ rk[4 * r + 1];
-        uint32_t t2 = T0(s2 & 0xFF) ^ rotl32(T0((s3 >> 8) & 0xFF), 8) ^ rotl32(T0((s0 >> 16) & 0xFF), 16) ^ rotl32(T0(s1 >> 24), 24) ^ rk[4 * r + 2];
-        uint32_t t3 = T0(s3 & 0xFF) ^ rotl32(T0((s0 >> 8) & 0xFF), 8) ^ rotl32(T0((s1 >> 16) & 0xFF), 16) ^ rotl32(T0(s2 >> 24), 24) ^ rk[4 * r + 3];
-        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
-    }
-    // final round: SubBytes + ShiftRows only; S(x) is byte 1 of T0[x]
-    #define SB(x) ((T0(x) >> 8) & 0xFFu)
-    w0 = (SB(s0 & 0xFF) | (SB((s1 >> 8) & 0xFF) << 8) | (SB((s2 >> 16) & 0xFF) << 16) | (SB(s3 >> 24) << 24)) ^ rk[56];
-    w1 = (SB(s1 & 0xFF) | (SB((s2 >> 8) & 0xFF) << 8) | (SB((s3 >> 16) & 0xFF) << 16) | (SB(s0 >> 24) << 24)) ^ rk[57];
-    w2 = (SB(s2 & 0xFF) | (SB((s3 >> 8) & 0xFF) << 8) | (SB((s0 >> 16) & 0xFF) << 16) | (SB(s1 >> 24) << 24)) ^ rk[58];
-    w3 = (SB(s3 & 0xFF) | (SB((s0 >> 8) & 0xFF) << 8) | (SB((s1 >> 16) & 0xFF) << 16) | (SB(s2 >> 24) << 24)) ^ rk[59];
-    #undef SB
-}
-
-__device__ static inline tsx_gf128 gf_from_le_words(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
-    tsx_gf128 r;
-    r.hi = ((uint64_t)bswap32(w0) << 32) | bswap32(w1);
-    r.lo = ((uint64_t)bswap32(w2) << 32) | bswap32(w3);
-    return r;
-}
-__device__ static inline void gf_to_le_words(const tsx_gf128& g, uint32_t w[4]) {
-    w[0] = bswap32((uint32_t)(g.hi >> 32)); w[1] = bswap32((uint32_t)g.hi);
-    w[2] = bswap32((uint32_t)(g.lo >> 32)); w[3] = bswap32((uint32_t)g.lo);
-}
-__device__ static inline tsx_gf128 gf_from_bytes(const uint8_t* p, uint32_t n) {   // zero padded
-    uint8_t b[16];
-    for (uint32_t i = 0; i < 16; i++) b[i] = i < n ? p[i] : 0;
-    tsx_gf128 r; r.hi = 0; r.lo = 0;
-    for (int i = 0; i < 8; i++) { r.hi = (r.hi << 8) | b[i]; r.lo = (r.lo << 8) | b[8 + i]; }
-    return r;
-}
-// multiply by x: one step to the right in GCM bit order, reduction by R = 0xE1 || 0^120
-__device__ static inline void gf_mulx(tsx_gf128& v) {
-    uint64_t carry = v.lo & 1u;
-    v.lo = (v.lo >> 1) | (v.hi << 63);
-    v.hi = (v.hi >> 1) ^ (0xE100000000000000ull & (0ull - carry));
-}
-// generic bit-serial product (SP 800-38D Algorithm 1)
-__device__ static tsx_gf128 gf_mul(const tsx_gf128& x, tsx_gf128 v) {
-    tsx_gf128 z; z.hi = 0; z.lo = 0;
-    for (int i = 0; i < 64; i++) {
-        uint64_t m = 0ull - ((x.hi >> (63 - i)) & 1u);
-        z.hi ^= v.hi & m; z.lo ^= v.lo & m;
-        gf_mulx(v);
-    }
-    for (int i = 0; i < 64; i++) {
-        uint64_t m = 0ull - ((x.lo >> (63 - i)) & 1u);
-        z.hi ^= v.hi & m; z.lo ^= v.lo & m;
-        gf_mulx(v);
-    }
-    return z;
-}
-__device__ static tsx_gf128 gf_pow_h(const tsx_gcm_key* key, uint32_t e) {
-    tsx_gf128 r; r.hi = 0x8000000000000000ull; r.lo = 0;
-    bool first = true;
-    for (int k = 0; e; k++, e >>= 1) {
-        if (!(e & 1u)) continue;
-        if (first) { r = key->hpow2[k]; first = false; }
-        else r = gf_mul(r, key->hpow2[k]);
-    }
-    return r;
-}
+#include "gcm_dev.h"
 
 // ---------------------------------------------------------------------------------------------------
 // per-key setup: round keys, H, powers of H, Shoup tables of H^256.  One 256-thread workgroup.
@@ -177,6 +102,16 @@ __global__ __launch_bounds__(256) void gcm_setup_kernel(const tsx_aes_tables* __
     if (t < 64) out->aad[t] = t < aad_len ? aad[t] : 0;
     if (t < 32) out->hpow2[t] = s_pow2[t];
     for (uint32_t d = t; d < 512; d += 256) out->hpow[d] = s_pow[d];
+    {   // 2-bit tables of H^64: entry (p, val) = val.bit1 * H^64 x^(2p)  xor  val.bit0 * H^64 x^(2p+1)
+        const uint32_t p = t >> 2, val = t & 3;
+        tsx_gf128 v = s_pow[64];
+        for (uint32_t i = 0; i < 2 * p; i++) gf_mulx(v);
+        tsx_gf128 r; r.hi = 0; r.lo = 0;
+        if (val & 2u) { r.hi ^= v.hi; r.lo ^= v.lo; }
+        gf_mulx(v);
+        if (val & 1u) { r.hi ^= v.hi; r.lo ^= v.lo; }
+        out->h64_tab[p][val] = r;
+    }
     for (uint32_t e = t; e < 512; e += 256) {                           // Shoup tables
         uint32_t p = e >> 4, val = e & 15;
         tsx_gf128 r; r.hi = 0; r.lo = 0;

@@ -358,6 +358,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     rc = ctx_reserve(c, n, max_len, flags, host, in_bytes, dst_size);
     if (rc) return rc;
     hipStream_t st = c->st;
+    bool fused = false;
     memset(&c->timing, 0, sizeof c->timing);
     const uint8_t* d_src = (const uint8_t*)src;
     uint8_t* d_dst = (uint8_t*)dst;
@@ -380,14 +381,24 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
         HIPCHK(hipEventRecord(c->ev[2], st));
         c->timing.crc_launches = 2;
     } else if (mode == 0) {
-        if (flags & TSX_CRC) { tsx_launch_crc32c(st, c->dev->d_crc, d_src, c->d_descs, n, max_len, c->d_partials, 0); c->timing.crc_launches = 2; }
+        // With compression the whole chain of a chunk runs in the wave that compresses it: CRC32C of the source chunk first, GCM over
+        // the finished frame last - one launch per batch.  The batch CRC / GCM kernels want 20 / 40 KiB of LDS per workgroup and, on
+        // a chip filled by the compressor waves of the batches in flight, sat hundreds of ms in the queue for a few ms of work.
+        // TSX_STAGES_SEPARATE=1 keeps one launch per stage (A/B measurements, tests of the stand-alone kernels).
+        const bool fuse_stages = comp && !getenv("TSX_STAGES_SEPARATE");
+        if ((flags & TSX_CRC) && !fuse_stages) { tsx_launch_crc32c(st, c->dev->d_crc, d_src, c->d_descs, n, max_len, c->d_partials, 0); c->timing.crc_launches = 2; }
         HIPCHK(hipEventRecord(c->ev[2], st));
         if (comp) {
+            fused = enc && fuse_stages;
+            tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr};
+            if (fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
+            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = d_dst; }
             c->timing.zstd_launches = tsx_launch_zstd_compress(st, c->dev->d_zc, d_src, c->d_descs, n, max_len, c->d_mid, c->mid_stride,
-                                                              c->d_zlen, c->d_status, c->d_zwork, params->zstd_profile);
+                                                              c->d_zlen, c->d_status, c->d_zwork, params->zstd_profile, fuse);
         }
         HIPCHK(hipEventRecord(c->ev[3], st));
-        if (enc) {
+        if (fused) {
+        } else if (enc) {
             hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_descs, n, (const uint32_t*)c->d_zlen,
                                (uint64_t)c->mid_stride, comp ? 1 : 0, 0, 0, c->d_gchunks, c->d_status);
             uint32_t glen = comp ? (uint32_t)tsx_transformed_bound(max_len, TSX_COMPRESS) : max_len;

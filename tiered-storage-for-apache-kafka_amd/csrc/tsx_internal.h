@@ -50,12 +50,20 @@ struct tsx_gcm_key {             // device-resident, derived per batch key by th
     tsx_gf128 hstride_tab[32][16];  // 4-bit tables of H^256: [nibble position][value]
     tsx_gf128 hpow[512];         // H^d, d = 0..511 (d = 0 is the identity)
     tsx_gf128 hpow2[32];         // H^(2^k)
+    tsx_gf128 h64_tab[64][4];    // 2-bit tables of H^64: [bit-pair position][value] (one-wave-per-message GCM, gcm_dev.h)
 };
 
 struct tsx_aes_tables {          // device-resident constants, built once per device at tsx_init
     uint32_t te0[256];           // T0[x] = {02.S(x), S(x), S(x), 03.S(x)} packed little-endian
 };
 void tsx_aes_build_tables(tsx_aes_tables* host_out);
+
+struct tsx_chain_fuse {          // stages the compressor wave of chunk i runs itself, around the compression (zstd_compress_kernel)
+    const tsx_crc_tables* crc;   // != nullptr: CRC32C of the source chunk -> descs[i].crc32c, before parsing it
+    const tsx_aes_tables* aes;
+    const tsx_gcm_key* key;      // != nullptr: GCM over the finished frame: IV||C||TAG -> out + descs[i].dst_off,
+    uint8_t* out;                //             descs[i].dst_len = frame + 28
+};
 
 struct tsx_gcm_chunk {           // per-chunk work item (device)
     uint64_t in_off;             // plaintext (encrypt) / IV||C||TAG (decrypt) offset within `in`

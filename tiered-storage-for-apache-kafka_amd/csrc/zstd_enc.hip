@@ -26,6 +26,8 @@
 //    constructions (Huffman tree, FSE normalisation: a few thousand dependent steps per block) stay on lane 0.
 // This is byte-stream work: no MFMA.  Algorithmic traffic per chunk: N bytes read + frame bytes written.
 #include "zstd_common.h"
+#include "gcm_dev.h"
+#include "crc_dev.h"
 
 #define LANES 64
 // "this value is the same in every lane": results of out-of-line calls and LDS broadcasts are divergent to the compiler;
@@ -143,6 +145,11 @@ struct EncLds {
             uint8_t scr[2 * ZS_SCR];
             alignas(16) uint8_t fwbuf[96];      // two far windows of 48 bytes (winner, long candidate at +1)
         } p;
+        struct {                // GCM tail over the finished frame (gcm_encrypt_wave)
+            tsx_gf128 tab[256];
+            uint32_t t0[256];
+        } g;
+        uint32_t crcTab[4 * 256];       // CRC32C head over the source chunk (crc32c_wave)
     };
 };
 
@@ -1377,9 +1384,28 @@ __device__ static bool wave_is_rle(const uint8_t* __restrict__ p, uint32_t n, ui
 // ---------------------------------------------------------------------------------------------------
 // the kernel: one wave per chunk
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, const tsx_chunk_desc* __restrict__ descs,
+// The frame is complete: publish its size and, when the batch is also encrypted, run GCM over it in this same wave.  A separate
+// GCM launch would need 40 KiB of LDS per workgroup on CUs whose LDS and VGPRs are held by compressor waves of the batches in
+// flight, and sat hundreds of ms in the queue for 20 ms of work; here it costs the wave a few ms of its second-long life.
+__device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ descs, uint32_t chunk, const uint8_t* frame, uint32_t flen,
+                                    uint32_t* __restrict__ zlen, int32_t* __restrict__ status, const tsx_chain_fuse fuse, EncLds& L, uint32_t lane) {
+    if (lane == 0) zlen[chunk] = flen;
+    if (!fuse.key) return;
+    __threadfence_block();
+    __syncthreads();
+    const uint64_t dstOff = descs[chunk].dst_off;
+    if ((uint64_t)flen + 28 > descs[chunk].dst_cap) {
+        if (lane == 0) { status[chunk] = TSX_E_DST_TOO_SMALL; descs[chunk].dst_len = 0; }
+        return;
+    }
+    gcm_encrypt_wave(fuse.aes, fuse.key, descs[chunk].iv, frame, flen, fuse.out + dstOff, L.g.t0, L.g.tab, lane);
+    if (lane == 0) descs[chunk].dst_len = flen + 28;
+}
+
+__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
                                                               uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
-                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile
+                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile,
+                                                              const tsx_chain_fuse fuse
 #ifdef TSX_PROF
                                                               , unsigned long long* __restrict__ prof_out
 #endif
@@ -1401,7 +1427,11 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
     uint8_t* const codes = ws + ZS_WS_CODES;
     uint8_t* const blockout = ws + ZS_WS_BLOCKOUT;
     uint32_t* const huftmp = (uint32_t*)(blockout + (256u << 10));                  // 4-byte aligned stream scratch
-    if (status[chunk] != TSX_OK) { if (lane == 0) zlen[chunk] = 0; return; }
+    if (fuse.crc) {
+        const uint32_t crc = crc32c_wave(fuse.crc, src, srcSize, L.crcTab, lane);
+        if (lane == 0) descs[chunk].crc32c = crc;
+    }
+    if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } return; }
 
     const zs_cparams cp = zs_level3_cparams(srcSize);
     {   // fresh tables (ZSTD_reset_matchState): zero hashLong[1 << hashLog] and hashSmall[1 << chainLog]
@@ -1427,7 +1457,8 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
     }
     uint8_t* op = frame + hdr;
     if (srcSize == 0) {
-        if (lane == 0) { op[0] = 1; op[1] = 0; op[2] = 0; zlen[chunk] = hdr + 3; }
+        if (lane == 0) { op[0] = 1; op[1] = 0; op[2] = 0; }
+        finish_frame(descs, chunk, frame, hdr + 3, zlen, status, fuse, L, lane);
         return;
     }
     if (lane == 0) { L.hufRepeat[0] = 0; L.hufRepeat[1] = 0; L.huf[0].maxSym = 0; L.huf[1].maxSym = 0; }
@@ -1506,7 +1537,11 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
         ipos += blockSize; remaining -= blockSize; op += cSize; first = false;
         __syncthreads();
     }
+#ifdef ZS_ABL_PARSE_ONLY
     if (lane == 0) zlen[chunk] = (uint32_t)(op - frame);
+#else
+    finish_frame(descs, chunk, frame, (uint32_t)(op - frame), zlen, status, fuse, L, lane);
+#endif
 #ifdef TSX_PROF
     if (lane == 0 && prof_out) { g_prof[14] = (unsigned long long)clock64() - g_prof[22]; for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i]; }
 #endif
@@ -1519,12 +1554,12 @@ size_t tsx_zstd_consts_bytes(void) { return sizeof(tsx_zstd_consts); }
 void tsx_zstd_build_consts(tsx_zstd_consts* h) { h->abi = 1; h->pad[0] = h->pad[1] = h->pad[2] = 0; }
 size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size_t)n * ZS_WS_BYTES; }
 
-uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* src, const tsx_chunk_desc* d_descs, uint32_t n,
+uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* src, tsx_chunk_desc* d_descs, uint32_t n,
                                   uint32_t /*max_len*/, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status, void* d_work,
-                                  uint32_t profile) {
+                                  uint32_t profile, tsx_chain_fuse fuse) {
     if (!n) return 0;
     hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
-                       (uint8_t*)d_work, profile
+                       (uint8_t*)d_work, profile, fuse
 #ifdef TSX_PROF
                        , g_prof_out
 #endif

@@ -8,10 +8,13 @@ void tsx_zstd_build_consts(tsx_zstd_consts* host_out);
 // Device workspace needed for a batch of n chunks of at most max_len bytes (compress or decompress).
 size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t max_len);
 // One Zstd frame per chunk (CompressionChunkEnumeration.java:50-63): chunk i = src + descs[i].src_off,
-// frame i written at mid + i * mid_stride, its size to zlen[i].  Returns the number of kernel launches.
-uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* src, const tsx_chunk_desc* d_descs,
+// frame i written at mid + i * mid_stride, its size to zlen[i].  With fuse.crc set the wave first
+// stores the CRC32C of its source chunk in descs[i].crc32c; with fuse.key set, the wave that wrote frame i also encrypts it
+// (EncryptionChunkEnumeration.java:66-84) to fuse.out + descs[i].dst_off and sets descs[i].dst_len (0 and
+// TSX_E_DST_TOO_SMALL in d_status when the slot is too small).  Returns the number of kernel launches.
+uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* src, tsx_chunk_desc* d_descs,
                                   uint32_t n, uint32_t max_len, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status,
-                                  void* d_work, uint32_t profile);
+                                  void* d_work, uint32_t profile, tsx_chain_fuse fuse);
 // Inverse (DecompressionChunkEnumeration.java:39-46): frame i at (from_mid ? frames + i*mid_stride :
 // frames + descs[i].src_off), length descs[i].src_len - (from_mid ? 28 : 0); output to dst + descs[i].dst_off,
 // descs[i].dst_len set; status TSX_E_BAD_SIZE / TSX_E_BAD_FRAME / TSX_E_DST_TOO_SMALL on failure.
