@@ -148,3 +148,22 @@ def test_decoder_survives_corrupt_frames(emu, oracle):
     for i in range(len(blobs)):
         if d["status"][i] == 0:
             assert len(outs[i]) <= sizes[i]
+
+
+def test_differential_fuzz_vs_libzstd(emu, oracle):
+    """Inputs that once diverged (tests/golden/fuzz_regress: a raw-literals fallback written over a Huffman attempt, found by
+    tools/fuzz_emu.py) plus a fixed-seed sample of the same generator: frames must be libzstd's, and decode back."""
+    _need157(oracle)
+    import glob
+    import os
+    from tests.fuzz_cases import gen_case
+    here = os.path.dirname(os.path.abspath(__file__))
+    cases = [np.fromfile(f, np.uint8) for f in sorted(glob.glob(os.path.join(here, "golden", "fuzz_regress", "*.bin")))]
+    assert len(cases) >= 5
+    rng = np.random.default_rng(20260923)
+    cases += [gen_case(rng) for _ in range(10)]
+    outs, d = pc.run_transform(emu, nat.COMPRESS, cases)
+    back, d2 = pc.run_detransform(emu, nat.COMPRESS, outs, [int(c.size) for c in cases])
+    for i, c in enumerate(cases):
+        assert d["status"][i] == 0 and outs[i] == oracle.zstd_compress_chunk(c.tobytes()), "case %d (n=%d): frame differs from libzstd" % (i, c.size)
+        assert d2["status"][i] == 0 and back[i] == c.tobytes(), "case %d (n=%d): round trip" % (i, c.size)

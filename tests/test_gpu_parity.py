@@ -223,3 +223,29 @@ def test_zstd_decoder_survives_corrupt_frames(gpu, oracle):
     good = oracle.zstd_compress_chunk(np.arange(5000, dtype=np.uint8).tobytes())       # the device still works afterwards
     outs, d = pc.run_detransform(gpu, nat.COMPRESS, [good], [5000])
     assert d["status"][0] == 0 and outs[0] == np.arange(5000, dtype=np.uint8).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_zstd_differential_fuzz_vs_libzstd(gpu, oracle):
+    """Several hundred structured random inputs (tests/fuzz_cases.py: segments of differing statistics with verbatim and edited
+    copies at all distances, sizes around the block boundaries) + the regression inputs: every frame must be libzstd 1.5.7's byte
+    for byte, the device decoder must restore it, and the full chain must match the oracle chain."""
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    import glob
+    import os
+    from tests.fuzz_cases import gen_case
+    here = os.path.dirname(os.path.abspath(__file__))
+    cases = [np.fromfile(f, np.uint8) for f in sorted(glob.glob(os.path.join(here, "golden", "fuzz_regress", "*.bin")))]
+    assert len(cases) >= 5
+    rng = np.random.default_rng(4242)
+    cases += [gen_case(rng) for _ in range(600)]
+    for lo in range(0, len(cases), 128):
+        part = cases[lo:lo + 128]
+        outs, d = pc.run_transform(gpu, nat.COMPRESS, part)
+        back, d2 = pc.run_detransform(gpu, nat.COMPRESS, outs, [int(c.size) for c in part])
+        for i, c in enumerate(part):
+            assert d["status"][i] == 0 and outs[i] == oracle.zstd_compress_chunk(c.tobytes()), "case %d (n=%d): frame differs from libzstd" % (lo + i, c.size)
+            assert d2["status"][i] == 0 and back[i] == c.tobytes(), "case %d (n=%d): round trip" % (lo + i, c.size)
+    pc.check_transform_vs_oracle(gpu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, cases[:64])

@@ -381,12 +381,24 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
                 const uint32_t tL = tag8(d8, hBitsL, tagBits), tS = tag4((uint32_t)d8, tagBits);
                 const uint32_t eL = ((tL << 1) << (idxBits - 1)) | (pos + 2), eS = ((tS << 1) << (idxBits - 1)) | (pos + 2);   // what this position inserts
                 WAVE_MEM_SYNC();
-                uint32_t cL = hashLong[hl];                          // lanes beyond the step read (harmlessly) too: no branches
-                uint32_t cS = hashSmall[hs];
-                uint32_t r1;                                          // bytes at pos + 1 - off1 (repcode check)
-                {   const uint32_t ra = off1 > 0 ? spos + 1 - off1 : spos;
-                    if (posWin && ip + 1 >= w.lo + off1) r1 = ring4(ring, ra); else r1 = ld32(src + ra);
+                // The repcode check of a position (bytes at pos + 1 - off1) precedes its table checks, and everything behind the
+                // step's first event is discarded: when those bytes are in the ring the first repcode hit is known BEFORE the table
+                // loads go out, and the lanes behind it need no probes (they re-read lane 0's entries: same lines, no extra HBM
+                // requests).  The hit lane itself still probes the long table (the "long match at +1" rule of the lane before it);
+                // lane K only provides that look-ahead and never needs the short table.
+                const uint32_t ra = off1 > 0 ? spos + 1 - off1 : spos;
+                const bool r1Near = posWin && ip + 1 >= w.lo + off1;
+                uint32_t r1 = 0, firstRep = LANES;
+                if (r1Near) {
+                    r1 = ring4(ring, ra);
+                    const unsigned long long rb = __ballot(searching && off1 > 0 && r1 == (uint32_t)(d8 >> 8));
+                    if (rb) firstRep = (uint32_t)__ffsll((long long)rb) - 1;
                 }
+                const bool probeL = inRange && lane <= firstRep, probeS = searching && lane < firstRep;
+                const uint32_t hl0 = __builtin_amdgcn_readfirstlane(hl), hs0 = __builtin_amdgcn_readfirstlane(hs);
+                uint32_t cL = hashLong[probeL ? hl : hl0];           // lanes beyond the step read (harmlessly) too: no branches
+                uint32_t cS = hashSmall[probeS ? hs : hs0];
+                if (!r1Near) r1 = ld32(src + ra);
                 if (afterMatch) {                                     // immediate repcode at ip (lane 0's position), wave-uniform
                     afterMatch = false;
                     const uint32_t r2 = (posWin && ip >= w.lo + off2) ? ring4(ring, ip - off2) : ld32(src + ip - off2);
@@ -426,8 +438,8 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
                 LT(3);                                                // 3: collision scoreboard
                 // candidates: from the ring when recent enough, else one global load each - all issued before any is used
                 const uint32_t iL = cL & idxMask, iS = cS & idxMask;
-                const bool vL = inRange && iL > plowIdx && ((cL ^ eL) & ~idxMask) == 0;      // in the window and same tag
-                const bool vS = searching && iS > plowIdx && ((cS ^ eS) & ~idxMask) == 0;
+                const bool vL = probeL && iL > plowIdx && ((cL ^ eL) & ~idxMask) == 0;       // in the window and same tag
+                const bool vS = probeS && iS > plowIdx && ((cS ^ eS) & ~idxMask) == 0;
                 const uint32_t pL = vL ? iL - 2 : w.lo, pS = vS ? iS - 2 : w.lo;
                 const bool nL = pL >= w.lo && pL + 8 <= w.hi, nS = pS >= w.lo && pS + 4 <= w.hi;
                 // far candidates: 48 bytes around each in one go (verification + both extensions); the rare ones too close to the
@@ -1049,6 +1061,7 @@ __device__ ZS_NOINLINE static uint32_t wave_huf_compress(uint8_t* ostart, uint8_
 // ---------------------------------------------------------------------------------------------------
 __device__ static uint32_t write_raw_literals(uint8_t* dst, const uint8_t* lit, uint32_t n, uint32_t lane) {
     const uint32_t fl = 1 + (n > 31) + (n > 4095);
+    WAVE_MEM_SYNC();                // the fallback overwrites what a Huffman attempt left at dst: other lanes' earlier stores come first
     if (lane == 0) {
         if (fl == 1) dst[0] = (uint8_t)(0 + (n << 3));
         else if (fl == 2) { const uint32_t v = 0 + (1 << 2) + (n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); }
@@ -1059,6 +1072,7 @@ __device__ static uint32_t write_raw_literals(uint8_t* dst, const uint8_t* lit, 
 }
 __device__ static uint32_t write_rle_literals(uint8_t* dst, const uint8_t* lit, uint32_t n, uint32_t lane) {
     const uint32_t fl = 1 + (n > 31) + (n > 4095);
+    WAVE_MEM_SYNC();
     if (lane == 0) {
         if (fl == 1) dst[0] = (uint8_t)(1 + (n << 3));
         else if (fl == 2) { const uint32_t v = 1 + (1 << 2) + (n << 4); dst[0] = (uint8_t)v; dst[1] = (uint8_t)(v >> 8); }
