@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="auto", choices=["auto", "full", "gcm_crc", "crc"])
     ap.add_argument("--segments", type=int, default=0, help="1 GiB segments per GPU (default: 8 for full, 1 otherwise)")
@@ -207,18 +207,30 @@ def main():
     # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_zstd.sh -> profiles/pmc_traffic.json:
     # FETCH_SIZE + WRITE_SIZE of the same kernel build and workload); null when no such measurement is recorded
     traffic = None
+    binding = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             rec = json.load(f).get("%s/%s/%d" % (workload, args.dist, n))
         if rec:
             traffic = rec["hbm_bytes_per_launch"]
+            if dom == "zstd" and "tcc_ea_rdreq" in rec:
+                # The resource that actually binds the hash-table parser: 64-B lines moved between L2 and memory at random
+                # addresses (one per 4-byte table probe / insertion).  Requests per launch from the committed PMC passes
+                # (TCC_EA0_RDREQ + WRREQ), rate over the whole timed region (all launches, as they overlapped), ceiling =
+                # what the chip sustains for the same read / write-back mix with waves that do nothing else
+                # (tools/ubench/mix.hip, profiles/r01_ubench_mix.txt: 44 G lines/s at 4096-5120 waves).
+                req = float(rec["tcc_ea_rdreq"] + rec["tcc_ea_wrreq"])
+                rate = req * args.steps / elapsed / 1e9
+                binding = {"resource": "random 64-B line accesses L2<->HBM (table probes + insertions)", "requests_per_launch": int(req),
+                           "achieved": round(rate, 2), "peak": 44.0, "unit": "G lines/s", "frac": round(rate / 44.0, 3),
+                           "peak_source": "profiles/r01_ubench_mix.txt (measured, same 58/42 read/write-back mix)"}
     except (OSError, ValueError, KeyError):
         pass
     roofline = {"bound": "hbm", "kernel": {"crc": "crc32c_partial_kernel", "gcm": "gcm_ctr_ghash_kernel", "zstd": "zstd_compress_kernel"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "launches_in_flight": T, "achieved_aggregate": round(achieved * T, 2),
-                "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage.items()}}
+                "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage.items()}, "binding_resource": binding}
 
     # ---- CPU baseline: the oracle port (libzstd + OpenSSL GCM + CRC32C), all host cores, bounded sample --
     cpu = None

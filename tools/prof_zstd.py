@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dist", default="K")
     ap.add_argument("--out", default="")
     ap.add_argument("--data", default="", help=".npy cache of the 256 distinct chunks (made on first use): keeps generator kernels out of rocprofv3 runs")
+    ap.add_argument("--chain", action="store_true", help="full chain (CRC head + compress + GCM tail in the compressor wave) instead of compress only")
     ap.add_argument("--lib", default="libtsxform_prof.so", help="libtsxform_prof.so (lap timers) or libtsxform.so (plain, for rocprofv3 runs)")
     args = ap.parse_args()
     import torch
@@ -47,7 +48,7 @@ def main():
     for i in range(uniq, n, uniq):
         m = min(uniq, n - i)
         src[i * CH:(i + m) * CH] = src[:m * CH]
-    flags = nat.COMPRESS
+    flags = (nat.COMPRESS | nat.ENCRYPT | nat.CRC) if args.chain else nat.COMPRESS
     slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
     dst = torch.empty(n * slot, dtype=torch.uint8, device=dev)
     prof = torch.zeros(n * 24, dtype=torch.int64, device=dev)
