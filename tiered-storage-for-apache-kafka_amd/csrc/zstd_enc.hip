@@ -24,7 +24,10 @@
 //  * The entropy stage of each block: histograms, Huffman bit packing, literal gathering and the FSE sequence bit stream
 //    run on all lanes (the three FSE state machines on three lanes, then prefix-summed bit packing); only the table
 //    constructions (Huffman tree, FSE normalisation: a few thousand dependent steps per block) stay on lane 0.
-// This is byte-stream work: no MFMA.  Algorithmic traffic per chunk: N bytes read + frame bytes written.
+//  * The wave also runs the stages either side of the compression when the batch asks for them (tsx_chain_fuse): CRC32C of
+//    the source chunk before parsing it (crc_dev.h), AES-256-GCM over the finished frame (gcm_dev.h) - one launch per
+//    batch; separate CRC / GCM launches starve for LDS on a chip full of compressor waves.
+// This is byte-stream work: no MFMA.  Algorithmic traffic per chunk: N bytes read + transformed bytes written.
 #include "zstd_common.h"
 #include "gcm_dev.h"
 #include "crc_dev.h"

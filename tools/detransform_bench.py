@@ -43,6 +43,32 @@ for it in range(3):
     print("detransform %d chunks: %.1f ms -> %.2f GiB/s of restored bytes (gcm %.1f ms, unzstd %.1f ms, crc %.1f ms)" % (n, el * 1e3, n * CH / 2**30 / el, t.gcm_ms, t.unzstd_ms, t.crc_ms))
 assert (e["status"] == 0).all() and (e["crc32c"] == crc).all() and torch.equal(back, src)
 print("round trip exact")
+# the same batch from T caller threads (own tsx_ctx, own output buffer), as the reference's fetch threads would: batches in flight
+import threading
+for T in (2, 3):
+    ctxs = [N.ctx_create(0, n, CH) for _ in range(T)]
+    backs = [torch.empty(n * CH, dtype=torch.uint8, device=dev) for _ in range(T)]
+    es = [e.copy() for _ in range(T)]
+    tms = [[0.0, 0.0, 0.0] for _ in range(T)]
+    reps = 4
+    def work(t):
+        for _ in range(reps):
+            N.detransform_batch(params, es[t], mid.data_ptr(), backs[t].data_ptr(), backs[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+            tt = N.ctx_timing(ctxs[t]); tms[t][0] += tt.gcm_ms; tms[t][1] += tt.unzstd_ms; tms[t][2] += tt.crc_ms
+    for t in range(T): work.__call__(t) if False else None
+    for t in range(T):
+        N.detransform_batch(params, es[t], mid.data_ptr(), backs[t].data_ptr(), backs[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+    tms = [[0.0, 0.0, 0.0] for _ in range(T)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    [x.start() for x in th]; [x.join() for x in th]
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    g = sum(x[0] for x in tms) / (T * reps); u = sum(x[1] for x in tms) / (T * reps); c = sum(x[2] for x in tms) / (T * reps)
+    print("detransform, %d batches in flight: %.1f ms per batch -> %.2f GiB/s of restored bytes (per call: gcm %.1f ms, unzstd %.1f ms, crc %.1f ms)" % (T, el * 1e3 / (T * reps), T * reps * n * CH / 2**30 / el, g, u, c))
+    for t in range(T):
+        assert (es[t]["status"] == 0).all() and (es[t]["crc32c"] == crc).all()
+        N.ctx_destroy(ctxs[t])
+    del backs
 if dprof is not None:
     m = dprof.cpu().numpy().reshape(n, 8).mean(axis=0)
     for k, name in enumerate(["block header + literals", "sequence tables", "FSE sequence decode", "execution", "rest"]):
