@@ -21,6 +21,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 typedef uint8_t BYTE; typedef uint16_t U16; typedef uint32_t U32; typedef uint64_t U64; typedef int64_t S64;
 
@@ -194,7 +196,9 @@ static size_t compressBlock_doubleFast(matchstate_t* ms, seqstore_t* ss, U32 rep
                 goto _match_stored;
             }
             hl1 = hashPtr(ip1, hBitsL, 8);
-            if (idxl0 > prefixLowestIndex) {
+            /* candidates AT the lowest prefix index are valid (>=): pinned by a differential case whose only table entry for
+             * a 5 KiB match sits exactly at endIndex - maxDistance (tests/golden/fuzz_regress/window_edge_*.bin) */
+            if (idxl0 >= prefixLowestIndex) {
                 if (rd64(matchl0) == rd64(ip)) {
                     mLength = count(ip + 8, matchl0 + 8, iend) + 8;
                     offset = (U32)(ip - matchl0);
@@ -203,7 +207,7 @@ static size_t compressBlock_doubleFast(matchstate_t* ms, seqstore_t* ss, U32 rep
                 }
             }
             idxl1 = hashLong[hl1]; matchl1 = base + idxl1;
-            if (idxs0 > prefixLowestIndex) {
+            if (idxs0 >= prefixLowestIndex) {
                 if (rd32(matchs0) == rd32(ip)) goto _search_next_long;
             }
             if (ip1 >= nextStep) { step++; nextStep += kStepIncr; }
@@ -219,7 +223,7 @@ _search_next_long:
         /* short match found: measure it, then prefer the long match at +1 only if it is strictly longer */
         mLength = count(ip + 4, matchs0 + 4, iend) + 4;
         offset = (U32)(ip - matchs0);
-        if ((idxl1 > prefixLowestIndex) && (rd64(matchl1) == rd64(ip1))) {
+        if ((idxl1 >= prefixLowestIndex) && (rd64(matchl1) == rd64(ip1))) {
             size_t const l1len = count(ip1 + 8, matchl1 + 8, iend) + 8;
             if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (U32)(ip - matchl1); matchs0 = matchl1; }
         }
@@ -1022,8 +1026,11 @@ size_t orc_l3_compress(const BYTE* src, size_t srcSize, BYTE* dst, size_t dstCap
             U32 const lastBlock = blockSize == remaining;
             const blockstate_t* prev = &bs[cur]; blockstate_t* next = &bs[cur ^ 1];
             size_t cSize;
-            {   /* ZSTD_window_enforceMaxDist */
-                U32 const blockEndIdx = (U32)((ip + blockSize) - ms.base), maxDist = 1u << cp.windowLog;
+            {   /* ZSTD_window_enforceMaxDist(&ms->window, ip, maxDist, ...): since 1.5.0 the window is slid to the block's START
+                 * (1.4.x passed ip + blockSize); match candidates are still bounded from the block's END through
+                 * ZSTD_getLowestPrefixIndex(ms, endIndex, windowLog) in the block compressor.  Pinned by differential cases
+                 * whose repcodes / matches lie between 2 MiB - blockSize and 2 MiB back (tests/golden/fuzz_regress). */
+                U32 const blockEndIdx = (U32)(ip - ms.base), maxDist = 1u << cp.windowLog;
                 if (blockEndIdx > maxDist) { U32 const newLow = blockEndIdx - maxDist; if (ms.dictLimit < newLow) ms.dictLimit = newLow; }
             }
             if (blockSize < 1 + 1 + 3 + 1 + 1) cSize = 0;               /* MIN_CBLOCK_SIZE + blockHeader + 1 + 1: don't even try */

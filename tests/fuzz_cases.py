@@ -5,10 +5,11 @@ import numpy as np
 from tsxform import synth
 
 
-def gen_case(rng):
+def gen_case(rng, total=None):
     """A byte string built from segments of different statistical character, with cross references at all distances."""
-    total = int(rng.choice([rng.integers(0, 300), rng.integers(300, 20000), rng.integers(20000, 140000), rng.integers(126000, 136000),
-                            rng.integers(140000, 420000), rng.integers(255000, 270000)]))
+    if total is None:
+        total = int(rng.choice([rng.integers(0, 300), rng.integers(300, 20000), rng.integers(20000, 140000), rng.integers(126000, 136000),
+                                rng.integers(140000, 420000), rng.integers(255000, 270000)]))
     parts, made = [], 0
     pool = []
     while made < total:
@@ -48,3 +49,17 @@ def gen_case(rng):
     return np.concatenate(parts)[:total] if parts else np.zeros(0, np.uint8)
 
 
+
+
+# Full-size chunks on which the sliding of the 2 MiB window decides the output: repcodes / match candidates that lie between
+# 2 MiB - blockSize and 2 MiB behind the block, one of them exactly AT the lowest valid index (found by tools/fuzz_gpu.py; a
+# restatement that slides the window to the block's end, or excludes the bound itself, differs from libzstd 1.5.7 on every one).
+WINDOW_EDGE_SEEDS = (1009, 1045, 1071, 1093, 1096, 1113)
+
+
+def window_edge_case(seed):
+    return gen_case(np.random.default_rng(seed), 4194304 - (seed % 3) * 40000)
+
+
+def window_edge_cases():
+    return [window_edge_case(s) for s in WINDOW_EDGE_SEEDS]

@@ -167,3 +167,13 @@ def test_differential_fuzz_vs_libzstd(emu, oracle):
     for i, c in enumerate(cases):
         assert d["status"][i] == 0 and outs[i] == oracle.zstd_compress_chunk(c.tobytes()), "case %d (n=%d): frame differs from libzstd" % (i, c.size)
         assert d2["status"][i] == 0 and back[i] == c.tobytes(), "case %d (n=%d): round trip" % (i, c.size)
+
+
+@pytest.mark.timeout(600)
+def test_window_edge_chunk(emu, oracle):
+    """One full 4 MiB chunk whose output depends on how the 2 MiB window slides (tests/fuzz_cases.py); the other five run on the GPU."""
+    _need157(oracle)
+    from tests.fuzz_cases import window_edge_case
+    c = window_edge_case(1071)
+    outs, d = pc.run_transform(emu, nat.COMPRESS, [c])
+    assert d["status"][0] == 0 and outs[0] == oracle.zstd_compress_chunk(c.tobytes())

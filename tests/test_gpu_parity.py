@@ -241,6 +241,9 @@ def test_zstd_differential_fuzz_vs_libzstd(gpu, oracle):
     assert len(cases) >= 5
     rng = np.random.default_rng(4242)
     cases += [gen_case(rng) for _ in range(600)]
+    # full-size chunks: the window-edge pins and a sample whose copies reach beyond the 2 MiB window
+    from tests.fuzz_cases import window_edge_cases
+    cases += window_edge_cases() + [gen_case(rng, 4194304 - int(rng.integers(0, 3)) * int(rng.integers(0, 70000))) for _ in range(58)]
     for lo in range(0, len(cases), 128):
         part = cases[lo:lo + 128]
         outs, d = pc.run_transform(gpu, nat.COMPRESS, part)

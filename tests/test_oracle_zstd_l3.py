@@ -60,3 +60,16 @@ def test_full_chunk_and_profiles(oracle):
     f0, f1 = oracle.zstd_l3_compress(mix, 0), oracle.zstd_l3_compress(mix, 1)
     assert oracle.zstd_decompress_chunk(f0) == mix and oracle.zstd_decompress_chunk(f1) == mix
     assert f1 == oracle.zstd_compress_chunk(mix)
+
+
+def test_window_sliding_and_structured_random_chunks(oracle):
+    """Full-size chunks where the 2 MiB window slides: since 1.5.0 libzstd slides it to the block's START, bounds match candidates
+    from the block's END and accepts a candidate AT that bound - each pinned by tests/fuzz_cases.py's window-edge chunks - plus a
+    sample of structured random inputs of all sizes (tools/fuzz_oracle.py runs the same comparison for as long as one likes)."""
+    _lib157(oracle)
+    from tests.fuzz_cases import gen_case, window_edge_cases
+    rng = np.random.default_rng(31337)
+    cases = window_edge_cases() + [gen_case(rng, int(rng.integers(2 << 20, (4 << 20) + 1))) for _ in range(24)] + [gen_case(rng) for _ in range(150)]
+    for i, c in enumerate(cases):
+        b = c.tobytes()
+        assert oracle.zstd_l3_compress(b, 1) == oracle.zstd_compress_chunk(b), "case %d (n=%d)" % (i, c.size)

@@ -311,9 +311,12 @@ __device__ static inline void store_seq(zs_seq* __restrict__ seqs, MfState& s, u
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ src, const uint32_t srcSize, const uint32_t blockStart,
                                                    const uint32_t blockSize, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
-                                                   const zs_cparams cp, const uint32_t plowIdxIn, uint32_t* rep, zs_seq* __restrict__ seqs,
+                                                   const zs_cparams cp, const uint32_t dictLimitIn, uint32_t* rep, zs_seq* __restrict__ seqs,
                                                    MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane) {
-    const uint32_t iend = UNI(blockStart + blockSize), plowIdx = UNI(plowIdxIn);
+    // ZSTD_getLowestPrefixIndex(ms, endIndex, windowLog): the window was slid to the block's START (dictLimit), match candidates
+    // are bounded from the block's END; a candidate AT the bound is valid (>=) - both pinned by tests/golden/fuzz_regress/window_*.bin
+    const uint32_t iend = UNI(blockStart + blockSize), dictLimit = UNI(dictLimitIn), maxDist = 1u << UNI(cp.windowLog);
+    const uint32_t plowIdx = (iend + 2 - dictLimit > maxDist) ? iend + 2 - maxDist : dictLimit;
     const uint32_t hBitsL = UNI(cp.hashLog), hBitsS = UNI(cp.chainLog), mls = UNI(cp.minMatch);
     const uint32_t srcCeil = (srcSize + ZS_FILL - 1) & ~(ZS_FILL - 1), lastPiece = (srcSize - 1) & ~15u;
     const uint32_t idxBits = 32u - (uint32_t)__clz((int)(srcSize + 2)), tagBits = 32u - idxBits, idxMask = (uint32_t)((1ull << idxBits) - 1);
@@ -321,7 +324,7 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
     uint32_t off1 = UNI(rep[0]), off2 = UNI(rep[1]), sav1 = 0, sav2 = 0;
     ms.nbSeq = 0; ms.litSize = 0;
     if (ip + 2 == plowIdx) ip++;
-    {   const uint32_t maxRep = ip + 2 - plowIdx;
+    {   const uint32_t cur = ip + 2, windowLow = (cur - dictLimit > maxDist) ? cur - maxDist : dictLimit, maxRep = cur - windowLow;
         if (off2 > maxRep) { sav2 = off2; off2 = 0; }
         if (off1 > maxRep) { sav1 = off1; off1 = 0; }
     }
@@ -441,8 +444,8 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
                 LT(3);                                                // 3: collision scoreboard
                 // candidates: from the ring when recent enough, else one global load each - all issued before any is used
                 const uint32_t iL = cL & idxMask, iS = cS & idxMask;
-                const bool vL = probeL && iL > plowIdx && ((cL ^ eL) & ~idxMask) == 0;       // in the window and same tag
-                const bool vS = probeS && iS > plowIdx && ((cS ^ eS) & ~idxMask) == 0;
+                const bool vL = probeL && iL >= plowIdx && ((cL ^ eL) & ~idxMask) == 0;       // in the window and same tag
+                const bool vS = probeS && iS >= plowIdx && ((cS ^ eS) & ~idxMask) == 0;
                 const uint32_t pL = vL ? iL - 2 : w.lo, pS = vS ? iS - 2 : w.lo;
                 const bool nL = pL >= w.lo && pL + 8 <= w.hi, nS = pS >= w.lo && pS + 4 <= w.hi;
                 // far candidates: 48 bytes around each in one go (verification + both extensions); the rare ones too close to the
@@ -1494,8 +1497,8 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
             blockSize = UNI(split_block_1_5_7(src + ipos, L, lane));
         PT(1);
         const uint32_t lastBlock = blockSize == remaining;
-        {   // ZSTD_window_enforceMaxDist
-            const uint32_t blockEndIdx = ipos + blockSize + 2, maxDist = 1u << cp.windowLog;
+        {   // ZSTD_window_enforceMaxDist(&ms->window, ip, maxDist, ...): libzstd >= 1.5.0 slides the window to the block's start
+            const uint32_t blockEndIdx = ipos + 2, maxDist = 1u << cp.windowLog;
             if (blockEndIdx > maxDist && dictLimit < blockEndIdx - maxDist) dictLimit = blockEndIdx - maxDist;
         }
         uint32_t cSize = 0;                                             // 0 -> raw block
