@@ -124,6 +124,8 @@ inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) {
     return hipemu_xchg(v, __builtin_ctzll(live));
 }
 inline unsigned __builtin_amdgcn_readlane(unsigned v, int lane) { return hipemu_xchg(v, lane); }
+// v_writelane_b32: the (wave-uniform) value lands in ONE lane of the destination register; no rendezvous needed
+inline unsigned __builtin_amdgcn_writelane(unsigned v, unsigned lane, unsigned old) { return hipemu::lane_id() == (lane & 63) ? v : old; }
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
     unsigned l = hipemu::lane_id();
     unsigned m = l >= 32 ? mask : (mask & ((1u << l) - 1));

@@ -37,16 +37,23 @@ __device__ static const short dMLnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1
 __device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
 __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
-#define ZS_DWIN 2048u
+#define ZS_DWIN 4096u
 #define ZS_HWIN 1024u
-static_assert(4 * (ZS_HWIN + 16) >= ZS_DWIN + 16, "the sequence window shares the Huffman windows' LDS");
+static_assert(4 * (ZS_HWIN + 16) >= ZS_DWIN + 32, "the sequence window shares the Huffman windows' LDS");
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 // sequence decoding entry: everything one state transition needs in one 8-byte LDS read (next-state base + bits, and the
 // symbol's own base value + number of extra bits, looked up once when the table is built instead of once per sequence)
 #define DUNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
+// v_writelane_b32: a wave-uniform value lands in lane `lane` of a per-lane register (this clang has the intrinsic, not the builtin)
+#ifdef HIPEMU
+#define tsx_writelane(v, lane, old) __builtin_amdgcn_writelane((uint32_t)(v), (uint32_t)(lane), (uint32_t)(old))
+#else
+extern "C" __device__ uint32_t tsx_writelane(uint32_t v, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
+#endif
 __device__ static inline uint64_t duni64(uint64_t v) { return ((uint64_t)DUNI(v >> 32) << 32) | DUNI(v); }
 struct alignas(8) SeqD { uint16_t base; uint8_t nb; uint8_t ebits; uint32_t bval; };
 __device__ static inline uint64_t seqd_raw(const SeqD* p) { uint64_t raw; __builtin_memcpy(&raw, p, 8); return raw; }   // base | nb << 16 | ebits << 24 | bval << 32
+__device__ static inline uint32_t seqd_lo(const SeqD* p) { uint32_t raw; __builtin_memcpy(&raw, p, 4); return raw; }            // base | nb << 16 | ebits << 24
 __device__ static inline SeqD seqd_load(const SeqD* p) {               // one ds_read_b64
     uint64_t raw; __builtin_memcpy(&raw, p, 8);
     SeqD e; e.base = (uint16_t)raw; e.nb = (uint8_t)(raw >> 16); e.ebits = (uint8_t)(raw >> 24); e.bval = (uint32_t)(raw >> 32);
@@ -66,7 +73,6 @@ struct DecLds {
     uint16_t symNext[64];
     uint32_t scal[16];
     uint32_t streamOff[5];
-    uint32_t rep[3];             // repeat-offset history, carried across the blocks of the frame (lane 0)
     alignas(16) uint8_t win[4 * (ZS_HWIN + 16)];   // literal stage: one window per Huffman stream; sequence stage: one window (ZS_DWIN)
 };
 
@@ -335,13 +341,13 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
     const uint32_t srcSize = from_mid ? d.src_len - 28 : d.src_len;
     uint8_t* __restrict__ out = dst_base + d.dst_off;
     uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
-    zs_seq* const seqs = (zs_seq*)(ws + ZS_WS_HASHLONG);           // the decoder needs no hash tables: 768 KiB = 49152 sequences
     uint8_t* const lit = ws + ZS_WS_LIT;
     int32_t err = TSX_OK;
 #ifdef TSX_PROF2
     unsigned long long dlt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast_ = (unsigned long long)clock64();
 #endif
     uint32_t opos = 0;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                           // repeat-offset history, carried across the blocks of the frame (wave-uniform)
     uint64_t contentSize = 0;
     uint32_t p = 0;
     bool hasChecksum = false;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
         p += fl;
     }
     if (contentSize > d.dst_cap) FAIL(TSX_E_DST_TOO_SMALL);
-    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; L.rep[0] = 1; L.rep[1] = 4; L.rep[2] = 8; }
+    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; }
     if (lane < 36) { L.cLLbase[lane] = dLLbase[lane]; L.cLLbits[lane] = dLLbits[lane]; }
     if (lane < 53) { L.cMLbase[lane] = dMLbase[lane]; L.cMLbits[lane] = dMLbits[lane]; }
     __syncthreads();
@@ -505,9 +511,10 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
             else if (nbSeq < 128) q += 1;
             else if (nbSeq < 255) { if (q + 2 > bsize) FAIL(DERR_FRAME); nbSeq = ((nbSeq - 128) << 8) + blk[q + 1]; q += 2; }
             else { if (q + 3 > bsize) FAIL(DERR_FRAME); nbSeq = blk[q + 1] + ((uint32_t)blk[q + 2] << 8) + 0x7F00; q += 3; }
-            if (nbSeq > ZS_WS_HASH_BYTES / sizeof(zs_seq)) FAIL(DERR_FRAME);     // 128 KiB / minMatch 3 = 43691 at most in a valid block
+            nbSeq = DUNI(nbSeq);                                        // loaded through the vector path: pin it (and every loop bound derived from it) to SGPRs
+            if (nbSeq > ZS_BLOCK_MAX / 3 + 1) FAIL(DERR_FRAME);            // 128 KiB / minMatch 3 = 43691 at most in a valid block
             if (nbSeq) {
-                if (lane == 0) {                                        // tables + the serial FSE chain -> seqs[]
+                if (lane == 0) {                                        // the three sequence tables
                     uint32_t e = 0, t = q;
                     do {
                         if (t >= bsize) { e = 1; break; }
@@ -548,31 +555,37 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                 __syncthreads();
                 if (L.scal[1]) FAIL(DERR_FRAME);
                 DLT(1);                                                 // 1: sequence tables
-                // The sequence bit stream is one serial chain, read backwards with up to four reloads per sequence.  From global
-                // memory every reload is a dependent round trip, so the wave stages the stream through an LDS window (all lanes
-                // copy, then decode until the reader gets close to the window's lower edge, repeat).  The chain itself is computed
-                // by EVERY lane on wave-uniform values (LDS reads broadcast, results pinned to SGPRs): scalar ALU and scalar
-                // branches instead of one active lane dragging exec masks through ~20 branches per sequence.
-                {
-                    const uint32_t t = DUNI(L.scal[2]), n = DUNI(bsize - t);
-                    const uint8_t* const stream = blk + t;
-                    const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog), nseq = DUNI(nbSeq);
-                    uint64_t c = 0; uint32_t consumed = 0;
-                    uint32_t pos = n >= 8 ? n - 8 : 0;                      // byte offset of the reader's 8-byte word in the stream
-                    uint32_t i = 0, sl = 0, so = 0, sm = 0;
-                    uint32_t rep0 = DUNI(L.rep[0]), rep1 = DUNI(L.rep[1]), rep2 = DUNI(L.rep[2]);
-                    uint32_t e = 0;
-                    bool started = false;
-                    const uint8_t* const win = L.win;
-#define SQ_READ(nb_) ((nb_) ? (uint32_t)((c << (consumed & 63)) >> (64 - (nb_))) : 0u)
-#define SQ_RELOAD() do {                                                                                                  \
-        if (consumed > 64) { e = 1; }                                                                                      \
-        else if (pos >= 8) { pos -= consumed >> 3; consumed &= 7; c = duni64(wld64(win, wbase, pos)); }                      \
-        else if (pos != 0) { uint32_t nbB = consumed >> 3; if (nbB > pos) nbB = pos; pos -= nbB; consumed -= nbB * 8; c = duni64(wld64(win, wbase, pos)); } \
-    } while (0)
-                    for (;;) {
-                        const uint32_t top = pos + 8 < n ? pos + 8 : n;
-                        const uint32_t wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
+            } else if (q != bsize) FAIL(DERR_FRAME);
+            // ---- decode and execute the sequences, 64 at a time (one per lane) ----
+            // The sequence bit stream is one serial chain (read backwards; each FSE state transition says how many bits the
+            // next one reads), staged through an LDS window that the whole wave refills.  Only the part of a sequence that IS
+            // serial runs serially: pass 1 walks the three state machines for up to 64 sequences as wave-uniform scalar code
+            // (three 4-byte table reads and one bit-window read per sequence) and drops each sequence's states and bit cursor
+            // into its own lane (v_writelane); pass 2 lets every lane pull its sequence's extra bits out of the window and form
+            // (literal length, match length, offset code) - all 64 at once; pass 3 resolves the repeat offsets in order (a short
+            // uniform loop over lane values), which makes the execution below order-free.
+            {
+                const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog);
+                const uint8_t* const win = L.win;
+                const uint8_t* stream = blk; uint32_t n = 0;
+                uint32_t B = 0, wbase = 0, sl = 0, so = 0, sm = 0, e = 0;       // B: bits of the stream not read yet (the cursor, from the top)
+                bool filled = false;
+                if (nbSeq) {
+                    const uint32_t t = DUNI(L.scal[2]);
+                    n = DUNI(bsize - t); stream = blk + t;                  // n >= 1 (checked with the tables)
+                    const uint32_t lastByte = DUNI(stream[n - 1]);          // BIT_initDStream: the last byte carries the end mark
+                    if (lastByte == 0) FAIL(DERR_FRAME);
+                    B = 8 * (n - 1) + dhb32(lastByte);
+                }
+                uint32_t lp = 0;
+                for (uint32_t g = 0; g < nbSeq; g += LANES) {
+                    const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
+                    // 64 sequences read at most 64 * 89 bits = 712 bytes below the cursor; every read is an 8-byte load at
+                    // byte (bit >> 3), so the window holds [wbase, (B >> 3) + 8) with the bytes past the stream's end as zeros
+                    if (!filled || (wbase != 0 && (B >> 3) < wbase + 720)) {
+                        __syncthreads();                                    // everyone is done with the previous window
+                        const uint32_t top = (B >> 3) + 8;
+                        wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
                         for (uint32_t k = lane * 16; wbase + k < top; k += LANES * 16) {
                             uint4 v;
                             if (wbase + k + 16 <= n) __builtin_memcpy(&v, stream + wbase + k, 16);
@@ -581,86 +594,84 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         }
                         __threadfence_block();
                         __syncthreads();
-                        if (!started) {                                     // BIT_initDStream: the last byte carries the end mark
-                            started = true;
-                            if (n == 0) e = 1;
-                            else {
-                                const uint32_t last = DUNI(win[n - 1 - wbase]);
-                                if (last == 0) e = 1;
-                                else if (n >= 8) { c = duni64(wld64(win, wbase, pos)); consumed = 8 - dhb32(last); }
-                                else {
-                                    uint64_t cc = 0;
-                                    for (uint32_t k = 0; k < n; k++) cc |= (uint64_t)DUNI(win[k]) << (8 * k);
-                                    c = cc; consumed = 8 - dhb32(last) + (8 - n) * 8;
-                                }
-                            }
-                            if (!e) {
-                                sl = SQ_READ(llLog); consumed += llLog; so = SQ_READ(ofLog); consumed += ofLog; sm = SQ_READ(mlLog); consumed += mlLog;
-                                SQ_RELOAD();
-                            }
+                        if (!filled) {                                      // initial states: LL, OF, ML (ZSTD_initFseState order)
+                            filled = true;
+                            const uint32_t lo = B - (llLog + ofLog + mlLog);              // <= 26 bits
+                            if ((int32_t)lo < 0) FAIL(DERR_FRAME);
+                            const uint32_t w = DUNI((uint32_t)(wld64(win, wbase, lo >> 3) >> (lo & 7)));
+                            sm = w & ((1u << mlLog) - 1); so = (w >> mlLog) & ((1u << ofLog) - 1); sl = (w >> (mlLog + ofLog)) & ((1u << llLog) - 1);
+                            B = lo;
                         }
-                        // One reload at the head of a sequence leaves >= 57 bits in the container (a sequence needs ~40 on
-                        // average, 89 at most), so the other reads reload only on demand: refilling is transparent to the bits
-                        // read, it only has to happen before the container runs dry.  One sequence moves the reader <= 12 bytes.
-#define SQ_NEED(nb_) do { if (consumed + (nb_) > 64) { SQ_RELOAD(); if (consumed + (nb_) > 64) e = 1; } } while (0)
-                        while (!e && i < nseq && (wbase == 0 || pos >= wbase + 24)) {
-                            SQ_RELOAD();
-                            const uint64_t rl = duni64(seqd_raw(&L.ll[sl])), ro = duni64(seqd_raw(&L.of[so])), rm = duni64(seqd_raw(&L.ml[sm]));
-                            const uint32_t oc = (uint32_t)(ro >> 24) & 0xFF, mbits = (uint32_t)(rm >> 24) & 0xFF, lbits = (uint32_t)(rl >> 24) & 0xFF;
-                            uint32_t offBase = (uint32_t)(ro >> 32);
-                            if (oc > 24) {                                  // up to 31 extra bits: read in two parts
-                                const uint32_t hi = oc - 24;
-                                SQ_NEED(hi); offBase += SQ_READ(hi) << 24; consumed += hi;
-                                SQ_NEED(24u); offBase += SQ_READ(24u); consumed += 24;
-                            } else { SQ_NEED(oc); offBase += SQ_READ(oc); consumed += oc; }
-                            SQ_NEED(mbits); const uint32_t ml = (uint32_t)(rm >> 32) + SQ_READ(mbits); consumed += mbits;
-                            SQ_NEED(lbits); const uint32_t ll = (uint32_t)(rl >> 32) + SQ_READ(lbits); consumed += lbits;
-                            uint32_t off;                                   // resolve the repeat codes here: the execution is order-free then
-                            if (offBase > 3) { off = offBase - 3; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                            else {
-                                const uint32_t idx = offBase - 1 + (ll == 0);
-                                if (idx == 0) off = rep0;
-                                else if (idx == 1) { off = rep1; rep1 = rep0; rep0 = off; }
-                                else if (idx == 2) { off = rep2; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                                else { off = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                            }
-                            if (lane == 0) { zs_seq sq; sq.offBase = off; sq.litLength = ll; sq.mlBase = ml; sq.litPos = 0; seqs[i] = sq; }
-                            if (i + 1 < nseq) {
-                                const uint32_t nbl = (uint32_t)(rl >> 16) & 0xFF, nbm = (uint32_t)(rm >> 16) & 0xFF, nbo = (uint32_t)(ro >> 16) & 0xFF;
-                                SQ_NEED(nbl + nbm + nbo);                   // <= 26 bits
-                                sl = ((uint32_t)rl & 0xFFFF) + SQ_READ(nbl); consumed += nbl;
-                                sm = ((uint32_t)rm & 0xFFFF) + SQ_READ(nbm); consumed += nbm;
-                                so = ((uint32_t)ro & 0xFFFF) + SQ_READ(nbo); consumed += nbo;
-                            }
-                            i++;
-                        }
-                        if (!e && i >= nseq) SQ_RELOAD();                   // normalise for the end-of-stream check
-#undef SQ_NEED
-                        __syncthreads();                                    // everyone is done with this window
-                        if (e || i >= nseq) break;
                     }
-#undef SQ_READ
-#undef SQ_RELOAD
-                    if (!e && !(pos == 0 && consumed == 64)) e = 1;        // BIT_endOfDStream
-                    if (lane == 0) { L.rep[0] = rep0; L.rep[1] = rep1; L.rep[2] = rep2; L.scal[1] = e; }
-                    __threadfence_block();
-                    __syncthreads();
-                }
-                if (L.scal[1]) FAIL(DERR_FRAME);
-            } else if (q != bsize) FAIL(DERR_FRAME);
-            DLT(2);                                                     // 2: FSE sequence decode
-            // ---- execute the sequences, 64 at a time (one per lane) ----
-            // Positions come from prefix sums, so literal runs and every match whose source lies before the group's first
-            // output byte are copied by their own lane, all at once; only matches that read bytes produced inside the same
-            // group (short offsets) are replayed in order with wave-wide copies.
-            {
-                uint32_t lp = 0;
-                for (uint32_t g = 0; g < nbSeq; g += LANES) {
-                    const uint32_t u = g + lane;
-                    const bool valid = u < nbSeq;
-                    zs_seq sq; sq.offBase = 1; sq.litLength = 0; sq.mlBase = 0; sq.litPos = 0;
-                    if (valid) sq = seqs[u];
-                    const uint32_t ll = sq.litLength, ml = sq.mlBase, off = sq.offBase;
+                    // pass 1: the chain.  Entry low dword = next-state base | nbBits << 16 | extra bits << 24.  The last sequence
+                    // of a block reads no state-update bits, so it is peeled off the loop; an over-read shows as a negative
+                    // cursor (collected in `bad`, checked once per group) and is clamped so that no load leaves the window.
+                    uint32_t recS = 0, recB = B, bad = 0;
+                    const uint32_t upd = g + cnt < nbSeq ? cnt : cnt - 1;
+                    for (uint32_t j = 0; j < upd; j++) {
+                        const uint32_t el = DUNI(seqd_lo(&L.ll[sl])), eo = DUNI(seqd_lo(&L.of[so])), em = DUNI(seqd_lo(&L.ml[sm]));
+                        recS = tsx_writelane(sl | (so << 9) | (sm << 17), j, recS);
+                        recB = tsx_writelane(B, j, recB);
+                        const uint32_t nbl = (el >> 16) & 0xFF, nbm = (em >> 16) & 0xFF, nbo = (eo >> 16) & 0xFF;
+                        // extra bits of the offset, match length, literal length, then the state updates: LL, ML, OF (ZSTD_decodeSequence order)
+                        const int32_t raw = (int32_t)(B - ((el >> 24) + (eo >> 24) + (em >> 24)) - (nbl + nbm + nbo));
+                        bad |= (uint32_t)raw;
+                        const uint32_t lo = (uint32_t)(raw < 0 ? 0 : raw);
+                        const uint32_t w = DUNI((uint32_t)(wld64(win, wbase, lo >> 3) >> (lo & 7)));
+                        so = (eo & 0xFFFF) + (w & ((1u << nbo) - 1));
+                        sm = (em & 0xFFFF) + ((w >> nbo) & ((1u << nbm) - 1));
+                        sl = (el & 0xFFFF) + ((w >> (nbo + nbm)) & ((1u << nbl) - 1));
+                        B = lo;
+                    }
+                    if (upd < cnt) {
+                        const uint32_t el = DUNI(seqd_lo(&L.ll[sl])), eo = DUNI(seqd_lo(&L.of[so])), em = DUNI(seqd_lo(&L.ml[sm]));
+                        recS = tsx_writelane(sl | (so << 9) | (sm << 17), upd, recS);
+                        recB = tsx_writelane(B, upd, recB);
+                        const int32_t raw = (int32_t)(B - ((el >> 24) + (eo >> 24) + (em >> 24)));
+                        bad |= (uint32_t)raw;
+                        B = (uint32_t)(raw < 0 ? 0 : raw);
+                    }
+                    e = bad >> 31;
+                    if (e) FAIL(DERR_FRAME);                                // the stream is shorter than its sequences need
+                    // pass 2: every lane decodes the fields of its own sequence from the window
+                    const bool valid = lane < cnt;
+                    uint32_t ll = 0, ml = 0, offBase = 4;
+                    if (valid) {
+                        const uint64_t rl = seqd_raw(&L.ll[recS & 511]), ro = seqd_raw(&L.of[(recS >> 9) & 255]), rm = seqd_raw(&L.ml[recS >> 17]);
+                        const uint32_t oc = (uint32_t)(ro >> 24) & 0xFF, mbits = (uint32_t)(rm >> 24) & 0xFF, lbits = (uint32_t)(rl >> 24) & 0xFF;
+                        const uint32_t lo1 = recB - oc;                                 // offset bits first (<= 31), then ML, then LL (<= 16 each)
+                        offBase = (uint32_t)(ro >> 32) + ((uint32_t)(wld64(win, wbase, lo1 >> 3) >> (lo1 & 7)) & ((1u << oc) - 1));
+                        const uint32_t lo2 = lo1 - mbits - lbits;
+                        const uint32_t w2 = (uint32_t)(wld64(win, wbase, lo2 >> 3) >> (lo2 & 7));
+                        ll = (uint32_t)(rl >> 32) + (w2 & ((1u << lbits) - 1));
+                        ml = (uint32_t)(rm >> 32) + ((w2 >> lbits) & ((1u << mbits) - 1));
+                    }
+                    // pass 3: repeat offsets, in order - branch-free selects on wave-uniform values.  Offset codes 1..3 name
+                    // the history entry idx = code - 1 (+ 1 when the literal length is 0; idx 3 = rep0 - 1); a new offset or idx >= 2
+                    // pushes the whole history down, idx 1 swaps the first two, idx 0 leaves it alone.
+                    uint32_t off = 0;
+                    {
+                        const unsigned long long ll0 = __ballot(valid && ll == 0);
+                        const uint32_t ll0lo = DUNI((uint32_t)ll0), ll0hi = DUNI((uint32_t)(ll0 >> 32));
+                        uint32_t r0 = DUNI(rep0), r1 = DUNI(rep1), r2 = DUNI(rep2);
+                        for (uint32_t j = 0; j < cnt; j++) {
+                            const uint32_t ob = __builtin_amdgcn_readlane(offBase, (int)j);
+                            const uint32_t z = ((j < 32 ? ll0lo : ll0hi) >> (j & 31)) & 1;
+                            const uint32_t idx = ob > 3 ? 4u : ob - 1 + z;
+                            const uint32_t c01 = idx == 0 ? r0 : r1, c23 = idx == 2 ? r2 : r0 - 1;
+                            uint32_t o_ = idx < 2 ? c01 : c23;
+                            o_ = idx > 3 ? ob - 3 : o_;
+                            r2 = idx >= 2 ? r1 : r2;
+                            r1 = idx >= 1 ? r0 : r1;
+                            r0 = o_;
+                            off = tsx_writelane(o_, j, off);
+                        }
+                        rep0 = r0; rep1 = r1; rep2 = r2;
+                    }
+                    DLT(2);                                                 // 2: FSE sequence decode
+                    // Execution.  Positions come from prefix sums, so literal runs and every match whose source lies before the
+                    // group's first output byte are copied by their own lane, all at once; only matches that read bytes produced
+                    // inside the same group (short offsets) are replayed in order with wave-wide copies.
                     uint32_t litIncl = ll, totIncl = ll + ml;
                     for (int o = 1; o < LANES; o <<= 1) {
                         const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
@@ -691,14 +702,16 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         __threadfence_block();
                     }
                     lp += groupLit; opos += groupTot;
+                    DLT(3);                                                 // 3: execution
                 }
+                if (nbSeq && B != 0) FAIL(DERR_FRAME);                     // BIT_endOfDStream: every bit of the stream was used
+                __syncthreads();                                            // the window's LDS is the next block's Huffman windows
                 const uint32_t tail = litSize - lp;
                 if ((uint64_t)opos + tail > contentSize) FAIL(DERR_FRAME);
                 for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
                 opos += tail;
                 __threadfence_block();
             }
-            DLT(3);                                                     // 3: execution
             p += bsize;
         } else FAIL(DERR_FRAME);
         __syncthreads();
