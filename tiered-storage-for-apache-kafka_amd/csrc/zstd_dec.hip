@@ -323,6 +323,28 @@ __device__ static inline void copy_small(uint8_t* __restrict__ dst, const uint8_
     if (r & 1) dst[t + (r & 6)] = b1;
 }
 
+// Non-overlapping copy by the whole wave (every lane calls it with the same arguments).
+__device__ static inline void copy_wave(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, uint32_t lane) {
+    for (uint32_t k = lane * 8; k + 8 <= n; k += LANES * 8) { const uint64_t v = dld64(src + k); __builtin_memcpy(dst + k, &v, 8); }
+    const uint32_t t = n & ~7u;
+    if (lane < (n & 7)) dst[t + lane] = src[t + lane];
+}
+#define ZS_LONG_RUN 128u
+// One run per lane (mine = this lane has one): the short ones all at once, each by its own lane; the long ones one after the
+// other, each by the whole wave (a single lane would spend one memory round trip per 32 bytes on them).
+__device__ static inline void exec_copies(uint8_t* dst, const uint8_t* src, uint32_t n, bool mine, uint32_t lane) {
+    const bool big = mine && n > ZS_LONG_RUN;
+    if (mine && !big) copy_small(dst, src, n);
+    unsigned long long bigm = __ballot(big);
+    const uint64_t d64 = (uint64_t)dst, s64 = (uint64_t)src;
+    while (bigm) {
+        const int i = __ffsll((long long)bigm) - 1;
+        bigm &= bigm - 1;
+        const uint64_t d = __shfl(d64, i), s_ = __shfl(s64, i);
+        copy_wave((uint8_t*)d, (const uint8_t*)s_, (uint32_t)__shfl(n, i), lane);
+    }
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------
 #define FAIL(code) do { err = (code); goto done; } while (0)
 
@@ -454,12 +476,19 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                     uint32_t o = 0; for (uint32_t k = 0; k < lane && k < 4; k++) o += mine ? sCnt[k] : 0;
                     const uint32_t cnt = mine ? sCnt[lane] : 0, sn = mine ? sOff[lane + 1] - sOff[lane] : 0, sbeg = mine ? t + sOff[lane] : 0;
                     uint8_t* const outp = lit + o;
-                    BitW hb; hb.bad = false; hb.c = 0; hb.consumed = 0; hb.pos = sn >= 8 ? sn - 8 : 0;
-                    uint32_t hi = 0; bool started = false, hdone = !mine;
-                    if (mine && sn == 0) { ok = false; hdone = true; }
-                    const uint32_t tableLog = L.hufLog;
+                    // Bh = bits of the stream not read yet (cursor from the top; the last byte carries the end mark).  A step
+                    // decodes four symbols (<= 44 bits) from ONE 8-byte window read at the cursor, no branches inside; the last
+                    // symbols of a stream (fewer than four left, or fewer than 44 bits) go one at a time, with the bits below
+                    // the stream's first one read as zeros like libzstd's container does.
+                    uint32_t hi = 0, Bh = 0; bool hdone = !mine;
+                    if (mine) {
+                        const uint32_t lastByte = sn ? blk[sbeg + sn - 1] : 0;
+                        if (lastByte == 0) { ok = false; hdone = true; }
+                        else Bh = 8 * (sn - 1) + dhb32(lastByte);
+                    }
+                    const uint32_t tableLog = L.hufLog, tmask = (1u << tableLog) - 1;
                     for (;;) {
-                        const uint32_t myTop = hdone ? 0 : (hb.pos + 8 < sn ? hb.pos + 8 : sn);
+                        const uint32_t myTop = hdone ? 0 : (Bh >> 3) + 8;                                // bytes past the stream's end are zeros
                         const uint32_t myWb = myTop > ZS_HWIN ? (myTop - ZS_HWIN + 15) & ~15u : 0;     // top - wb <= ZS_HWIN = one 16-byte piece per lane
                         for (uint32_t s_ = 0; s_ < streams; s_++) {
                             const uint32_t top = __shfl(myTop, s_), wb = __shfl(myWb, s_), beg = __shfl(sbeg, s_), n_ = __shfl(sn, s_);
@@ -475,24 +504,30 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         __syncthreads();
                         if (!hdone) {
                             const uint8_t* const win = &L.win[lane * (ZS_HWIN + 16)];
-                            if (!started) { bw_init(hb, win, myWb, sn); started = true; if (hb.bad) { ok = false; hdone = true; } }
-                            while (!hdone && hi < cnt && (myWb == 0 || hb.pos >= myWb + 8)) {       // four symbols (<= 44 bits) per reload
-                                if (!bw_reload(hb, win, myWb)) { ok = false; hdone = true; break; }
-                                uint32_t packed = 0; const uint32_t m = cnt - hi < 4 ? cnt - hi : 4;
-                                for (uint32_t j = 0; j < m; j++) {
-                                    const uint16_t e = L.huf[(hb.c << (hb.consumed & 63)) >> (64 - tableLog)];
-                                    hb.consumed += e >> 8;
-                                    packed |= (uint32_t)(e & 0xFF) << (8 * j);
-                                }
-                                if (m == 4) __builtin_memcpy(outp + hi, &packed, 4);
-                                else for (uint32_t j = 0; j < m; j++) outp[hi + j] = (uint8_t)(packed >> (8 * j));
-                                hi += m;
+                            while (hi + 4 <= cnt && Bh >= 44 && ((Bh - 44) >> 3) >= myWb) {
+                                const uint32_t lo = Bh - 44;
+                                const uint64_t c = wld64(win, myWb, lo >> 3) >> (lo & 7);               // bits [lo, lo + 57) of the stream
+                                const uint32_t e0 = L.huf[(uint32_t)(c >> (44 - tableLog)) & tmask];
+                                uint32_t used = e0 >> 8;
+                                const uint32_t e1 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
+                                used += e1 >> 8;
+                                const uint32_t e2 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
+                                used += e2 >> 8;
+                                const uint32_t e3 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
+                                used += e3 >> 8;
+                                const uint32_t packed = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+                                __builtin_memcpy(outp + hi, &packed, 4);
+                                hi += 4; Bh -= used;
                             }
-                            if (!hdone && hi >= cnt) {
-                                if (hb.consumed > 64) ok = false;
-                                else { bw_reload(hb, win, myWb); if (!bw_finished(hb)) ok = false; }
-                                hdone = true;
+                            while (hi < cnt && (hi + 4 > cnt || Bh < 44)) {                              // the stream's tail
+                                const uint32_t need = Bh < tableLog ? Bh : tableLog, lo = Bh - need;
+                                if ((lo >> 3) < myWb) break;                                             // behind the window: refill first
+                                const uint32_t bits = (uint32_t)(wld64(win, myWb, lo >> 3) >> (lo & 7)) & ((1u << need) - 1);
+                                const uint32_t e = L.huf[(bits << (tableLog - need)) & tmask];
+                                if ((e >> 8) > Bh) { ok = false; hdone = true; break; }                   // reads past the stream's first bit
+                                outp[hi++] = (uint8_t)e; Bh -= e >> 8;
                             }
+                            if (!hdone && hi >= cnt) { if (Bh != 0) ok = false; hdone = true; }           // every bit used, none missing
                         }
                         __syncthreads();
                         if (__all(hdone)) break;
@@ -681,26 +716,46 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                     if (lp + groupLit > litSize || (uint64_t)opos + groupTot > contentSize) FAIL(DERR_FRAME);
                     const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
                     if (__any(valid && ml && (off == 0 || off > mOut))) FAIL(DERR_FRAME);
-                    copy_small(out + myOut, litPtr + myLit, ll);
-                    const bool early = valid && ml && mOut - off + ml <= opos;
-                    if (early) copy_small(out + mOut, out + mOut - off, ml);
-                    unsigned long long late = __ballot(valid && ml && !early);
-                    __threadfence_block();
-                    while (late) {
-                        const int i = __ffsll((long long)late) - 1;
-                        late &= late - 1;
-                        const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
-                        const uint32_t from = dpos - o_;
-                        if (o_ >= LANES || o_ >= m_) {
-                            for (uint32_t k = 0; k < m_; k += LANES) {
-                                if (k && o_ < m_) __threadfence_block();          // a 64-byte step may read bytes written by the previous step
-                                if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
+                    // Short runs are copied by their own lane (all lanes at once), long ones (> ZS_LONG_RUN bytes) by the whole wave.
+                    // A match is ready when its source bytes are final: before the group's first output byte, or - after the
+                    // fence that follows each round - inside literal runs and matches already copied.  Each round copies every
+                    // pending match whose source touches no earlier pending match's destination; a match that overlaps its own
+                    // destination (offset < length) is replayed by the whole wave, in 64-byte steps or as a periodic pattern.
+                    const uint32_t s0 = mOut - off;
+                    exec_copies(out + myOut, litPtr + myLit, ll, valid && ll, lane);
+                    unsigned long long pend = __ballot(valid && ml);
+                    bool first = true;
+                    do {
+                        const bool mineP = (pend >> lane) & 1;
+                        bool blocked = mineP && off < ml;
+                        if (first) blocked = mineP && s0 + ml > opos;                          // round 0: only sources before the group
+                        else
+                            for (unsigned long long m = pend; m; m &= m - 1) {
+                                const int j = __ffsll((long long)m) - 1;
+                                const uint32_t dj = __builtin_amdgcn_readlane(mOut, j), ej = dj + __builtin_amdgcn_readlane(ml, j);
+                                if ((uint32_t)j < lane && s0 < ej && s0 + ml > dj) blocked = true;
                             }
-                        } else {
-                            for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];   // periodic pattern
+                        const unsigned long long ready = __ballot(mineP && !blocked);
+                        if (ready || first) {
+                            exec_copies(out + mOut, out + s0, ml, (ready >> lane) & 1, lane);
+                            pend &= ~ready;
+                            first = false;
+                        } else {                                                                // the first pending match overlaps itself
+                            const int i = __ffsll((long long)pend) - 1;
+                            pend &= pend - 1;
+                            const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
+                            const uint32_t from = dpos - o_;
+                            if (o_ >= LANES) {
+                                for (uint32_t k = 0; k < m_; k += LANES) {
+                                    if (k) __threadfence_block();                               // a 64-byte step may read bytes written by the previous step
+                                    if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
+                                }
+                            } else {
+                                for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];   // periodic pattern
+                            }
                         }
                         __threadfence_block();
-                    }
+                    } while (pend);
                     lp += groupLit; opos += groupTot;
                     DLT(3);                                                 // 3: execution
                 }
