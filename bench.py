@@ -39,6 +39,7 @@ def parse():
                          "latency cover).  1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
     return ap.parse_args()
 
 
@@ -190,6 +191,36 @@ def main():
                 assert got == exp, "transformed bytes differ from the oracle for chunk %d (libzstd %s)" % (i, o.zstd_version())
             verified += 1
 
+    # ---- the inverse chain (fetchLogSegment side), outside the timed region: BASELINE configs[4] asks for the round trip --
+    # tsx_detransform_batch over the batch just produced (GCM tag check + decrypt, Zstd frame decode, CRC32C of the restored
+    # bytes), device resident like the forward step; restored bytes must equal the source segment byte for byte.
+    inverse = None
+    if workload != "crc" and not args.no_inverse:
+        back = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+        e = np.zeros(n, nat.DESC_DTYPE)
+        e["src_off"] = d["dst_off"]; e["src_len"] = d["dst_len"]; e["iv"] = d["iv"]
+        e["dst_off"] = np.arange(n, dtype=np.uint64) * CH; e["dst_cap"] = CH
+        N.detransform_batch(params, e, dst.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE, ctx=ctx)     # warm-up
+        fence()
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            N.detransform_batch(params, e, dst.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE, ctx=ctx)
+        fence()
+        inv_s = (time.perf_counter() - t1) / reps
+        if world > 1:
+            tt = torch.tensor([inv_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            inv_s = float(tt.item())
+        tm = N.ctx_timing(ctx)
+        exact = bool((e["status"] == 0).all() and (e["dst_len"] == CH).all() and (e["crc32c"] == d["crc32c"]).all() and torch.equal(back, src))
+        # reported, not asserted: a fetch-side failure must not take the forward measurement's line with it
+        inverse = {"metric": "GiB/s of restored bytes, tsx_detransform_batch (GCM verify+decrypt, Zstd decode, CRC32C), one batch at a time",
+                   "value": round(float(n) * CH * world / GiB / inv_s, 4), "unit": "GiB/s", "ms_per_batch": round(inv_s * 1e3, 3),
+                   "stage_ms": {"gcm": round(tm.gcm_ms, 3), "unzstd": round(tm.unzstd_ms, 3), "crc": round(tm.crc_ms, 3)},
+                   "round_trip_exact": exact}
+        del back
+
     # ---- roofline of the dominant kernel (HIP events on the library's own stream, per launch) ----------
     dom = max(stage, key=lambda k: stage[k])
     ms = stage[dom] / max(launches[dom], 1)
@@ -263,7 +294,7 @@ def main():
                        "parallelism": "segment-major shard, %d rank(s), no data-path collective" % world,
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
                        "verified_chunks_vs_oracle": verified},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "detransform": inverse,
         }
         print(json.dumps(line))
     for c in ctxs:

@@ -227,6 +227,75 @@ __device__ static inline void seq_fill(const DecLds& L, SeqD& e, uint32_t sym, i
     else if (kind == 1) { e.ebits = (uint8_t)sym; e.bval = 1u << sym; }
     else { e.ebits = L.cMLbits[sym]; e.bval = L.cMLbase[sym]; }
 }
+// The same table (FSE_buildDTable: spread the symbols with the odd stride `step`, number each symbol's cells in ascending
+// position) built by the whole wave instead of one lane walking 2 x 512 cells through dependent LDS accesses:
+//  * the spread visits the cells in the order (i * step) & mask, i = 0, 1, ..., skipping the cells above `high` that the
+//    low-probability symbols (count -1) own; so cell u is the r-th one filled, r = i(u) - #{low cells visited before},
+//    i(u) = u * step^-1 mod size, and its symbol is the one whose run of the cumulative counts holds r;
+//  * cells are numbered 64 at a time in ascending position: a cell's state number is its symbol's running count (kept in
+//    lane `symbol`) plus its rank among the same-symbol lanes of the round.
+// norm[] is in LDS (L.norm), maxSym < 64.  Returns false (wave-uniform) when the counts do not fill the table.
+__device__ static bool fse_buildSeqTable_wave(SeqD* dt, DecLds& L, uint32_t maxSym, uint32_t tableLog, int kind, uint32_t lane) {
+    const uint32_t size = 1u << tableLog, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint16_t* const cum = (uint16_t*)L.cellSym;                           // [64] exclusive prefix of the positive counts
+    uint16_t* const lowI = cum + 64;                                      // [<= 64] visit index of each low-probability cell
+    uint8_t* const lowSym = L.cellSym + 256;                              // [<= 64] symbol of the k-th low-probability cell
+    const int nv = lane <= maxSym ? (int)L.norm[lane] : 0;
+    const uint32_t c = nv > 0 ? (uint32_t)nv : 0;
+    const bool lowp = nv == -1;
+    uint32_t incl = c;
+    for (uint32_t o = 1; o < LANES; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const uint32_t total = __shfl(incl, LANES - 1);
+    const unsigned long long lowMask = __ballot(lowp);
+    const uint32_t nLow = (uint32_t)__popcll(lowMask);
+    if (total + nLow != size) return false;
+    uint32_t inv = step;                                                  // odd: step * step = 1 (mod 8); each Newton step doubles the bits
+    for (int it = 0; it < 3; it++) inv *= 2u - step * inv;
+    inv &= mask;
+    __syncthreads();                                                      // the scratch may still be read as the previous table's
+    cum[lane] = (uint16_t)(incl - c);
+    if (lowp) {
+        const uint32_t k = (uint32_t)__popcll(lowMask & ((1ull << lane) - 1));   // low cells go to the top, in symbol order
+        lowI[k] = (uint16_t)(((size - 1 - k) * inv) & mask); lowSym[k] = (uint8_t)lane;
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t next = lowp ? 1u : c;                                        // symNext of symbol `lane`
+    const uint32_t high = size - 1 - nLow;
+    for (uint32_t base = 0; base < size; base += LANES) {
+        const uint32_t u = base + lane;
+        const bool active = u < size;
+        uint32_t sym = 0;
+        if (active) {
+            if (u > high) sym = lowSym[size - 1 - u];
+            else {
+                const uint32_t i = (u * inv) & mask;
+                uint32_t r = i;
+                for (uint32_t k = 0; k < nLow; k++) r -= lowI[k] < i ? 1u : 0u;
+                for (uint32_t b = 32; b; b >>= 1) if (cum[sym + b] <= r) sym += b;     // the last symbol whose run starts at or before r
+            }
+        }
+        uint32_t ns = 1;
+        unsigned long long rem = __ballot(active);
+        while (rem) {
+            const uint32_t cur = __shfl(sym, __ffsll((long long)rem) - 1);
+            const unsigned long long m = __ballot(active && sym == cur);
+            const uint32_t first = __shfl(next, (int)cur);
+            if (active && sym == cur) ns = first + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (lane == cur) next += (uint32_t)__popcll(m);
+            rem &= ~m;
+        }
+        if (active) {
+            const uint32_t nb = tableLog - dhb32(ns);
+            SeqD e; e.nb = (uint8_t)nb; e.base = (uint16_t)((ns << nb) - size);
+            seq_fill(L, e, sym, kind);
+            dt[u] = e;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    return true;
+}
 __device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t n) {
     if (n < 1) return 0;
     const uint32_t hb = src[0];
@@ -549,46 +618,54 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
             nbSeq = DUNI(nbSeq);                                        // loaded through the vector path: pin it (and every loop bound derived from it) to SGPRs
             if (nbSeq > ZS_BLOCK_MAX / 3 + 1) FAIL(DERR_FRAME);            // 128 KiB / minMatch 3 = 43691 at most in a valid block
             if (nbSeq) {
-                if (lane == 0) {                                        // the three sequence tables
-                    uint32_t e = 0, t = q;
-                    do {
-                        if (t >= bsize) { e = 1; break; }
-                        const uint32_t modes = blk[t++];
-                        if (modes & 3) { e = 1; break; }
-                        const uint32_t m[3] = {(modes >> 6) & 3, (modes >> 4) & 3, (modes >> 2) & 3};
-                        for (int k = 0; k < 3 && !e; k++) {
-                            SeqD* dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
-                            uint32_t* logp = k == 0 ? &L.llLog : k == 1 ? &L.ofLog : &L.mlLog;
-                            int* validp = k == 0 ? &L.llValid : k == 1 ? &L.ofValid : &L.mlValid;
-                            const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
-                            if (m[k] == 0) {
-                                const short* dn = k == 0 ? dLLnorm : k == 1 ? dOFnorm : dMLnorm;
-                                const uint32_t dmax = k == 0 ? 35 : k == 1 ? 28 : 52, dlog = k == 1 ? 5 : 6;
-                                for (uint32_t s = 0; s <= dmax; s++) L.norm[s] = dn[s];
-                                fse_buildDTable(dt, L.cellSym, L.norm, dmax, dlog, L.symNext, [k](SeqD& e, uint32_t sym) { seq_fill(L, e, sym, k); });
-                                *logp = dlog; *validp = 1;
-                            } else if (m[k] == 1) {
-                                if (t >= bsize) { e = 1; break; }
-                                const uint32_t s = blk[t++];
-                                if (s > maxSymK) { e = 1; break; }
-                                dt[0].nb = 0; dt[0].base = 0; seq_fill(L, dt[0], s, k);
-                                *logp = 0; *validp = 1;
-                            } else if (m[k] == 2) {
-                                uint32_t ms = maxSymK, tl;
-                                const uint32_t used = fse_readNCount(L.norm, &ms, &tl, blk + t, bsize - t, maxLogK);
-                                if (!used || !fse_buildDTable(dt, L.cellSym, L.norm, ms, tl, L.symNext, [k](SeqD& e, uint32_t sym) { seq_fill(L, e, sym, k); })) { e = 1; break; }
-                                t += used; *logp = tl; *validp = 1;
-                            } else if (!*validp) { e = 1; break; }
+                // The three sequence tables (literal lengths, offsets, match lengths).  Lane 0 parses each table description
+                // (a short serial bit parse); the decoding table itself is built by the whole wave (fse_buildSeqTable_wave).
+                if (q >= bsize) FAIL(DERR_FRAME);
+                const uint32_t modes = DUNI(blk[q]);
+                uint32_t t = q + 1;
+                if (modes & 3) FAIL(DERR_FRAME);
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
+                    SeqD* const dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
+                    uint32_t* const logp = k == 0 ? &L.llLog : k == 1 ? &L.ofLog : &L.mlLog;
+                    int* const validp = k == 0 ? &L.llValid : k == 1 ? &L.ofValid : &L.mlValid;
+                    const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
+                    if (mode == 0) {                                    // predefined distribution
+                        const short* const dn = k == 0 ? dLLnorm : k == 1 ? dOFnorm : dMLnorm;
+                        const uint32_t dmax = k == 0 ? 35 : k == 1 ? 28 : 52, dlog = k == 1 ? 5 : 6;
+                        if (lane <= dmax) L.norm[lane] = dn[lane];
+                        if (lane == 0) { *logp = dlog; *validp = 1; }
+                        __threadfence_block();
+                        __syncthreads();
+                        if (!fse_buildSeqTable_wave(dt, L, dmax, dlog, k, lane)) FAIL(DERR_FRAME);
+                    } else if (mode == 1) {                             // RLE: one symbol, no state bits
+                        if (t >= bsize) FAIL(DERR_FRAME);
+                        const uint32_t sym = DUNI(blk[t]);
+                        t++;
+                        if (sym > maxSymK) FAIL(DERR_FRAME);
+                        if (lane == 0) { dt[0].nb = 0; dt[0].base = 0; seq_fill(L, dt[0], sym, k); *logp = 0; *validp = 1; }
+                    } else if (mode == 2) {                             // FSE-compressed distribution
+                        if (t >= bsize) FAIL(DERR_FRAME);
+                        if (lane == 0) {
+                            uint32_t ms = maxSymK, tl = 0;
+                            const uint32_t used = fse_readNCount(L.norm, &ms, &tl, blk + t, bsize - t, maxLogK);
+                            L.scal[0] = used; L.scal[3] = ms; L.scal[4] = tl;
+                            if (used) { *logp = tl; *validp = 1; }
                         }
-                        if (e) break;
-                        if (t >= bsize) { e = 1; break; }
-                        L.scal[2] = t;
-                    } while (0);
-                    L.scal[1] = e;
+                        __threadfence_block();
+                        __syncthreads();
+                        const uint32_t used = DUNI(L.scal[0]), ms = DUNI(L.scal[3]), tl = DUNI(L.scal[4]);
+                        if (!used || !fse_buildSeqTable_wave(dt, L, ms, tl, k, lane)) FAIL(DERR_FRAME);
+                        t += used;
+                    } else {                                            // repeat the previous block's table
+                        __syncthreads();
+                        if (!*validp) FAIL(DERR_FRAME);
+                    }
                 }
+                if (t >= bsize) FAIL(DERR_FRAME);
+                if (lane == 0) L.scal[2] = t;
                 __threadfence_block();
                 __syncthreads();
-                if (L.scal[1]) FAIL(DERR_FRAME);
                 DLT(1);                                                 // 1: sequence tables
             } else if (q != bsize) FAIL(DERR_FRAME);
             // ---- decode and execute the sequences, 64 at a time (one per lane) ----
