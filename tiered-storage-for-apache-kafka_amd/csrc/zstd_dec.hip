@@ -367,7 +367,7 @@ __device__ static bool huf_decodeStream(uint8_t* __restrict__ out, uint32_t coun
 
 // Per-lane copy of a short, non-overlapping run (a literal run, or a match whose source is already final): up to four
 // 8-byte loads are in flight before the first store, so a run of <= 32 bytes costs one memory round trip.
-__device__ static inline void copy_small(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
+__device__ static __forceinline__ void copy_small(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
     uint32_t k = 0;
     while (n - k >= 32) {
         const uint64_t a = dld64(src + k), b = dld64(src + k + 8), c = dld64(src + k + 16), d = dld64(src + k + 24);
@@ -393,7 +393,7 @@ __device__ static inline void copy_small(uint8_t* __restrict__ dst, const uint8_
 }
 
 // Non-overlapping copy by the whole wave (every lane calls it with the same arguments).
-__device__ static inline void copy_wave(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, uint32_t lane) {
+__device__ static __forceinline__ void copy_wave(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n, uint32_t lane) {
     for (uint32_t k = lane * 8; k + 8 <= n; k += LANES * 8) { const uint64_t v = dld64(src + k); __builtin_memcpy(dst + k, &v, 8); }
     const uint32_t t = n & ~7u;
     if (lane < (n & 7)) dst[t + lane] = src[t + lane];
@@ -401,7 +401,7 @@ __device__ static inline void copy_wave(uint8_t* __restrict__ dst, const uint8_t
 #define ZS_LONG_RUN 128u
 // One run per lane (mine = this lane has one): the short ones all at once, each by its own lane; the long ones one after the
 // other, each by the whole wave (a single lane would spend one memory round trip per 32 bytes on them).
-__device__ static inline void exec_copies(uint8_t* dst, const uint8_t* src, uint32_t n, bool mine, uint32_t lane) {
+__device__ static __forceinline__ void exec_copies(uint8_t* dst, const uint8_t* src, uint32_t n, bool mine, uint32_t lane) {
     const bool big = mine && n > ZS_LONG_RUN;
     if (mine && !big) copy_small(dst, src, n);
     unsigned long long bigm = __ballot(big);
@@ -758,25 +758,38 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         ll = (uint32_t)(rl >> 32) + (w2 & ((1u << lbits) - 1));
                         ml = (uint32_t)(rm >> 32) + ((w2 >> lbits) & ((1u << mbits) - 1));
                     }
-                    // pass 3: repeat offsets, in order - branch-free selects on wave-uniform values.  Offset codes 1..3 name
-                    // the history entry idx = code - 1 (+ 1 when the literal length is 0; idx 3 = rep0 - 1); a new offset or idx >= 2
-                    // pushes the whole history down, idx 1 swaps the first two, idx 0 leaves it alone.
-                    uint32_t off = 0;
+                    // pass 3: repeat offsets.  A sequence with a new offset (code > 3) knows it already and only pushes it onto the
+                    // history; the scalar loop visits just the sequences that USE the history (codes 1..3), in order, first
+                    // folding in the new offsets pushed since the previous visit (only the last three matter).  Code c names
+                    // history entry idx = c - 1 (+ 1 when the literal length is 0; idx 3 = rep0 - 1); idx >= 2 pushes the whole
+                    // history down, idx 1 swaps the first two, idx 0 leaves it alone.  All on wave-uniform values, no branches.
+                    uint32_t off = offBase - 3;
                     {
                         const unsigned long long ll0 = __ballot(valid && ll == 0);
-                        const uint32_t ll0lo = DUNI((uint32_t)ll0), ll0hi = DUNI((uint32_t)(ll0 >> 32));
+                        unsigned long long users = __ballot(valid && offBase <= 3);
                         uint32_t r0 = DUNI(rep0), r1 = DUNI(rep1), r2 = DUNI(rep2);
-                        for (uint32_t j = 0; j < cnt; j++) {
+                        uint32_t prev = 0;                                                  // first sequence not folded in yet
+                        for (;;) {
+                            const uint32_t j = users ? (uint32_t)__ffsll((long long)users) - 1 : cnt;      // next user, or the group's end
+                            const uint32_t gap = j - prev;                                  // new offsets pushed by sequences [prev, j)
+                            const uint32_t a1 = __builtin_amdgcn_readlane(offBase, (int)(j >= 1 ? j - 1 : 0)) - 3;
+                            const uint32_t a2 = __builtin_amdgcn_readlane(offBase, (int)(j >= 2 ? j - 2 : 0)) - 3;
+                            const uint32_t a3 = __builtin_amdgcn_readlane(offBase, (int)(j >= 3 ? j - 3 : 0)) - 3;
+                            const uint32_t n2 = gap >= 3 ? a3 : gap == 2 ? r0 : gap == 1 ? r1 : r2;
+                            const uint32_t n1 = gap >= 2 ? a2 : gap == 1 ? r0 : r1;
+                            const uint32_t n0 = gap >= 1 ? a1 : r0;
+                            r0 = n0; r1 = n1; r2 = n2;
+                            if (!users) break;
+                            users &= users - 1;
                             const uint32_t ob = __builtin_amdgcn_readlane(offBase, (int)j);
-                            const uint32_t z = ((j < 32 ? ll0lo : ll0hi) >> (j & 31)) & 1;
-                            const uint32_t idx = ob > 3 ? 4u : ob - 1 + z;
+                            const uint32_t idx = ob - 1 + (uint32_t)((ll0 >> j) & 1);       // 0..3
                             const uint32_t c01 = idx == 0 ? r0 : r1, c23 = idx == 2 ? r2 : r0 - 1;
-                            uint32_t o_ = idx < 2 ? c01 : c23;
-                            o_ = idx > 3 ? ob - 3 : o_;
+                            const uint32_t o_ = idx < 2 ? c01 : c23;
                             r2 = idx >= 2 ? r1 : r2;
                             r1 = idx >= 1 ? r0 : r1;
                             r0 = o_;
                             off = tsx_writelane(o_, j, off);
+                            prev = j + 1;
                         }
                         rep0 = r0; rep1 = r1; rep2 = r2;
                     }
