@@ -124,6 +124,17 @@ inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) {
     return hipemu_xchg(v, __builtin_ctzll(live));
 }
 inline unsigned __builtin_amdgcn_readlane(unsigned v, int lane) { return hipemu_xchg(v, lane); }
+// DPP row shifts (row = 16 lanes): row_shl:n (ctrl 0x100 + n) gives lane i the value of lane i + n, row_shr:n (0x110 + n) of
+// lane i - n; a source outside the row yields 0 with bound_ctrl, else `old`.  Other controls are not emulated.
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool bound_ctrl) {
+    int l = (int)hipemu::lane_id(), r = l & 15, s = r;
+    if (ctrl > 0x100 && ctrl <= 0x10F) s = r + (ctrl - 0x100);
+    else if (ctrl > 0x110 && ctrl <= 0x11F) s = r - (ctrl - 0x110);
+    else std::abort();
+    const bool in = s >= 0 && s < 16;
+    const int v = hipemu_xchg(src, in ? (l & ~15) + s : l);
+    return in ? v : (bound_ctrl ? 0 : old);
+}
 // v_writelane_b32: the (wave-uniform) value lands in ONE lane of the destination register; no rendezvous needed
 inline unsigned __builtin_amdgcn_writelane(unsigned v, unsigned lane, unsigned old) { return hipemu::lane_id() == (lane & 63) ? v : old; }
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {

@@ -41,8 +41,9 @@ __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builti
 #define ZS_HWIN 1024u
 static_assert(4 * (ZS_HWIN + 16) >= ZS_DWIN + 32, "the sequence window shares the Huffman windows' LDS");
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
-// sequence decoding entry: everything one state transition needs in one 8-byte LDS read (next-state base + bits, and the
-// symbol's own base value + number of extra bits, looked up once when the table is built instead of once per sequence)
+// sequence decoding entry, one dword: next-state base (bits 0-8) | nbBits (9-13) | nbBits + the symbol's number of extra
+// bits (14-20) | the symbol (21-26).  Bits 9-20 are laid out so that ONE add sums both counts over the three tables (no carry:
+// 3 x 9 < 32, 3 x 40 < 128).  The symbol's base value comes from a small per-code table when the lanes decode the fields.
 #define DUNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
 // v_writelane_b32: a wave-uniform value lands in lane `lane` of a per-lane register (this clang has the intrinsic, not the builtin)
 #ifdef HIPEMU
@@ -51,18 +52,27 @@ struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 extern "C" __device__ uint32_t tsx_writelane(uint32_t v, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
 #endif
 __device__ static inline uint64_t duni64(uint64_t v) { return ((uint64_t)DUNI(v >> 32) << 32) | DUNI(v); }
-struct alignas(8) SeqD { uint16_t base; uint8_t nb; uint8_t ebits; uint32_t bval; };
-__device__ static inline uint64_t seqd_raw(const SeqD* p) { uint64_t raw; __builtin_memcpy(&raw, p, 8); return raw; }   // base | nb << 16 | ebits << 24 | bval << 32
-__device__ static inline uint32_t seqd_lo(const SeqD* p) { uint32_t raw; __builtin_memcpy(&raw, p, 4); return raw; }            // base | nb << 16 | ebits << 24
-__device__ static inline SeqD seqd_load(const SeqD* p) {               // one ds_read_b64
-    uint64_t raw; __builtin_memcpy(&raw, p, 8);
-    SeqD e; e.base = (uint16_t)raw; e.nb = (uint8_t)(raw >> 16); e.ebits = (uint8_t)(raw >> 24); e.bval = (uint32_t)(raw >> 32);
-    return e;
-}
+typedef uint32_t SeqD;
+#define SEQD(base_, nb_, ebits_, sym_) ((uint32_t)(base_) | ((uint32_t)(nb_) << 9) | ((uint32_t)((nb_) + (ebits_)) << 14) | ((uint32_t)(sym_) << 21))
+#define SEQD_BASE(e_) ((e_) & 0x1FFu)
+#define SEQD_NB(e_) (((e_) >> 9) & 0x1Fu)
+#define SEQD_TOT(e_) (((e_) >> 14) & 0x7Fu)
+#define SEQD_EBITS(e_) (SEQD_TOT(e_) - SEQD_NB(e_))
+#define SEQD_SYM(e_) (((e_) >> 21) & 0x3Fu)
+#define SEQD_COUNTS(e_) (((e_) >> 9) & 0xFFFu)                        /* nbBits | (nbBits + extra bits) << 5 */
+#ifdef HIPEMU
+#define TSX_SCHED_BARRIER() do {} while (0)
+#else
+#define TSX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+// row_shl:n - lane i reads lane i + n of its row of 16, 0 past the row's end
+#define DPP_SHL(v_, n_) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v_), 0x100 + (n_), 0xF, 0xF, true))
 struct DecLds {
     uint16_t huf[2048];          // (nbBits << 8) | symbol; Max_Number_of_Bits of a literals tree is 11 (RFC 8878 4.2.1)
     uint32_t hufLog; int hufValid;
     SeqD ll[512], of[256], ml[512];
+    SeqD zeroEntry;              // the 'table' of the lanes that run no state machine
+    alignas(8) uint16_t rec[LANES * 4];   // pass 1 -> pass 2: the three states of each of the group's 64 sequences
     uint8_t cellSym[512];        // table construction scratch: symbol of each cell
     uint32_t cLLbase[36], cMLbase[53]; uint8_t cLLbits[36], cMLbits[53];   // LDS copies of the length code tables
     FseD wt[64];                 // FSE table of the Huffman-weight stream (tableLog <= 6)
@@ -221,12 +231,8 @@ __device__ static bool fse_buildDTable(E* dt, uint8_t* cellSym, const short* nor
     }
     return true;
 }
-// kind 0 = literal lengths, 1 = offsets, 2 = match lengths
-__device__ static inline void seq_fill(const DecLds& L, SeqD& e, uint32_t sym, int kind) {
-    if (kind == 0) { e.ebits = L.cLLbits[sym]; e.bval = L.cLLbase[sym]; }
-    else if (kind == 1) { e.ebits = (uint8_t)sym; e.bval = 1u << sym; }
-    else { e.ebits = L.cMLbits[sym]; e.bval = L.cMLbase[sym]; }
-}
+// kind 0 = literal lengths, 1 = offsets, 2 = match lengths: extra bits / base value of a code
+__device__ static inline uint32_t seq_ebits(const DecLds& L, uint32_t sym, int kind) { return kind == 0 ? L.cLLbits[sym] : kind == 1 ? sym : L.cMLbits[sym]; }
 // The same table (FSE_buildDTable: spread the symbols with the odd stride `step`, number each symbol's cells in ascending
 // position) built by the whole wave instead of one lane walking 2 x 512 cells through dependent LDS accesses:
 //  * the spread visits the cells in the order (i * step) & mask, i = 0, 1, ..., skipping the cells above `high` that the
@@ -287,9 +293,7 @@ __device__ static bool fse_buildSeqTable_wave(SeqD* dt, DecLds& L, uint32_t maxS
         }
         if (active) {
             const uint32_t nb = tableLog - dhb32(ns);
-            SeqD e; e.nb = (uint8_t)nb; e.base = (uint16_t)((ns << nb) - size);
-            seq_fill(L, e, sym, kind);
-            dt[u] = e;
+            dt[u] = SEQD((ns << nb) - size, nb, seq_ebits(L, sym, kind), sym);
         }
     }
     __threadfence_block();
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
         p += fl;
     }
     if (contentSize > d.dst_cap) FAIL(TSX_E_DST_TOO_SMALL);
-    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; }
+    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; L.zeroEntry = 0; }
     if (lane < 36) { L.cLLbase[lane] = dLLbase[lane]; L.cLLbits[lane] = dLLbits[lane]; }
     if (lane < 53) { L.cMLbase[lane] = dMLbase[lane]; L.cMLbits[lane] = dMLbits[lane]; }
     __syncthreads();
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                         const uint32_t sym = DUNI(blk[t]);
                         t++;
                         if (sym > maxSymK) FAIL(DERR_FRAME);
-                        if (lane == 0) { dt[0].nb = 0; dt[0].base = 0; seq_fill(L, dt[0], sym, k); *logp = 0; *validp = 1; }
+                        if (lane == 0) { dt[0] = SEQD(0, 0, seq_ebits(L, sym, k), sym); *logp = 0; *validp = 1; }
                     } else if (mode == 2) {                             // FSE-compressed distribution
                         if (t >= bsize) FAIL(DERR_FRAME);
                         if (lane == 0) {
@@ -680,7 +684,11 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                 const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog);
                 const uint8_t* const win = L.win;
                 const uint8_t* stream = blk; uint32_t n = 0;
-                uint32_t B = 0, wbase = 0, sl = 0, so = 0, sm = 0, e = 0;       // B: bits of the stream not read yet (the cursor, from the top)
+                uint32_t B = 0, wbase = 0, e = 0;                               // B: bits of the stream not read yet (the cursor, from the top)
+                // lanes 0, 1, 2 = the LL, ML, OF state machines; the others carry state 0 through an all-zero entry
+                const SeqD* const tbl = lane == 0 ? L.ll : lane == 1 ? L.ml : lane == 2 ? L.of : &L.zeroEntry;
+                uint16_t* const recp = &L.rec[lane < 3 ? lane : 3];
+                uint32_t st = 0;
                 bool filled = false;
                 if (nbSeq) {
                     const uint32_t t = DUNI(L.scal[2]);
@@ -694,7 +702,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                     const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
                     // 64 sequences read at most 64 * 89 bits = 712 bytes below the cursor; every read is an 8-byte load at
                     // byte (bit >> 3), so the window holds [wbase, (B >> 3) + 8) with the bytes past the stream's end as zeros
-                    if (!filled || (wbase != 0 && (B >> 3) < wbase + 720)) {
+                    if (!filled || (wbase != 0 && (B >> 3) < wbase + 736)) {
                         __syncthreads();                                    // everyone is done with the previous window
                         const uint32_t top = (B >> 3) + 8;
                         wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
@@ -711,52 +719,75 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
                             const uint32_t lo = B - (llLog + ofLog + mlLog);              // <= 26 bits
                             if ((int32_t)lo < 0) FAIL(DERR_FRAME);
                             const uint32_t w = DUNI((uint32_t)(wld64(win, wbase, lo >> 3) >> (lo & 7)));
-                            sm = w & ((1u << mlLog) - 1); so = (w >> mlLog) & ((1u << ofLog) - 1); sl = (w >> (mlLog + ofLog)) & ((1u << llLog) - 1);
+                            const uint32_t sm = w & ((1u << mlLog) - 1), so = (w >> mlLog) & ((1u << ofLog) - 1), sl = (w >> (mlLog + ofLog)) & ((1u << llLog) - 1);
+                            st = lane == 0 ? sl : lane == 1 ? sm : lane == 2 ? so : 0;
                             B = lo;
                         }
                     }
-                    // pass 1: the chain.  Entry low dword = next-state base | nbBits << 16 | extra bits << 24.  The last sequence
-                    // of a block reads no state-update bits, so it is peeled off the loop; an over-read shows as a negative
-                    // cursor (collected in `bad`, checked once per group) and is clamped so that no load leaves the window.
-                    uint32_t recS = 0, recB = B, bad = 0;
+                    // pass 1: the chain, on the vector unit.  Lanes 0, 1, 2 run the LL, ML and OF state machines (that is the order
+                    // in which a sequence's state-update bits sit in the stream, highest first); one table read serves all three,
+                    // two DPP adds give every machine the bits below its own field and lane 0 the sequence's bit total, and the
+                    // 8 bytes that hold the update bits are read together with the entries from the cursor alone ([B - 56.., B));
+                    // only a sequence that reads more than 56 bits needs a second, dependent read.  The scalar unit - ONE per CU,
+                    // shared by every wave - keeps just the cursor and the loop.  The states go to LDS (rec) for pass 2; an
+                    // over-read shows as a negative cursor (collected in `bad`, checked once per group) and is clamped so that no
+                    // load leaves the window.  The last sequence of a block reads no update bits: peeled off the loop.
+                    uint32_t bad = 0;
+                    const uint32_t Bgroup = B;
                     const uint32_t upd = g + cnt < nbSeq ? cnt : cnt - 1;
                     for (uint32_t j = 0; j < upd; j++) {
-                        const uint32_t el = DUNI(seqd_lo(&L.ll[sl])), eo = DUNI(seqd_lo(&L.of[so])), em = DUNI(seqd_lo(&L.ml[sm]));
-                        recS = tsx_writelane(sl | (so << 9) | (sm << 17), j, recS);
-                        recB = tsx_writelane(B, j, recB);
-                        const uint32_t nbl = (el >> 16) & 0xFF, nbm = (em >> 16) & 0xFF, nbo = (eo >> 16) & 0xFF;
+                        const uint32_t p8 = (B >> 3) > 7 ? (B >> 3) - 7 : 0;                            // >= wbase: the window's margin
+                        uint64_t c8 = wld64(win, wbase, p8);
+                        const uint32_t e_ = tbl[st];
+                        recp[j * 4] = (uint16_t)st;
+                        TSX_SCHED_BARRIER();                                                           // both reads are in flight before anything waits
+                        const uint32_t pc = SEQD_COUNTS(e_);
+                        const uint32_t qc = pc + DPP_SHL(pc, 1) + DPP_SHL(pc, 2);                       // own + the machines below
                         // extra bits of the offset, match length, literal length, then the state updates: LL, ML, OF (ZSTD_decodeSequence order)
-                        const int32_t raw = (int32_t)(B - ((el >> 24) + (eo >> 24) + (em >> 24)) - (nbl + nbm + nbo));
+                        const int32_t raw = (int32_t)(B - DUNI(qc >> 5));
                         bad |= (uint32_t)raw;
                         const uint32_t lo = (uint32_t)(raw < 0 ? 0 : raw);
-                        const uint32_t w = DUNI((uint32_t)(wld64(win, wbase, lo >> 3) >> (lo & 7)));
-                        so = (eo & 0xFFFF) + (w & ((1u << nbo) - 1));
-                        sm = (em & 0xFFFF) + ((w >> nbo) & ((1u << nbm) - 1));
-                        sl = (el & 0xFFFF) + ((w >> (nbo + nbm)) & ((1u << nbl) - 1));
+                        uint32_t sh = lo - 8 * p8;
+                        if (lo < 8 * p8) { c8 = wld64(win, wbase, lo >> 3); sh = lo & 7; }             // rare
+                        st = SEQD_BASE(e_) + ((uint32_t)(c8 >> (sh + ((qc - pc) & 31))) & ((1u << (pc & 31)) - 1));
                         B = lo;
                     }
                     if (upd < cnt) {
-                        const uint32_t el = DUNI(seqd_lo(&L.ll[sl])), eo = DUNI(seqd_lo(&L.of[so])), em = DUNI(seqd_lo(&L.ml[sm]));
-                        recS = tsx_writelane(sl | (so << 9) | (sm << 17), upd, recS);
-                        recB = tsx_writelane(B, upd, recB);
-                        const int32_t raw = (int32_t)(B - ((el >> 24) + (eo >> 24) + (em >> 24)));
+                        const uint32_t e_ = tbl[st];
+                        recp[upd * 4] = (uint16_t)st;
+                        const uint32_t eb = SEQD_EBITS(e_);
+                        const int32_t raw = (int32_t)(B - DUNI(eb + DPP_SHL(eb, 1) + DPP_SHL(eb, 2)));
                         bad |= (uint32_t)raw;
                         B = (uint32_t)(raw < 0 ? 0 : raw);
                     }
                     e = bad >> 31;
                     if (e) FAIL(DERR_FRAME);                                // the stream is shorter than its sequences need
-                    // pass 2: every lane decodes the fields of its own sequence from the window
+                    __threadfence_block();
+                    __syncthreads();
+                    // pass 2: every lane decodes the fields of its own sequence from the window; its cursor is the group's minus
+                    // the bits of the sequences before it (prefix sum)
                     const bool valid = lane < cnt;
                     uint32_t ll = 0, ml = 0, offBase = 4;
-                    if (valid) {
-                        const uint64_t rl = seqd_raw(&L.ll[recS & 511]), ro = seqd_raw(&L.of[(recS >> 9) & 255]), rm = seqd_raw(&L.ml[recS >> 17]);
-                        const uint32_t oc = (uint32_t)(ro >> 24) & 0xFF, mbits = (uint32_t)(rm >> 24) & 0xFF, lbits = (uint32_t)(rl >> 24) & 0xFF;
-                        const uint32_t lo1 = recB - oc;                                 // offset bits first (<= 31), then ML, then LL (<= 16 each)
-                        offBase = (uint32_t)(ro >> 32) + ((uint32_t)(wld64(win, wbase, lo1 >> 3) >> (lo1 & 7)) & ((1u << oc) - 1));
-                        const uint32_t lo2 = lo1 - mbits - lbits;
-                        const uint32_t w2 = (uint32_t)(wld64(win, wbase, lo2 >> 3) >> (lo2 & 7));
-                        ll = (uint32_t)(rl >> 32) + (w2 & ((1u << lbits) - 1));
-                        ml = (uint32_t)(rm >> 32) + ((w2 >> lbits) & ((1u << mbits) - 1));
+                    {
+                        uint32_t el = 0, eo = 0, em = 0, mine = 0;
+                        if (valid) {
+                            uint64_t r; __builtin_memcpy(&r, &L.rec[lane * 4], 8);
+                            el = L.ll[(uint32_t)r & 0xFFFF]; em = L.ml[(uint32_t)(r >> 16) & 0xFFFF]; eo = L.of[(uint32_t)(r >> 32) & 0xFFFF];
+                            mine = SEQD_TOT(el) + SEQD_TOT(eo) + SEQD_TOT(em);
+                            if (g + lane + 1 == nbSeq) mine = SEQD_EBITS(el) + SEQD_EBITS(eo) + SEQD_EBITS(em);
+                        }
+                        uint32_t incl = mine;
+                        for (uint32_t o = 1; o < LANES; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                        if (valid) {
+                            const uint32_t oc = SEQD_EBITS(eo), mbits = SEQD_EBITS(em), lbits = SEQD_EBITS(el);
+                            const uint32_t lbase = L.cLLbase[SEQD_SYM(el)], mbase = L.cMLbase[SEQD_SYM(em)];
+                            const uint32_t lo1 = Bgroup - (incl - mine) - oc;           // offset bits first (<= 31), then ML, then LL (<= 16 each)
+                            offBase = (1u << oc) + ((uint32_t)(wld64(win, wbase, lo1 >> 3) >> (lo1 & 7)) & ((1u << oc) - 1));
+                            const uint32_t lo2 = lo1 - mbits - lbits;
+                            const uint32_t w2 = (uint32_t)(wld64(win, wbase, lo2 >> 3) >> (lo2 & 7));
+                            ll = lbase + (w2 & ((1u << lbits) - 1));
+                            ml = mbase + ((w2 >> lbits) & ((1u << mbits) - 1));
+                        }
                     }
                     // pass 3: repeat offsets.  A sequence with a new offset (code > 3) knows it already and only pushes it onto the
                     // history; the scalar loop visits just the sequences that USE the history (codes 1..3), in order, first
