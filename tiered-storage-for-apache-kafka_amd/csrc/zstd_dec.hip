@@ -38,8 +38,7 @@ __device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__c
 __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
 #define ZS_DWIN 4096u
-#define ZS_HWIN 1024u
-static_assert(4 * (ZS_HWIN + 16) >= ZS_DWIN + 32, "the sequence window shares the Huffman windows' LDS");
+#define ZS_HWIN 512u
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 // sequence decoding entry, one dword: next-state base (bits 0-8) | nbBits (9-13) | nbBits + the symbol's number of extra
 // bits (14-20) | the symbol (21-26).  Bits 9-20 are laid out so that ONE add sums both counts over the three tables (no carry:
@@ -67,6 +66,15 @@ typedef uint32_t SeqD;
 #endif
 // row_shl:n - lane i reads lane i + n of its row of 16, 0 past the row's end
 #define DPP_SHL(v_, n_) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v_), 0x100 + (n_), 0xF, 0xF, true))
+// what the literal wave hands to the sequence wave for one block
+struct BlkDesc { uint32_t off, bsize, btype, last, litInPlace, litOff, litSize, q; };
+// Wave-level rendezvous: the lanes of ONE wave run in lockstep, so this is only a memory fence + a compiler barrier on the
+// device (a workgroup barrier here would wait for the chunk's other wave, which is somewhere else entirely).
+#ifdef HIPEMU
+#define WAVE_SYNC() hipemu::wave_barrier()
+#else
+#define WAVE_SYNC() do { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 struct DecLds {
     uint16_t huf[2048];          // (nbBits << 8) | symbol; Max_Number_of_Bits of a literals tree is 11 (RFC 8878 4.2.1)
     uint32_t hufLog; int hufValid;
@@ -83,7 +91,12 @@ struct DecLds {
     uint16_t symNext[64];
     uint32_t scal[16];
     uint32_t streamOff[5];
-    alignas(16) uint8_t win[4 * (ZS_HWIN + 16)];   // literal stage: one window per Huffman stream; sequence stage: one window (ZS_DWIN)
+    // the literal wave's own scratch and windows (the two waves of a chunk run concurrently)
+    short normH[16]; uint16_t symNextH[16]; uint8_t cellSymH[64]; uint32_t scalH[4];
+    BlkDesc desc[2];             // literal wave -> sequence wave, block k in slot k & 1
+    int32_t err;                 // first error of either wave
+    alignas(16) uint8_t hwin[4 * (ZS_HWIN + 16)];   // one window per Huffman stream
+    alignas(16) uint8_t swin[ZS_DWIN + 32];        // the sequence bit stream's window
 };
 
 // ---- backward bit reader (BIT_DStream) -----------------------------------------------------------------
@@ -258,14 +271,13 @@ __device__ static bool fse_buildSeqTable_wave(SeqD* dt, DecLds& L, uint32_t maxS
     uint32_t inv = step;                                                  // odd: step * step = 1 (mod 8); each Newton step doubles the bits
     for (int it = 0; it < 3; it++) inv *= 2u - step * inv;
     inv &= mask;
-    __syncthreads();                                                      // the scratch may still be read as the previous table's
+    WAVE_SYNC();                                                          // the scratch may still be read as the previous table's
     cum[lane] = (uint16_t)(incl - c);
     if (lowp) {
         const uint32_t k = (uint32_t)__popcll(lowMask & ((1ull << lane) - 1));   // low cells go to the top, in symbol order
         lowI[k] = (uint16_t)(((size - 1 - k) * inv) & mask); lowSym[k] = (uint8_t)lane;
     }
-    __threadfence_block();
-    __syncthreads();
+    WAVE_SYNC();
     uint32_t next = lowp ? 1u : c;                                        // symNext of symbol `lane`
     const uint32_t high = size - 1 - nLow;
     for (uint32_t base = 0; base < size; base += LANES) {
@@ -296,8 +308,7 @@ __device__ static bool fse_buildSeqTable_wave(SeqD* dt, DecLds& L, uint32_t maxS
             dt[u] = SEQD((ns << nb) - size, nb, seq_ebits(L, sym, kind), sym);
         }
     }
-    __threadfence_block();
-    __syncthreads();
+    WAVE_SYNC();
     return true;
 }
 __device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t n) {
@@ -312,9 +323,9 @@ __device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t
         used = 1 + hb;
         if (hb < 2 || used > n) return 0;
         uint32_t maxSym = 12, tl;
-        const uint32_t h = fse_readNCount(L.norm, &maxSym, &tl, src + 1, hb, 6);
+        const uint32_t h = fse_readNCount(L.normH, &maxSym, &tl, src + 1, hb, 6);
         if (!h) return 0;
-        if (!fse_buildDTable(L.wt, L.cellSym, L.norm, maxSym, tl, L.symNext, [](FseD& e, uint32_t sym) { e.sym = (uint8_t)sym; })) return 0;
+        if (!fse_buildDTable(L.wt, L.cellSymH, L.normH, maxSym, tl, L.symNextH, [](FseD& e, uint32_t sym) { e.sym = (uint8_t)sym; })) return 0;
         BitR b; br_init(b, src + 1 + h, hb - h);
         if (b.bad) return 0;
         uint32_t s1 = (uint32_t)br_read(b, tl), s2 = (uint32_t)br_read(b, tl);
@@ -419,9 +430,10 @@ __device__ static __forceinline__ void exec_copies(uint8_t* dst, const uint8_t* 
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------
-#define FAIL(code) do { err = (code); goto done; } while (0)
+#define FAIL(code) do { err = (code); goto done; } while (0)                 /* both waves, before the block loop */
+#define RFAIL(code) do { myErr = (code); goto block_end; } while (0)        /* one wave, inside its role */
 
-__global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+__global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
                                                                 tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
                                                                 int32_t* __restrict__ status, uint8_t* __restrict__ work
 #ifdef TSX_PROF2
@@ -429,14 +441,14 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
 #endif
                                                                 ) {
     __shared__ DecLds L;
-    const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
+    const uint32_t lane = threadIdx.x & (LANES - 1), role = DUNI(threadIdx.x >> 6), chunk = blockIdx.x;   // role 0: sequences + execution, role 1: literals
     if (status[chunk] != TSX_OK) return;
     const tsx_chunk_desc d = descs[chunk];
     const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
     const uint32_t srcSize = from_mid ? d.src_len - 28 : d.src_len;
     uint8_t* __restrict__ out = dst_base + d.dst_off;
     uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
-    uint8_t* const lit = ws + ZS_WS_LIT;
+    uint8_t* const litBuf[2] = {ws + ZS_WS_LIT, ws + ZS_WS_HASHLONG};    // literals of block k -> buffer k & 1 (the decoder needs no hash tables)
     int32_t err = TSX_OK;
 #ifdef TSX_PROF2
     unsigned long long dlt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast_ = (unsigned long long)clock64();
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                           // repeat-offset history, carried across the blocks of the frame (wave-uniform)
     uint64_t contentSize = 0;
     uint32_t p = 0;
-    bool hasChecksum = false;
+    bool hasChecksum = false, prodDone = false;
     // ---- frame header ----
     if (srcSize < 6) FAIL(DERR_FRAME);
     if (src[0] != 0x28 || src[1] != 0xB5 || src[2] != 0x2F || src[3] != 0xFD) FAIL(DERR_FRAME);
@@ -468,439 +480,480 @@ __global__ __launch_bounds__(LANES) void zstd_decompress_kernel(const uint8_t* _
         p += fl;
     }
     if (contentSize > d.dst_cap) FAIL(TSX_E_DST_TOO_SMALL);
-    if (lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; L.zeroEntry = 0; }
-    if (lane < 36) { L.cLLbase[lane] = dLLbase[lane]; L.cLLbits[lane] = dLLbits[lane]; }
-    if (lane < 53) { L.cMLbase[lane] = dMLbase[lane]; L.cMLbits[lane] = dMLbits[lane]; }
+    if (role == 0 && lane == 0) { L.hufValid = 0; L.llValid = 0; L.ofValid = 0; L.mlValid = 0; L.zeroEntry = 0; L.err = TSX_OK; }
+    if (role == 0 && lane < 36) { L.cLLbase[lane] = dLLbase[lane]; L.cLLbits[lane] = dLLbits[lane]; }
+    if (role == 0 && lane < 53) { L.cMLbase[lane] = dMLbase[lane]; L.cMLbits[lane] = dMLbits[lane]; }
     __syncthreads();
-    // ---- blocks ----
-    for (;;) {
-        if (p + 3 > srcSize) FAIL(DERR_FRAME);
-        const uint32_t bh = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
-        p += 3;
-        const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
-        if (btype == 0) {                                               // raw
-            if (p + bsize > srcSize || opos + (uint64_t)bsize > contentSize) FAIL(DERR_FRAME);
-            for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = src[p + i];
-            p += bsize; opos += bsize;
-        } else if (btype == 1) {                                        // RLE
-            if (p + 1 > srcSize || opos + (uint64_t)bsize > contentSize) FAIL(DERR_FRAME);
-            const uint8_t b = src[p];
-            for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = b;
-            p += 1; opos += bsize;
-        } else if (btype == 2) {
-            if (bsize > ZS_BLOCK_MAX || p + bsize > srcSize || bsize < 2) FAIL(DERR_FRAME);
-            const uint8_t* const blk = src + p;
-            // ---- literals section ----
-            const uint32_t b0 = blk[0], ltype = b0 & 3, sf = (b0 >> 2) & 3;
-            uint32_t litSize = 0, q = 0;
-            const uint8_t* litPtr = lit;
-            if (ltype < 2) {
-                uint32_t hl;
-                if (sf == 0 || sf == 2) { litSize = b0 >> 3; hl = 1; }
-                else if (sf == 1) { if (bsize < 2) FAIL(DERR_FRAME); litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4); hl = 2; }
-                else { if (bsize < 3) FAIL(DERR_FRAME); litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4) + ((uint32_t)blk[2] << 12); hl = 3; }
-                if (litSize > ZS_BLOCK_MAX) FAIL(DERR_FRAME);
-                if (ltype == 0) { if (hl + litSize > bsize) FAIL(DERR_FRAME); litPtr = blk + hl; q = hl + litSize; }
-                else {
-                    if (hl + 1 > bsize) FAIL(DERR_FRAME);
-                    const uint8_t b = blk[hl];
-                    for (uint32_t i = lane; i < litSize; i += LANES) lit[i] = b;
-                    q = hl + 1;
-                }
-            } else {
-                uint32_t hl, bits, streams; uint64_t v = 0;
-                if (sf == 0) { hl = 3; bits = 10; streams = 1; }
-                else if (sf == 1) { hl = 3; bits = 10; streams = 4; }
-                else if (sf == 2) { hl = 4; bits = 14; streams = 4; }
-                else { hl = 5; bits = 18; streams = 4; }
-                if (hl > bsize) FAIL(DERR_FRAME);
-                for (uint32_t i = 0; i < hl; i++) v |= (uint64_t)blk[i] << (8 * i);
-                litSize = (uint32_t)(v >> 4) & ((1u << bits) - 1);
-                const uint32_t csize = (uint32_t)(v >> (4 + bits)) & ((1u << bits) - 1);
-                if (litSize > ZS_BLOCK_MAX || hl + csize > bsize || litSize == 0) FAIL(DERR_FRAME);
-                uint32_t t = hl;
-                if (ltype == 2) {
-                    if (lane == 0) L.scal[0] = huf_readTable(L, blk + hl, csize);
-                    __syncthreads();
-                    const uint32_t used = L.scal[0];
-                    __syncthreads();
-                    if (!used) FAIL(DERR_FRAME);
-                    t += used;
-                } else if (!L.hufValid) FAIL(DERR_FRAME);
-                const uint32_t payload = hl + csize - t;
-                // stream layout
-                uint32_t sOff[5], sCnt[4];
-                if (streams == 1) { sOff[0] = 0; sOff[1] = payload; sCnt[0] = litSize; }
-                else {
-                    if (payload < 10) FAIL(DERR_FRAME);
-                    const uint32_t s1 = blk[t] | (blk[t + 1] << 8), s2 = blk[t + 2] | (blk[t + 3] << 8), s3 = blk[t + 4] | (blk[t + 5] << 8);
-                    if (6 + (uint64_t)s1 + s2 + s3 >= payload) FAIL(DERR_FRAME);
-                    sOff[0] = 6; sOff[1] = 6 + s1; sOff[2] = sOff[1] + s2; sOff[3] = sOff[2] + s3; sOff[4] = payload;
-                    const uint32_t seg = (litSize + 3) / 4;
-                    if (3 * seg > litSize) FAIL(DERR_FRAME);
-                    sCnt[0] = sCnt[1] = sCnt[2] = seg; sCnt[3] = litSize - 3 * seg;
-                }
-                // The (1 or 4) Huffman streams decode on lanes 0..3, each through its own LDS window of the stream, refilled by
-                // the whole wave whenever a lane gets close to its window's lower edge (a reload from global memory would be a
-                // dependent round trip every four symbols).
-                bool ok = true;
-                {
-                    const bool mine = lane < streams;
-                    uint32_t o = 0; for (uint32_t k = 0; k < lane && k < 4; k++) o += mine ? sCnt[k] : 0;
-                    const uint32_t cnt = mine ? sCnt[lane] : 0, sn = mine ? sOff[lane + 1] - sOff[lane] : 0, sbeg = mine ? t + sOff[lane] : 0;
-                    uint8_t* const outp = lit + o;
-                    // Bh = bits of the stream not read yet (cursor from the top; the last byte carries the end mark).  A step
-                    // decodes four symbols (<= 44 bits) from ONE 8-byte window read at the cursor, no branches inside; the last
-                    // symbols of a stream (fewer than four left, or fewer than 44 bits) go one at a time, with the bits below
-                    // the stream's first one read as zeros like libzstd's container does.
-                    uint32_t hi = 0, Bh = 0; bool hdone = !mine;
-                    if (mine) {
-                        const uint32_t lastByte = sn ? blk[sbeg + sn - 1] : 0;
-                        if (lastByte == 0) { ok = false; hdone = true; }
-                        else Bh = 8 * (sn - 1) + dhb32(lastByte);
-                    }
-                    const uint32_t tableLog = L.hufLog, tmask = (1u << tableLog) - 1;
-                    for (;;) {
-                        const uint32_t myTop = hdone ? 0 : (Bh >> 3) + 8;                                // bytes past the stream's end are zeros
-                        const uint32_t myWb = myTop > ZS_HWIN ? (myTop - ZS_HWIN + 15) & ~15u : 0;     // top - wb <= ZS_HWIN = one 16-byte piece per lane
-                        for (uint32_t s_ = 0; s_ < streams; s_++) {
-                            const uint32_t top = __shfl(myTop, s_), wb = __shfl(myWb, s_), beg = __shfl(sbeg, s_), n_ = __shfl(sn, s_);
-                            const uint32_t k = lane * 16;
-                            if (wb + k < top) {
-                                uint4 v;
-                                if (wb + k + 16 <= n_) __builtin_memcpy(&v, blk + beg + wb + k, 16);
-                                else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wb + k + j < n_ ? blk[beg + wb + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
-                                *reinterpret_cast<uint4*>(&L.win[s_ * (ZS_HWIN + 16) + k]) = v;
+    // ---- blocks: wave 1 (literals) works one block ahead of wave 0 (sequences + execution) ----
+    // Iteration `it`: wave 1 parses block it's header and literals section (Huffman streams -> litBuf[it & 1]) and publishes
+    // L.desc[it & 1]; wave 0 decodes and executes the sequences of block it - 1.  One workgroup barrier per iteration; an error
+    // of either wave is posted in L.err and ends both after the barrier.  Neither phase of a block waits for the other's
+    // memory latency any more: the serial chains of the two phases run side by side.
+    for (uint32_t it = 0;; it++) {
+        int32_t myErr = TSX_OK;
+        // Was block it - 1 the frame's last one?  Each wave answers from its own registers (a descriptor slot may already be
+        // rewritten by the other wave when the barrier opens): wave 1 finished producing, wave 0 consumed a block marked last.
+        bool frameDone = role == 1 ? prodDone : false;
+        {
+            if (role == 1) {
+                if (!prodDone) {
+                    uint8_t* const lit = litBuf[it & 1];
+                    if (p + 3 > srcSize) RFAIL(DERR_FRAME);
+                    const uint32_t bh = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+                    p += 3;
+                    const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+                    BlkDesc bd; bd.off = p; bd.bsize = bsize; bd.btype = btype; bd.last = last; bd.litInPlace = 0; bd.litOff = 0; bd.litSize = 0; bd.q = 0;
+                    if (btype == 0) { if (p + bsize > srcSize) RFAIL(DERR_FRAME); p += bsize; }
+                    else if (btype == 1) { if (p + 1 > srcSize) RFAIL(DERR_FRAME); p += 1; }
+                    else if (btype == 2) {
+                        if (bsize > ZS_BLOCK_MAX || p + bsize > srcSize || bsize < 2) RFAIL(DERR_FRAME);
+                        const uint8_t* const blk = src + p;
+                        const uint32_t b0 = blk[0], ltype = b0 & 3, sf = (b0 >> 2) & 3;
+                        uint32_t litSize = 0, q = 0;
+                        uint32_t litInPlace = 0, litOff = 0;
+                        if (ltype < 2) {
+                            uint32_t hl;
+                            if (sf == 0 || sf == 2) { litSize = b0 >> 3; hl = 1; }
+                            else if (sf == 1) { if (bsize < 2) RFAIL(DERR_FRAME); litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4); hl = 2; }
+                            else { if (bsize < 3) RFAIL(DERR_FRAME); litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4) + ((uint32_t)blk[2] << 12); hl = 3; }
+                            if (litSize > ZS_BLOCK_MAX) RFAIL(DERR_FRAME);
+                            if (ltype == 0) { if (hl + litSize > bsize) RFAIL(DERR_FRAME); litInPlace = 1; litOff = hl; q = hl + litSize; }
+                            else {
+                                if (hl + 1 > bsize) RFAIL(DERR_FRAME);
+                                const uint8_t b = blk[hl];
+                                for (uint32_t i = lane; i < litSize; i += LANES) lit[i] = b;
+                                q = hl + 1;
                             }
-                        }
-                        __threadfence_block();
-                        __syncthreads();
-                        if (!hdone) {
-                            const uint8_t* const win = &L.win[lane * (ZS_HWIN + 16)];
-                            while (hi + 4 <= cnt && Bh >= 44 && ((Bh - 44) >> 3) >= myWb) {
-                                const uint32_t lo = Bh - 44;
-                                const uint64_t c = wld64(win, myWb, lo >> 3) >> (lo & 7);               // bits [lo, lo + 57) of the stream
-                                const uint32_t e0 = L.huf[(uint32_t)(c >> (44 - tableLog)) & tmask];
-                                uint32_t used = e0 >> 8;
-                                const uint32_t e1 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
-                                used += e1 >> 8;
-                                const uint32_t e2 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
-                                used += e2 >> 8;
-                                const uint32_t e3 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
-                                used += e3 >> 8;
-                                const uint32_t packed = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
-                                __builtin_memcpy(outp + hi, &packed, 4);
-                                hi += 4; Bh -= used;
+                        } else {
+                            uint32_t hl, bits, streams; uint64_t v = 0;
+                            if (sf == 0) { hl = 3; bits = 10; streams = 1; }
+                            else if (sf == 1) { hl = 3; bits = 10; streams = 4; }
+                            else if (sf == 2) { hl = 4; bits = 14; streams = 4; }
+                            else { hl = 5; bits = 18; streams = 4; }
+                            if (hl > bsize) RFAIL(DERR_FRAME);
+                            for (uint32_t i = 0; i < hl; i++) v |= (uint64_t)blk[i] << (8 * i);
+                            litSize = (uint32_t)(v >> 4) & ((1u << bits) - 1);
+                            const uint32_t csize = (uint32_t)(v >> (4 + bits)) & ((1u << bits) - 1);
+                            if (litSize > ZS_BLOCK_MAX || hl + csize > bsize || litSize == 0) RFAIL(DERR_FRAME);
+                            uint32_t t = hl;
+                            if (ltype == 2) {
+                                if (lane == 0) L.scalH[0] = huf_readTable(L, blk + hl, csize);
+                                WAVE_SYNC();
+                                const uint32_t used = L.scalH[0];
+                                WAVE_SYNC();
+                                if (!used) RFAIL(DERR_FRAME);
+                                t += used;
+                            } else if (!L.hufValid) RFAIL(DERR_FRAME);
+                            const uint32_t payload = hl + csize - t;
+                            // stream layout
+                            uint32_t sOff[5], sCnt[4];
+                            if (streams == 1) { sOff[0] = 0; sOff[1] = payload; sCnt[0] = litSize; }
+                            else {
+                                if (payload < 10) RFAIL(DERR_FRAME);
+                                const uint32_t s1 = blk[t] | (blk[t + 1] << 8), s2 = blk[t + 2] | (blk[t + 3] << 8), s3 = blk[t + 4] | (blk[t + 5] << 8);
+                                if (6 + (uint64_t)s1 + s2 + s3 >= payload) RFAIL(DERR_FRAME);
+                                sOff[0] = 6; sOff[1] = 6 + s1; sOff[2] = sOff[1] + s2; sOff[3] = sOff[2] + s3; sOff[4] = payload;
+                                const uint32_t seg = (litSize + 3) / 4;
+                                if (3 * seg > litSize) RFAIL(DERR_FRAME);
+                                sCnt[0] = sCnt[1] = sCnt[2] = seg; sCnt[3] = litSize - 3 * seg;
                             }
-                            while (hi < cnt && (hi + 4 > cnt || Bh < 44)) {                              // the stream's tail
-                                const uint32_t need = Bh < tableLog ? Bh : tableLog, lo = Bh - need;
-                                if ((lo >> 3) < myWb) break;                                             // behind the window: refill first
-                                const uint32_t bits = (uint32_t)(wld64(win, myWb, lo >> 3) >> (lo & 7)) & ((1u << need) - 1);
-                                const uint32_t e = L.huf[(bits << (tableLog - need)) & tmask];
-                                if ((e >> 8) > Bh) { ok = false; hdone = true; break; }                   // reads past the stream's first bit
-                                outp[hi++] = (uint8_t)e; Bh -= e >> 8;
-                            }
-                            if (!hdone && hi >= cnt) { if (Bh != 0) ok = false; hdone = true; }           // every bit used, none missing
-                        }
-                        __syncthreads();
-                        if (__all(hdone)) break;
-                    }
-                }
-                if (__any(!ok)) FAIL(DERR_FRAME);
-                q = hl + csize;
-            }
-            __threadfence_block();
-            __syncthreads();
-            DLT(0);                                                     // 0: block header + literals section
-            // ---- sequences section ----
-            if (q >= bsize) FAIL(DERR_FRAME);
-            uint32_t nbSeq = blk[q];
-            if (nbSeq == 0) q += 1;
-            else if (nbSeq < 128) q += 1;
-            else if (nbSeq < 255) { if (q + 2 > bsize) FAIL(DERR_FRAME); nbSeq = ((nbSeq - 128) << 8) + blk[q + 1]; q += 2; }
-            else { if (q + 3 > bsize) FAIL(DERR_FRAME); nbSeq = blk[q + 1] + ((uint32_t)blk[q + 2] << 8) + 0x7F00; q += 3; }
-            nbSeq = DUNI(nbSeq);                                        // loaded through the vector path: pin it (and every loop bound derived from it) to SGPRs
-            if (nbSeq > ZS_BLOCK_MAX / 3 + 1) FAIL(DERR_FRAME);            // 128 KiB / minMatch 3 = 43691 at most in a valid block
-            if (nbSeq) {
-                // The three sequence tables (literal lengths, offsets, match lengths).  Lane 0 parses each table description
-                // (a short serial bit parse); the decoding table itself is built by the whole wave (fse_buildSeqTable_wave).
-                if (q >= bsize) FAIL(DERR_FRAME);
-                const uint32_t modes = DUNI(blk[q]);
-                uint32_t t = q + 1;
-                if (modes & 3) FAIL(DERR_FRAME);
-                for (int k = 0; k < 3; k++) {
-                    const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
-                    SeqD* const dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
-                    uint32_t* const logp = k == 0 ? &L.llLog : k == 1 ? &L.ofLog : &L.mlLog;
-                    int* const validp = k == 0 ? &L.llValid : k == 1 ? &L.ofValid : &L.mlValid;
-                    const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
-                    if (mode == 0) {                                    // predefined distribution
-                        const short* const dn = k == 0 ? dLLnorm : k == 1 ? dOFnorm : dMLnorm;
-                        const uint32_t dmax = k == 0 ? 35 : k == 1 ? 28 : 52, dlog = k == 1 ? 5 : 6;
-                        if (lane <= dmax) L.norm[lane] = dn[lane];
-                        if (lane == 0) { *logp = dlog; *validp = 1; }
-                        __threadfence_block();
-                        __syncthreads();
-                        if (!fse_buildSeqTable_wave(dt, L, dmax, dlog, k, lane)) FAIL(DERR_FRAME);
-                    } else if (mode == 1) {                             // RLE: one symbol, no state bits
-                        if (t >= bsize) FAIL(DERR_FRAME);
-                        const uint32_t sym = DUNI(blk[t]);
-                        t++;
-                        if (sym > maxSymK) FAIL(DERR_FRAME);
-                        if (lane == 0) { dt[0] = SEQD(0, 0, seq_ebits(L, sym, k), sym); *logp = 0; *validp = 1; }
-                    } else if (mode == 2) {                             // FSE-compressed distribution
-                        if (t >= bsize) FAIL(DERR_FRAME);
-                        if (lane == 0) {
-                            uint32_t ms = maxSymK, tl = 0;
-                            const uint32_t used = fse_readNCount(L.norm, &ms, &tl, blk + t, bsize - t, maxLogK);
-                            L.scal[0] = used; L.scal[3] = ms; L.scal[4] = tl;
-                            if (used) { *logp = tl; *validp = 1; }
-                        }
-                        __threadfence_block();
-                        __syncthreads();
-                        const uint32_t used = DUNI(L.scal[0]), ms = DUNI(L.scal[3]), tl = DUNI(L.scal[4]);
-                        if (!used || !fse_buildSeqTable_wave(dt, L, ms, tl, k, lane)) FAIL(DERR_FRAME);
-                        t += used;
-                    } else {                                            // repeat the previous block's table
-                        __syncthreads();
-                        if (!*validp) FAIL(DERR_FRAME);
-                    }
-                }
-                if (t >= bsize) FAIL(DERR_FRAME);
-                if (lane == 0) L.scal[2] = t;
-                __threadfence_block();
-                __syncthreads();
-                DLT(1);                                                 // 1: sequence tables
-            } else if (q != bsize) FAIL(DERR_FRAME);
-            // ---- decode and execute the sequences, 64 at a time (one per lane) ----
-            // The sequence bit stream is one serial chain (read backwards; each FSE state transition says how many bits the
-            // next one reads), staged through an LDS window that the whole wave refills.  Only the part of a sequence that IS
-            // serial runs serially: pass 1 walks the three state machines for up to 64 sequences as wave-uniform scalar code
-            // (three 4-byte table reads and one bit-window read per sequence) and drops each sequence's states and bit cursor
-            // into its own lane (v_writelane); pass 2 lets every lane pull its sequence's extra bits out of the window and form
-            // (literal length, match length, offset code) - all 64 at once; pass 3 resolves the repeat offsets in order (a short
-            // uniform loop over lane values), which makes the execution below order-free.
-            {
-                const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog);
-                const uint8_t* const win = L.win;
-                const uint8_t* stream = blk; uint32_t n = 0;
-                uint32_t B = 0, wbase = 0, e = 0;                               // B: bits of the stream not read yet (the cursor, from the top)
-                // lanes 0, 1, 2 = the LL, ML, OF state machines; the others carry state 0 through an all-zero entry
-                const SeqD* const tbl = lane == 0 ? L.ll : lane == 1 ? L.ml : lane == 2 ? L.of : &L.zeroEntry;
-                uint16_t* const recp = &L.rec[lane < 3 ? lane : 3];
-                uint32_t st = 0;
-                bool filled = false;
-                if (nbSeq) {
-                    const uint32_t t = DUNI(L.scal[2]);
-                    n = DUNI(bsize - t); stream = blk + t;                  // n >= 1 (checked with the tables)
-                    const uint32_t lastByte = DUNI(stream[n - 1]);          // BIT_initDStream: the last byte carries the end mark
-                    if (lastByte == 0) FAIL(DERR_FRAME);
-                    B = 8 * (n - 1) + dhb32(lastByte);
-                }
-                uint32_t lp = 0;
-                for (uint32_t g = 0; g < nbSeq; g += LANES) {
-                    const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
-                    // 64 sequences read at most 64 * 89 bits = 712 bytes below the cursor; every read is an 8-byte load at
-                    // byte (bit >> 3), so the window holds [wbase, (B >> 3) + 8) with the bytes past the stream's end as zeros
-                    if (!filled || (wbase != 0 && (B >> 3) < wbase + 736)) {
-                        __syncthreads();                                    // everyone is done with the previous window
-                        const uint32_t top = (B >> 3) + 8;
-                        wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
-                        for (uint32_t k = lane * 16; wbase + k < top; k += LANES * 16) {
-                            uint4 v;
-                            if (wbase + k + 16 <= n) __builtin_memcpy(&v, stream + wbase + k, 16);
-                            else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wbase + k + j < n ? stream[wbase + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
-                            *reinterpret_cast<uint4*>(&L.win[k]) = v;
-                        }
-                        __threadfence_block();
-                        __syncthreads();
-                        if (!filled) {                                      // initial states: LL, OF, ML (ZSTD_initFseState order)
-                            filled = true;
-                            const uint32_t lo = B - (llLog + ofLog + mlLog);              // <= 26 bits
-                            if ((int32_t)lo < 0) FAIL(DERR_FRAME);
-                            const uint32_t w = DUNI((uint32_t)(wld64(win, wbase, lo >> 3) >> (lo & 7)));
-                            const uint32_t sm = w & ((1u << mlLog) - 1), so = (w >> mlLog) & ((1u << ofLog) - 1), sl = (w >> (mlLog + ofLog)) & ((1u << llLog) - 1);
-                            st = lane == 0 ? sl : lane == 1 ? sm : lane == 2 ? so : 0;
-                            B = lo;
-                        }
-                    }
-                    // pass 1: the chain, on the vector unit.  Lanes 0, 1, 2 run the LL, ML and OF state machines (that is the order
-                    // in which a sequence's state-update bits sit in the stream, highest first); one table read serves all three,
-                    // two DPP adds give every machine the bits below its own field and lane 0 the sequence's bit total, and the
-                    // 8 bytes that hold the update bits are read together with the entries from the cursor alone ([B - 56.., B));
-                    // only a sequence that reads more than 56 bits needs a second, dependent read.  The scalar unit - ONE per CU,
-                    // shared by every wave - keeps just the cursor and the loop.  The states go to LDS (rec) for pass 2; an
-                    // over-read shows as a negative cursor (collected in `bad`, checked once per group) and is clamped so that no
-                    // load leaves the window.  The last sequence of a block reads no update bits: peeled off the loop.
-                    uint32_t bad = 0;
-                    const uint32_t Bgroup = B;
-                    const uint32_t upd = g + cnt < nbSeq ? cnt : cnt - 1;
-                    for (uint32_t j = 0; j < upd; j++) {
-                        const uint32_t p8 = (B >> 3) > 7 ? (B >> 3) - 7 : 0;                            // >= wbase: the window's margin
-                        uint64_t c8 = wld64(win, wbase, p8);
-                        const uint32_t e_ = tbl[st];
-                        recp[j * 4] = (uint16_t)st;
-                        TSX_SCHED_BARRIER();                                                           // both reads are in flight before anything waits
-                        const uint32_t pc = SEQD_COUNTS(e_);
-                        const uint32_t qc = pc + DPP_SHL(pc, 1) + DPP_SHL(pc, 2);                       // own + the machines below
-                        // extra bits of the offset, match length, literal length, then the state updates: LL, ML, OF (ZSTD_decodeSequence order)
-                        const int32_t raw = (int32_t)(B - DUNI(qc >> 5));
-                        bad |= (uint32_t)raw;
-                        const uint32_t lo = (uint32_t)(raw < 0 ? 0 : raw);
-                        uint32_t sh = lo - 8 * p8;
-                        if (lo < 8 * p8) { c8 = wld64(win, wbase, lo >> 3); sh = lo & 7; }             // rare
-                        st = SEQD_BASE(e_) + ((uint32_t)(c8 >> (sh + ((qc - pc) & 31))) & ((1u << (pc & 31)) - 1));
-                        B = lo;
-                    }
-                    if (upd < cnt) {
-                        const uint32_t e_ = tbl[st];
-                        recp[upd * 4] = (uint16_t)st;
-                        const uint32_t eb = SEQD_EBITS(e_);
-                        const int32_t raw = (int32_t)(B - DUNI(eb + DPP_SHL(eb, 1) + DPP_SHL(eb, 2)));
-                        bad |= (uint32_t)raw;
-                        B = (uint32_t)(raw < 0 ? 0 : raw);
-                    }
-                    e = bad >> 31;
-                    if (e) FAIL(DERR_FRAME);                                // the stream is shorter than its sequences need
-                    __threadfence_block();
-                    __syncthreads();
-                    // pass 2: every lane decodes the fields of its own sequence from the window; its cursor is the group's minus
-                    // the bits of the sequences before it (prefix sum)
-                    const bool valid = lane < cnt;
-                    uint32_t ll = 0, ml = 0, offBase = 4;
-                    {
-                        uint32_t el = 0, eo = 0, em = 0, mine = 0;
-                        if (valid) {
-                            uint64_t r; __builtin_memcpy(&r, &L.rec[lane * 4], 8);
-                            el = L.ll[(uint32_t)r & 0xFFFF]; em = L.ml[(uint32_t)(r >> 16) & 0xFFFF]; eo = L.of[(uint32_t)(r >> 32) & 0xFFFF];
-                            mine = SEQD_TOT(el) + SEQD_TOT(eo) + SEQD_TOT(em);
-                            if (g + lane + 1 == nbSeq) mine = SEQD_EBITS(el) + SEQD_EBITS(eo) + SEQD_EBITS(em);
-                        }
-                        uint32_t incl = mine;
-                        for (uint32_t o = 1; o < LANES; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-                        if (valid) {
-                            const uint32_t oc = SEQD_EBITS(eo), mbits = SEQD_EBITS(em), lbits = SEQD_EBITS(el);
-                            const uint32_t lbase = L.cLLbase[SEQD_SYM(el)], mbase = L.cMLbase[SEQD_SYM(em)];
-                            const uint32_t lo1 = Bgroup - (incl - mine) - oc;           // offset bits first (<= 31), then ML, then LL (<= 16 each)
-                            offBase = (1u << oc) + ((uint32_t)(wld64(win, wbase, lo1 >> 3) >> (lo1 & 7)) & ((1u << oc) - 1));
-                            const uint32_t lo2 = lo1 - mbits - lbits;
-                            const uint32_t w2 = (uint32_t)(wld64(win, wbase, lo2 >> 3) >> (lo2 & 7));
-                            ll = lbase + (w2 & ((1u << lbits) - 1));
-                            ml = mbase + ((w2 >> lbits) & ((1u << mbits) - 1));
-                        }
-                    }
-                    // pass 3: repeat offsets.  A sequence with a new offset (code > 3) knows it already and only pushes it onto the
-                    // history; the scalar loop visits just the sequences that USE the history (codes 1..3), in order, first
-                    // folding in the new offsets pushed since the previous visit (only the last three matter).  Code c names
-                    // history entry idx = c - 1 (+ 1 when the literal length is 0; idx 3 = rep0 - 1); idx >= 2 pushes the whole
-                    // history down, idx 1 swaps the first two, idx 0 leaves it alone.  All on wave-uniform values, no branches.
-                    uint32_t off = offBase - 3;
-                    {
-                        const unsigned long long ll0 = __ballot(valid && ll == 0);
-                        unsigned long long users = __ballot(valid && offBase <= 3);
-                        uint32_t r0 = DUNI(rep0), r1 = DUNI(rep1), r2 = DUNI(rep2);
-                        uint32_t prev = 0;                                                  // first sequence not folded in yet
-                        for (;;) {
-                            const uint32_t j = users ? (uint32_t)__ffsll((long long)users) - 1 : cnt;      // next user, or the group's end
-                            const uint32_t gap = j - prev;                                  // new offsets pushed by sequences [prev, j)
-                            const uint32_t a1 = __builtin_amdgcn_readlane(offBase, (int)(j >= 1 ? j - 1 : 0)) - 3;
-                            const uint32_t a2 = __builtin_amdgcn_readlane(offBase, (int)(j >= 2 ? j - 2 : 0)) - 3;
-                            const uint32_t a3 = __builtin_amdgcn_readlane(offBase, (int)(j >= 3 ? j - 3 : 0)) - 3;
-                            const uint32_t n2 = gap >= 3 ? a3 : gap == 2 ? r0 : gap == 1 ? r1 : r2;
-                            const uint32_t n1 = gap >= 2 ? a2 : gap == 1 ? r0 : r1;
-                            const uint32_t n0 = gap >= 1 ? a1 : r0;
-                            r0 = n0; r1 = n1; r2 = n2;
-                            if (!users) break;
-                            users &= users - 1;
-                            const uint32_t ob = __builtin_amdgcn_readlane(offBase, (int)j);
-                            const uint32_t idx = ob - 1 + (uint32_t)((ll0 >> j) & 1);       // 0..3
-                            const uint32_t c01 = idx == 0 ? r0 : r1, c23 = idx == 2 ? r2 : r0 - 1;
-                            const uint32_t o_ = idx < 2 ? c01 : c23;
-                            r2 = idx >= 2 ? r1 : r2;
-                            r1 = idx >= 1 ? r0 : r1;
-                            r0 = o_;
-                            off = tsx_writelane(o_, j, off);
-                            prev = j + 1;
-                        }
-                        rep0 = r0; rep1 = r1; rep2 = r2;
-                    }
-                    DLT(2);                                                 // 2: FSE sequence decode
-                    // Execution.  Positions come from prefix sums, so literal runs and every match whose source lies before the
-                    // group's first output byte are copied by their own lane, all at once; only matches that read bytes produced
-                    // inside the same group (short offsets) are replayed in order with wave-wide copies.
-                    uint32_t litIncl = ll, totIncl = ll + ml;
-                    for (int o = 1; o < LANES; o <<= 1) {
-                        const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
-                        if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
-                    }
-                    const uint32_t groupLit = __shfl(litIncl, LANES - 1), groupTot = __shfl(totIncl, LANES - 1);
-                    if (lp + groupLit > litSize || (uint64_t)opos + groupTot > contentSize) FAIL(DERR_FRAME);
-                    const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
-                    if (__any(valid && ml && (off == 0 || off > mOut))) FAIL(DERR_FRAME);
-                    // Short runs are copied by their own lane (all lanes at once), long ones (> ZS_LONG_RUN bytes) by the whole wave.
-                    // A match is ready when its source bytes are final: before the group's first output byte, or - after the
-                    // fence that follows each round - inside literal runs and matches already copied.  Each round copies every
-                    // pending match whose source touches no earlier pending match's destination; a match that overlaps its own
-                    // destination (offset < length) is replayed by the whole wave, in 64-byte steps or as a periodic pattern.
-                    const uint32_t s0 = mOut - off;
-                    exec_copies(out + myOut, litPtr + myLit, ll, valid && ll, lane);
-                    unsigned long long pend = __ballot(valid && ml);
-                    bool first = true;
-                    do {
-                        const bool mineP = (pend >> lane) & 1;
-                        bool blocked = mineP && off < ml;
-                        if (first) blocked = mineP && s0 + ml > opos;                          // round 0: only sources before the group
-                        else
-                            for (unsigned long long m = pend; m; m &= m - 1) {
-                                const int j = __ffsll((long long)m) - 1;
-                                const uint32_t dj = __builtin_amdgcn_readlane(mOut, j), ej = dj + __builtin_amdgcn_readlane(ml, j);
-                                if ((uint32_t)j < lane && s0 < ej && s0 + ml > dj) blocked = true;
-                            }
-                        const unsigned long long ready = __ballot(mineP && !blocked);
-                        if (ready || first) {
-                            exec_copies(out + mOut, out + s0, ml, (ready >> lane) & 1, lane);
-                            pend &= ~ready;
-                            first = false;
-                        } else {                                                                // the first pending match overlaps itself
-                            const int i = __ffsll((long long)pend) - 1;
-                            pend &= pend - 1;
-                            const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
-                            const uint32_t from = dpos - o_;
-                            if (o_ >= LANES) {
-                                for (uint32_t k = 0; k < m_; k += LANES) {
-                                    if (k) __threadfence_block();                               // a 64-byte step may read bytes written by the previous step
-                                    if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
+                            // The (1 or 4) Huffman streams decode on lanes 0..3, each through its own LDS window of the stream, refilled by
+                            // the whole wave whenever a lane gets close to its window's lower edge (a reload from global memory would be a
+                            // dependent round trip every four symbols).
+                            bool ok = true;
+                            {
+                                const bool mine = lane < streams;
+                                uint32_t o = 0; for (uint32_t k = 0; k < lane && k < 4; k++) o += mine ? sCnt[k] : 0;
+                                const uint32_t cnt = mine ? sCnt[lane] : 0, sn = mine ? sOff[lane + 1] - sOff[lane] : 0, sbeg = mine ? t + sOff[lane] : 0;
+                                uint8_t* const outp = lit + o;
+                                // Bh = bits of the stream not read yet (cursor from the top; the last byte carries the end mark).  A step
+                                // decodes four symbols (<= 44 bits) from ONE 8-byte window read at the cursor, no branches inside; the last
+                                // symbols of a stream (fewer than four left, or fewer than 44 bits) go one at a time, with the bits below
+                                // the stream's first one read as zeros like libzstd's container does.
+                                uint32_t hi = 0, Bh = 0; bool hdone = !mine;
+                                if (mine) {
+                                    const uint32_t lastByte = sn ? blk[sbeg + sn - 1] : 0;
+                                    if (lastByte == 0) { ok = false; hdone = true; }
+                                    else Bh = 8 * (sn - 1) + dhb32(lastByte);
                                 }
-                            } else {
-                                for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];   // periodic pattern
+                                const uint32_t tableLog = L.hufLog, tmask = (1u << tableLog) - 1;
+                                for (;;) {
+                                    const uint32_t myTop = hdone ? 0 : (Bh >> 3) + 8;                                // bytes past the stream's end are zeros
+                                    const uint32_t myWb = myTop > ZS_HWIN ? (myTop - ZS_HWIN + 15) & ~15u : 0;     // top - wb <= ZS_HWIN = one 16-byte piece per lane
+                                    for (uint32_t s_ = 0; s_ < streams; s_++) {
+                                        const uint32_t top = __shfl(myTop, s_), wb = __shfl(myWb, s_), beg = __shfl(sbeg, s_), n_ = __shfl(sn, s_);
+                                        const uint32_t k = lane * 16;
+                                        if (wb + k < top) {
+                                            uint4 v;
+                                            if (wb + k + 16 <= n_) __builtin_memcpy(&v, blk + beg + wb + k, 16);
+                                            else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wb + k + j < n_ ? blk[beg + wb + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
+                                            *reinterpret_cast<uint4*>(&L.hwin[s_ * (ZS_HWIN + 16) + k]) = v;
+                                        }
+                                    }
+                                    __threadfence_block();
+                                    WAVE_SYNC();
+                                    if (!hdone) {
+                                        const uint8_t* const win = &L.hwin[lane * (ZS_HWIN + 16)];
+                                        while (hi + 4 <= cnt && Bh >= 44 && ((Bh - 44) >> 3) >= myWb) {
+                                            const uint32_t lo = Bh - 44;
+                                            const uint64_t c = wld64(win, myWb, lo >> 3) >> (lo & 7);               // bits [lo, lo + 57) of the stream
+                                            const uint32_t e0 = L.huf[(uint32_t)(c >> (44 - tableLog)) & tmask];
+                                            uint32_t used = e0 >> 8;
+                                            const uint32_t e1 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
+                                            used += e1 >> 8;
+                                            const uint32_t e2 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
+                                            used += e2 >> 8;
+                                            const uint32_t e3 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
+                                            used += e3 >> 8;
+                                            const uint32_t packed = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+                                            __builtin_memcpy(outp + hi, &packed, 4);
+                                            hi += 4; Bh -= used;
+                                        }
+                                        while (hi < cnt && (hi + 4 > cnt || Bh < 44)) {                              // the stream's tail
+                                            const uint32_t need = Bh < tableLog ? Bh : tableLog, lo = Bh - need;
+                                            if ((lo >> 3) < myWb) break;                                             // behind the window: refill first
+                                            const uint32_t bits = (uint32_t)(wld64(win, myWb, lo >> 3) >> (lo & 7)) & ((1u << need) - 1);
+                                            const uint32_t e = L.huf[(bits << (tableLog - need)) & tmask];
+                                            if ((e >> 8) > Bh) { ok = false; hdone = true; break; }                   // reads past the stream's first bit
+                                            outp[hi++] = (uint8_t)e; Bh -= e >> 8;
+                                        }
+                                        if (!hdone && hi >= cnt) { if (Bh != 0) ok = false; hdone = true; }           // every bit used, none missing
+                                    }
+                                    WAVE_SYNC();
+                                    if (__all(hdone)) break;
+                                }
+                            }
+                            if (__any(!ok)) RFAIL(DERR_FRAME);
+                            q = hl + csize;
+                        }
+                        bd.litInPlace = litInPlace; bd.litOff = litOff; bd.litSize = litSize; bd.q = q;
+                        p += bsize;
+                    } else RFAIL(DERR_FRAME);
+                    if (last) {
+                        if (hasChecksum) { if (p + 4 > srcSize) RFAIL(DERR_FRAME); p += 4; }
+                        if (p != srcSize) RFAIL(DERR_FRAME);
+                        prodDone = true;
+                    }
+                    if (lane == 0) L.desc[it & 1] = bd;
+                    DLT(0);                                             // 0: block header + literals section
+                }
+            } else if (it >= 1) {
+                const BlkDesc* const bdp = &L.desc[(it - 1) & 1];
+                const uint32_t bsize = DUNI(bdp->bsize), btype = DUNI(bdp->btype), boff = DUNI(bdp->off);
+                frameDone = DUNI(bdp->last) != 0;
+                if (btype == 0) {                                       // raw
+                    if (opos + (uint64_t)bsize > contentSize) RFAIL(DERR_FRAME);
+                    for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = src[boff + i];
+                    opos += bsize;
+                    __threadfence_block();
+                } else if (btype == 1) {                                // RLE
+                    if (opos + (uint64_t)bsize > contentSize) RFAIL(DERR_FRAME);
+                    const uint8_t b = src[boff];
+                    for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = b;
+                    opos += bsize;
+                    __threadfence_block();
+                } else {
+                    const uint8_t* const blk = src + boff;
+                    const uint32_t litSize = DUNI(bdp->litSize);
+                    uint32_t q = DUNI(bdp->q);
+                    const uint8_t* const litPtr = DUNI(bdp->litInPlace) ? blk + DUNI(bdp->litOff) : litBuf[(it - 1) & 1];
+                    if (q >= bsize) RFAIL(DERR_FRAME);
+                    uint32_t nbSeq = blk[q];
+                    if (nbSeq == 0) q += 1;
+                    else if (nbSeq < 128) q += 1;
+                    else if (nbSeq < 255) { if (q + 2 > bsize) RFAIL(DERR_FRAME); nbSeq = ((nbSeq - 128) << 8) + blk[q + 1]; q += 2; }
+                    else { if (q + 3 > bsize) RFAIL(DERR_FRAME); nbSeq = blk[q + 1] + ((uint32_t)blk[q + 2] << 8) + 0x7F00; q += 3; }
+                    nbSeq = DUNI(nbSeq);                                        // loaded through the vector path: pin it (and every loop bound derived from it) to SGPRs
+                    if (nbSeq > ZS_BLOCK_MAX / 3 + 1) RFAIL(DERR_FRAME);            // 128 KiB / minMatch 3 = 43691 at most in a valid block
+                    if (nbSeq) {
+                        // The three sequence tables (literal lengths, offsets, match lengths).  Lane 0 parses each table description
+                        // (a short serial bit parse); the decoding table itself is built by the whole wave (fse_buildSeqTable_wave).
+                        if (q >= bsize) RFAIL(DERR_FRAME);
+                        const uint32_t modes = DUNI(blk[q]);
+                        uint32_t t = q + 1;
+                        if (modes & 3) RFAIL(DERR_FRAME);
+                        for (int k = 0; k < 3; k++) {
+                            const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
+                            SeqD* const dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
+                            uint32_t* const logp = k == 0 ? &L.llLog : k == 1 ? &L.ofLog : &L.mlLog;
+                            int* const validp = k == 0 ? &L.llValid : k == 1 ? &L.ofValid : &L.mlValid;
+                            const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
+                            if (mode == 0) {                                    // predefined distribution
+                                const short* const dn = k == 0 ? dLLnorm : k == 1 ? dOFnorm : dMLnorm;
+                                const uint32_t dmax = k == 0 ? 35 : k == 1 ? 28 : 52, dlog = k == 1 ? 5 : 6;
+                                if (lane <= dmax) L.norm[lane] = dn[lane];
+                                if (lane == 0) { *logp = dlog; *validp = 1; }
+                                __threadfence_block();
+                                WAVE_SYNC();
+                                if (!fse_buildSeqTable_wave(dt, L, dmax, dlog, k, lane)) RFAIL(DERR_FRAME);
+                            } else if (mode == 1) {                             // RLE: one symbol, no state bits
+                                if (t >= bsize) RFAIL(DERR_FRAME);
+                                const uint32_t sym = DUNI(blk[t]);
+                                t++;
+                                if (sym > maxSymK) RFAIL(DERR_FRAME);
+                                if (lane == 0) { dt[0] = SEQD(0, 0, seq_ebits(L, sym, k), sym); *logp = 0; *validp = 1; }
+                            } else if (mode == 2) {                             // FSE-compressed distribution
+                                if (t >= bsize) RFAIL(DERR_FRAME);
+                                if (lane == 0) {
+                                    uint32_t ms = maxSymK, tl = 0;
+                                    const uint32_t used = fse_readNCount(L.norm, &ms, &tl, blk + t, bsize - t, maxLogK);
+                                    L.scal[0] = used; L.scal[3] = ms; L.scal[4] = tl;
+                                    if (used) { *logp = tl; *validp = 1; }
+                                }
+                                __threadfence_block();
+                                WAVE_SYNC();
+                                const uint32_t used = DUNI(L.scal[0]), ms = DUNI(L.scal[3]), tl = DUNI(L.scal[4]);
+                                if (!used || !fse_buildSeqTable_wave(dt, L, ms, tl, k, lane)) RFAIL(DERR_FRAME);
+                                t += used;
+                            } else {                                            // repeat the previous block's table
+                                WAVE_SYNC();
+                                if (!*validp) RFAIL(DERR_FRAME);
                             }
                         }
+                        if (t >= bsize) RFAIL(DERR_FRAME);
+                        if (lane == 0) L.scal[2] = t;
                         __threadfence_block();
-                    } while (pend);
-                    lp += groupLit; opos += groupTot;
-                    DLT(3);                                                 // 3: execution
+                        WAVE_SYNC();
+                        DLT(1);                                                 // 1: sequence tables
+                    } else if (q != bsize) RFAIL(DERR_FRAME);
+                    // ---- decode and execute the sequences, 64 at a time (one per lane) ----
+                    // The sequence bit stream is one serial chain (read backwards; each FSE state transition says how many bits the
+                    // next one reads), staged through an LDS window that the whole wave refills.  Only the part of a sequence that IS
+                    // serial runs serially: pass 1 walks the three state machines for up to 64 sequences as wave-uniform scalar code
+                    // (three 4-byte table reads and one bit-window read per sequence) and drops each sequence's states and bit cursor
+                    // into its own lane (v_writelane); pass 2 lets every lane pull its sequence's extra bits out of the window and form
+                    // (literal length, match length, offset code) - all 64 at once; pass 3 resolves the repeat offsets in order (a short
+                    // uniform loop over lane values), which makes the execution below order-free.
+                    {
+                        const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog);
+                        const uint8_t* const win = L.swin;
+                        const uint8_t* stream = blk; uint32_t n = 0;
+                        uint32_t B = 0, wbase = 0, e = 0;                               // B: bits of the stream not read yet (the cursor, from the top)
+                        // lanes 0, 1, 2 = the LL, ML, OF state machines; the others carry state 0 through an all-zero entry
+                        const SeqD* const tbl = lane == 0 ? L.ll : lane == 1 ? L.ml : lane == 2 ? L.of : &L.zeroEntry;
+                        uint16_t* const recp = &L.rec[lane < 3 ? lane : 3];
+                        uint32_t st = 0;
+                        bool filled = false;
+                        if (nbSeq) {
+                            const uint32_t t = DUNI(L.scal[2]);
+                            n = DUNI(bsize - t); stream = blk + t;                  // n >= 1 (checked with the tables)
+                            const uint32_t lastByte = DUNI(stream[n - 1]);          // BIT_initDStream: the last byte carries the end mark
+                            if (lastByte == 0) RFAIL(DERR_FRAME);
+                            B = 8 * (n - 1) + dhb32(lastByte);
+                        }
+                        uint32_t lp = 0;
+                        for (uint32_t g = 0; g < nbSeq; g += LANES) {
+                            const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
+                            // 64 sequences read at most 64 * 89 bits = 712 bytes below the cursor; every read is an 8-byte load at
+                            // byte (bit >> 3), so the window holds [wbase, (B >> 3) + 8) with the bytes past the stream's end as zeros
+                            if (!filled || (wbase != 0 && (B >> 3) < wbase + 736)) {
+                                WAVE_SYNC();                                    // everyone is done with the previous window
+                                const uint32_t top = (B >> 3) + 8;
+                                wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
+                                for (uint32_t k = lane * 16; wbase + k < top; k += LANES * 16) {
+                                    uint4 v;
+                                    if (wbase + k + 16 <= n) __builtin_memcpy(&v, stream + wbase + k, 16);
+                                    else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wbase + k + j < n ? stream[wbase + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
+                                    *reinterpret_cast<uint4*>(&L.swin[k]) = v;
+                                }
+                                __threadfence_block();
+                                WAVE_SYNC();
+                                if (!filled) {                                      // initial states: LL, OF, ML (ZSTD_initFseState order)
+                                    filled = true;
+                                    const uint32_t lo = B - (llLog + ofLog + mlLog);              // <= 26 bits
+                                    if ((int32_t)lo < 0) RFAIL(DERR_FRAME);
+                                    const uint32_t w = DUNI((uint32_t)(wld64(win, wbase, lo >> 3) >> (lo & 7)));
+                                    const uint32_t sm = w & ((1u << mlLog) - 1), so = (w >> mlLog) & ((1u << ofLog) - 1), sl = (w >> (mlLog + ofLog)) & ((1u << llLog) - 1);
+                                    st = lane == 0 ? sl : lane == 1 ? sm : lane == 2 ? so : 0;
+                                    B = lo;
+                                }
+                            }
+                            // pass 1: the chain, on the vector unit.  Lanes 0, 1, 2 run the LL, ML and OF state machines (that is the order
+                            // in which a sequence's state-update bits sit in the stream, highest first); one table read serves all three,
+                            // two DPP adds give every machine the bits below its own field and lane 0 the sequence's bit total, and the
+                            // 8 bytes that hold the update bits are read together with the entries from the cursor alone ([B - 56.., B));
+                            // only a sequence that reads more than 56 bits needs a second, dependent read.  The scalar unit - ONE per CU,
+                            // shared by every wave - keeps just the cursor and the loop.  The states go to LDS (rec) for pass 2; an
+                            // over-read shows as a negative cursor (collected in `bad`, checked once per group) and is clamped so that no
+                            // load leaves the window.  The last sequence of a block reads no update bits: peeled off the loop.
+                            uint32_t bad = 0;
+                            const uint32_t Bgroup = B;
+                            const uint32_t upd = g + cnt < nbSeq ? cnt : cnt - 1;
+                            for (uint32_t j = 0; j < upd; j++) {
+                                const uint32_t p8 = (B >> 3) > 7 ? (B >> 3) - 7 : 0;                            // >= wbase: the window's margin
+                                uint64_t c8 = wld64(win, wbase, p8);
+                                const uint32_t e_ = tbl[st];
+                                recp[j * 4] = (uint16_t)st;
+                                TSX_SCHED_BARRIER();                                                           // both reads are in flight before anything waits
+                                const uint32_t pc = SEQD_COUNTS(e_);
+                                const uint32_t qc = pc + DPP_SHL(pc, 1) + DPP_SHL(pc, 2);                       // own + the machines below
+                                // extra bits of the offset, match length, literal length, then the state updates: LL, ML, OF (ZSTD_decodeSequence order)
+                                const int32_t raw = (int32_t)(B - DUNI(qc >> 5));
+                                bad |= (uint32_t)raw;
+                                const uint32_t lo = (uint32_t)(raw < 0 ? 0 : raw);
+                                uint32_t sh = lo - 8 * p8;
+                                if (lo < 8 * p8) { c8 = wld64(win, wbase, lo >> 3); sh = lo & 7; }             // rare
+                                st = SEQD_BASE(e_) + ((uint32_t)(c8 >> (sh + ((qc - pc) & 31))) & ((1u << (pc & 31)) - 1));
+                                B = lo;
+                            }
+                            if (upd < cnt) {
+                                const uint32_t e_ = tbl[st];
+                                recp[upd * 4] = (uint16_t)st;
+                                const uint32_t eb = SEQD_EBITS(e_);
+                                const int32_t raw = (int32_t)(B - DUNI(eb + DPP_SHL(eb, 1) + DPP_SHL(eb, 2)));
+                                bad |= (uint32_t)raw;
+                                B = (uint32_t)(raw < 0 ? 0 : raw);
+                            }
+                            e = bad >> 31;
+                            if (e) RFAIL(DERR_FRAME);                                // the stream is shorter than its sequences need
+                            __threadfence_block();
+                            WAVE_SYNC();
+                            // pass 2: every lane decodes the fields of its own sequence from the window; its cursor is the group's minus
+                            // the bits of the sequences before it (prefix sum)
+                            const bool valid = lane < cnt;
+                            uint32_t ll = 0, ml = 0, offBase = 4;
+                            {
+                                uint32_t el = 0, eo = 0, em = 0, mine = 0;
+                                if (valid) {
+                                    uint64_t r; __builtin_memcpy(&r, &L.rec[lane * 4], 8);
+                                    el = L.ll[(uint32_t)r & 0xFFFF]; em = L.ml[(uint32_t)(r >> 16) & 0xFFFF]; eo = L.of[(uint32_t)(r >> 32) & 0xFFFF];
+                                    mine = SEQD_TOT(el) + SEQD_TOT(eo) + SEQD_TOT(em);
+                                    if (g + lane + 1 == nbSeq) mine = SEQD_EBITS(el) + SEQD_EBITS(eo) + SEQD_EBITS(em);
+                                }
+                                uint32_t incl = mine;
+                                for (uint32_t o = 1; o < LANES; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+                                if (valid) {
+                                    const uint32_t oc = SEQD_EBITS(eo), mbits = SEQD_EBITS(em), lbits = SEQD_EBITS(el);
+                                    const uint32_t lbase = L.cLLbase[SEQD_SYM(el)], mbase = L.cMLbase[SEQD_SYM(em)];
+                                    const uint32_t lo1 = Bgroup - (incl - mine) - oc;           // offset bits first (<= 31), then ML, then LL (<= 16 each)
+                                    offBase = (1u << oc) + ((uint32_t)(wld64(win, wbase, lo1 >> 3) >> (lo1 & 7)) & ((1u << oc) - 1));
+                                    const uint32_t lo2 = lo1 - mbits - lbits;
+                                    const uint32_t w2 = (uint32_t)(wld64(win, wbase, lo2 >> 3) >> (lo2 & 7));
+                                    ll = lbase + (w2 & ((1u << lbits) - 1));
+                                    ml = mbase + ((w2 >> lbits) & ((1u << mbits) - 1));
+                                }
+                            }
+                            // pass 3: repeat offsets.  A sequence with a new offset (code > 3) knows it already and only pushes it onto the
+                            // history; the scalar loop visits just the sequences that USE the history (codes 1..3), in order, first
+                            // folding in the new offsets pushed since the previous visit (only the last three matter).  Code c names
+                            // history entry idx = c - 1 (+ 1 when the literal length is 0; idx 3 = rep0 - 1); idx >= 2 pushes the whole
+                            // history down, idx 1 swaps the first two, idx 0 leaves it alone.  All on wave-uniform values, no branches.
+                            uint32_t off = offBase - 3;
+                            {
+                                const unsigned long long ll0 = __ballot(valid && ll == 0);
+                                unsigned long long users = __ballot(valid && offBase <= 3);
+                                uint32_t r0 = DUNI(rep0), r1 = DUNI(rep1), r2 = DUNI(rep2);
+                                uint32_t prev = 0;                                                  // first sequence not folded in yet
+                                for (;;) {
+                                    const uint32_t j = users ? (uint32_t)__ffsll((long long)users) - 1 : cnt;      // next user, or the group's end
+                                    const uint32_t gap = j - prev;                                  // new offsets pushed by sequences [prev, j)
+                                    const uint32_t a1 = __builtin_amdgcn_readlane(offBase, (int)(j >= 1 ? j - 1 : 0)) - 3;
+                                    const uint32_t a2 = __builtin_amdgcn_readlane(offBase, (int)(j >= 2 ? j - 2 : 0)) - 3;
+                                    const uint32_t a3 = __builtin_amdgcn_readlane(offBase, (int)(j >= 3 ? j - 3 : 0)) - 3;
+                                    const uint32_t n2 = gap >= 3 ? a3 : gap == 2 ? r0 : gap == 1 ? r1 : r2;
+                                    const uint32_t n1 = gap >= 2 ? a2 : gap == 1 ? r0 : r1;
+                                    const uint32_t n0 = gap >= 1 ? a1 : r0;
+                                    r0 = n0; r1 = n1; r2 = n2;
+                                    if (!users) break;
+                                    users &= users - 1;
+                                    const uint32_t ob = __builtin_amdgcn_readlane(offBase, (int)j);
+                                    const uint32_t idx = ob - 1 + (uint32_t)((ll0 >> j) & 1);       // 0..3
+                                    const uint32_t c01 = idx == 0 ? r0 : r1, c23 = idx == 2 ? r2 : r0 - 1;
+                                    const uint32_t o_ = idx < 2 ? c01 : c23;
+                                    r2 = idx >= 2 ? r1 : r2;
+                                    r1 = idx >= 1 ? r0 : r1;
+                                    r0 = o_;
+                                    off = tsx_writelane(o_, j, off);
+                                    prev = j + 1;
+                                }
+                                rep0 = r0; rep1 = r1; rep2 = r2;
+                            }
+                            DLT(2);                                                 // 2: FSE sequence decode
+                            // Execution.  Positions come from prefix sums, so literal runs and every match whose source lies before the
+                            // group's first output byte are copied by their own lane, all at once; only matches that read bytes produced
+                            // inside the same group (short offsets) are replayed in order with wave-wide copies.
+                            uint32_t litIncl = ll, totIncl = ll + ml;
+                            for (int o = 1; o < LANES; o <<= 1) {
+                                const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
+                                if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
+                            }
+                            const uint32_t groupLit = __shfl(litIncl, LANES - 1), groupTot = __shfl(totIncl, LANES - 1);
+                            if (lp + groupLit > litSize || (uint64_t)opos + groupTot > contentSize) RFAIL(DERR_FRAME);
+                            const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
+                            if (__any(valid && ml && (off == 0 || off > mOut))) RFAIL(DERR_FRAME);
+                            // Short runs are copied by their own lane (all lanes at once), long ones (> ZS_LONG_RUN bytes) by the whole wave.
+                            // A match is ready when its source bytes are final: before the group's first output byte, or - after the
+                            // fence that follows each round - inside literal runs and matches already copied.  Each round copies every
+                            // pending match whose source touches no earlier pending match's destination; a match that overlaps its own
+                            // destination (offset < length) is replayed by the whole wave, in 64-byte steps or as a periodic pattern.
+                            const uint32_t s0 = mOut - off;
+                            exec_copies(out + myOut, litPtr + myLit, ll, valid && ll, lane);
+                            unsigned long long pend = __ballot(valid && ml);
+                            bool first = true;
+                            do {
+                                const bool mineP = (pend >> lane) & 1;
+                                bool blocked = mineP && off < ml;
+                                if (first) blocked = mineP && s0 + ml > opos;                          // round 0: only sources before the group
+                                else
+                                    for (unsigned long long m = pend; m; m &= m - 1) {
+                                        const int j = __ffsll((long long)m) - 1;
+                                        const uint32_t dj = __builtin_amdgcn_readlane(mOut, j), ej = dj + __builtin_amdgcn_readlane(ml, j);
+                                        if ((uint32_t)j < lane && s0 < ej && s0 + ml > dj) blocked = true;
+                                    }
+                                const unsigned long long ready = __ballot(mineP && !blocked);
+                                if (ready || first) {
+                                    exec_copies(out + mOut, out + s0, ml, (ready >> lane) & 1, lane);
+                                    pend &= ~ready;
+                                    first = false;
+                                } else {                                                                // the first pending match overlaps itself
+                                    const int i = __ffsll((long long)pend) - 1;
+                                    pend &= pend - 1;
+                                    const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
+                                    const uint32_t from = dpos - o_;
+                                    if (o_ >= LANES) {
+                                        for (uint32_t k = 0; k < m_; k += LANES) {
+                                            if (k) __threadfence_block();                               // a 64-byte step may read bytes written by the previous step
+                                            if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
+                                        }
+                                    } else {
+                                        for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];   // periodic pattern
+                                    }
+                                }
+                                __threadfence_block();
+                            } while (pend);
+                            lp += groupLit; opos += groupTot;
+                            DLT(3);                                                 // 3: execution
+                        }
+                        if (nbSeq && B != 0) RFAIL(DERR_FRAME);                     // BIT_endOfDStream: every bit of the stream was used
+                        WAVE_SYNC();                                            // the window's LDS is the next block's Huffman windows
+                        const uint32_t tail = litSize - lp;
+                        if ((uint64_t)opos + tail > contentSize) RFAIL(DERR_FRAME);
+                        for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
+                        opos += tail;
+                        __threadfence_block();
+                    }
                 }
-                if (nbSeq && B != 0) FAIL(DERR_FRAME);                     // BIT_endOfDStream: every bit of the stream was used
-                __syncthreads();                                            // the window's LDS is the next block's Huffman windows
-                const uint32_t tail = litSize - lp;
-                if ((uint64_t)opos + tail > contentSize) FAIL(DERR_FRAME);
-                for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
-                opos += tail;
-                __threadfence_block();
             }
-            p += bsize;
-        } else FAIL(DERR_FRAME);
+        }
+block_end:
+        if (myErr != TSX_OK && lane == 0) L.err = myErr;
+        DLT(4);                                                         // 4: this wave's work outside the named phases
+        __threadfence_block();
         __syncthreads();
-        if (last) break;
+        DLT(5);                                                         // 5: waiting for the other wave
+        const int32_t posted = (int32_t)DUNI(L.err);
+        if (posted != TSX_OK) { err = posted; break; }
+        if (frameDone) break;
     }
-    if (hasChecksum) { if (p + 4 > srcSize) FAIL(DERR_FRAME); p += 4; }
-    if (p != srcSize || opos != contentSize) FAIL(DERR_FRAME);
+    if (err == TSX_OK && opos != contentSize) err = DERR_FRAME;         // (wave 0's opos; wave 1's stays 0 and it reports nothing)
 done:
 #ifdef TSX_PROF2
-    DLT(4);
-    if (lane == 0 && dprof) for (int i_ = 0; i_ < 8; i_++) dprof[(size_t)chunk * 8 + i_] = dlt_[i_];
+    if (lane == 0 && dprof) {                                           // laps: literal wave -> slots 0, 6 (wait); sequence wave -> 1..4, 7 (wait)
+        if (role == 1) { dprof[(size_t)chunk * 8 + 0] = dlt_[0] + dlt_[4]; dprof[(size_t)chunk * 8 + 6] = dlt_[5]; }
+        else { for (int i_ = 1; i_ < 5; i_++) dprof[(size_t)chunk * 8 + i_] = dlt_[i_]; dprof[(size_t)chunk * 8 + 7] = dlt_[5]; }
+    }
 #endif
-    if (lane == 0) {
+    if (role == 0 && lane == 0) {
         if (err != TSX_OK) { status[chunk] = err; descs[chunk].dst_len = 0; }
         else descs[chunk].dst_len = opos;
     }
@@ -909,7 +962,7 @@ done:
 uint32_t tsx_launch_zstd_decompress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* frames, int from_mid, uint64_t mid_stride,
                                     tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work) {
     if (!n) return 0;
-    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work
+    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(2 * LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work
 #ifdef TSX_PROF2
                        , g_dprof_out
 #endif

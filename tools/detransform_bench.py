@@ -71,5 +71,7 @@ for T in (2, 3):
     del backs
 if dprof is not None:
     m = dprof.cpu().numpy().reshape(n, 8).mean(axis=0)
-    for k, name in enumerate(["block header + literals", "sequence tables", "FSE sequence decode", "execution", "rest"]):
-        print("  %-26s %12.0f cycles (%.1f%%)" % (name, m[k], 100 * m[k] / m[:5].sum()))
+    # two waves per chunk: the literal wave (slots 0, 6) runs one block ahead of the sequence wave (slots 1..4, 7)
+    for k, name in [(0, "literal wave: headers + literals"), (6, "literal wave: waiting"), (1, "sequence wave: tables"), (2, "sequence wave: FSE decode"),
+                    (3, "sequence wave: execution"), (4, "sequence wave: rest"), (7, "sequence wave: waiting")]:
+        print("  %-34s %12.0f cycles" % (name, m[k]))
