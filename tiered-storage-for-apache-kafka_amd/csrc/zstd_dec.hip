@@ -93,7 +93,8 @@ struct DecLds {
     uint32_t streamOff[5];
     // the literal wave's own scratch and windows (the two waves of a chunk run concurrently)
     short normH[16]; uint16_t symNextH[16]; uint8_t cellSymH[64]; uint32_t scalH[4];
-    BlkDesc desc[2];             // literal wave -> sequence wave, block k in slot k & 1
+    BlkDesc desc[3];             // block k in slot k % 3: written by the literal stage, read by the sequence and execution stages
+    uint32_t nseq[2];            // sequence stage -> execution stage: number of sequences of block k in slot k & 1
     int32_t err;                 // first error of either wave
     alignas(16) uint8_t hwin[4 * (ZS_HWIN + 16)];   // one window per Huffman stream
     alignas(16) uint8_t swin[ZS_DWIN + 32];        // the sequence bit stream's window
@@ -414,6 +415,9 @@ __device__ static __forceinline__ void copy_wave(uint8_t* __restrict__ dst, cons
     if (lane < (n & 7)) dst[t + lane] = src[t + lane];
 }
 #define ZS_LONG_RUN 128u
+#define ZS_DSEQ_CAP 43712u            /* >= 128 KiB / 3 sequences per block; 3 x 4 x cap bytes fit ZS_WS_SEQS and ZS_WS_STBITS.. */
+static_assert(12u * ZS_DSEQ_CAP <= 16u * (ZS_MAX_SEQ + 64) && 12u * ZS_DSEQ_CAP <= 6u * ZS_WS_CODE_STRIDE + ZS_BLOCKOUT_CAP, "sequence arrays fit the workspace regions they borrow");
+static_assert(ZS_WS_HASHLONG + (192u << 10) + ZS_BLOCK_MAX + 256 <= ZS_WS_SEQS, "literal buffers fit the hash-table region");
 // One run per lane (mine = this lane has one): the short ones all at once, each by its own lane; the long ones one after the
 // other, each by the whole wave (a single lane would spend one memory round trip per 32 bytes on them).
 __device__ static __forceinline__ void exec_copies(uint8_t* dst, const uint8_t* src, uint32_t n, bool mine, uint32_t lane) {
@@ -448,7 +452,9 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
     const uint32_t srcSize = from_mid ? d.src_len - 28 : d.src_len;
     uint8_t* __restrict__ out = dst_base + d.dst_off;
     uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
-    uint8_t* const litBuf[2] = {ws + ZS_WS_LIT, ws + ZS_WS_HASHLONG};    // literals of block k -> buffer k & 1 (the decoder needs no hash tables)
+    // literals of block k -> litBuf[k % 3], its sequences -> seqBuf[k & 1] (three arrays of ZS_DSEQ_CAP dwords); the decoder needs no hash tables
+    uint8_t* const litBuf[3] = {ws + ZS_WS_LIT, ws + ZS_WS_HASHLONG, ws + ZS_WS_HASHLONG + (192u << 10)};
+    uint8_t* const seqBuf[2] = {ws + ZS_WS_SEQS, ws + ZS_WS_STBITS};
     int32_t err = TSX_OK;
 #ifdef TSX_PROF2
     unsigned long long dlt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast_ = (unsigned long long)clock64();
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                           // repeat-offset history, carried across the blocks of the frame (wave-uniform)
     uint64_t contentSize = 0;
     uint32_t p = 0;
-    bool hasChecksum = false, prodDone = false;
+    bool hasChecksum = false, prodDone = false, fseDone = false, frameDone = false;
     // ---- frame header ----
     if (srcSize < 6) FAIL(DERR_FRAME);
     if (src[0] != 0x28 || src[1] != 0xB5 || src[2] != 0x2F || src[3] != 0xFD) FAIL(DERR_FRAME);
@@ -493,11 +499,12 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
         int32_t myErr = TSX_OK;
         // Was block it - 1 the frame's last one?  Each wave answers from its own registers (a descriptor slot may already be
         // rewritten by the other wave when the barrier opens): wave 1 finished producing, wave 0 consumed a block marked last.
-        bool frameDone = role == 1 ? prodDone : false;
+        // wave 0 is done one iteration before wave 1 executes the last block: it leaves the loop when that iteration ends
+        const bool fseWasDone = fseDone;
         {
             if (role == 1) {
                 if (!prodDone) {
-                    uint8_t* const lit = litBuf[it & 1];
+                    uint8_t* const lit = litBuf[it % 3];
                     if (p + 3 > srcSize) RFAIL(DERR_FRAME);
                     const uint32_t bh = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
                     p += 3;
@@ -634,29 +641,105 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
                         if (p != srcSize) RFAIL(DERR_FRAME);
                         prodDone = true;
                     }
-                    if (lane == 0) L.desc[it & 1] = bd;
+                    if (lane == 0) L.desc[it % 3] = bd;
                     DLT(0);                                             // 0: block header + literals section
                 }
-            } else if (it >= 1) {
-                const BlkDesc* const bdp = &L.desc[(it - 1) & 1];
+                if (it >= 2 && !frameDone) {
+                    // ---- wave 1, second half: execute block it - 2 (its literals were decoded two iterations ago, its sequences one) ----
+                    const BlkDesc* const bdp = &L.desc[(it - 2) % 3];
+                    const uint32_t bsize = DUNI(bdp->bsize), btype = DUNI(bdp->btype), boff = DUNI(bdp->off);
+                    frameDone = DUNI(bdp->last) != 0;
+                    if (btype == 0) {                                   // raw
+                        if (opos + (uint64_t)bsize > contentSize) RFAIL(DERR_FRAME);
+                        for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = src[boff + i];
+                        opos += bsize;
+                        __threadfence_block();
+                    } else if (btype == 1) {                            // RLE
+                        if (opos + (uint64_t)bsize > contentSize) RFAIL(DERR_FRAME);
+                        const uint8_t b = src[boff];
+                        for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = b;
+                        opos += bsize;
+                        __threadfence_block();
+                    } else {
+                        const uint32_t litSize = DUNI(bdp->litSize), nbSeq = DUNI(L.nseq[(it - 2) & 1]);
+                        const uint8_t* const litPtr = DUNI(bdp->litInPlace) ? src + boff + DUNI(bdp->litOff) : litBuf[(it - 2) % 3];
+                        const uint32_t* const sLL = (const uint32_t*)seqBuf[(it - 2) & 1]; const uint32_t* const sML = sLL + ZS_DSEQ_CAP; const uint32_t* const sOF = sML + ZS_DSEQ_CAP;
+                        uint32_t lp = 0;
+                        for (uint32_t g = 0; g < nbSeq; g += LANES) {
+                            const uint32_t cnt = nbSeq - g < LANES ? nbSeq - g : LANES;
+                            const bool valid = lane < cnt;
+                            const uint32_t ll = valid ? sLL[g + lane] : 0, ml = valid ? sML[g + lane] : 0, off = valid ? sOF[g + lane] : 0;
+                            // Execution.  Positions come from prefix sums, so literal runs and every match whose source lies before the
+                            // group's first output byte are copied by their own lane, all at once; only matches that read bytes produced
+                            // inside the same group (short offsets) are replayed in order with wave-wide copies.
+                            uint32_t litIncl = ll, totIncl = ll + ml;
+                            for (int o = 1; o < LANES; o <<= 1) {
+                                const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
+                                if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
+                            }
+                            const uint32_t groupLit = __shfl(litIncl, LANES - 1), groupTot = __shfl(totIncl, LANES - 1);
+                            if (lp + groupLit > litSize || (uint64_t)opos + groupTot > contentSize) RFAIL(DERR_FRAME);
+                            const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
+                            if (__any(valid && ml && (off == 0 || off > mOut))) RFAIL(DERR_FRAME);
+                            // Short runs are copied by their own lane (all lanes at once), long ones (> ZS_LONG_RUN bytes) by the whole wave.
+                            // A match is ready when its source bytes are final: before the group's first output byte, or - after the
+                            // fence that follows each round - inside literal runs and matches already copied.  Each round copies every
+                            // pending match whose source touches no earlier pending match's destination; a match that overlaps its own
+                            // destination (offset < length) is replayed by the whole wave, in 64-byte steps or as a periodic pattern.
+                            const uint32_t s0 = mOut - off;
+                            exec_copies(out + myOut, litPtr + myLit, ll, valid && ll, lane);
+                            unsigned long long pend = __ballot(valid && ml);
+                            bool first = true;
+                            do {
+                                const bool mineP = (pend >> lane) & 1;
+                                bool blocked = mineP && off < ml;
+                                if (first) blocked = mineP && s0 + ml > opos;                          // round 0: only sources before the group
+                                else
+                                    for (unsigned long long m = pend; m; m &= m - 1) {
+                                        const int j = __ffsll((long long)m) - 1;
+                                        const uint32_t dj = __builtin_amdgcn_readlane(mOut, j), ej = dj + __builtin_amdgcn_readlane(ml, j);
+                                        if ((uint32_t)j < lane && s0 < ej && s0 + ml > dj) blocked = true;
+                                    }
+                                const unsigned long long ready = __ballot(mineP && !blocked);
+                                if (ready || first) {
+                                    exec_copies(out + mOut, out + s0, ml, (ready >> lane) & 1, lane);
+                                    pend &= ~ready;
+                                    first = false;
+                                } else {                                                                // the first pending match overlaps itself
+                                    const int i = __ffsll((long long)pend) - 1;
+                                    pend &= pend - 1;
+                                    const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
+                                    const uint32_t from = dpos - o_;
+                                    if (o_ >= LANES) {
+                                        for (uint32_t k = 0; k < m_; k += LANES) {
+                                            if (k) __threadfence_block();                               // a 64-byte step may read bytes written by the previous step
+                                            if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
+                                        }
+                                    } else {
+                                        for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];   // periodic pattern
+                                    }
+                                }
+                                __threadfence_block();
+                            } while (pend);
+                            lp += groupLit; opos += groupTot;
+                        }
+                        const uint32_t tail = litSize - lp;
+                        if ((uint64_t)opos + tail > contentSize) RFAIL(DERR_FRAME);
+                        for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
+                        opos += tail;
+                        __threadfence_block();
+                    }
+                    DLT(3);                                             // 3: execution
+                }
+            } else if (it >= 1 && !fseDone) {
+                // ---- wave 0: the sequences of block it - 1 -> (literal length, match length, offset) arrays in seqBuf[(it - 1) & 1] ----
+                const BlkDesc* const bdp = &L.desc[(it - 1) % 3];
                 const uint32_t bsize = DUNI(bdp->bsize), btype = DUNI(bdp->btype), boff = DUNI(bdp->off);
-                frameDone = DUNI(bdp->last) != 0;
-                if (btype == 0) {                                       // raw
-                    if (opos + (uint64_t)bsize > contentSize) RFAIL(DERR_FRAME);
-                    for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = src[boff + i];
-                    opos += bsize;
-                    __threadfence_block();
-                } else if (btype == 1) {                                // RLE
-                    if (opos + (uint64_t)bsize > contentSize) RFAIL(DERR_FRAME);
-                    const uint8_t b = src[boff];
-                    for (uint32_t i = lane; i < bsize; i += LANES) out[opos + i] = b;
-                    opos += bsize;
-                    __threadfence_block();
-                } else {
+                if (DUNI(bdp->last)) fseDone = true;
+                if (btype == 2) {
+                    uint32_t* const sLL = (uint32_t*)seqBuf[(it - 1) & 1]; uint32_t* const sML = sLL + ZS_DSEQ_CAP; uint32_t* const sOF = sML + ZS_DSEQ_CAP;
                     const uint8_t* const blk = src + boff;
-                    const uint32_t litSize = DUNI(bdp->litSize);
                     uint32_t q = DUNI(bdp->q);
-                    const uint8_t* const litPtr = DUNI(bdp->litInPlace) ? blk + DUNI(bdp->litOff) : litBuf[(it - 1) & 1];
                     if (q >= bsize) RFAIL(DERR_FRAME);
                     uint32_t nbSeq = blk[q];
                     if (nbSeq == 0) q += 1;
@@ -741,7 +824,6 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
                             if (lastByte == 0) RFAIL(DERR_FRAME);
                             B = 8 * (n - 1) + dhb32(lastByte);
                         }
-                        uint32_t lp = 0;
                         for (uint32_t g = 0; g < nbSeq; g += LANES) {
                             const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
                             // 64 sequences read at most 64 * 89 bits = 712 bytes below the cursor; every read is an 8-byte load at
@@ -868,70 +950,12 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
                                 }
                                 rep0 = r0; rep1 = r1; rep2 = r2;
                             }
+                            if (valid) { sLL[g + lane] = ll; sML[g + lane] = ml; sOF[g + lane] = off; }
                             DLT(2);                                                 // 2: FSE sequence decode
-                            // Execution.  Positions come from prefix sums, so literal runs and every match whose source lies before the
-                            // group's first output byte are copied by their own lane, all at once; only matches that read bytes produced
-                            // inside the same group (short offsets) are replayed in order with wave-wide copies.
-                            uint32_t litIncl = ll, totIncl = ll + ml;
-                            for (int o = 1; o < LANES; o <<= 1) {
-                                const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
-                                if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
-                            }
-                            const uint32_t groupLit = __shfl(litIncl, LANES - 1), groupTot = __shfl(totIncl, LANES - 1);
-                            if (lp + groupLit > litSize || (uint64_t)opos + groupTot > contentSize) RFAIL(DERR_FRAME);
-                            const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
-                            if (__any(valid && ml && (off == 0 || off > mOut))) RFAIL(DERR_FRAME);
-                            // Short runs are copied by their own lane (all lanes at once), long ones (> ZS_LONG_RUN bytes) by the whole wave.
-                            // A match is ready when its source bytes are final: before the group's first output byte, or - after the
-                            // fence that follows each round - inside literal runs and matches already copied.  Each round copies every
-                            // pending match whose source touches no earlier pending match's destination; a match that overlaps its own
-                            // destination (offset < length) is replayed by the whole wave, in 64-byte steps or as a periodic pattern.
-                            const uint32_t s0 = mOut - off;
-                            exec_copies(out + myOut, litPtr + myLit, ll, valid && ll, lane);
-                            unsigned long long pend = __ballot(valid && ml);
-                            bool first = true;
-                            do {
-                                const bool mineP = (pend >> lane) & 1;
-                                bool blocked = mineP && off < ml;
-                                if (first) blocked = mineP && s0 + ml > opos;                          // round 0: only sources before the group
-                                else
-                                    for (unsigned long long m = pend; m; m &= m - 1) {
-                                        const int j = __ffsll((long long)m) - 1;
-                                        const uint32_t dj = __builtin_amdgcn_readlane(mOut, j), ej = dj + __builtin_amdgcn_readlane(ml, j);
-                                        if ((uint32_t)j < lane && s0 < ej && s0 + ml > dj) blocked = true;
-                                    }
-                                const unsigned long long ready = __ballot(mineP && !blocked);
-                                if (ready || first) {
-                                    exec_copies(out + mOut, out + s0, ml, (ready >> lane) & 1, lane);
-                                    pend &= ~ready;
-                                    first = false;
-                                } else {                                                                // the first pending match overlaps itself
-                                    const int i = __ffsll((long long)pend) - 1;
-                                    pend &= pend - 1;
-                                    const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
-                                    const uint32_t from = dpos - o_;
-                                    if (o_ >= LANES) {
-                                        for (uint32_t k = 0; k < m_; k += LANES) {
-                                            if (k) __threadfence_block();                               // a 64-byte step may read bytes written by the previous step
-                                            if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
-                                        }
-                                    } else {
-                                        for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];   // periodic pattern
-                                    }
-                                }
-                                __threadfence_block();
-                            } while (pend);
-                            lp += groupLit; opos += groupTot;
-                            DLT(3);                                                 // 3: execution
                         }
                         if (nbSeq && B != 0) RFAIL(DERR_FRAME);                     // BIT_endOfDStream: every bit of the stream was used
-                        WAVE_SYNC();                                            // the window's LDS is the next block's Huffman windows
-                        const uint32_t tail = litSize - lp;
-                        if ((uint64_t)opos + tail > contentSize) RFAIL(DERR_FRAME);
-                        for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
-                        opos += tail;
-                        __threadfence_block();
                     }
+                    if (lane == 0) L.nseq[(it - 1) & 1] = nbSeq;
                 }
             }
         }
@@ -943,17 +967,17 @@ block_end:
         DLT(5);                                                         // 5: waiting for the other wave
         const int32_t posted = (int32_t)DUNI(L.err);
         if (posted != TSX_OK) { err = posted; break; }
-        if (frameDone) break;
+        if (role == 1 ? frameDone : fseWasDone) break;
     }
-    if (err == TSX_OK && opos != contentSize) err = DERR_FRAME;         // (wave 0's opos; wave 1's stays 0 and it reports nothing)
+    if (role == 1 && err == TSX_OK && opos != contentSize) err = DERR_FRAME;
 done:
 #ifdef TSX_PROF2
-    if (lane == 0 && dprof) {                                           // laps: literal wave -> slots 0, 6 (wait); sequence wave -> 1..4, 7 (wait)
-        if (role == 1) { dprof[(size_t)chunk * 8 + 0] = dlt_[0] + dlt_[4]; dprof[(size_t)chunk * 8 + 6] = dlt_[5]; }
-        else { for (int i_ = 1; i_ < 5; i_++) dprof[(size_t)chunk * 8 + i_] = dlt_[i_]; dprof[(size_t)chunk * 8 + 7] = dlt_[5]; }
+    if (lane == 0 && dprof) {                                           // laps: wave 1 -> slots 0 (literals), 3 (execution), 6 (wait); wave 0 -> 1, 2, 4, 7 (wait)
+        if (role == 1) { dprof[(size_t)chunk * 8 + 0] = dlt_[0] + dlt_[4]; dprof[(size_t)chunk * 8 + 3] = dlt_[3]; dprof[(size_t)chunk * 8 + 6] = dlt_[5]; }
+        else { dprof[(size_t)chunk * 8 + 1] = dlt_[1]; dprof[(size_t)chunk * 8 + 2] = dlt_[2]; dprof[(size_t)chunk * 8 + 4] = dlt_[4]; dprof[(size_t)chunk * 8 + 7] = dlt_[5]; }
     }
 #endif
-    if (role == 0 && lane == 0) {
+    if (role == 1 && lane == 0) {
         if (err != TSX_OK) { status[chunk] = err; descs[chunk].dst_len = 0; }
         else descs[chunk].dst_len = opos;
     }
