@@ -437,7 +437,7 @@ __device__ static __forceinline__ void exec_copies(uint8_t* dst, const uint8_t* 
 #define FAIL(code) do { err = (code); goto done; } while (0)                 /* both waves, before the block loop */
 #define RFAIL(code) do { myErr = (code); goto block_end; } while (0)        /* one wave, inside its role */
 
-__global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+__global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6))) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
                                                                 tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
                                                                 int32_t* __restrict__ status, uint8_t* __restrict__ work
 #ifdef TSX_PROF2
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
 #endif
                                                                 ) {
     __shared__ DecLds L;
-    const uint32_t lane = threadIdx.x & (LANES - 1), role = DUNI(threadIdx.x >> 6), chunk = blockIdx.x;   // role 0: sequences + execution, role 1: literals
+    const uint32_t lane = threadIdx.x & (LANES - 1), role = DUNI(threadIdx.x >> 6), chunk = blockIdx.x;   // wave 0: sequence streams, wave 1: literals, wave 2: execution
     if (status[chunk] != TSX_OK) return;
     const tsx_chunk_desc d = descs[chunk];
     const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
@@ -499,8 +499,6 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
         int32_t myErr = TSX_OK;
         // Was block it - 1 the frame's last one?  Each wave answers from its own registers (a descriptor slot may already be
         // rewritten by the other wave when the barrier opens): wave 1 finished producing, wave 0 consumed a block marked last.
-        // wave 0 is done one iteration before wave 1 executes the last block: it leaves the loop when that iteration ends
-        const bool fseWasDone = fseDone;
         {
             if (role == 1) {
                 if (!prodDone) {
@@ -644,8 +642,9 @@ __global__ __launch_bounds__(2 * LANES) void zstd_decompress_kernel(const uint8_
                     if (lane == 0) L.desc[it % 3] = bd;
                     DLT(0);                                             // 0: block header + literals section
                 }
-                if (it >= 2 && !frameDone) {
-                    // ---- wave 1, second half: execute block it - 2 (its literals were decoded two iterations ago, its sequences one) ----
+            } else if (role == 2) {
+                if (it >= 2) {
+                    // ---- wave 2: execute block it - 2 (its literals were decoded two iterations ago, its sequences one) ----
                     const BlkDesc* const bdp = &L.desc[(it - 2) % 3];
                     const uint32_t bsize = DUNI(bdp->bsize), btype = DUNI(bdp->btype), boff = DUNI(bdp->off);
                     frameDone = DUNI(bdp->last) != 0;
@@ -967,17 +966,19 @@ block_end:
         DLT(5);                                                         // 5: waiting for the other wave
         const int32_t posted = (int32_t)DUNI(L.err);
         if (posted != TSX_OK) { err = posted; break; }
-        if (role == 1 ? frameDone : fseWasDone) break;
+        if (role == 0 ? fseDone : role == 1 ? prodDone : frameDone) break;     // a wave that has nothing left to do leaves; the barrier counts live waves
     }
-    if (role == 1 && err == TSX_OK && opos != contentSize) err = DERR_FRAME;
+    if (role == 2 && err == TSX_OK && opos != contentSize) err = DERR_FRAME;
 done:
 #ifdef TSX_PROF2
-    if (lane == 0 && dprof) {                                           // laps: wave 1 -> slots 0 (literals), 3 (execution), 6 (wait); wave 0 -> 1, 2, 4, 7 (wait)
-        if (role == 1) { dprof[(size_t)chunk * 8 + 0] = dlt_[0] + dlt_[4]; dprof[(size_t)chunk * 8 + 3] = dlt_[3]; dprof[(size_t)chunk * 8 + 6] = dlt_[5]; }
-        else { dprof[(size_t)chunk * 8 + 1] = dlt_[1]; dprof[(size_t)chunk * 8 + 2] = dlt_[2]; dprof[(size_t)chunk * 8 + 4] = dlt_[4]; dprof[(size_t)chunk * 8 + 7] = dlt_[5]; }
+    if (lane == 0 && dprof) {                                           // laps: wave 1 -> 0 (literals), 6 (wait); wave 2 -> 3 (execution), 5 (wait); wave 0 -> 1, 2, 4, 7 (wait)
+        unsigned long long* const dp = dprof + (size_t)chunk * 8;
+        if (role == 1) { dp[0] = dlt_[0] + dlt_[4]; dp[6] = dlt_[5]; }
+        else if (role == 2) { dp[3] = dlt_[3] + dlt_[4]; dp[5] = dlt_[5]; }
+        else { dp[1] = dlt_[1]; dp[2] = dlt_[2]; dp[4] = dlt_[4]; dp[7] = dlt_[5]; }
     }
 #endif
-    if (role == 1 && lane == 0) {
+    if (role == 2 && lane == 0) {
         if (err != TSX_OK) { status[chunk] = err; descs[chunk].dst_len = 0; }
         else descs[chunk].dst_len = opos;
     }
@@ -986,7 +987,7 @@ done:
 uint32_t tsx_launch_zstd_decompress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* frames, int from_mid, uint64_t mid_stride,
                                     tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work) {
     if (!n) return 0;
-    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(2 * LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work
+    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(3 * LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work
 #ifdef TSX_PROF2
                        , g_dprof_out
 #endif

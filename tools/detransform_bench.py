@@ -71,7 +71,7 @@ for T in (2, 3):
     del backs
 if dprof is not None:
     m = dprof.cpu().numpy().reshape(n, 8).mean(axis=0)
-    # two waves per chunk, three stages one block apart: wave 1 = literals of block k + execution of block k - 2, wave 0 = sequences of block k - 1
-    for k, name in [(0, "wave 1: headers + literals"), (3, "wave 1: execution"), (6, "wave 1: waiting"), (1, "wave 0: sequence tables"),
-                    (2, "wave 0: FSE decode"), (4, "wave 0: rest"), (7, "wave 0: waiting")]:
+    # three waves per chunk, one per stage, one block apart: wave 1 = literals of block k, wave 0 = sequences of block k - 1, wave 2 = execution of block k - 2
+    for k, name in [(0, "wave 1: headers + literals"), (6, "wave 1: waiting"), (1, "wave 0: sequence tables"), (2, "wave 0: FSE decode"), (4, "wave 0: rest"),
+                    (7, "wave 0: waiting"), (3, "wave 2: execution"), (5, "wave 2: waiting")]:
         print("  %-34s %12.0f cycles" % (name, m[k]))
