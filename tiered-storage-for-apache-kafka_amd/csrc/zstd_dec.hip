@@ -37,8 +37,8 @@ __device__ static const short dMLnorm[53] = {1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1
 __device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }
 __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
-#define ZS_DWIN 4096u
-#define ZS_HWIN 512u
+#define ZS_DWIN 2048u
+#define ZS_HWIN 256u
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 // sequence decoding entry, one dword: next-state base (bits 0-8) | nbBits (9-13) | nbBits + the symbol's number of extra
 // bits (14-20) | the symbol (21-26).  Bits 9-20 are laid out so that ONE add sums both counts over the three tables (no carry:
@@ -76,7 +76,11 @@ struct BlkDesc { uint32_t off, bsize, btype, last, litInPlace, litOff, litSize, 
 #define WAVE_SYNC() do { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
 struct DecLds {
-    uint16_t huf[2048];          // (nbBits << 8) | symbol; Max_Number_of_Bits of a literals tree is 11 (RFC 8878 4.2.1)
+    // Literal Huffman table, indexed by the next 11 bits of a stream (Max_Number_of_Bits of a literals tree is 11, RFC 8878
+    // 4.2.1): up to three whole symbols that those bits decode to | total bits << 24 | number of symbols << 28
+    uint32_t hufX[2048];
+    uint16_t hufRs[16], hufSymStart[16];   // canonical form: first table index / first entry of hufSorted of each weight
+    uint8_t hufSorted[256];                // symbols by (weight, symbol)
     uint32_t hufLog; int hufValid;
     SeqD ll[512], of[256], ml[512];
     SeqD zeroEntry;              // the 'table' of the lanes that run no state machine
@@ -352,18 +356,40 @@ __device__ static uint32_t huf_readTable(DecLds& L, const uint8_t* src, uint32_t
     const uint32_t lastW = dhb32(rest) + 1;
     L.weights[nw++] = (uint8_t)lastW; L.rankCount[lastW]++;
     if (L.rankCount[1] < 2 || (L.rankCount[1] & 1)) return 0;
-    uint32_t next = 0;
-    for (uint32_t w = 1; w <= tableLog; w++) { L.rankStart[w] = next; next += L.rankCount[w] << (w - 1); }
-    for (uint32_t s = 0; s < nw; s++) {
-        const uint32_t w = L.weights[s];
-        if (!w) continue;
-        const uint32_t len = (1u << w) >> 1, nb = tableLog + 1 - w;
-        const uint16_t e = (uint16_t)((nb << 8) | s);
-        for (uint32_t i = L.rankStart[w]; i < L.rankStart[w] + len; i++) L.huf[i] = e;
-        L.rankStart[w] += len;
+    // canonical layout: weight-1 symbols (the longest codes, tableLog bits) own the lowest table indices, one index each; a
+    // symbol of weight w owns 1 << (w - 1) consecutive indices and is coded on tableLog + 1 - w bits
+    uint32_t next = 0, cnt = 0;
+    for (uint32_t w = 1; w <= tableLog; w++) {
+        L.hufRs[w] = (uint16_t)next; next += L.rankCount[w] << (w - 1);
+        L.hufSymStart[w] = (uint16_t)cnt; L.rankStart[w] = cnt; cnt += L.rankCount[w];
     }
+    L.hufRs[tableLog + 1] = (uint16_t)next;
+    for (uint32_t sy = 0; sy < nw; sy++) { const uint32_t w = L.weights[sy]; if (w) L.hufSorted[L.rankStart[w]++] = (uint8_t)sy; }
     L.hufLog = tableLog; L.hufValid = 1;
     return used;
+}
+
+// One symbol from the canonical form: idx = the next tableLog bits (zero-padded below the stream's first bit).  -> symbol | nbBits << 8
+__device__ static inline uint32_t huf_decode1(const DecLds& L, uint32_t idx, uint32_t tableLog) {
+    uint32_t w = 1;
+    for (uint32_t ww = 2; ww <= tableLog; ww++) if (L.hufRs[ww] <= idx) w = ww;          // empty weights share their start with the next one
+    const uint32_t sym = L.hufSorted[L.hufSymStart[w] + ((idx - L.hufRs[w]) >> (w - 1))];
+    return sym | ((tableLog + 1 - w) << 8);
+}
+// The 11-bit multi-symbol table, built by the whole wave: entry x = the (up to three) symbols whose codes fit entirely in x.
+__device__ static void huf_buildX_wave(DecLds& L, uint32_t lane) {
+    const uint32_t tl = L.hufLog, mask = (1u << tl) - 1;
+    for (uint32_t x = lane; x < 2048; x += LANES) {
+        uint32_t pos = 0, ns = 0, syms = 0;
+        for (uint32_t k = 0; k < 3 && pos < 11; k++) {
+            const uint32_t rem = 11 - pos;
+            const uint32_t idx = rem >= tl ? (x >> (rem - tl)) & mask : (x << (tl - rem)) & mask;
+            const uint32_t e = huf_decode1(L, idx, tl);
+            if ((e >> 8) > rem) break;                                 // this code runs past the 11 bits
+            syms |= (e & 0xFF) << (8 * k); pos += e >> 8; ns++;
+        }
+        L.hufX[x] = syms | (pos << 24) | (ns << 28);
+    }
 }
 
 // one Huffman stream -> exactly `count` symbols; false when the stream is malformed
@@ -547,6 +573,8 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                                 const uint32_t used = L.scalH[0];
                                 WAVE_SYNC();
                                 if (!used) RFAIL(DERR_FRAME);
+                                huf_buildX_wave(L, lane);
+                                WAVE_SYNC();
                                 t += used;
                             } else if (!L.hufValid) RFAIL(DERR_FRAME);
                             const uint32_t payload = hl + csize - t;
@@ -599,26 +627,25 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                                     WAVE_SYNC();
                                     if (!hdone) {
                                         const uint8_t* const win = &L.hwin[lane * (ZS_HWIN + 16)];
-                                        while (hi + 4 <= cnt && Bh >= 44 && ((Bh - 44) >> 3) >= myWb) {
-                                            const uint32_t lo = Bh - 44;
-                                            const uint64_t c = wld64(win, myWb, lo >> 3) >> (lo & 7);               // bits [lo, lo + 57) of the stream
-                                            const uint32_t e0 = L.huf[(uint32_t)(c >> (44 - tableLog)) & tmask];
-                                            uint32_t used = e0 >> 8;
-                                            const uint32_t e1 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
-                                            used += e1 >> 8;
-                                            const uint32_t e2 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
-                                            used += e2 >> 8;
-                                            const uint32_t e3 = L.huf[(uint32_t)(c >> (44 - tableLog - used)) & tmask];
-                                            used += e3 >> 8;
-                                            const uint32_t packed = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
-                                            __builtin_memcpy(outp + hi, &packed, 4);
-                                            hi += 4; Bh -= used;
+                                        // five table reads per 8-byte window read: each yields the one to three symbols coded in the next 11 bits
+                                        while (hi + 16 <= cnt && Bh >= 56 && ((Bh - 56) >> 3) >= myWb) {
+                                            const uint32_t lo = Bh - 56;
+                                            const uint64_t c = wld64(win, myWb, lo >> 3) >> (lo & 7);               // bits [lo, lo + 56) of the stream
+                                            uint32_t used = 0;
+                                            #pragma unroll
+                                            for (int k = 0; k < 5; k++) {
+                                                const uint32_t e = L.hufX[(uint32_t)(c >> (45 - used)) & 0x7FF];
+                                                const uint32_t sy = e & 0xFFFFFF;                                  // one byte of slack behind the symbols
+                                                __builtin_memcpy(outp + hi, &sy, 4);
+                                                hi += e >> 28; used += (e >> 24) & 15;
+                                            }
+                                            Bh -= used;
                                         }
-                                        while (hi < cnt && (hi + 4 > cnt || Bh < 44)) {                              // the stream's tail
+                                        while (hi < cnt && (hi + 16 > cnt || Bh < 56)) {                             // the stream's tail, one symbol at a time
                                             const uint32_t need = Bh < tableLog ? Bh : tableLog, lo = Bh - need;
                                             if ((lo >> 3) < myWb) break;                                             // behind the window: refill first
                                             const uint32_t bits = (uint32_t)(wld64(win, myWb, lo >> 3) >> (lo & 7)) & ((1u << need) - 1);
-                                            const uint32_t e = L.huf[(bits << (tableLog - need)) & tmask];
+                                            const uint32_t e = huf_decode1(L, (bits << (tableLog - need)) & tmask, tableLog);
                                             if ((e >> 8) > Bh) { ok = false; hdone = true; break; }                   // reads past the stream's first bit
                                             outp[hi++] = (uint8_t)e; Bh -= e >> 8;
                                         }
