@@ -119,11 +119,12 @@ inline unsigned long long __ballot(int pred) {
 }
 inline int __any(int p) { return __ballot(p) != 0; }
 inline int __all(int p) { return __ballot(!p) == 0; }
-inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) {
+inline int __builtin_amdgcn_readfirstlane(int v) {                 // int like the real builtin
     unsigned long long live = hipemu::wave_live_mask();
     return hipemu_xchg(v, __builtin_ctzll(live));
 }
-inline unsigned __builtin_amdgcn_readlane(unsigned v, int lane) { return hipemu_xchg(v, lane); }
+// the real builtin is  int __builtin_amdgcn_readlane(int, int): a result OR-ed into a 64-bit value sign-extends - keep that visible here
+inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu_xchg(v, lane); }
 // DPP row shifts (row = 16 lanes): row_shl:n (ctrl 0x100 + n) gives lane i the value of lane i + n, row_shr:n (0x110 + n) of
 // lane i - n; a source outside the row yields 0 with bound_ctrl, else `old`.  Other controls are not emulated.
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool bound_ctrl) {

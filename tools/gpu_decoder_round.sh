@@ -1,6 +1,5 @@
 #!/bin/bash
-# One GPU-box call: parity tests, the inverse chain with the current decoder vs the previous one (libtsxform_decold.so, built from
-# the parent commit's zstd_dec.hip) and its phase laps (libtsxform_prof2.so), the bench line, rocprofv3 kernel stats of the bench.
+# One GPU-box call: parity tests, the inverse chain (timing, batches in flight, phase laps from libtsxform_prof2.so), the bench line, rocprofv3 kernel stats of the bench.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/dec
@@ -8,8 +7,7 @@ rm -rf $O; mkdir -p $O
 cd $R
 timeout 170 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 timeout 120 python tools/detransform_bench.py 2048 libtsxform.so > $O/detransform_new.txt 2>&1; tail -4 $O/detransform_new.txt
-[ -f tiered-storage-for-apache-kafka_amd/libtsxform_decold.so ] && timeout 100 python tools/detransform_bench.py 2048 libtsxform_decold.so > $O/detransform_old.txt 2>&1; tail -3 $O/detransform_old.txt
-[ -f tiered-storage-for-apache-kafka_amd/libtsxform_prof2.so ] && timeout 100 python tools/detransform_bench.py 2048 libtsxform_prof2.so > $O/detransform_prof2.txt 2>&1; tail -6 $O/detransform_prof2.txt
+[ -f tiered-storage-for-apache-kafka_amd/libtsxform_prof2.so ] && timeout 100 python tools/detransform_bench.py 2048 libtsxform_prof2.so > $O/detransform_prof2.txt 2>&1; tail -9 $O/detransform_prof2.txt
 timeout 240 python bench.py --steps 9 --warmup 1 2> $O/bench_full.err | tail -1 > $O/bench_full.json; cat $O/bench_full.json | cut -c1-400
 cd /tmp
 timeout 150 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/stats.log 2>&1
