@@ -177,3 +177,23 @@ def test_window_edge_chunk(emu, oracle):
     c = window_edge_case(1071)
     outs, d = pc.run_transform(emu, nat.COMPRESS, [c])
     assert d["status"][0] == 0 and outs[0] == oracle.zstd_compress_chunk(c.tobytes())
+
+
+def test_decoder_pipeline_over_many_mixed_blocks(emu, oracle):
+    """The decoder's three stages (literals / sequence streams / execution) run one block apart on the chunk's three waves:
+    frames of 1, 2, 3 and ~10 blocks, with raw, RLE and compressed blocks, raw / RLE / Huffman / treeless literals and
+    predefined / RLE / FSE / repeat sequence tables next to each other (levels 1, 3 and 19 choose differently)."""
+    K = synth.gen_chunk("K", 9, 1, 3, 600000); R = synth.gen_chunk("R", 9, 1, 4, 300000)
+    many = np.concatenate([K[:300000], R[:140000], np.zeros(262144, np.uint8), K[300000:420000], np.full(131072, 7, np.uint8),
+                           R[140000:150000], K[420000:600000], np.tile(np.frombuffer(b"0123456789abcdef", np.uint8), 9000)])
+    inputs = {"1 block": K[:100000], "2 blocks": K[:200000], "3 blocks": K[:380000], "many": many,
+              "tiny blocks": np.concatenate([K[:131072], K[:40], R[:131072], K[40:90]])}
+    for level in (1, 3, 19):
+        blobs = [oracle.zstd_compress_chunk(v.tobytes(), level) for v in inputs.values()]
+        kinds = set()
+        for b in blobs:
+            kinds |= {(blk.btype, getattr(blk, "lit_type", None)) for blk in zi.parse_frame(b)[1]}
+        outs, d = pc.run_detransform(emu, nat.COMPRESS, blobs, [int(v.size) for v in inputs.values()])
+        for i, (name, v) in enumerate(inputs.items()):
+            assert d["status"][i] == 0 and outs[i] == v.tobytes(), (name, level)
+        assert {k[0] for k in kinds} >= {"compressed", "raw"}, kinds
