@@ -1,4 +1,4 @@
-// Zstandard frame decoder — gfx950, one 64-lane wavefront per chunk.
+// Zstandard frame decoder — gfx950, one workgroup of three 64-lane wavefronts per chunk.
 //
 // Replaces zstd-jni's  Zstd.decompressedSize(chunk) / Zstd.decompress(chunk, size)
 //   core/src/main/java/io/aiven/kafka/tieredstorage/transform/DecompressionChunkEnumeration.java:39-46
@@ -9,11 +9,14 @@
 // "Invalid decompressed size"), TSX_E_DST_TOO_SMALL, TSX_E_BAD_FRAME for anything malformed.  A content
 // checksum, when present, is skipped, not verified (the reference's writer never emits one).
 //
-// Work split inside the wave: header parsing and table construction are scalar (lane 0, tables in LDS and
-// kept across blocks for the repeat modes); the four Huffman literal streams decode on four lanes at once;
-// the FSE sequence stream is a serial dependency chain (lane 0) that only produces (literal length, match
-// length, offset) triples; executing them — literal copies and match copies, the bulk of the bytes — uses all
-// 64 lanes, with a fence only when a match reads bytes written since the previous fence.
+// A block goes through three stages, each a serial chain that keeps only a few lanes busy, so the chunk's three
+// waves run them one block apart and meet at one workgroup barrier per block:
+//   wave 1  block headers + literals: the 1 or 4 Huffman streams on lanes 0-3, through per-stream LDS windows and an
+//           11-bit table that yields up to three symbols per read                          -> literal buffer k % 3
+//   wave 0  sequence stream: the LL / ML / OF state machines in lanes 0-2 (one table read, two DPP adds per sequence),
+//           then every lane extracts its own sequence's extra bits; repeat offsets resolved in order -> arrays k & 1
+//   wave 2  execution: 64 sequences per step, positions by prefix sums, copies in dependency rounds  -> the output
+// Every loop is bounded by sizes read from the frame; every index into LDS or the workspace is checked against them.
 #include "zstd_common.h"
 
 #define LANES 64
@@ -50,7 +53,6 @@ struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 #else
 extern "C" __device__ uint32_t tsx_writelane(uint32_t v, uint32_t lane, uint32_t old) __asm("llvm.amdgcn.writelane.i32");
 #endif
-__device__ static inline uint64_t duni64(uint64_t v) { return ((uint64_t)DUNI(v >> 32) << 32) | DUNI(v); }
 typedef uint32_t SeqD;
 #define SEQD(base_, nb_, ebits_, sym_) ((uint32_t)(base_) | ((uint32_t)(nb_) << 9) | ((uint32_t)((nb_) + (ebits_)) << 14) | ((uint32_t)(sym_) << 21))
 #define SEQD_BASE(e_) ((e_) & 0x1FFu)
@@ -142,42 +144,10 @@ __device__ static inline bool br_reload(BitR& b) {
     b.c = dld64(b.ptr);
     return true;
 }
-__device__ static inline bool br_finished(const BitR& b) { return b.ptr == b.start && b.consumed == 64; }
 
-// The same reader over a window of the stream held in LDS: win[0 ..) = stream bytes [wbase ..); positions are offsets
-// in the stream, so no pointer ever leaves the window array.
-struct BitW { uint64_t c; uint32_t pos, consumed; bool bad; };
+// An 8-byte read from a window of a bit stream held in LDS: win[0 ..) = stream bytes [wbase ..), positions are offsets in the
+// stream, so no pointer ever leaves the window array.
 __device__ static inline uint64_t wld64(const uint8_t* win, uint32_t wbase, uint32_t pos) { return dld64(win + (pos - wbase)); }
-__device__ static void bw_init(BitW& b, const uint8_t* win, uint32_t wbase, uint32_t n) {
-    b.bad = false; b.consumed = 0; b.c = 0; b.pos = 0;
-    if (n == 0) { b.bad = true; return; }
-    const uint8_t last = win[n - 1 - wbase];
-    if (last == 0) { b.bad = true; return; }
-    if (n >= 8) { b.pos = n - 8; b.c = wld64(win, wbase, b.pos); b.consumed = 8 - dhb32(last); }
-    else {
-        uint64_t c = 0;
-        for (uint32_t i = 0; i < n; i++) c |= (uint64_t)win[i] << (8 * i);      // n < 8: wbase == 0
-        b.c = c;
-        b.consumed = 8 - dhb32(last) + (8 - n) * 8;
-    }
-}
-__device__ static inline uint64_t bw_read(BitW& b, uint32_t nb) {
-    if (!nb) return 0;
-    const uint64_t v = (b.c << (b.consumed & 63)) >> (64 - nb);
-    b.consumed += nb;
-    return v;
-}
-__device__ static inline bool bw_reload(BitW& b, const uint8_t* win, uint32_t wbase) {
-    if (b.consumed > 64) return false;
-    if (b.pos >= 8) { b.pos -= b.consumed >> 3; b.consumed &= 7; b.c = wld64(win, wbase, b.pos); return true; }
-    if (b.pos == 0) return true;
-    uint32_t nbBytes = b.consumed >> 3;
-    if (nbBytes > b.pos) nbBytes = b.pos;
-    b.pos -= nbBytes; b.consumed -= nbBytes * 8;
-    b.c = wld64(win, wbase, b.pos);
-    return true;
-}
-__device__ static inline bool bw_finished(const BitW& b) { return b.pos == 0 && b.consumed == 64; }
 
 // ---- FSE table description + decoding table (lane 0) ---------------------------------------------------------
 // returns bytes consumed, 0 on error
@@ -390,21 +360,6 @@ __device__ static void huf_buildX_wave(DecLds& L, uint32_t lane) {
         }
         L.hufX[x] = syms | (pos << 24) | (ns << 28);
     }
-}
-
-// one Huffman stream -> exactly `count` symbols; false when the stream is malformed
-__device__ static bool huf_decodeStream(uint8_t* __restrict__ out, uint32_t count, const uint8_t* __restrict__ src, uint32_t n, const uint16_t* __restrict__ table, uint32_t tableLog) {
-    BitR b; br_init(b, src, n);
-    if (b.bad) return false;
-    for (uint32_t i = 0; i < count; i++) {
-        if ((i & 3) == 0 && !br_reload(b)) return false;       // 4 x 12 bits fit between reloads
-        const uint16_t e = table[br_look(b, tableLog)];
-        b.consumed += e >> 8;
-        out[i] = (uint8_t)e;
-    }
-    if (b.consumed > 64) return false;
-    br_reload(b);
-    return br_finished(b);
 }
 
 // Per-lane copy of a short, non-overlapping run (a literal run, or a match whose source is already final): up to four
