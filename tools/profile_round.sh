@@ -9,6 +9,7 @@ python bench.py --steps 12 --warmup 1 2>/dev/null | tail -1 > $O/bench_full.json
 python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_full_inflight1.json
 python bench.py --workload gcm_crc --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/bench_gcm_crc.json
 python bench.py --workload crc --steps 20 --warmup 2 2>/dev/null | tail -1 > $O/bench_crc.json
+python tools/detransform_bench.py 2048 libtsxform.so 2>&1 | grep -v amdgpu.ids > $O/detransform.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-verify > $O/stats.log 2>&1
 find $O/stats -name "*kernel_trace.csv" -delete; find $O/stats -name "*agent_info.csv" -delete; head -c 200000 $O/stats.log > $O/stats.log.head; rm -f $O/stats.log
