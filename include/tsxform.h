@@ -43,6 +43,12 @@ extern "C" {
 /* where src/dst live */
 #define TSX_MEM_HOST   0 /* host pointers: staged through pinned memory + H2D/D2H on the ctx stream */
 #define TSX_MEM_DEVICE 1 /* device pointers (same HIP runtime/process): no copies                    */
+/* host pointers, transformed chunks written BACK TO BACK into dst in batch order - the bytes of the `.log` object (or of a
+ * multipart part buffer) exactly as TransformFinisher.java:134-151 (SequenceInputStream over the chunks) hands them to
+ * ObjectUploader.upload / S3MultiPartOutputStream.java:89-122, without the bound-sized slot per chunk and the gather copy
+ * behind it.  tsx_transform_batch only.  descs[i].dst_off / dst_cap are ignored on entry; on return dst_off is chunk i's
+ * offset in dst and dst_len its size; a chunk that no longer fits dst_size gets TSX_E_DST_TOO_SMALL (and so do all after it). */
+#define TSX_MEM_HOST_PACKED 2
 
 /* status / error codes (0 = ok, negative = error) */
 #define TSX_OK               0

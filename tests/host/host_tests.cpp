@@ -247,6 +247,27 @@ static void backendTests(bool full) {
                                                                  chunkSize == 0 ? (int)data.size() : chunkSize, 16);
         CHECK(DetransformFinisher(d).toBytes() == data);
     };
+    // the object assembled in place (TSX_MEM_HOST_PACKED through TransformFinisher::toBytesPacked) is byte for
+    // byte the object the per-chunk path builds, with the same chunk index - for every chain and for chunking disabled
+    auto packedEqualsChunked = [&](const Bytes& data, int chunkSize, bool compression, bool encryption) {
+        auto make = [&] {
+            std::shared_ptr<TransformChunkEnumeration> t = std::make_shared<BaseTransformChunkEnumeration>(stream(data), chunkSize);
+            if (compression || encryption)
+                t = std::make_shared<GpuTransformChunkEnumeration>(be, t, compression, encryption ? std::optional<DataKeyAndAAD>(DataKeyAndAAD{KEY, AAD}) : std::nullopt, countingIv(), 7);
+            return t;
+        };
+        TransformFinisher a(make(), (int)data.size(), chunkSize != 0), b(make(), (int)data.size(), chunkSize != 0);
+        const Bytes chunked = a.toBytes(), packed = b.toBytesPacked();
+        CHECK(packed == chunked);
+        auto ia = a.chunkIndex(), ib = b.chunkIndex();
+        CHECK(ia->isFixed() == ib->isFixed() && ia->chunks().size() == ib->chunks().size());
+        for (size_t i = 0; i < ia->chunks().size(); i++)
+            CHECK(ia->chunks()[i].transformedPosition == ib->chunks()[i].transformedPosition && ia->chunks()[i].transformedSize == ib->chunks()[i].transformedSize);
+    };
+    run("TransformFinisher.toBytesPacked (upload sink without per-chunk copies)", [&] {
+        for (int c : {0, 4096 + 3, 16384})
+            for (int mode = 1; mode < 4; mode++) packedEqualsChunked(text, c, (mode & 1) != 0, (mode & 2) != 0);
+    });
     const int S = ORIGINAL_SIZE;
     run("TransformsEndToEndTest.plaintext", [&] { for (int c : {0, 1024, 1024 * 2, 1024 * 5 + 3, S - 1, S * 2}) endToEnd(original, c, false, false); });
     run("TransformsEndToEndTest.encryption", [&] { for (int c : {0, 1024 * 5 + 3, 16384 + 2, S - 1, S * 2}) endToEnd(original, c, false, true); });

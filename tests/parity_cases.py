@@ -47,6 +47,9 @@ def run_transform(N, flags, chunks, key=synth.KEY, aad=synth.AAD, mem=None, prof
         N.transform_batch(p, d, ds, dd, dst.size, nat.MEM_DEVICE)
         N.d2h(dst, dd)
         N.device_free(ds); N.device_free(dd)
+    elif mem == "packed":                                               # TSX_MEM_HOST_PACKED: outputs back to back, offsets are results
+        N.transform_batch(p, d, src, dst, dst.size, nat.MEM_HOST_PACKED)
+        return [dst[int(d["dst_off"][i]):int(d["dst_off"][i]) + int(d["dst_len"][i])].tobytes() for i in range(len(sizes))], d
     else:
         N.transform_batch(p, d, src, dst, dst.size)
     outs = [dst[doff[i]:doff[i] + d["dst_len"][i]].tobytes() for i in range(len(sizes))]

@@ -6,6 +6,7 @@ import pytest
 
 import tsxform
 from tests import parity_cases as pc
+from tsxform import synth
 
 nat = tsxform._native
 
@@ -108,3 +109,37 @@ def test_explicit_context_and_timing(emu):
     t = emu.ctx_timing(ctx)
     assert t.gcm_launches == 2 and t.total_ms >= 0
     emu.ctx_destroy(ctx)
+
+
+def test_packed_host_output_is_the_object_bytes(emu):
+    """TSX_MEM_HOST_PACKED: the transformed chunks land back to back in the caller's buffer - the `.log` object as
+    TransformFinisher.java:134-151 concatenates it - with the same bytes as the slot-per-chunk layout."""
+    from tests import parity_cases as pc
+    chunks = [synth.gen_chunk("K", 3, 0, i, n) for i, n in enumerate((70000, 1, 4096, 0, 33333, 65537))]
+    for flags in (nat.ENCRYPT | nat.CRC, nat.COMPRESS | nat.ENCRYPT | nat.CRC, nat.COMPRESS):
+        if (flags & nat.COMPRESS) and not getattr(tsxform, "HAVE_ZSTD", False):
+            continue
+        slots, d0 = pc.run_transform(emu, flags, chunks)
+        packed, d1 = pc.run_transform(emu, flags, chunks, mem="packed")
+        assert packed == slots and (d1["status"] == 0).all() and (d1["crc32c"] == d0["crc32c"]).all()
+        ends = np.cumsum(d1["dst_len"].astype(np.int64))
+        assert (d1["dst_off"].astype(np.int64) == ends - d1["dst_len"]).all()          # offsets = running sum of the sizes
+    # a buffer that holds only the first chunks: the rest are reported per chunk, nothing is written past the end
+    sizes = [len(b) for b in slots]
+    flags = nat.COMPRESS if getattr(tsxform, "HAVE_ZSTD", False) else nat.ENCRYPT
+    ref, _ = pc.run_transform(emu, flags, chunks)
+    room = len(ref[0]) + len(ref[1]) + 7
+    N = emu
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    lens = [int(c.size) for c in chunks]
+    soff, doff, caps, st, dt = pc.layout(lens, flags, N)
+    src = np.zeros(max(st, 16), np.uint8)
+    for c, o_ in zip(chunks, soff):
+        src[o_:o_ + c.size] = c
+    d = pc.make_descs(lens, soff, doff, caps)
+    dst = np.full(room + 64, 0xEE, np.uint8)
+    N.transform_batch(p, d, src, dst, room, nat.MEM_HOST_PACKED)
+    assert list(d["status"][:2]) == [0, 0] and (d["status"][2:] == nat.E_DST_TOO_SMALL).all() and (d["dst_len"][2:] == 0).all()
+    assert dst[:len(ref[0])].tobytes() == ref[0] and (dst[room:] == 0xEE).all()
+    with pytest.raises(Exception):
+        N.detransform_batch(p, d, src, dst, dst.size, nat.MEM_HOST_PACKED)             # transform only

@@ -28,3 +28,17 @@ def test_full_size_and_mixed_block_frames_of_stock_libzstd(gpu, oracle, level):
     outs, d = pc.run_detransform(gpu, nat.COMPRESS, blobs, [int(v.size) for v in inputs.values()])
     for i, (name, v) in enumerate(inputs.items()):
         assert d["status"][i] == 0 and outs[i] == v.tobytes(), (name, level)
+
+
+def test_packed_host_output_on_the_device(gpu, oracle):
+    """TSX_MEM_HOST_PACKED (the `.log` object assembled in the caller's buffer): same bytes as the slot-per-chunk layout and as
+    the oracle chain, offsets = running sum of the sizes; full-size chunks included."""
+    chunks = [synth.gen_chunk("K", 3, 0, i, n) for i, n in enumerate((70000, 1, synth.CHUNK, 0, 33333, synth.CHUNK, 65537))]
+    for flags in (nat.ENCRYPT | nat.CRC, nat.COMPRESS | nat.ENCRYPT | nat.CRC):
+        slots, d0 = pc.run_transform(gpu, flags, chunks)
+        packed, d1 = pc.run_transform(gpu, flags, chunks, mem="packed")
+        assert packed == slots and (d1["status"] == 0).all() and (d1["crc32c"] == d0["crc32c"]).all()
+        ends = np.cumsum(d1["dst_len"].astype(np.int64))
+        assert (d1["dst_off"].astype(np.int64) == ends - d1["dst_len"]).all()
+        for i in (0, 2, 6):
+            assert packed[i] == pc.oracle_transform(oracle, flags, chunks[i], i)

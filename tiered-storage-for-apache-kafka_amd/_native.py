@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtsxform.so")
 
 COMPRESS, ENCRYPT, CRC = 1, 2, 4
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_PACKED = 0, 1, 2
 OK, E_INVAL, E_DEVICE, E_NOMEM, E_DST_TOO_SMALL, E_TAG_MISMATCH, E_BAD_FRAME, E_BAD_SIZE, E_SHORT_CHUNK, E_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 ZSTD_PROFILE_1_5_6, ZSTD_PROFILE_1_5_7 = 0, 1

@@ -342,7 +342,9 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTi
 static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, void* dst,
                      size_t dst_size, int mem_kind, int mode /*0 transform, 1 detransform, 2 crc only*/) {
     if (!descs || (n && !src) || (mode != 2 && (!params || (n && !dst)))) return TSX_E_INVAL;
-    if (mem_kind != TSX_MEM_HOST && mem_kind != TSX_MEM_DEVICE) return TSX_E_INVAL;
+    if (mem_kind != TSX_MEM_HOST && mem_kind != TSX_MEM_DEVICE && mem_kind != TSX_MEM_HOST_PACKED) return TSX_E_INVAL;
+    const bool packed = mem_kind == TSX_MEM_HOST_PACKED;
+    if (packed && mode != 0) return TSX_E_INVAL;
     const uint32_t flags = mode == 2 ? TSX_CRC : params->flags;
     if (flags & ~(TSX_COMPRESS | TSX_ENCRYPT | TSX_CRC)) return TSX_E_INVAL;
     if (mode != 2) {
@@ -352,10 +354,21 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     }
     if (n == 0) return TSX_OK;
     uint32_t max_len; size_t in_bytes;
-    int rc = validate(descs, n, dst_size, mode != 2, &max_len, &in_bytes);
+    size_t out_bytes = dst_size;                                        // size of the output area the kernels see
+    if (packed) {
+        // the kernels still write one bound-sized slot per chunk - on the device; only the bytes produced cross PCIe, straight
+        // to their final place in the caller's buffer
+        uint32_t longest = 0;
+        for (uint32_t i = 0; i < n; i++) if (descs[i].src_len > longest) longest = descs[i].src_len;
+        const size_t slot = (tsx_transformed_bound(longest, flags) + 63) & ~(size_t)63;
+        if (slot >= ((size_t)1 << 32)) return TSX_E_INVAL;
+        for (uint32_t i = 0; i < n; i++) { descs[i].dst_off = (uint64_t)i * slot; descs[i].dst_cap = (uint32_t)slot; }
+        out_bytes = (size_t)n * slot;
+    }
+    int rc = validate(descs, n, out_bytes, mode != 2, &max_len, &in_bytes);
     if (rc) return rc;
-    const bool host = mem_kind == TSX_MEM_HOST;
-    rc = ctx_reserve(c, n, max_len, flags, host, in_bytes, dst_size);
+    const bool host = mem_kind != TSX_MEM_DEVICE;
+    rc = ctx_reserve(c, n, max_len, flags, host, in_bytes, out_bytes);
     if (rc) return rc;
     hipStream_t st = c->st;
     bool fused = false;
@@ -442,7 +455,18 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     if (mode != 1) hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_descs, (const int32_t*)c->d_status, n);
     HIPCHK(hipEventRecord(c->ev[5], st));
     HIPCHK(hipMemcpyAsync(descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
-    if (host && mode != 2) {
+    if (packed) {
+        HIPCHK(hipStreamSynchronize(st));                               // sizes first: they say where each chunk goes
+        size_t at = 0; bool full = false;
+        for (uint32_t i = 0; i < n; i++) {
+            const size_t slot_off = descs[i].dst_off;
+            descs[i].dst_off = at;
+            if (descs[i].status != TSX_OK) { descs[i].dst_len = 0; continue; }
+            if (full || at + descs[i].dst_len > dst_size) { full = true; descs[i].status = TSX_E_DST_TOO_SMALL; descs[i].dst_len = 0; continue; }
+            if (descs[i].dst_len) HIPCHK(hipMemcpyAsync((uint8_t*)dst + at, c->d_out + slot_off, descs[i].dst_len, hipMemcpyDeviceToHost, st));
+            at += descs[i].dst_len;
+        }
+    } else if (host && mode != 2) {
         // only the bytes each chunk produced travel back (a compressed chunk fills ~1/3 of its slot): the descriptors
         // first, then one copy per run of chunks whose outputs are adjacent in dst
         HIPCHK(hipStreamSynchronize(st));

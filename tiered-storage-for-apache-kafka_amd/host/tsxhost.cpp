@@ -249,6 +249,10 @@ void Backend::transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_de
     const int rc = f_->transform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
     if (rc) throw std::runtime_error(std::string("tsx_transform_batch: ") + f_->strerr(rc));
 }
+void Backend::transformBatchPacked(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
+    const int rc = f_->transform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST_PACKED);
+    if (rc) throw std::runtime_error(std::string("tsx_transform_batch: ") + f_->strerr(rc));
+}
 void Backend::detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
     const int rc = f_->detransform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
     if (rc) throw std::runtime_error(std::string("tsx_detransform_batch: ") + f_->strerr(rc));
@@ -469,6 +473,43 @@ void GpuTransformChunkEnumeration::fillBatchIfNeeded() {
         ready_.emplace_back(dst.begin() + (long)d[i].dst_off, dst.begin() + (long)(d[i].dst_off + d[i].dst_len));
     }
 }
+size_t GpuTransformChunkEnumeration::appendNextBatchPacked(Bytes& object, std::vector<int>& sizes) {
+    if (next_ < ready_.size()) throw std::logic_error("appendNextBatchPacked after nextElement inside a batch");
+    std::vector<Bytes> in;
+    while ((int)in.size() < batch_ && inner_->hasMoreElements()) in.push_back(inner_->nextElement());
+    if (in.empty()) return 0;
+    const uint32_t flags = (compress_ ? TSX_COMPRESS : 0u) | (enc_ ? TSX_ENCRYPT : 0u) | (withCrc_ ? TSX_CRC : 0u);
+    const size_t at = object.size();
+    size_t total = 0;
+    if ((flags & (TSX_COMPRESS | TSX_ENCRYPT)) == 0) {                   // pure base: the chunks are the object
+        for (const Bytes& c : in) {
+            object.insert(object.end(), c.begin(), c.end());
+            total += c.size(); sizes.push_back((int)c.size());
+            if (withCrc_) crcs_.push_back(be_->crc32c(c.data(), c.size()));
+        }
+        return total;
+    }
+    std::vector<tsx_chunk_desc> d(in.size());
+    size_t so = 0, bound = 0;
+    for (size_t i = 0; i < in.size(); i++) {
+        memset(&d[i], 0, sizeof d[i]);
+        d[i].src_off = so; d[i].src_len = (uint32_t)in[i].size(); so += align16(in[i].size()) + 16;
+        bound += be_->transformedBound(in[i].size(), flags);
+        if (enc_) iv_(d[i].iv);
+    }
+    Bytes src(so + 16);
+    for (size_t i = 0; i < in.size(); i++) if (!in[i].empty()) memcpy(src.data() + d[i].src_off, in[i].data(), in[i].size());
+    const tsx_batch_params p = makeParams(flags, enc_ ? &enc_->dataKey : nullptr, enc_ ? &enc_->aad : nullptr, profile_);
+    object.resize(at + bound);                                         // room for the worst case, trimmed to what was produced
+    be_->transformBatchPacked(p, d, src.data(), object.data() + at, bound);
+    for (size_t i = 0; i < in.size(); i++) {
+        if (d[i].status != TSX_OK) { object.resize(at); throw std::runtime_error(be_->strerror(d[i].status)); }
+        if (withCrc_) crcs_.push_back(d[i].crc32c);
+        sizes.push_back((int)d[i].dst_len); total += d[i].dst_len;
+    }
+    object.resize(at + total);
+    return total;
+}
 bool GpuTransformChunkEnumeration::hasMoreElements() { fillBatchIfNeeded(); return next_ < ready_.size(); }
 Bytes GpuTransformChunkEnumeration::nextElement() {
     fillBatchIfNeeded();
@@ -501,6 +542,18 @@ std::shared_ptr<ChunkIndex> TransformFinisher::chunkIndex() {                   
         chunkIndex_ = builder_->finish(size);
     }
     return chunkIndex_;
+}
+Bytes TransformFinisher::toBytesPacked() {
+    auto* gpu = dynamic_cast<GpuTransformChunkEnumeration*>(inner_.get());
+    if (!gpu) return toBytes();
+    Bytes out;
+    std::vector<int> sizes;
+    while (gpu->appendNextBatchPacked(out, sizes)) {}
+    // the index sees the same sizes in the same order as through nextElement() (TransformFinisher.java:101-110)
+    if (sizes.empty()) return out;                                     // nothing passed through: like toBytes(), no index is built
+    for (size_t i = 0; i + 1 < sizes.size(); i++) builder_->addChunk(sizes[i]);
+    chunkIndex_ = builder_->finish(sizes.back());
+    return out;
 }
 Bytes TransformFinisher::toBytes() {
     Bytes out;

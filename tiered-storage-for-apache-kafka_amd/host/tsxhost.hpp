@@ -148,6 +148,8 @@ public:
     Backend& operator=(const Backend&) = delete;
     // one batch over host buffers; throws std::runtime_error on a batch-level failure, per-chunk status stays in descs
     void transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
+    // the same with TSX_MEM_HOST_PACKED: transformed chunks back to back in dst, offsets and sizes returned in descs
+    void transformBatchPacked(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
     void detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
     uint32_t crc32c(const uint8_t* data, size_t n);              // java.util.zip.CRC32C of one byte range (tsx_crc32c_batch)
     size_t transformedBound(size_t n, uint32_t flags) const;
@@ -243,6 +245,11 @@ public:
     bool hasMoreElements() override;
     Bytes nextElement() override;
     const std::vector<uint32_t>& crc32cOfOriginalChunks() const { return crcs_; }   // out of band, filled when withCrc
+    // the next batch (up to batchChunks chunks of `inner`) transformed straight to the end of `object`, chunk
+    // after chunk (TSX_MEM_HOST_PACKED) - the growing `.log` object or a multipart part buffer
+    // (S3MultiPartOutputStream.java:89-122) - instead of one Bytes per chunk and a gather copy.  Appends each chunk's
+    // transformed size to `sizes`; returns the bytes appended, 0 when `inner` is exhausted.  Do not mix with nextElement().
+    size_t appendNextBatchPacked(Bytes& object, std::vector<int>& sizes);
 
 private:
     void fillBatchIfNeeded();
@@ -268,6 +275,8 @@ public:
     Bytes nextElement();                                  // the reference wraps it in a ByteArrayInputStream
     std::shared_ptr<ChunkIndex> chunkIndex();             // "Chunk index was not built, was finisher used?"
     Bytes toBytes();                                      // SequenceInputStream(this) drained: the transformed .log object
+    // the same object, assembled batch-wise in place when the chain is the GPU enumeration (no per-chunk Bytes, no gather copy)
+    Bytes toBytesPacked();
     // TransformFinisher.toInputStream(): chunks are pulled (and transformed, batch-wise) only as the consumer reads;
     // with a bucket the stream is rate limited (TransformFinisher.java:146-151)
     std::shared_ptr<InputStream> toInputStream(std::shared_ptr<class TokenBucket> rateLimitingBucket = nullptr);
