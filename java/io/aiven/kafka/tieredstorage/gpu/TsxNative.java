@@ -57,6 +57,14 @@ public final class TsxNative {
     public static native int transformBatch(int flags, byte[] key, byte[] aad, int zstdProfile,
                                             ByteBuffer descs, int n, ByteBuffer src, ByteBuffer dst);
 
+    /**
+     * tsx_transform_batch with TSX_MEM_HOST_PACKED: the transformed chunks are written back to back into {@code dst} - the
+     * upload's own buffer (a multipart part, TransformFinisher's object) - and each descriptor returns its chunk's offset and
+     * size; a chunk that does not fit any more comes back with TSX_E_DST_TOO_SMALL.
+     */
+    public static native int transformBatchPacked(int flags, byte[] key, byte[] aad, int zstdProfile,
+                                                  ByteBuffer descs, int n, ByteBuffer src, ByteBuffer dst);
+
     public static native int detransformBatch(int flags, byte[] key, byte[] aad,
                                               ByteBuffer descs, int n, ByteBuffer src, ByteBuffer dst);
 }

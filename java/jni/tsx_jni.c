@@ -43,7 +43,7 @@ static int fill_params(JNIEnv* env, tsx_batch_params* p, jint flags, jbyteArray 
     return TSX_OK;
 }
 
-static jint run(JNIEnv* env, int detransform, jint flags, jbyteArray key, jbyteArray aad, jint profile,
+static jint run(JNIEnv* env, int detransform, int mem_kind, jint flags, jbyteArray key, jbyteArray aad, jint profile,
                 jobject descs, jint n, jobject src, jobject dst) {
     tsx_batch_params p;
     int rc = fill_params(env, &p, flags, key, aad, profile);
@@ -53,8 +53,8 @@ static jint run(JNIEnv* env, int detransform, jint flags, jbyteArray key, jbyteA
         void* o = (*env)->GetDirectBufferAddress(env, dst);
         const jlong cap = (*env)->GetDirectBufferCapacity(env, dst);
         if (!d || !s || !o || (*env)->GetDirectBufferCapacity(env, descs) < (jlong)n * (jlong)sizeof(tsx_chunk_desc)) rc = TSX_E_INVAL;
-        else rc = detransform ? tsx_detransform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, TSX_MEM_HOST)
-                              : tsx_transform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, TSX_MEM_HOST);
+        else rc = detransform ? tsx_detransform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, mem_kind)
+                              : tsx_transform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, mem_kind);
     }
     memset(&p, 0, sizeof p);              /* the key does not outlive the call (ownership) */
     return rc;
@@ -63,11 +63,18 @@ static jint run(JNIEnv* env, int detransform, jint flags, jbyteArray key, jbyteA
 JNIEXPORT jint JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_transformBatch(
     JNIEnv* env, jclass cls, jint flags, jbyteArray key, jbyteArray aad, jint profile, jobject descs, jint n, jobject src, jobject dst) {
     (void)cls;
-    return run(env, 0, flags, key, aad, profile, descs, n, src, dst);
+    return run(env, 0, TSX_MEM_HOST, flags, key, aad, profile, descs, n, src, dst);
+}
+
+/* TSX_MEM_HOST_PACKED: dst is the upload's own buffer (a multipart part, a mapped file); chunk i lands at descs[i].dst_off */
+JNIEXPORT jint JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_transformBatchPacked(
+    JNIEnv* env, jclass cls, jint flags, jbyteArray key, jbyteArray aad, jint profile, jobject descs, jint n, jobject src, jobject dst) {
+    (void)cls;
+    return run(env, 0, TSX_MEM_HOST_PACKED, flags, key, aad, profile, descs, n, src, dst);
 }
 
 JNIEXPORT jint JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_detransformBatch(
     JNIEnv* env, jclass cls, jint flags, jbyteArray key, jbyteArray aad, jobject descs, jint n, jobject src, jobject dst) {
     (void)cls;
-    return run(env, 1, flags, key, aad, 1, descs, n, src, dst);
+    return run(env, 1, TSX_MEM_HOST, flags, key, aad, 1, descs, n, src, dst);
 }
