@@ -63,10 +63,8 @@ typedef uint32_t SeqD;
 #define SEQD_COUNTS(e_) (((e_) >> 9) & 0xFFFu)                        /* nbBits | (nbBits + extra bits) << 5 */
 #ifdef HIPEMU
 #define TSX_SCHED_BARRIER() do {} while (0)
-#define TSX_SETPRIO(p_) do {} while (0)
 #else
 #define TSX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#define TSX_SETPRIO(p_) __builtin_amdgcn_s_setprio(p_)          /* issue priority of this wave among the SIMD's waves, 0..3 */
 #endif
 // row_shl:n - lane i reads lane i + n of its row of 16, 0 past the row's end
 #define DPP_SHL(v_, n_) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v_), 0x100 + (n_), 0xF, 0xF, true))
@@ -807,7 +805,6 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                             if (lastByte == 0) RFAIL(DERR_FRAME);
                             B = 8 * (n - 1) + dhb32(lastByte);
                         }
-                        TSX_SETPRIO(3);                                         // the sequence stage is the chunk's critical path: its chain goes first
                         for (uint32_t g = 0; g < nbSeq; g += LANES) {
                             const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
                             // 64 sequences read at most 64 * 89 bits = 712 bytes below the cursor; every read is an 8-byte load at
@@ -937,7 +934,6 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                             if (valid) { sLL[g + lane] = ll; sML[g + lane] = ml; sOF[g + lane] = off; }
                             DLT(2);                                                 // 2: FSE sequence decode
                         }
-                        TSX_SETPRIO(0);
                         if (nbSeq && B != 0) RFAIL(DERR_FRAME);                     // BIT_endOfDStream: every bit of the stream was used
                     }
                     if (lane == 0) L.nseq[(it - 1) & 1] = nbSeq;
