@@ -24,6 +24,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#ifndef ORC_STAT_VISIT      /* analysis hooks (tools/stats/parse_stats.c); no-ops in the oracle build */
+#define ORC_STAT_VISIT() do {} while (0)
+#define ORC_STAT_EVENT(type, dist) do {} while (0)
+#define ORC_STAT_IMMREP() do {} while (0)
+#define ORC_STAT_CAND(isLong, inwin, dist, eq) do {} while (0)
+#endif
+
 typedef uint8_t BYTE; typedef uint16_t U16; typedef uint32_t U32; typedef uint64_t U64; typedef int64_t S64;
 
 #define KB *(1u << 10)
@@ -189,9 +196,13 @@ static size_t compressBlock_doubleFast(matchstate_t* ms, seqstore_t* ss, U32 rep
             curr = (U32)(ip - base);
             matchs0 = base + idxs0;
             hashLong[hl0] = hashSmall[hs0] = curr;
+            ORC_STAT_VISIT();
+            ORC_STAT_CAND(1, idxl0 >= prefixLowestIndex, (U32)(ip - matchl0), idxl0 >= prefixLowestIndex && rd64(matchl0) == rd64(ip));
+            ORC_STAT_CAND(0, idxs0 >= prefixLowestIndex, (U32)(ip - matchs0), idxs0 >= prefixLowestIndex && rd32(matchs0) == rd32(ip));
             if ((offset_1 > 0) & (rd32(ip + 1 - offset_1) == rd32(ip + 1))) {
                 mLength = count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
                 ip++;
+                ORC_STAT_EVENT(1, offset_1);
                 storeSeq(ss, (size_t)(ip - anchor), anchor, 1 /* REPCODE1_TO_OFFBASE */, mLength);
                 goto _match_stored;
             }
@@ -202,6 +213,7 @@ static size_t compressBlock_doubleFast(matchstate_t* ms, seqstore_t* ss, U32 rep
                 if (rd64(matchl0) == rd64(ip)) {
                     mLength = count(ip + 8, matchl0 + 8, iend) + 8;
                     offset = (U32)(ip - matchl0);
+                    ORC_STAT_EVENT(2, offset);
                     while (((ip > anchor) & (matchl0 > prefixLowest)) && (ip[-1] == matchl0[-1])) { ip--; matchl0--; mLength++; }
                     goto _match_found;
                 }
@@ -225,8 +237,9 @@ _search_next_long:
         offset = (U32)(ip - matchs0);
         if ((idxl1 >= prefixLowestIndex) && (rd64(matchl1) == rd64(ip1))) {
             size_t const l1len = count(ip1 + 8, matchl1 + 8, iend) + 8;
-            if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (U32)(ip - matchl1); matchs0 = matchl1; }
-        }
+            if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (U32)(ip - matchl1); matchs0 = matchl1; ORC_STAT_EVENT(4, offset); }
+            else ORC_STAT_EVENT(3, offset);
+        } else ORC_STAT_EVENT(3, offset);
         while (((ip > anchor) & (matchs0 > prefixLowest)) && (ip[-1] == matchs0[-1])) { ip--; matchs0--; mLength++; }
 _match_found:
         offset_2 = offset_1; offset_1 = offset;
@@ -246,6 +259,7 @@ _match_stored:
                 U32 const tmpOff = offset_2; offset_2 = offset_1; offset_1 = tmpOff;
                 hashSmall[hashPtr(ip, hBitsS, mls)] = (U32)(ip - base);
                 hashLong[hashPtr(ip, hBitsL, 8)] = (U32)(ip - base);
+                ORC_STAT_IMMREP();
                 storeSeq(ss, 0, anchor, 1, rLength);
                 ip += rLength; anchor = ip;
             }

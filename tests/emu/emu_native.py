@@ -19,10 +19,13 @@ def build():
 def get():
     global _emu
     if _emu is None:
-        build()
+        lib = os.environ.get("TSX_EMU_LIB")         # a private copy (long fuzz runs survive rebuilds of the in-tree file)
+        if not lib:
+            build()
+            lib = EMU_LIB
         sys.path.insert(0, _ROOT)
         import tsxform
-        n = tsxform._native.Native(EMU_LIB)
+        n = tsxform._native.Native(lib)
         os.environ["TSX_ALLOW_ANY_ARCH"] = "1"      # the emulator reports arch "emu"
         n.init()
         _emu = n

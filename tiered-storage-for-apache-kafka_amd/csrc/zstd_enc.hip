@@ -36,6 +36,38 @@
 // "this value is the same in every lane": results of out-of-line calls and LDS broadcasts are divergent to the compiler;
 // pinning the parser's state to SGPRs turns its control flow into scalar branches instead of exec-mask juggling.
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
+// A function that is not inlined into the kernel receives generic pointers (flat_load / flat_store: both wait counters, no
+// scalar base).  The parser says what it knows: its tables, the chunk and the sequence array are global memory, and their base
+// addresses are the same in every lane.
+#ifdef HIPEMU
+#define ZS_GLOBAL
+#else
+#define ZS_GLOBAL __attribute__((address_space(1)))
+#endif
+typedef const ZS_GLOBAL uint8_t* gbytes_t;
+typedef ZS_GLOBAL uint32_t* gwords_t;
+struct __attribute__((packed)) zs_u64u { uint64_t v; };
+struct __attribute__((packed)) zs_u32u { uint32_t v; };
+__device__ static inline uint64_t gld64(gbytes_t p) { return reinterpret_cast<const ZS_GLOBAL zs_u64u*>(p)->v; }
+__device__ static inline uint32_t gld32(gbytes_t p) { return reinterpret_cast<const ZS_GLOBAL zs_u32u*>(p)->v; }
+__device__ static inline uint4 ld128a(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }     // 16-byte aligned
+#ifndef HIPEMU
+typedef uint32_t zs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ static inline uint4 ld128a(gbytes_t p) { const zs_u32x4 t = *reinterpret_cast<const ZS_GLOBAL zs_u32x4*>(p); return make_uint4(t.x, t.y, t.z, t.w); }
+#endif
+#ifdef HIPEMU
+__device__ static inline void zs_put_seq(zs_seq* p, uint32_t offBase, uint32_t litLength, uint32_t mlBase, uint32_t litPos) { zs_seq q; q.offBase = offBase; q.litLength = litLength; q.mlBase = mlBase; q.litPos = litPos; *p = q; }
+#else
+__device__ static inline void zs_put_seq(ZS_GLOBAL zs_seq* p, uint32_t offBase, uint32_t litLength, uint32_t mlBase, uint32_t litPos) {
+    zs_u32x4 t; t.x = offBase; t.y = litLength; t.z = mlBase; t.w = litPos;                    // field order of zs_seq
+    *reinterpret_cast<ZS_GLOBAL zs_u32x4*>(p) = t;
+}
+#endif
+template <class T> __device__ static inline T* uni_ptr(T* p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = UNI((uint32_t)a), hi = UNI((uint32_t)(a >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
 #define ZS_RING 4096u         /* LDS source window of the parser (bytes) */
 #define ZS_RWM (ZS_RING / 4 - 1)
 #define ZS_FILL 2048u         /* refill granule */
@@ -194,14 +226,14 @@ __device__ static inline uint32_t ring1(const uint32_t* ring, uint32_t p) { retu
 
 // Append chunk bytes [w.hi, w.hi + ZS_FILL) to the ring (16-byte pieces; pieces that start beyond the chunk are skipped
 // by re-reading the last valid piece, so nothing outside the caller's buffer granule is touched).
-__device__ __forceinline__ static void win_append(const uint8_t* __restrict__ src, uint32_t lastPiece, uint32_t* ring, Win& w, uint32_t lane) {
+template <class SP> __device__ __forceinline__ static void win_append(SP src, uint32_t lastPiece, uint32_t* ring, Win& w, uint32_t lane) {
     uint4 v[ZS_FILL / 1024];
     WAVE_MEM_SYNC();                                                  // (emulator) no lane may still be reading the slots replaced here
 #pragma unroll
     for (uint32_t k = 0; k < ZS_FILL / 1024; k++) {
         uint32_t pp = w.hi + k * 1024 + lane * 16;
         if (pp > lastPiece) pp = lastPiece;
-        v[k] = *reinterpret_cast<const uint4*>(src + pp);
+        v[k] = ld128a(src + pp);
     }
 #pragma unroll
     for (uint32_t k = 0; k < ZS_FILL / 1024; k++)
@@ -212,7 +244,7 @@ __device__ __forceinline__ static void win_append(const uint8_t* __restrict__ sr
     WAVE_MEM_SYNC();
 }
 // make [ip, ip + ZS_SAFE) resident (or everything up to the end of the chunk)
-__device__ __forceinline__ static void win_ensure(const uint8_t* __restrict__ src, uint32_t srcCeil, uint32_t lastPiece, uint32_t* ring, Win& w,
+template <class SP> __device__ __forceinline__ static void win_ensure(SP src, uint32_t srcCeil, uint32_t lastPiece, uint32_t* ring, Win& w,
                                                   uint32_t ip, uint32_t lane) {
     if (ip < w.lo || ip > w.hi + ZS_RING / 2) {                      // far jump: restart the ring behind ip
         WAVE_MEM_SYNC();
@@ -299,6 +331,9 @@ __device__ static inline void store_seq(zs_seq* __restrict__ seqs, MfState& s, u
     s.litSize += litLen; s.nbSeq++;
 }
 
+#ifndef ZS_PARSER
+#define ZS_PARSER 2           /* 1: first form of the parser (match_block), 2: match_block2 */
+#endif
 #ifndef ZS_W0
 #define ZS_W0 8u              /* first speculation width of a search run */
 #endif
@@ -566,6 +601,327 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
     ms.litSize += ms.lastLL;
     PT(4);
     LT(0); LT_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Parser, second form (ZS_PARSER == 2).  Same serial algorithm, same tables, same output; what changed is what a step costs.
+// The first form spends ~700 instructions and 2K+1 table lines per step on speculation that the content seldom honours: on
+// log-like data 54 % of all sequences start at the FIRST position searched after the previous match and 69 % within two
+// (tools/stats/parse_stats.c), so K = 8 first steps read 17 table lines to use 2-4, and every lane fetched 96 bytes around both
+// of its candidates although only the step's first event is ever used.  Here:
+//   * lane roles: lane 0 = the complementary insertion at curr + 2, lanes 1.. = consecutive positions from ip - 2 (lanes 1, 2 are
+//     the complementary insertions at ip - 2 / ip - 1, lanes 3.. the K search positions, lane 3 + K the look-ahead for the "long
+//     match at +1" rule, lane 63 fetches the bytes of the immediate-repcode check): the complementary insertions of the previous
+//     match share the hash computation, the collision check and the store instructions of the next step;
+//   * K starts at ZS_K0 (2) after a match and widens (ZS_K1, then doubling) only while nothing is found;
+//   * two lanes of a step that touch the same bucket are not patched up but avoided: a byte scoreboard in LDS (converging to the
+//     lowest lane id per slot) finds the first lane with an earlier partner and the step is cut in front of it - before the table
+//     loads are issued, so a cut costs no memory traffic; only the look-ahead lane is resolved exactly (one ballot);
+//   * only the step's first (potential) event is verified: the wave compares the 64 bytes around that ONE candidate with the ring
+//     (8 behind, 56 ahead: verification, forward and backward extension in one round trip, one byte per lane, one ballot); a
+//     tag's false positive (1/512) is struck out and the next event of the same step taken.
+// ---------------------------------------------------------------------------------------------------
+#ifndef ZS_K0
+#define ZS_K0 2u              /* search positions of the first step after a match */
+#endif
+#ifndef ZS_K1
+#define ZS_K1 16u             /* ... of the second step; doubling from there */
+#endif
+#define ZS_KMAX 59u
+// the rare continuations (matches longer than the 64 bytes the first comparison covers) stay out of line
+__device__ ZS_NOINLINE static uint32_t count_more(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, uint32_t a, uint32_t b, uint32_t iend, uint32_t lane) {
+    FarWin fw; fw.lo = fw.hi = 0; fw.buf = nullptr;
+    return wave_count(src, ring, w, fw, a, b, iend, lane);
+}
+__device__ ZS_NOINLINE static uint32_t count_more_back(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, uint32_t ip, uint32_t match, uint32_t anchor,
+                                                       uint32_t low, uint32_t lane) {
+    FarWin fw; fw.lo = fw.hi = 0; fw.buf = nullptr;
+    return wave_count_back(src, ring, w, fw, ip, match, anchor, low, lane);
+}           /* lanes 3..61 search, 62 looks ahead, 63 serves the immediate repcode */
+
+// bit i = lane i is valid and chunk byte pa + i - nb equals byte pb + i - nb (pb < pa).  Bytes come from the ring when the whole
+// 64-byte span is resident, else from global memory (valid lanes only touch [0, srcSize)).
+__device__ __forceinline__ static unsigned long long eq_mask(const gbytes_t src, const uint32_t* ring, const Win w, uint32_t pa, uint32_t pb,
+                                                             uint32_t nb, bool valid, uint32_t lane) {
+    const bool aR = pa >= w.lo + nb && pa + (64 - nb) <= w.hi;
+    const bool bR = pb >= w.lo + nb && pb + (64 - nb) <= w.hi;
+    const uint32_t ia = valid ? pa + lane - nb : pa, ib = valid ? pb + lane - nb : pb;
+    uint32_t x, y;
+    if (bR) y = ring1(ring, ib); else y = src[ib];
+    if (aR) x = ring1(ring, ia); else x = src[ia];
+    return __ballot(valid && x == y);
+}
+__device__ static inline uint32_t cto64(unsigned long long m) { return m == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m) - 1; }
+
+__device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src, const uint32_t srcSize_, const uint32_t blockStart,
+                                                    const uint32_t blockSize_, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
+                                                    const zs_cparams cp, const uint32_t dictLimitIn, uint32_t* rep, zs_seq* __restrict__ seqs,
+                                                    MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane) {
+    const gbytes_t gsrc = (gbytes_t)uni_ptr(src);
+    const gwords_t gL = (gwords_t)uni_ptr(hashLong), gS = (gwords_t)uni_ptr(hashSmall);
+    ZS_GLOBAL zs_seq* const gseqs = (ZS_GLOBAL zs_seq*)uni_ptr(seqs);
+    const uint32_t srcSize = UNI(srcSize_);
+    uint32_t nbSeq = 0, litSize = 0;
+    static_assert(sizeof(zs_seq) == 16, "zs_put_seq writes the four fields as one 16-byte store");
+    const uint32_t iend = UNI(blockStart + blockSize_), blockSize = UNI(blockSize_), dictLimit = UNI(dictLimitIn), maxDist = 1u << UNI(cp.windowLog);
+    const uint32_t plowIdx = (iend + 2 - dictLimit > maxDist) ? iend + 2 - maxDist : dictLimit;
+    const uint32_t hBitsL = UNI(cp.hashLog), hBitsS = UNI(cp.chainLog), mls = UNI(cp.minMatch);
+    const uint32_t srcCeil = (srcSize + ZS_FILL - 1) & ~(ZS_FILL - 1), lastPiece = (srcSize - 1) & ~15u;
+    const uint32_t idxBits = 32u - (uint32_t)__clz((int)(srcSize + 2)), tagBits = 32u - idxBits, idxMask = (uint32_t)((1ull << idxBits) - 1);
+    uint32_t ip = UNI(blockStart), anchor = ip;
+    uint32_t off1 = UNI(rep[0]), off2 = UNI(rep[1]), sav1 = 0, sav2 = 0;
+    if (ip + 2 == plowIdx) ip++;
+    {   const uint32_t cur = ip + 2, windowLow = (cur - dictLimit > maxDist) ? cur - maxDist : dictLimit, maxRep = cur - windowLow;
+        if (off2 > maxRep) { sav2 = off2; off2 = 0; }
+        if (off1 > maxRep) { sav1 = off1; off1 = 0; }
+    }
+    Win w; w.lo = w.hi = 0;
+    (void)fwbuf;
+#define STORE_SEQ(ll_, lp_, ob_, ml_) do { if (lane == 0) zs_put_seq(&gseqs[nbSeq], (ob_), (ll_), (ml_) - 3, (lp_)); \
+                                           litSize += (ll_); nbSeq++; } while (0)
+    if (blockSize >= 8) {
+        const uint32_t ilimit = iend - 8;
+        bool afterMatch = false;          // the immediate-repcode check (offset_2 at ip) of the match just stored is still due
+        bool comp = false;                // ... and so are its complementary insertions (X = curr + 2, ip - 2, ip - 1)
+        bool runStart = true;
+        uint32_t X = 0, step = 1, nextStep = 0, width = ZS_K0;
+        for (;;) {                                                    // one iteration per wave step
+            if (runStart) { step = 1; nextStep = ip + 256; width = ZS_K0; runStart = false; }
+            uint32_t K = 0;
+            const bool tail = ip + step > ilimit;
+            if (tail) {
+                if (!(ip <= ilimit && (comp || afterMatch))) break;
+            } else {
+                if (step == 1) {
+                    K = ilimit - ip;
+                    const uint32_t K1 = nextStep > ip + 1 ? nextStep - ip : 1;
+                    if (K1 < K) K = K1;
+                } else {
+                    uint32_t K1 = 1;
+                    if (nextStep > ip + step) K1 = (nextStep - ip - 1) / step + 1;
+                    K = (ilimit - step - ip) / step + 1;
+                    if (K1 < K) K = K1;
+                }
+                if (width < K) K = width;
+            }
+            if (ip + ZS_SAFE > w.hi || ip < w.lo) win_ensure(gsrc, srcCeil, lastPiece, ring, w, ip, lane);
+            // ---- positions, hashes, table entries ----
+            const uint32_t pos = lane == 0 ? X : lane < 3 ? ip + lane - 3 : ip + (lane - 3) * step;
+            const bool compL = comp && lane < 2, compS = comp && (lane == 0 || lane == 2);
+            bool searching = lane >= 3 && lane < 3 + K;
+            const bool lane3 = lane == 3;                             // ip itself: searched (K > 0) or only checked for the immediate repcode
+            const bool mayUse = compL || compS || (lane >= 3 && lane <= 3 + K);
+            const uint32_t spos = mayUse ? pos : ip;                  // an address every lane may read
+            const bool posWin = ip + K * step + 8 <= w.hi && (!comp || (X >= w.lo && ip >= w.lo + 2));
+            uint64_t d8;
+            if (posWin) d8 = ring8(ring, spos); else { d8 = gld64(gsrc + spos); LOADED64(d8); }
+            const uint32_t hl = hash8(d8, hBitsL), hs = hashS(d8, hBitsS, mls);
+            const uint32_t tL = tag8(d8, hBitsL, tagBits), tS = tag4((uint32_t)d8, tagBits);
+            const uint32_t eL = ((tL << 1) << (idxBits - 1)) | (pos + 2), eS = ((tS << 1) << (idxBits - 1)) | (pos + 2);
+            // ---- repcode pre-check: with the bytes at pos + 1 - off1 in the ring the first repcode hit is known before any probe ----
+            const bool r1Near = K > 0 && off1 > 0 && posWin && ip + 1 >= w.lo + off1;
+            uint32_t r1 = 0;
+            if (r1Near) {
+                r1 = ring4(ring, searching ? pos + 1 - off1 : ip);
+                const unsigned long long rb = __ballot(searching && r1 == (uint32_t)(d8 >> 8));
+                if (rb) { const uint32_t fr = (uint32_t)__ffsll((long long)rb) - 1; K = fr - 2; searching = lane >= 3 && lane <= fr; }
+            }
+            // ---- two lanes, one bucket: find the first lane with an earlier partner and stop in front of it ----
+            bool shadowL0 = false, shadowS0 = false;                  // lane 0's insertion is overwritten by lane 1's / lane 2's
+            if (comp) {
+                shadowL0 = __builtin_amdgcn_readlane(hl, 0) == __builtin_amdgcn_readlane(hl, 1);
+                shadowS0 = __builtin_amdgcn_readlane(hs, 0) == __builtin_amdgcn_readlane(hs, 2);
+            }
+            bool flagLook = false;
+            if (K > 0) {
+                const bool partL = compL || (lane >= 3 && lane <= 3 + K), partS = compS || searching;
+                const uint32_t sl = hl & (ZS_SCR - 1), ss = ZS_SCR + (hs & (ZS_SCR - 1));
+                WAVE_MEM_SYNC();
+                if (partL) scr[sl] = (uint8_t)lane;
+                if (partS) scr[ss] = (uint8_t)lane;
+                WAVE_MEM_SYNC();
+                uint32_t rL = partL ? scr[sl] : lane, rS = partS ? scr[ss] : lane;
+                while (__any(lane < rL || lane < rS)) {               // converge on the lowest lane id of every shared slot
+                    WAVE_MEM_SYNC();
+                    if (lane < rL) scr[sl] = (uint8_t)lane;
+                    if (lane < rS) scr[ss] = (uint8_t)lane;
+                    WAVE_MEM_SYNC();
+                    rL = partL ? scr[sl] : lane; rS = partS ? scr[ss] : lane;
+                }
+                const unsigned long long fb = __ballot(lane >= 3 && (rL < lane || rS < lane));
+                if (fb) {
+                    const uint32_t t = (uint32_t)__ffsll((long long)fb) - 1;
+                    if (t == 3) {
+                        // ip itself shares a slot with a complementary insertion: make those first, then search
+                        if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
+                        if (lane == 1) gL[hl] = eL;
+                        if (lane == 2) gS[hs] = eS;
+                        comp = false;
+                        PCNT(19, 1);
+                        continue;
+                    }
+                    if (t <= 3 + K) {                                 // lanes 3 .. t - 1 search, lane t looks ahead
+                        if (t < 3 + K) PCNT(19, 1);
+                        K = t - 3; searching = searching && lane < t; flagLook = true;
+                    }
+                }
+            }
+            const uint32_t look = 3 + K;
+            // ---- probes (K + 1 long, K short), the far bytes of the repcode checks ----
+            const bool probeL = K > 0 && lane >= 3 && lane <= look, probeS = searching;
+            const uint32_t hl3 = __builtin_amdgcn_readlane(hl, 3), hs3 = __builtin_amdgcn_readlane(hs, 3);
+            uint32_t cL = 0, cS = 0;
+            if (K > 0) {
+                cL = gL[probeL ? hl : hl3];
+                cS = gS[probeS ? hs : hs3];
+            }
+            const bool r2Near = afterMatch && posWin && ip >= w.lo + off2;
+            const bool needFar = (K > 0 && off1 > 0 && !r1Near) || (afterMatch && !r2Near);
+            uint32_t rfar = 0;
+            if (needFar) {
+                uint32_t fa = (searching && off1 > 0) ? pos + 1 - off1 : ip;
+                if (lane == 63 && afterMatch) fa = ip - off2;
+                rfar = gld32(gsrc + fa);
+            }
+            if (K > 0 && off1 > 0 && !r1Near) r1 = rfar;
+            PCNT(12, 1); PCNT(15, K);
+            // ---- the immediate repcode of the previous match (offset_2 at ip) ----
+            if (afterMatch) {
+                afterMatch = false;
+                const uint32_t r2 = r2Near ? ring4(ring, ip - off2) : (uint32_t)__builtin_amdgcn_readlane(rfar, 63);
+                const uint32_t d0 = __builtin_amdgcn_readlane((uint32_t)d8, 3);
+                if (UNI(r2) == d0) {
+                    const uint32_t a = ip + 4;
+                    uint32_t n = cto64(eq_mask(gsrc, ring, w, a, a - off2, 0, a + lane < iend, lane));
+                    if (n == 64) n += UNI(count_more(src, ring, w, a + 64, a + 64 - off2, iend, lane));
+                    const uint32_t rlen = 4 + n;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    if (comp) {
+                        if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
+                        if (lane == 1) gL[hl] = eL;
+                        if (lane == 2) gS[hs] = eS;
+                        comp = false;
+                    }
+                    WAVE_MEM_SYNC();                                  // (emulator) the insertion at ip comes after the complementary ones
+                    if (lane3) { gS[hs] = eS; gL[hl] = eL; }
+                    STORE_SEQ(0, ip, 1, rlen);
+                    ip += rlen; anchor = ip;
+                    PCNT(13, 1);
+                    afterMatch = ip <= ilimit && off2 > 0;
+                    runStart = true;
+                    continue;
+                }
+            }
+            // ---- the look-ahead lane sees the insertion an earlier lane of this step makes into its bucket ----
+            if (flagLook) {
+                const uint32_t hk = __builtin_amdgcn_readlane(hl, look);
+                const unsigned long long em = __ballot((compL || searching) && hl == hk && !(lane == 0 && shadowL0));
+                if (em) { const uint32_t e = 63u - (uint32_t)__clzll((long long)em); const uint32_t ee = __builtin_amdgcn_readlane(eL, e); if (lane == look) cL = ee; }
+            }
+            // ---- events ----
+            const uint32_t iL = cL & idxMask, iS = cS & idxMask;
+            bool vL = probeL && iL >= plowIdx && ((cL ^ eL) & ~idxMask) == 0;        // in the window and same tag
+            bool vS = probeS && iS >= plowIdx && ((cS ^ eS) & ~idxMask) == 0;
+            const bool repOK = searching && off1 > 0 && r1 == (uint32_t)(d8 >> 8);
+            int f = -1;
+            uint32_t start = 0, mlen = 0, offBase = 0;
+            bool isRep = false;
+            for (;;) {
+                const uint32_t ev = !searching ? 0u : repOK ? 1u : vL ? 2u : vS ? 3u : 0u;
+                const unsigned long long bm = __ballot(ev != 0);
+                if (!bm) { f = -1; break; }
+                f = __ffsll((long long)bm) - 1;
+                const uint32_t evf = __builtin_amdgcn_readlane(ev, f);
+                const uint32_t posf = ip + ((uint32_t)f - 3) * step;
+                if (evf == 1) {                                       // repcode at posf + 1
+                    start = posf + 1;
+                    const uint32_t a = start + 4;
+                    uint32_t n = cto64(eq_mask(gsrc, ring, w, a, a - off1, 0, a + lane < iend, lane));
+                    if (n == 64) n += UNI(count_more(src, ring, w, a + 64, a + 64 - off1, iend, lane));
+                    mlen = 4 + n; offBase = 1; isRep = true;
+                    break;
+                }
+                const uint32_t lowPos = plowIdx - 2;
+                if (evf == 2) {                                       // long match at posf
+                    uint32_t mpos = __builtin_amdgcn_readlane(iL, f) - 2;
+                    uint32_t lim = posf - anchor; if (mpos - lowPos < lim) lim = mpos - lowPos;
+                    const bool valid = lane < 8 ? (8 - lane) <= lim : posf + (lane - 8) < iend;
+                    const unsigned long long m = eq_mask(gsrc, ring, w, posf, mpos, 8, valid, lane);
+                    if (((m >> 8) & 0xFF) != 0xFF) { if (lane == (uint32_t)f) vL = false; PCNT(21, 1); continue; }     // a tag's false positive
+                    uint32_t fwd = cto64(m >> 8);
+                    if (fwd == 56) fwd += UNI(count_more(src, ring, w, posf + 56, mpos + 56, iend, lane));
+                    uint32_t back = (uint32_t)__clz((int)~(((uint32_t)m & 0xFF) << 24));
+                    if (back == 8 && lim > 8) back += UNI(count_more_back(src, ring, w, posf - 8, mpos - 8, anchor, lowPos, lane));
+                    start = posf - back; mpos -= back; mlen = fwd + back;
+                    offBase = start - mpos + 3;
+                    break;
+                }
+                {                                                     // short match at posf; a strictly longer long match at +1 wins
+                    uint32_t mpos = __builtin_amdgcn_readlane(iS, f) - 2;
+                    uint32_t lim = posf - anchor; if (mpos - lowPos < lim) lim = mpos - lowPos;
+                    const bool valid = lane < 8 ? (8 - lane) <= lim : posf + (lane - 8) < iend;
+                    unsigned long long m = eq_mask(gsrc, ring, w, posf, mpos, 8, valid, lane);
+                    if (((m >> 8) & 0xF) != 0xF) { if (lane == (uint32_t)f) vS = false; PCNT(21, 1); continue; }
+                    uint32_t fwd = cto64(m >> 8);
+                    if (fwd == 56) fwd += UNI(count_more(src, ring, w, posf + 56, mpos + 56, iend, lane));
+                    uint32_t sp = posf;
+                    if (__builtin_amdgcn_readlane((uint32_t)vL, f + 1)) {
+                        const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(iL, f + 1) - 2;
+                        uint32_t lim1 = p1 - anchor; if (m1 - lowPos < lim1) lim1 = m1 - lowPos;
+                        const bool valid1 = lane < 8 ? (8 - lane) <= lim1 : p1 + (lane - 8) < iend;
+                        const unsigned long long mm = eq_mask(gsrc, ring, w, p1, m1, 8, valid1, lane);
+                        if (((mm >> 8) & 0xFF) == 0xFF) {
+                            uint32_t f1 = cto64(mm >> 8);
+                            if (f1 == 56) f1 += UNI(count_more(src, ring, w, p1 + 56, m1 + 56, iend, lane));
+                            if (f1 > fwd) { sp = p1; mpos = m1; fwd = f1; m = mm; lim = lim1; }
+                        }
+                    }
+                    uint32_t back = (uint32_t)__clz((int)~(((uint32_t)m & 0xFF) << 24));
+                    if (back == 8 && lim > 8) back += UNI(count_more_back(src, ring, w, sp - 8, mpos - 8, anchor, lowPos, lane));
+                    start = sp - back; mpos -= back; mlen = fwd + back;
+                    offBase = start - mpos + 3;
+                    break;
+                }
+            }
+            // ---- commit: the visited positions insert themselves, then the pending complementary insertions ----
+            const uint32_t lastIns = f >= 0 ? (uint32_t)f : 2 + K;
+            if (lane >= 3 && lane <= lastIns) { gL[hl] = eL; gS[hs] = eS; }
+            if (comp) {
+                if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
+                if (lane == 1) gL[hl] = eL;
+                if (lane == 2) gS[hs] = eS;
+                comp = false;
+            }
+            if (f < 0) {
+                if (tail) break;
+                const bool inc = ip + K * step >= nextStep;
+                ip += K * step;
+                if (inc) { step++; nextStep += 256; }
+                width = width < ZS_K1 ? ZS_K1 : (width * 2 > ZS_KMAX ? ZS_KMAX : width * 2);
+                continue;
+            }
+            if (!isRep) {
+                off2 = off1; off1 = offBase - 3;
+                WAVE_MEM_SYNC();                                      // (emulator) ... after the insertions of the visited positions
+                if (step < 4 && lane == (uint32_t)f + 1) gL[hl] = eL;              // hashLong[hl1] = ip1
+            }
+            STORE_SEQ(start - anchor, anchor, offBase, mlen);
+            X = ip + ((uint32_t)f - 3) * step + 2;                    // curr + 2
+            ip = UNI(start + mlen); anchor = ip;
+            off1 = UNI(off1); off2 = UNI(off2);
+            PCNT(13, 1);
+            comp = ip <= ilimit;
+            afterMatch = comp && off2 > 0;
+            runStart = true;
+        }
+    }
+    sav2 = (sav1 != 0 && off1 != 0) ? sav1 : sav2;
+    rep[0] = off1 ? off1 : sav1;
+    rep[1] = off2 ? off2 : sav2;
+    ms.nbSeq = nbSeq; ms.lastLL = iend - anchor; ms.anchor = anchor;
+    ms.litSize = litSize + ms.lastLL;
+#undef STORE_SEQ
+    PT(4);
 }
 
 // Per-lane copy of a short run with up to 32 bytes of loads in flight before the first store (a byte loop would pay one
@@ -1505,7 +1861,11 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
         if (blockSize >= 7) {
             uint32_t rep[3] = {repc[0], repc[1], repc[2]};
             MfState ms;
+#if ZS_PARSER == 2
+            match_block2(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane);
+#else
             match_block(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane);
+#endif
             __threadfence_block();
             __syncthreads();
 #ifdef ZS_ABL_PARSE_ONLY
