@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TSX_ABI_VERSION 1
+#define TSX_ABI_VERSION 2 /* 2: ctx-less calls spread over all initialised devices; tsx_set_thread_device, tsx_host_register */
 
 /* flags: which stages of the chain run.  Replaces the reference's chain construction
  * RemoteStorageManager.transformation(), core/.../RemoteStorageManager.java:434-453
@@ -41,7 +41,10 @@ extern "C" {
 #define TSX_CRC      0x4u /* CRC32C of the ORIGINAL chunk bytes, out of band       */
 
 /* where src/dst live */
-#define TSX_MEM_HOST   0 /* host pointers: staged through pinned memory + H2D/D2H on the ctx stream */
+/* host pointers.  The batch is cut into pieces of >= 64 MiB whose H2D copy, kernels and D2H copy overlap on three streams of the
+ * ctx (not when compressing: that kernel wants the whole batch in flight and dwarfs the copies).  Any host memory works - pageable
+ * buffers are staged by the HIP runtime; buffers pinned once with tsx_host_register() are copied by DMA without a staging pass. */
+#define TSX_MEM_HOST   0
 #define TSX_MEM_DEVICE 1 /* device pointers (same HIP runtime/process): no copies                    */
 /* host pointers, transformed chunks written BACK TO BACK into dst in batch order - the bytes of the `.log` object (or of a
  * multipart part buffer) exactly as TransformFinisher.java:134-151 (SequenceInputStream over the chunks) hands them to
@@ -120,6 +123,17 @@ int  tsx_device_count(void);
 int  tsx_ctx_create(int device_index, uint32_t max_chunks, uint32_t max_chunk_size, tsx_ctx** out);
 void tsx_ctx_destroy(tsx_ctx* ctx);
 int  tsx_ctx_timing(const tsx_ctx* ctx, tsx_timing* out);
+int  tsx_ctx_device(const tsx_ctx* ctx);                /* device index (0 .. tsx_device_count()-1) the ctx lives on */
+
+/* Device of the calling thread's ctx-less calls: 0 .. tsx_device_count()-1, or -1 = automatic (least loaded).  The JVM side
+ * passes  segment hash % devices  so that the chunks of one segment stay on one GPU (segment s -> GPU s mod N). */
+int  tsx_set_thread_device(int device_index);
+/* Pool of the ctx-less calls on one device: idle contexts kept (at most 8), contexts out right now, batches served so far. */
+int  tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use, uint64_t* batches);
+
+/* Pin / unpin a host buffer that is reused for TSX_MEM_HOST(_PACKED) batches (hipHostRegister): optional, see TSX_MEM_HOST. */
+int  tsx_host_register(void* p, size_t bytes);
+int  tsx_host_unregister(void* p);
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 /* Upper bound of the transformed size of an n-byte chunk: ZSTD_compressBound(n) if compressing,
@@ -128,7 +142,9 @@ size_t tsx_transformed_bound(size_t n, uint32_t flags);
 
 /* Forward chain over a batch of n chunks: [Zstd frame] -> [IV||AES-256-GCM(C)||TAG], CRC32C(original).
  * Replaces CompressionChunkEnumeration.nextElement + EncryptionChunkEnumeration.nextElement for the
- * whole batch.  ctx == NULL borrows a pooled context on device 0. */
+ * whole batch.  ctx == NULL borrows a pooled context: on the device the calling thread chose with tsx_set_thread_device(),
+ * else on the initialised device with the fewest batches in flight (one JVM drives all GPUs of the node from >= 10 RLM
+ * threads, README.md:218-222). */
 int tsx_transform_batch(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n,
                         const void* src, void* dst, size_t dst_size, int mem_kind);
 

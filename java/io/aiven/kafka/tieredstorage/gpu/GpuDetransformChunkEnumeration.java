@@ -8,7 +8,6 @@
 package io.aiven.kafka.tieredstorage.gpu;
 
 import java.nio.ByteBuffer;
-import java.nio.ByteOrder;
 import java.util.ArrayDeque;
 import java.util.ArrayList;
 import java.util.List;
@@ -35,6 +34,10 @@ public class GpuDetransformChunkEnumeration implements DetransformChunkEnumerati
         this.encryption = encryption;
         this.maxOriginalChunkSize = maxOriginalChunkSize;
         this.batchChunks = batchChunks;
+        if (batchChunks < 1 || (long) batchChunks * ((long) maxOriginalChunkSize + 64) >= Integer.MAX_VALUE - 64) {
+            throw new IllegalArgumentException("batchChunks * chunk size must stay below 2 GiB, got " + batchChunks + " chunks of "
+                + maxOriginalChunkSize + " bytes");
+        }
     }
 
     @Override
@@ -71,7 +74,8 @@ public class GpuDetransformChunkEnumeration implements DetransformChunkEnumerati
             return;
         }
         final int flags = (compressed ? TsxNative.COMPRESS : 0) | (encryption != null ? TsxNative.ENCRYPT : 0);
-        final ByteBuffer descs = ByteBuffer.allocateDirect(in.size() * TsxNative.DESC_BYTES).order(ByteOrder.LITTLE_ENDIAN);
+        final TsxNative.Buffers buffers = TsxNative.Buffers.get();     // per-thread, reused, pinned
+        final ByteBuffer descs = buffers.descs(in.size());
         long srcSize = 0;
         long dstSize = 0;
         for (int i = 0; i < in.size(); i++) {
@@ -82,11 +86,13 @@ public class GpuDetransformChunkEnumeration implements DetransformChunkEnumerati
             descs.putLong(base + TsxNative.DESC_DST_OFF, dstSize);
             descs.putInt(base + TsxNative.DESC_SRC_LEN, len);
             descs.putInt(base + TsxNative.DESC_DST_CAP, (int) cap);
+            descs.putInt(base + TsxNative.DESC_DST_LEN, 0);
+            descs.putInt(base + TsxNative.DESC_STATUS, 0);
             srcSize += align16(len) + 16;
             dstSize += align16(cap) + 16;
         }
-        final ByteBuffer src = ByteBuffer.allocateDirect((int) srcSize + 16);
-        final ByteBuffer dst = ByteBuffer.allocateDirect((int) dstSize + 16);
+        final ByteBuffer src = buffers.src(srcSize + 16);
+        final ByteBuffer dst = buffers.dst(dstSize + 16);
         for (int i = 0; i < in.size(); i++) {
             src.position((int) descs.getLong(i * TsxNative.DESC_BYTES + TsxNative.DESC_SRC_OFF));
             src.put(in.get(i));

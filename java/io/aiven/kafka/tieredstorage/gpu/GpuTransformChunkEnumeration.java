@@ -10,7 +10,6 @@
 package io.aiven.kafka.tieredstorage.gpu;
 
 import java.nio.ByteBuffer;
-import java.nio.ByteOrder;
 import java.security.SecureRandom;
 import java.util.ArrayDeque;
 import java.util.ArrayList;
@@ -30,17 +29,38 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
     private final DataKeyAndAAD keyAndAad;   // null: no encryption
     private final int batchChunks;
     private final SecureRandom random;
+    private final int zstdProfile;
+    private final int device;
     private final Integer transformedChunkSize;
     private final ArrayDeque<byte[]> ready = new ArrayDeque<>();
 
+    /**
+     * @param zstdProfile TsxNative.ZSTD_PROFILE_1_5_6 (the libzstd inside the reference's zstd-jni 1.5.6-9, core/build.gradle:29)
+     *                    or ZSTD_PROFILE_1_5_7; configuration key {@code gpu.zstd.profile} - INTEGRATION.md says what each
+     *                    profile has been compared with
+     * @param segmentHash any stable hash of the segment (e.g. of its RemoteLogSegmentId): its batches go to GPU
+     *                    floorMod(segmentHash, deviceCount) so that the node's GPUs are all used and one segment stays on one
+     */
     public GpuTransformChunkEnumeration(final TransformChunkEnumeration inner, final boolean compress,
                                         final DataKeyAndAAD keyAndAad, final int batchChunks,
-                                        final SecureRandom random) {
+                                        final SecureRandom random, final int zstdProfile, final int segmentHash) {
         this.inner = Objects.requireNonNull(inner, "inner cannot be null");
         this.compress = compress;
         this.keyAndAad = keyAndAad;
         this.batchChunks = batchChunks;
         this.random = random;
+        if (zstdProfile != TsxNative.ZSTD_PROFILE_1_5_6 && zstdProfile != TsxNative.ZSTD_PROFILE_1_5_7) {
+            throw new IllegalArgumentException("unknown Zstd profile " + zstdProfile);
+        }
+        this.zstdProfile = zstdProfile;
+        this.device = Math.floorMod(segmentHash, TsxNative.deviceCount());
+        // src and dst of a batch live in one direct ByteBuffer each (< 2 GiB)
+        final long perChunk = TsxNative.transformedBound(inner.originalChunkSize(),
+            (compress ? TsxNative.COMPRESS : 0) | (keyAndAad != null ? TsxNative.ENCRYPT : 0)) + 32;
+        if (batchChunks < 1 || (long) batchChunks * perChunk >= Integer.MAX_VALUE - 64) {
+            throw new IllegalArgumentException("batchChunks * chunk size must stay below 2 GiB, got " + batchChunks + " chunks of "
+                + inner.originalChunkSize() + " bytes");
+        }
         final Integer innerSize = inner.transformedChunkSize();
         if (compress || innerSize == null) {
             this.transformedChunkSize = null;
@@ -90,7 +110,8 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
             return;
         }
         final int flags = (compress ? TsxNative.COMPRESS : 0) | (keyAndAad != null ? TsxNative.ENCRYPT : 0);
-        final ByteBuffer descs = ByteBuffer.allocateDirect(in.size() * TsxNative.DESC_BYTES).order(ByteOrder.LITTLE_ENDIAN);
+        final TsxNative.Buffers buffers = TsxNative.Buffers.get();     // per-thread, reused, pinned
+        final ByteBuffer descs = buffers.descs(in.size());
         long srcSize = 0;
         long dstSize = 0;
         final byte[] iv = new byte[IV_SIZE];
@@ -101,6 +122,8 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
             descs.putLong(base + TsxNative.DESC_DST_OFF, dstSize);
             descs.putInt(base + TsxNative.DESC_SRC_LEN, in.get(i).length);
             descs.putInt(base + TsxNative.DESC_DST_CAP, (int) cap);
+            descs.putInt(base + TsxNative.DESC_DST_LEN, 0);
+            descs.putInt(base + TsxNative.DESC_STATUS, 0);
             if (keyAndAad != null) {
                 random.nextBytes(iv);                      // the IV never comes from the device
                 for (int k = 0; k < IV_SIZE; k++) {
@@ -110,16 +133,16 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
             srcSize += align16(in.get(i).length) + 16;
             dstSize += align16(cap) + 16;
         }
-        final ByteBuffer src = ByteBuffer.allocateDirect((int) srcSize + 16);
-        final ByteBuffer dst = ByteBuffer.allocateDirect((int) dstSize + 16);
+        final ByteBuffer src = buffers.src(srcSize + 16);
+        final ByteBuffer dst = buffers.dst(dstSize + 16);
         for (int i = 0; i < in.size(); i++) {
             src.position((int) descs.getLong(i * TsxNative.DESC_BYTES + TsxNative.DESC_SRC_OFF));
             src.put(in.get(i));
         }
+        TsxNative.setThreadDevice(device);
         final int rc = TsxNative.transformBatch(flags,
             keyAndAad != null ? keyAndAad.dataKey.getEncoded() : null,
-            keyAndAad != null ? keyAndAad.aad : null,
-            0 /* TSX_ZSTD_PROFILE_1_5_6: the libzstd inside zstd-jni 1.5.6-9 */, descs, in.size(), src, dst);
+            keyAndAad != null ? keyAndAad.aad : null, zstdProfile, descs, in.size(), src, dst);
         if (rc != TsxNative.OK) {
             throw new RuntimeException(TsxNative.strerror(rc));
         }

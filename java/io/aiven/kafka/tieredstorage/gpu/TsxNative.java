@@ -27,6 +27,10 @@ public final class TsxNative {
     public static final int DESC_STATUS = 32;
     public static final int DESC_IV = 36;
 
+    /** TSX_ZSTD_PROFILE_*: which libzstd release the compressor reproduces (INTEGRATION.md, "Zstd profile"). */
+    public static final int ZSTD_PROFILE_1_5_6 = 0;
+    public static final int ZSTD_PROFILE_1_5_7 = 1;
+
     static {
         System.loadLibrary("tsxform_jni");   // links libtsxform.so
         final int devices = init();
@@ -43,6 +47,66 @@ public final class TsxNative {
     private static native int init();
 
     public static native String strerror(int code);
+
+    /** tsx_device_count: GPUs the library drives (all visible ones). */
+    public static native int deviceCount();
+
+    /** tsx_set_thread_device: device of the calling thread's batches, -1 = the least loaded one. */
+    public static native int setThreadDevice(int device);
+
+    /** tsx_host_register / tsx_host_unregister: pin a direct buffer that is reused for batches. */
+    public static native int hostRegister(ByteBuffer buf);
+
+    public static native int hostUnregister(ByteBuffer buf);
+
+    /**
+     * Per-thread, grow-only direct buffers (src, dst, descriptors) of the calling thread, pinned once per (re)allocation:
+     * no off-heap allocation and no page faults on the hot path, and the copies go by DMA.
+     */
+    public static final class Buffers {
+        private static final ThreadLocal<Buffers> LOCAL = ThreadLocal.withInitial(Buffers::new);
+        private ByteBuffer src;
+        private ByteBuffer dst;
+        private ByteBuffer descs;
+
+        public static Buffers get() {
+            return LOCAL.get();
+        }
+
+        private static ByteBuffer grow(final ByteBuffer old, final long need, final boolean pin) {
+            if (need > Integer.MAX_VALUE - 64) {
+                // one direct ByteBuffer holds < 2 GiB: the batch size is bounded at construction time of the enumerations
+                throw new IllegalArgumentException("batch of " + need + " bytes exceeds a direct ByteBuffer");
+            }
+            if (old != null && old.capacity() >= need) {
+                old.clear();
+                return old;
+            }
+            if (old != null && pin) {
+                hostUnregister(old);
+            }
+            final ByteBuffer fresh = ByteBuffer.allocateDirect((int) (need + need / 8 + 64)).order(java.nio.ByteOrder.LITTLE_ENDIAN);
+            if (pin) {
+                hostRegister(fresh);          // best effort: an unpinned buffer still works (runtime-staged copies)
+            }
+            return fresh;
+        }
+
+        public ByteBuffer src(final long need) {
+            src = grow(src, need, true);
+            return src;
+        }
+
+        public ByteBuffer dst(final long need) {
+            dst = grow(dst, need, true);
+            return dst;
+        }
+
+        public ByteBuffer descs(final int n) {
+            descs = grow(descs, (long) n * DESC_BYTES, false);
+            return descs;
+        }
+    }
 
     /** tsx_transformed_bound. */
     public static native long transformedBound(long n, int flags);

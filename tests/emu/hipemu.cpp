@@ -3,6 +3,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <mutex>
 #include <vector>
 
 extern "C" void hipemu_switch(void** from_sp, void* to_sp);
@@ -113,7 +114,11 @@ static void init_fiber(Fiber& f) {
     f.done = false;
 }
 
+// One grid at a time: the scheduler state (and `__shared__` = static storage) is process-wide, while the front end under test is
+// called from several host threads (pooled contexts, device hints).
+static std::mutex g_grid_mu;
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry) {
+    std::lock_guard<std::mutex> grid_lock(g_grid_mu);
     unsigned nthreads = block.x * block.y * block.z;
     Block blk;
     blk.fibers.resize(nthreads);
@@ -156,9 +161,13 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry) {
 struct hipemu_stream { int dummy; };
 struct hipemu_event { std::chrono::steady_clock::time_point t; };
 
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// HIPEMU_DEVICES=n makes the harness report n identical "devices" (one address space), so the multi-device dispatch of the
+// front end (context pools per device, device hints) can be exercised without hardware.
+static int emu_devices() { const char* e = getenv("HIPEMU_DEVICES"); int n = e ? atoi(e) : 1; return n < 1 ? 1 : n > 16 ? 16 : n; }
+static thread_local int g_emu_dev = 0;
+hipError_t hipGetDeviceCount(int* n) { *n = emu_devices(); return hipSuccess; }
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= emu_devices()) return hipErrorInvalidValue; g_emu_dev = d; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = g_emu_dev; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     std::memset(p, 0, sizeof *p);
     std::snprintf(p->name, sizeof p->name, "hipemu (CPU test harness)");
@@ -171,6 +180,9 @@ hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+hipError_t hipHostUnregister(void*) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }

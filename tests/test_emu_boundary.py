@@ -1,0 +1,178 @@
+"""The C-ABI front end (csrc/tsx_api.hip) under the CPU emulator: device selection of the ctx-less calls, pooled contexts,
+the staged host-memory pipeline, key hygiene, failed-chunk scrubbing and argument validation.  Same source as the product
+library; the GPU twins of the data-path cases are in tests/test_gpu_parity.py."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import tsxform
+from tests import parity_cases as pc
+from tsxform import synth
+
+nat = tsxform._native
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_py(code, **env):
+    e = dict(os.environ, TSX_ALLOW_ANY_ARCH="1", **{k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def test_ctxless_calls_use_every_device(emu):
+    """tsx_init(2): ctx-less batches alternate between the devices (least loaded, ties round-robin), a thread's device hint pins
+    them, a burst of callers leaves at most 8 idle contexts per device (a broker JVM must reach all 8 GPUs)."""
+    out = _run_py("""
+        import threading, numpy as np
+        import tsxform
+        from tests import parity_cases as pc
+        from tests.emu import emu_native
+        nat = tsxform._native
+        N = nat.Native(emu_native.build())
+        assert N.init(2) == 2 and "2 device(s)" in N.version()
+        src = np.zeros(64, np.uint8); src[:9] = np.frombuffer(b"123456789", np.uint8)
+        def crc():
+            d = pc.make_descs([9], [0], [0], [0]); N.crc32c_batch(d, src); assert d["crc32c"][0] == 0xE3069283
+        for _ in range(6): crc()
+        assert [N.pool_stats(i)["batches"] for i in (0, 1)] == [3, 3]
+        N.set_thread_device(1)
+        for _ in range(4): crc()
+        assert [N.pool_stats(i)["batches"] for i in (0, 1)] == [3, 7]
+        N.set_thread_device(-1)
+        try:
+            N.set_thread_device(2); raise SystemExit("device 2 accepted")
+        except nat.TsxError as e:
+            assert e.code == nat.E_INVAL
+        c = N.ctx_create(1); assert N.ctx_device(c) == 1; N.ctx_destroy(c)
+        th = [threading.Thread(target=lambda: [crc() for _ in range(3)]) for _ in range(24)]
+        [t.start() for t in th]; [t.join() for t in th]
+        s = [N.pool_stats(i) for i in (0, 1)]
+        assert all(x["in_use"] == 0 and 1 <= x["idle"] <= 8 for x in s), s
+        assert s[0]["batches"] + s[1]["batches"] == 10 + 72 and min(x["batches"] for x in s) >= 20, s
+        N.shutdown()
+        assert "uninitialised" in N.version()
+        print("ok")
+    """, HIPEMU_DEVICES=2)
+    assert out.strip().endswith("ok")
+
+
+def test_detransform_crc_on_a_fresh_context_with_generous_slots(emu):
+    """the CRC of the restored bytes runs over dst_cap-sized slots; a fresh context sized its partial sums from the
+    (small) transformed chunks only.  64 tiny chunks restored into 4 MiB slots on a new ctx."""
+    n, cap = 64, 4 << 20
+    chunks = [synth.gen_chunk("K", 3, 0, i, 700 + i) for i in range(n)]
+    outs, d0 = pc.run_transform(emu, nat.ENCRYPT | nat.CRC, chunks)
+    soff, st = [], 0
+    for b in outs:
+        soff.append(st); st += (len(b) + 15) // 16 * 16 + 16
+    src = np.zeros(st, np.uint8)
+    for b, o_ in zip(outs, soff):
+        src[o_:o_ + len(b)] = np.frombuffer(b, np.uint8)
+    dst = np.zeros(n * cap, np.uint8)
+    d = pc.make_descs([len(b) for b in outs], soff, [i * cap for i in range(n)], [cap] * n)
+    ctx = emu.ctx_create(0, 0, 0)
+    try:
+        emu.detransform_batch(nat.Native.make_params(nat.ENCRYPT | nat.CRC, synth.KEY, synth.AAD), d, src, dst, dst.size, ctx=ctx)
+    finally:
+        emu.ctx_destroy(ctx)
+    assert (d["status"] == 0).all() and (d["crc32c"] == d0["crc32c"]).all()
+    for i, c in enumerate(chunks):
+        assert dst[i * cap:i * cap + c.size].tobytes() == c.tobytes()
+
+
+def test_failed_tag_check_leaves_nothing_in_a_device_slot_and_no_key_behind(emu):
+    chunks = pc.edge_chunks("R", [3000, 5000, 70001])
+    outs, _ = pc.run_transform(emu, nat.ENCRYPT, chunks)
+    forged = bytearray(outs[1]); forged[100] ^= 1
+    blobs = [outs[0], bytes(forged), outs[2]]
+    soff, st = [], 0
+    for b in blobs:
+        soff.append(st); st += (len(b) + 15) // 16 * 16 + 16
+    src = np.zeros(st, np.uint8)
+    for b, o_ in zip(blobs, soff):
+        src[o_:o_ + len(b)] = np.frombuffer(b, np.uint8)
+    doff = [0, 4096, 16384]; total = 16384 + 70016
+    d = pc.make_descs([len(b) for b in blobs], soff, doff, [3008, 5008, 70016])
+    ds, dd = emu.device_malloc(src.size), emu.device_malloc(total)
+    emu.h2d(ds, src); emu.h2d(dd, np.full(total, 0xAB, np.uint8))
+    ctx = emu.ctx_create(0, 0, 0)
+    try:
+        emu.detransform_batch(nat.Native.make_params(nat.ENCRYPT, synth.KEY, synth.AAD), d, ds, dd, total, nat.MEM_DEVICE, ctx=ctx)
+        assert emu.lib.tsx_debug_key_residue(ctx) == 0          # round keys, H powers, raw key and AAD are gone
+    finally:
+        emu.ctx_destroy(ctx)
+    back = np.zeros(total, np.uint8); emu.d2h(back, dd)
+    emu.device_free(ds); emu.device_free(dd)
+    assert list(d["status"]) == [0, nat.E_TAG_MISMATCH, 0] and d["dst_len"][1] == 0
+    assert back[0:3000].tobytes() == chunks[0].tobytes() and back[16384:16384 + 70001].tobytes() == chunks[2].tobytes()
+    assert not back[4096:4096 + 5008].any(), "unauthenticated plaintext left in the caller's slot"
+
+
+def test_key_is_wiped_after_a_failed_batch_too(emu):
+    ctx = emu.ctx_create(0, 0, 0)
+    try:
+        src = np.zeros(64, np.uint8); dst = np.zeros(16, np.uint8)
+        d = pc.make_descs([32], [0], [0], [16])                      # slot too small: per-chunk failure
+        emu.transform_batch(nat.Native.make_params(nat.ENCRYPT, synth.KEY, synth.AAD), d, src, dst, dst.size, ctx=ctx)
+        assert d["status"][0] == nat.E_DST_TOO_SMALL and emu.lib.tsx_debug_key_residue(ctx) == 0
+    finally:
+        emu.ctx_destroy(ctx)
+
+
+def test_validation_is_overflow_safe_and_leaves_descriptors_alone(emu):
+    src = np.zeros(4096, np.uint8); dst = np.zeros(8192, np.uint8)
+    p = nat.Native.make_params(nat.ENCRYPT, synth.KEY, synth.AAD)
+    d = pc.make_descs([100], [0], [(1 << 64) - 16], [128])         # dst_off + dst_cap wraps around
+    with pytest.raises(nat.TsxError) as e:
+        emu.transform_batch(p, d, src, dst, dst.size)
+    assert e.value.code == nat.E_INVAL
+    d = pc.make_descs([100], [0], [8192 - 64], [128])               # ends 64 bytes beyond dst
+    with pytest.raises(nat.TsxError):
+        emu.transform_batch(p, d, src, dst, dst.size)
+    d = pc.make_descs([100, 100], [0, 8], [777, 999], [5, 6])        # packed: unaligned src_off -> INVAL, dst fields untouched
+    with pytest.raises(nat.TsxError):
+        emu.transform_batch(p, d, src, dst, dst.size, nat.MEM_HOST_PACKED)
+    assert list(d["dst_off"]) == [777, 999] and list(d["dst_cap"]) == [5, 6]
+
+
+@pytest.mark.parametrize("flags", [nat.ENCRYPT | nat.CRC, nat.CRC, 0])
+def test_staged_pipeline_equals_single_shot(emu, flags, monkeypatch):
+    """TSX_MEM_HOST batches are cut into pieces (copy-in / kernels / copy-out overlapped); forced down to 4 KiB pieces here so that 23
+    chunks make ~20 of them.  Outputs, descriptors and the inverse must equal the un-pipelined run."""
+    chunks = pc.edge_chunks("K", [0, 1, 17, 300, 4096, 5000, 65537, 12, 70001, 33, 2048, 9000, 100, 4097, 1, 31000, 16, 15, 8191, 8192, 8193, 700, 64])
+    monkeypatch.setenv("TSX_NO_PIPELINE", "1")
+    ref, dref = pc.run_transform(emu, flags, chunks)
+    refp, dpk = pc.run_transform(emu, flags, chunks, mem="packed")
+    monkeypatch.delenv("TSX_NO_PIPELINE")
+    monkeypatch.setenv("TSX_SUB_BYTES", "4096")
+    got, dgot = pc.run_transform(emu, flags, chunks)
+    gotp, dgp = pc.run_transform(emu, flags, chunks, mem="packed")
+    assert got == ref and gotp == refp == ref
+    for f in ("dst_len", "crc32c", "status"):
+        assert (dgot[f] == dref[f]).all() and (dgp[f] == dpk[f]).all(), f
+    assert (dgp["dst_off"] == dpk["dst_off"]).all()
+    back, d2 = pc.run_detransform(emu, flags, got, [int(c.size) for c in chunks])
+    assert (d2["status"] == 0).all() and [b for b in back] == [c.tobytes() for c in chunks]
+    sizes = [int(c.size) for c in chunks]
+    soff, _, _, st, _ = pc.layout(sizes, 0, emu)
+    src = np.zeros(st, np.uint8)
+    for c, o_ in zip(chunks, soff):
+        src[o_:o_ + c.size] = c
+    d = pc.make_descs(sizes, soff, [0] * len(sizes), [0] * len(sizes))
+    emu.crc32c_batch(d, src)
+    if flags & nat.CRC:
+        assert (d["crc32c"] == dref["crc32c"]).all()
+
+
+def test_host_register_roundtrip(emu):
+    buf = np.zeros(1 << 16, np.uint8)
+    emu.host_register(buf)
+    d = pc.make_descs([9], [0], [0], [0]); buf[:9] = np.frombuffer(b"123456789", np.uint8)
+    emu.crc32c_batch(d, buf)
+    assert d["crc32c"][0] == 0xE3069283
+    emu.host_unregister(buf)

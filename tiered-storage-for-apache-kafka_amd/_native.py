@@ -43,7 +43,7 @@ assert DESC_DTYPE.itemsize == C.sizeof(ChunkDesc) == 48
 EXPORTS = ["tsx_abi_version", "tsx_version", "tsx_strerror", "tsx_init", "tsx_shutdown", "tsx_device_count",
            "tsx_ctx_create", "tsx_ctx_destroy", "tsx_ctx_timing", "tsx_transformed_bound", "tsx_transform_batch",
            "tsx_detransform_batch", "tsx_crc32c_batch", "tsx_device_malloc", "tsx_device_free", "tsx_memcpy_h2d",
-           "tsx_memcpy_d2h"]
+           "tsx_memcpy_d2h", "tsx_ctx_device", "tsx_set_thread_device", "tsx_pool_stats", "tsx_host_register", "tsx_host_unregister"]
 
 
 class TsxError(RuntimeError):
@@ -79,6 +79,12 @@ class Native:
         L.tsx_device_free.restype = C.c_int; L.tsx_device_free.argtypes = [C.c_int, vp]
         L.tsx_memcpy_h2d.restype = C.c_int; L.tsx_memcpy_h2d.argtypes = [C.c_int, vp, vp, sz]
         L.tsx_memcpy_d2h.restype = C.c_int; L.tsx_memcpy_d2h.argtypes = [C.c_int, vp, vp, sz]
+        L.tsx_ctx_device.restype = C.c_int; L.tsx_ctx_device.argtypes = [vp]
+        L.tsx_set_thread_device.restype = C.c_int; L.tsx_set_thread_device.argtypes = [C.c_int]
+        L.tsx_pool_stats.restype = C.c_int
+        L.tsx_pool_stats.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.tsx_host_register.restype = C.c_int; L.tsx_host_register.argtypes = [vp, sz]
+        L.tsx_host_unregister.restype = C.c_int; L.tsx_host_unregister.argtypes = [vp]
         self.lib = L
         self.path = path
         self._inited = False
@@ -113,6 +119,28 @@ class Native:
         t = Timing()
         self.check(self.lib.tsx_ctx_timing(h, C.byref(t)))
         return t
+
+    def ctx_device(self, h):
+        return self.check(self.lib.tsx_ctx_device(h))
+
+    def set_thread_device(self, device_index):
+        """Device of this thread's ctx-less calls (-1: least loaded)."""
+        self.check(self.lib.tsx_set_thread_device(device_index))
+
+    def pool_stats(self, device_index=0):
+        idle, in_use, batches = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self.check(self.lib.tsx_pool_stats(device_index, C.byref(idle), C.byref(in_use), C.byref(batches)))
+        return {"idle": idle.value, "in_use": in_use.value, "batches": batches.value}
+
+    def host_register(self, arr):
+        self.check(self.lib.tsx_host_register(arr.ctypes.data, arr.nbytes))
+
+    def host_unregister(self, arr):
+        self.check(self.lib.tsx_host_unregister(arr.ctypes.data))
+
+    def shutdown(self):
+        self.lib.tsx_shutdown()
+        self._inited = False
 
     def transformed_bound(self, n, flags):
         return self.lib.tsx_transformed_bound(n, flags)

@@ -1,5 +1,6 @@
 // C-ABI front end of libtsxform: device/context management and the batch pipelines.
 // See include/tsxform.h for the contract and the reference call sites each entry point replaces.
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -18,6 +19,7 @@ static void tsx_set_err(const char* what, hipError_t e) {
     if (getenv("TSX_DEBUG")) fprintf(stderr, "[tsxform] %s\n", g_last_err);
 }
 
+struct tsx_ctx;
 struct tsx_device {
     int hip_id = -1;
     tsx_crc_tables* d_crc = nullptr;
@@ -25,12 +27,21 @@ struct tsx_device {
     tsx_zstd_consts* d_zc = nullptr;
     char name[256] = {0};
     char arch[256] = {0};
+    // pooled contexts of the ctx-less calls: idle ones, how many are out, batches served (all under g_mu)
+    std::vector<tsx_ctx*> idle;
+    uint32_t in_use = 0;
+    uint64_t batches = 0;
 };
+
+#define TSX_MAX_SUBS 64                 /* sub-batches of one host-memory batch (staging pipeline) */
+#define TSX_SUB_BYTES ((size_t)64 << 20) /* input bytes per sub-batch: >= 1000 workgroups of the GCM / CRC kernels */
+#define TSX_POOL_MAX_IDLE 8             /* idle pooled contexts kept per device; the rest are destroyed on release */
 
 struct tsx_ctx {
     int dev_index = 0;
     tsx_device* dev = nullptr;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;                      // kernels (+ descriptor copies)
+    hipStream_t st_in = nullptr, st_out = nullptr; // H2D / D2H of the host-memory staging pipeline
     // device workspace (grown on demand)
     tsx_chunk_desc* d_descs = nullptr; size_t descs_cap = 0;
     tsx_gcm_chunk* d_gchunks = nullptr;
@@ -44,25 +55,26 @@ struct tsx_ctx {
     uint8_t* d_mid = nullptr; size_t mid_cap = 0;  // compressed frames between the Zstd and GCM stages
     size_t mid_stride = 0;
     void* d_zwork = nullptr; size_t zwork_cap = 0; // Zstd per-chunk workspace
-    hipEvent_t ev[8] = {nullptr};
+    hipEvent_t ev[4] = {nullptr};                  // batch begin / end, first H2D, last D2H
+    hipEvent_t sub_ev[TSX_MAX_SUBS][6] = {{nullptr}}; // per sub-batch: stage boundaries 0..4 (st), [5] = staged in (st_in)
     tsx_timing timing{};
     bool pooled = false;
 };
 
 static std::mutex g_mu;
 static std::vector<tsx_device> g_devs;
-static std::vector<tsx_ctx*> g_pool;
-static char g_version[384];
+static uint32_t g_rr = 0;
+static thread_local int t_dev_hint = -1;
+static const char kUninitVersion[] = "tsxform 0.2 (gfx950 HIP; uninitialised)";
+static char g_version_buf[2][384];
+static unsigned g_version_gen = 0;
+static std::atomic<const char*> g_version{kUninitVersion};
 
 extern "C" uint32_t tsx_abi_version(void) { return TSX_ABI_VERSION; }
 
-extern "C" const char* tsx_version(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    snprintf(g_version, sizeof g_version,
-             "tsxform 0.1 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; device: %s)",
-             g_devs.empty() ? "uninitialised" : g_devs[0].name);
-    return g_version;
-}
+// The string is composed in a buffer no reader can see yet and published with one pointer store at the end of a successful
+// tsx_init: callers never observe a half-written string and need no lock.
+extern "C" const char* tsx_version(void) { return g_version.load(std::memory_order_acquire); }
 
 extern "C" const char* tsx_strerror(int code) {
     switch (code) {
@@ -80,26 +92,20 @@ extern "C" const char* tsx_strerror(int code) {
     }
 }
 
-extern "C" int tsx_init(int device_count, const int* device_ids) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_devs.empty()) return (int)g_devs.size();
-    int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
-        snprintf(g_last_err, sizeof g_last_err, "no HIP device visible");
-        return TSX_E_DEVICE;
-    }
-    int want = device_count <= 0 ? visible : device_count;
-    if (want > visible) return TSX_E_INVAL;
-    tsx_crc_tables* hc = new (std::nothrow) tsx_crc_tables;
-    tsx_aes_tables* ha = new (std::nothrow) tsx_aes_tables;
-    tsx_zstd_consts* hz = (tsx_zstd_consts*)malloc(tsx_zstd_consts_bytes());
-    if (!hc || !ha || !hz) return TSX_E_NOMEM;
-    tsx_crc_build_tables(hc);
-    tsx_aes_build_tables(ha);
-    tsx_zstd_build_consts(hz);
-    std::vector<tsx_device> devs;
+static void device_free_consts(tsx_device& d) {
+    if (d.hip_id < 0) return;
+    hipSetDevice(d.hip_id);
+    if (d.d_crc) hipFree(d.d_crc);
+    if (d.d_aes) hipFree(d.d_aes);
+    if (d.d_zc) hipFree(d.d_zc);
+    d.d_crc = nullptr; d.d_aes = nullptr; d.d_zc = nullptr;
+}
+
+static int init_devices(std::vector<tsx_device>& devs, int want, const int* device_ids, const tsx_crc_tables* hc, const tsx_aes_tables* ha,
+                        const tsx_zstd_consts* hz) {
     for (int i = 0; i < want; i++) {
-        tsx_device d;
+        devs.emplace_back();
+        tsx_device& d = devs.back();
         d.hip_id = device_ids ? device_ids[i] : i;
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, d.hip_id));
@@ -116,10 +122,40 @@ extern "C" int tsx_init(int device_count, const int* device_ids) {
         HIPCHK(hipMemcpy(d.d_crc, hc, sizeof(tsx_crc_tables), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.d_aes, ha, sizeof(tsx_aes_tables), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.d_zc, hz, tsx_zstd_consts_bytes(), hipMemcpyHostToDevice));
-        devs.push_back(d);
+    }
+    return TSX_OK;
+}
+
+extern "C" int tsx_init(int device_count, const int* device_ids) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_devs.empty()) return (int)g_devs.size();
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+        snprintf(g_last_err, sizeof g_last_err, "no HIP device visible");
+        return TSX_E_DEVICE;
+    }
+    int want = device_count <= 0 ? visible : device_count;
+    if (want > visible) return TSX_E_INVAL;
+    tsx_crc_tables* hc = new (std::nothrow) tsx_crc_tables;
+    tsx_aes_tables* ha = new (std::nothrow) tsx_aes_tables;
+    tsx_zstd_consts* hz = (tsx_zstd_consts*)malloc(tsx_zstd_consts_bytes());
+    int rc = TSX_E_NOMEM;
+    std::vector<tsx_device> devs;
+    devs.reserve((size_t)want);
+    if (hc && ha && hz) {
+        tsx_crc_build_tables(hc);
+        tsx_aes_build_tables(ha);
+        tsx_zstd_build_consts(hz);
+        rc = init_devices(devs, want, device_ids, hc, ha, hz);
     }
     delete hc; delete ha; free(hz);
-    g_devs = devs;
+    if (rc != TSX_OK) { for (auto& d : devs) device_free_consts(d); return rc; }   // nothing of a failed init stays allocated
+    g_devs.swap(devs);
+    char* vb = g_version_buf[g_version_gen++ & 1];
+    snprintf(vb, sizeof g_version_buf[0],
+             "tsxform 0.2 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; %d device(s): %s)",
+             (int)g_devs.size(), g_devs[0].name);
+    g_version.store(vb, std::memory_order_release);
     return (int)g_devs.size();
 }
 
@@ -130,23 +166,27 @@ extern "C" int tsx_device_count(void) {
 
 static void ctx_free_device_mem(tsx_ctx* c) {
     hipSetDevice(c->dev->hip_id);
+    // the key schedule and the raw key never outlive the context in readable form
+    if (c->d_key) hipMemset(c->d_key, 0, sizeof(tsx_gcm_key));
+    if (c->d_keyraw) hipMemset(c->d_keyraw, 0, 128);
     void* ptrs[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen, c->d_partials, c->d_key, c->d_keyraw, c->d_in, c->d_out, c->d_mid, c->d_zwork};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    for (auto& row : c->sub_ev) for (auto& e : row) if (e) hipEventDestroy(e);
     if (c->st) hipStreamDestroy(c->st);
+    if (c->st_in) hipStreamDestroy(c->st_in);
+    if (c->st_out) hipStreamDestroy(c->st_out);
 }
 
 extern "C" void tsx_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (tsx_ctx* c : g_pool) { ctx_free_device_mem(c); delete c; }
-    g_pool.clear();
     for (auto& d : g_devs) {
-        hipSetDevice(d.hip_id);
-        if (d.d_crc) hipFree(d.d_crc);
-        if (d.d_aes) hipFree(d.d_aes);
-        if (d.d_zc) hipFree(d.d_zc);
+        for (tsx_ctx* c : d.idle) { ctx_free_device_mem(c); delete c; }
+        d.idle.clear();
+        device_free_consts(d);
     }
     g_devs.clear();
+    g_version.store(kUninitVersion, std::memory_order_release);
 }
 
 template <class T>
@@ -160,7 +200,8 @@ static int grow(T** p, size_t* cap, size_t need) {
     return TSX_OK;
 }
 
-static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t flags, bool host_mem, size_t in_bytes, size_t out_bytes) {
+// max_out: largest output slot of the batch (detransform: the CRC of the restored bytes runs over dst_cap-sized slots)
+static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_out, uint32_t flags, bool host_mem, size_t in_bytes, size_t out_bytes) {
     HIPCHK(hipSetDevice(c->dev->hip_id));
     if (n > c->descs_cap || !c->d_descs) {
         void* olds[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen};
@@ -173,10 +214,13 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t flags,
         HIPCHK(hipMalloc((void**)&c->d_zlen, cap * sizeof(uint32_t)));
         c->descs_cap = cap;
     }
-    // partials: GCM needs 4 u32 per 64 KiB sub-block of the (possibly expanded) stage input, CRC 1 per 256 KiB
+    // partials: GCM needs 4 u32 per 64 KiB sub-block of the (possibly expanded) stage input, CRC 1 per 256 KiB of the
+    // bytes it runs over - the source chunks on the way in, the dst_cap-sized output slots on the way back
     size_t bound = tsx_transformed_bound(max_len, flags & TSX_COMPRESS) + 64;
     size_t subs = (bound + TSX_GCM_SUB_BYTES - 1) / TSX_GCM_SUB_BYTES + 1;
-    int rc = grow(&c->d_partials, &c->partials_cap, (size_t)n * subs * 4);
+    size_t crc_subs = ((size_t)(max_out > max_len ? max_out : max_len) + TSX_CRC_SUB_BYTES - 1) / TSX_CRC_SUB_BYTES + 1;
+    size_t per_chunk = subs * 4 > crc_subs ? subs * 4 : crc_subs;
+    int rc = grow(&c->d_partials, &c->partials_cap, (size_t)n * per_chunk);
     if (rc) return rc;
     if (host_mem) {
         if ((rc = grow(&c->d_in, &c->in_cap, in_bytes + 64))) return rc;
@@ -194,6 +238,18 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t flags,
     return TSX_OK;
 }
 
+static int ctx_init_device_objects(tsx_ctx* c) {
+    HIPCHK(hipSetDevice(c->dev->hip_id));
+    HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->st_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->st_out, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    for (auto& e : c->sub_ev[0]) HIPCHK(hipEventCreate(&e));      // the other rows are created by the first pipelined batch
+    HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
+    HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
+    return TSX_OK;
+}
+
 extern "C" int tsx_ctx_create(int device_index, uint32_t max_chunks, uint32_t max_chunk_size, tsx_ctx** out) {
     if (!out) return TSX_E_INVAL;
     tsx_device* dev;
@@ -206,15 +262,9 @@ extern "C" int tsx_ctx_create(int device_index, uint32_t max_chunks, uint32_t ma
     tsx_ctx* c = new (std::nothrow) tsx_ctx;
     if (!c) return TSX_E_NOMEM;
     c->dev_index = device_index; c->dev = dev;
-    HIPCHK(hipSetDevice(dev->hip_id));
-    HIPCHK(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
-    for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
-    HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
-    HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
-    if (max_chunks && max_chunk_size) {
-        int rc = ctx_reserve(c, max_chunks, max_chunk_size, 0, false, 0, 0);
-        if (rc) { ctx_free_device_mem(c); delete c; return rc; }
-    }
+    int rc = ctx_init_device_objects(c);
+    if (rc == TSX_OK && max_chunks && max_chunk_size) rc = ctx_reserve(c, max_chunks, max_chunk_size, max_chunk_size, 0, false, 0, 0);
+    if (rc) { ctx_free_device_mem(c); delete c; return rc; }     // a half-built context leaves nothing behind
     *out = c;
     return TSX_OK;
 }
@@ -231,20 +281,62 @@ extern "C" int tsx_ctx_timing(const tsx_ctx* c, tsx_timing* out) {
     return TSX_OK;
 }
 
+extern "C" int tsx_ctx_device(const tsx_ctx* c) { return c ? c->dev_index : TSX_E_INVAL; }
+
+// ---- ctx-less calls: which device, which pooled context ---------------------------------------------
+// One JVM per broker drives ALL GPUs of the node from >= 10 RLM threads plus the ChunkCache pool (README.md:218-222,
+// RemoteStorageManager.java:212): a ctx-less call goes to the device its thread asked for (tsx_set_thread_device: the JVM side
+// passes segment hash % devices, SURVEY 8e "segment s -> GPU s mod N"), otherwise to the device with the fewest batches in
+// flight (ties broken round-robin).
+extern "C" int tsx_set_thread_device(int device_index) {
+    if (device_index >= 0) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (device_index >= (int)g_devs.size()) return TSX_E_INVAL;
+    }
+    t_dev_hint = device_index < 0 ? -1 : device_index;
+    return TSX_OK;
+}
+
+extern "C" int tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use, uint64_t* batches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL;
+    if (idle) *idle = (uint32_t)g_devs[device_index].idle.size();
+    if (in_use) *in_use = g_devs[device_index].in_use;
+    if (batches) *batches = g_devs[device_index].batches;
+    return TSX_OK;
+}
+
 static tsx_ctx* pool_acquire(int* rc) {
+    int di = -1;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_pool.empty()) { tsx_ctx* c = g_pool.back(); g_pool.pop_back(); return c; }
+        const int nd = (int)g_devs.size();
+        if (nd == 0) { snprintf(g_last_err, sizeof g_last_err, "tsx_init has not succeeded"); *rc = TSX_E_DEVICE; return nullptr; }
+        if (t_dev_hint >= 0 && t_dev_hint < nd) di = t_dev_hint;
+        else {
+            const int first = (int)(g_rr++ % (uint32_t)nd);
+            di = first;
+            for (int k = 1; k < nd; k++) { const int j = (first + k) % nd; if (g_devs[j].in_use < g_devs[di].in_use) di = j; }
+        }
+        tsx_device& d = g_devs[di];
+        d.in_use++; d.batches++;
+        if (!d.idle.empty()) { tsx_ctx* c = d.idle.back(); d.idle.pop_back(); return c; }
     }
     tsx_ctx* c = nullptr;
-    *rc = tsx_ctx_create(0, 0, 0, &c);
-    if (*rc) return nullptr;
+    *rc = tsx_ctx_create(di, 0, 0, &c);
+    if (*rc) { std::lock_guard<std::mutex> lk(g_mu); g_devs[di].in_use--; return nullptr; }
     c->pooled = true;
     return c;
 }
 static void pool_release(tsx_ctx* c) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_pool.push_back(c);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        tsx_device& d = *c->dev;
+        d.in_use--;
+        if (d.idle.size() < TSX_POOL_MAX_IDLE) { d.idle.push_back(c); return; }
+    }
+    ctx_free_device_mem(c);                                            // a burst of callers does not pin its workspaces forever
+    delete c;
 }
 
 // ZSTD_compressBound(n) = n + (n >> 8) + (n < 128 KiB ? ((128 KiB - n) >> 11) : 0)
@@ -323,21 +415,252 @@ __global__ void publish_status_kernel(tsx_chunk_desc* descs, const int32_t* stat
     if (status[i] != TSX_OK) descs[i].dst_len = 0;
 }
 
+// Zeroes what a failed chunk of the inverse chain left in its output slot (device-memory calls: a forged chunk's
+// unauthenticated plaintext must not stay readable - JCE's doFinal releases nothing on a bad tag,
+// DecryptionChunkEnumeration.java:54-62).  Up to min(dst_cap, src_len) bytes can have been written.
+__global__ __launch_bounds__(256) void scrub_failed_kernel(const tsx_chunk_desc* __restrict__ descs, const int32_t* __restrict__ status,
+                                                           uint8_t* __restrict__ dst, uint32_t blocks_per_chunk) {
+    const uint32_t i = blockIdx.x / blocks_per_chunk, part = blockIdx.x % blocks_per_chunk;
+    if (status[i] == TSX_OK) return;
+    const tsx_chunk_desc d = descs[i];
+    const uint32_t len = d.src_len < d.dst_cap ? d.src_len : d.dst_cap;
+    uint8_t* o = dst + d.dst_off;
+    const uint32_t q = len >> 4;                                         // slots are 16-byte aligned
+    uint4 z; z.x = z.y = z.z = z.w = 0;
+    for (uint32_t p = part * 256 + threadIdx.x; p < q; p += blocks_per_chunk * 256) reinterpret_cast<uint4*>(o)[p] = z;
+    if (part == 0) for (uint32_t b = (q << 4) + threadIdx.x; b < len; b += 256) o[b] = 0;
+}
+
 // ---- batch drivers ---------------------------------------------------------------------------------
-static int validate(const tsx_chunk_desc* descs, uint32_t n, size_t dst_size, bool need_dst, uint32_t* max_len, size_t* in_bytes) {
-    *max_len = 0; *in_bytes = 0;
+static int validate(const tsx_chunk_desc* descs, uint32_t n, size_t dst_size, bool need_dst, uint32_t* max_len, uint32_t* max_out,
+                    size_t* in_bytes, bool* monotonic) {
+    *max_len = 0; *max_out = 0; *in_bytes = 0; *monotonic = true;
+    uint64_t prev_src_end = 0, prev_dst_end = 0;
     for (uint32_t i = 0; i < n; i++) {
         const tsx_chunk_desc& d = descs[i];
         if ((d.src_off & 15) || (need_dst && (d.dst_off & 15))) return TSX_E_INVAL;       // 16-byte aligned slots
-        if (need_dst && (d.dst_off + d.dst_cap > dst_size)) return TSX_E_INVAL;
+        if (need_dst && (d.dst_off > dst_size || d.dst_cap > dst_size - d.dst_off)) return TSX_E_INVAL;   // no wrap-around
         if (d.src_len >= (1u << 30) + 4096) return TSX_E_INVAL;                             // chunk.size <= 2^30 - 1 (RemoteStorageManagerConfig.java:122-130)
+        if (d.src_off > ((uint64_t)1 << 62)) return TSX_E_INVAL;
         if (d.src_len > *max_len) *max_len = d.src_len;
+        if (need_dst && d.dst_cap > *max_out) *max_out = d.dst_cap;
         if (d.src_off + d.src_len > *in_bytes) *in_bytes = d.src_off + d.src_len;
+        if (d.src_off < prev_src_end || (need_dst && d.dst_off < prev_dst_end)) *monotonic = false;
+        prev_src_end = d.src_off + d.src_len;
+        if (need_dst) prev_dst_end = d.dst_off + d.dst_cap;
     }
     return TSX_OK;
 }
 
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
+
+struct tsx_sub { uint32_t lo, n; size_t in_lo, in_hi; };     // chunks [lo, lo + n), their input bytes [in_lo, in_hi) of src
+
+struct tsx_run {                                              // what one batch needs everywhere below
+    tsx_ctx* c; const tsx_batch_params* params; tsx_chunk_desc* descs; uint32_t n; const void* src; void* dst; size_t dst_size;
+    int mem_kind, mode; uint32_t flags, max_len, max_out; bool host, packed, enc, comp, fuse_stages;
+    const uint8_t* d_src; uint8_t* d_dst;
+};
+
+// Enqueues the kernels of chunks [lo, lo + n) on the context's compute stream; e[0..3] are recorded at the stage boundaries.
+static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e) {
+    tsx_ctx* c = r.c;
+    hipStream_t st = c->st;
+    const uint32_t n = sb.n, lo = sb.lo, flags = r.flags;
+    tsx_chunk_desc* dd = c->d_descs + lo;
+    int32_t* ds = c->d_status + lo;
+    uint32_t* dz = c->d_zlen + lo;
+    tsx_gcm_chunk* dg = c->d_gchunks + lo;
+    uint8_t* dmid = c->d_mid ? c->d_mid + (size_t)lo * c->mid_stride : nullptr;
+    void* dzw = c->d_zwork;                                            // per-chunk workspace is indexed from 0 in every launch
+    tsx_timing& t = c->timing;
+    HIPCHK(hipMemcpyAsync(dd, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
+    HIPCHK(hipEventRecord(e[0], st));
+    if (r.mode == 2) {
+        tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, c->d_partials, 0);
+        HIPCHK(hipEventRecord(e[1], st)); HIPCHK(hipEventRecord(e[2], st));
+        t.crc_launches += 2;
+    } else if (r.mode == 0) {
+        // With compression the whole chain of a chunk runs in the wave that compresses it: CRC32C of the source chunk first, GCM over
+        // the finished frame last - one launch per batch.  The batch CRC / GCM kernels want 20 / 40 KiB of LDS per workgroup and, on
+        // a chip filled by the compressor waves of the batches in flight, sat hundreds of ms in the queue for a few ms of work.
+        // TSX_STAGES_SEPARATE=1 keeps one launch per stage (A/B measurements, tests of the stand-alone kernels).
+        if ((flags & TSX_CRC) && !r.fuse_stages) { tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, c->d_partials, 0); t.crc_launches += 2; }
+        HIPCHK(hipEventRecord(e[1], st));
+        bool fused = false;
+        if (r.comp) {
+            fused = r.enc && r.fuse_stages;
+            tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr};
+            if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
+            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = r.d_dst; }
+            t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
+                                                       r.params->zstd_profile, fuse);
+        }
+        HIPCHK(hipEventRecord(e[2], st));
+        if (fused) {
+        } else if (r.enc) {
+            hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, n, (const uint32_t*)dz,
+                               (uint64_t)c->mid_stride, r.comp ? 1 : 0, 0, 0, dg, ds);
+            uint32_t glen = r.comp ? (uint32_t)tsx_transformed_bound(r.max_len, TSX_COMPRESS) : r.max_len;
+            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, glen, r.comp ? dmid : r.d_src, r.d_dst, c->d_partials, ds, 0);
+            t.gcm_launches += 2;
+        } else {
+            uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
+            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz,
+                               (uint64_t)c->mid_stride, r.comp ? 1 : 0, r.comp ? (const uint8_t*)dmid : r.d_src, r.d_dst, ds, bpc);
+        }
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
+    } else {
+        HIPCHK(hipEventRecord(e[1], st));
+        const uint8_t* zsrc = r.d_src;    // where the Zstd frames live when there is no encryption
+        if (r.enc) {
+            hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, n, (const uint32_t*)dz,
+                               (uint64_t)c->mid_stride, 0, 1, r.comp ? 1 : 0, dg, ds);
+            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, r.max_len, r.d_src, r.comp ? dmid : r.d_dst, c->d_partials, ds, 1);
+            t.gcm_launches += 2;
+            zsrc = dmid;
+        }
+        HIPCHK(hipEventRecord(e[2], st));
+        if (r.comp) {
+            t.unzstd_launches += tsx_launch_zstd_decompress(st, c->dev->d_zc, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.d_dst, ds, dzw);
+        } else if (!r.enc) {
+            uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
+            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz, (uint64_t)0, 0, r.d_src, r.d_dst, ds, bpc);
+        }
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
+        if (r.enc && !r.comp) {            // decrypted straight into the caller's slots: nothing of a chunk that failed its tag check stays
+            uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
+            hipLaunchKernelGGL(scrub_failed_kernel, dim3(n * bpc), dim3(256), 0, st, (const tsx_chunk_desc*)dd, (const int32_t*)ds, r.d_dst, bpc);
+        }
+    }
+    HIPCHK(hipEventRecord(e[3], st));
+    if (r.mode == 1 && (flags & TSX_CRC)) {
+        // CRC of the restored bytes; upper bound of a restored chunk is its slot capacity
+        tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, c->d_partials, 1);
+        t.crc_launches += 2;
+    }
+    HIPCHK(hipMemcpyAsync(r.descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(e[4], st));
+    return TSX_OK;
+}
+
+// The bytes chunks [lo, lo + n) produced travel back on st_out (host-memory batches; their descriptors are on the host already).
+// Exactly dst_len bytes per chunk: a slot's slack may hold bytes of an earlier batch on this (possibly pooled) context.
+static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, bool* packed_full) {
+    tsx_ctx* c = r.c;
+    for (uint32_t i = sb.lo; i < sb.lo + sb.n; i++) {
+        tsx_chunk_desc& d = r.descs[i];
+        if (r.packed) {
+            const size_t slot_off = d.dst_off;
+            d.dst_off = *packed_at;
+            if (d.status != TSX_OK) { d.dst_len = 0; continue; }
+            if (*packed_full || *packed_at + d.dst_len > r.dst_size) { *packed_full = true; d.status = TSX_E_DST_TOO_SMALL; d.dst_len = 0; continue; }
+            if (d.dst_len) HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + *packed_at, c->d_out + slot_off, d.dst_len, hipMemcpyDeviceToHost, c->st_out));
+            *packed_at += d.dst_len;
+        } else {
+            if (d.status != TSX_OK || d.dst_len == 0) continue;
+            HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + d.dst_off, c->d_out + d.dst_off, d.dst_len, hipMemcpyDeviceToHost, c->st_out));
+        }
+    }
+    return TSX_OK;
+}
+
+static int run_batch_inner(tsx_run& r) {
+    tsx_ctx* c = r.c;
+    const uint32_t n = r.n;
+    uint32_t max_len, max_out; size_t in_bytes; bool monotonic;
+    // src-side validation first: nothing of the caller's descriptors is touched by a call that fails with TSX_E_INVAL
+    int rc = validate(r.descs, n, r.dst_size, r.mode != 2 && !r.packed, &max_len, &max_out, &in_bytes, &monotonic);
+    if (rc) return rc;
+    size_t out_bytes = r.dst_size;                                      // size of the output area the kernels see
+    if (r.packed) {
+        // the kernels still write one bound-sized slot per chunk - on the device; only the bytes produced cross PCIe, straight
+        // to their final place in the caller's buffer
+        const size_t slot = (tsx_transformed_bound(max_len, r.flags) + 63) & ~(size_t)63;
+        if (slot >= ((size_t)1 << 32)) return TSX_E_INVAL;
+        for (uint32_t i = 0; i < n; i++) { r.descs[i].dst_off = (uint64_t)i * slot; r.descs[i].dst_cap = (uint32_t)slot; }
+        out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
+    }
+    r.max_len = max_len; r.max_out = max_out;
+    rc = ctx_reserve(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, out_bytes);
+    if (rc) return rc;
+    r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
+    r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
+    hipStream_t st = c->st;
+    memset(&c->timing, 0, sizeof c->timing);
+    // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap (three streams).  Not
+    // with compression on the way in: that kernel is bound by per-chunk latency and wants every chunk of the batch in flight at
+    // once, and its ~0.5 s dwarf the copies.  Device-memory batches have nothing to overlap.
+    std::vector<tsx_sub> subs;
+    const bool pipelined = r.host && monotonic && !(r.mode == 0 && r.comp) && !getenv("TSX_NO_PIPELINE");
+    if (pipelined) {
+        size_t budget = TSX_SUB_BYTES;
+        if (const char* e = getenv("TSX_SUB_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }     // tests / tuning
+        if (in_bytes / TSX_SUB_BYTES + 1 > TSX_MAX_SUBS) budget = in_bytes / TSX_MAX_SUBS + 1;
+        uint32_t lo = 0;
+        while (lo < n) {
+            uint32_t hi = lo; size_t bytes = 0;
+            while (hi < n && (bytes < budget || hi == lo) && subs.size() + 1 <= TSX_MAX_SUBS) { bytes += r.descs[hi].src_len; hi++; }
+            if (subs.size() + 1 == TSX_MAX_SUBS) hi = n;
+            subs.push_back({lo, hi - lo, (size_t)r.descs[lo].src_off, (size_t)(r.descs[hi - 1].src_off + r.descs[hi - 1].src_len)});
+            lo = hi;
+        }
+    } else subs.push_back({0, n, 0, in_bytes});
+    for (size_t k = 1; k < subs.size(); k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventRecord(c->ev[0], st));
+    if (r.enc) {
+        HIPCHK(hipMemcpyAsync(c->d_keyraw, r.params->key, 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->d_keyraw + 32, r.params->aad, 64, hipMemcpyHostToDevice, st));
+        tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
+    }
+    if (r.host) HIPCHK(hipEventRecord(c->ev[2], c->st_in));
+    size_t packed_at = 0; bool packed_full = false;
+    const size_t ns = subs.size();
+    // software pipeline on the host: copy-in + kernels of piece k are queued before the host waits for piece k - 1's descriptors
+    // (they say how many bytes each chunk produced) and queues its copy-out
+    for (size_t k = 0; k <= ns; k++) {
+        if (k < ns) {
+            const tsx_sub& sb = subs[k];
+            hipEvent_t* e = c->sub_ev[k];
+            if (r.host) {
+                // pageable memory is staged by the runtime (the call returns when the source has been read); memory pinned with
+                // tsx_host_register goes by DMA and the call returns at once - either way the copy overlaps the kernels of piece k - 1
+                if (sb.in_hi > sb.in_lo) HIPCHK(hipMemcpyAsync(c->d_in + sb.in_lo, (const uint8_t*)r.src + sb.in_lo, sb.in_hi - sb.in_lo, hipMemcpyHostToDevice, c->st_in));
+                HIPCHK(hipEventRecord(e[5], c->st_in));
+                HIPCHK(hipStreamWaitEvent(st, e[5], 0));
+            }
+            if ((rc = launch_stages(r, sb, e))) return rc;
+        }
+        if (k > 0 && r.host && r.mode != 2) {
+            const tsx_sub& sb = subs[k - 1];
+            HIPCHK(hipEventSynchronize(c->sub_ev[k - 1][4]));          // descriptors of piece k - 1 are on the host
+            if ((rc = copy_back(r, sb, &packed_at, &packed_full))) return rc;
+        }
+    }
+    if (r.host) HIPCHK(hipEventRecord(c->ev[3], c->st_out));
+    HIPCHK(hipEventRecord(c->ev[1], st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (r.host) { HIPCHK(hipStreamSynchronize(c->st_in)); HIPCHK(hipStreamSynchronize(c->st_out)); }
+    HIPCHK(hipGetLastError());
+    tsx_timing& t = c->timing;
+    for (size_t k = 0; k < ns; k++) {
+        hipEvent_t* e = c->sub_ev[k];
+        const float a = ev_ms(e[0], e[1]), b = ev_ms(e[1], e[2]), d = ev_ms(e[2], e[3]), f = ev_ms(e[3], e[4]);
+        if (r.mode == 2) t.crc_ms += a;
+        else if (r.mode == 0) { t.crc_ms += (r.flags & TSX_CRC) ? a : 0; t.zstd_ms += r.comp ? b : 0; t.gcm_ms += d; }
+        else { t.gcm_ms += r.enc ? b : 0; t.unzstd_ms += d; t.crc_ms += (r.flags & TSX_CRC) ? f : 0; }
+    }
+    t.total_ms = ev_ms(c->ev[0], c->ev[1]);
+    if (r.host) {
+        // with pieces in flight the copies overlap the kernels: h2d_ms / d2h_ms are the spans of the copy streams, not additive
+        t.h2d_ms = ev_ms(c->ev[2], c->sub_ev[ns - 1][5]);
+        t.d2h_ms = r.mode != 2 ? ev_ms(c->sub_ev[0][4], c->ev[3]) : 0;
+        const float tail = ev_ms(c->ev[0], c->ev[3]);
+        if (r.mode != 2 && tail > t.total_ms) t.total_ms = tail;
+    }
+    return TSX_OK;
+}
 
 static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, void* dst,
                      size_t dst_size, int mem_kind, int mode /*0 transform, 1 detransform, 2 crc only*/) {
@@ -353,151 +676,23 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
         if ((flags & TSX_COMPRESS) && params->zstd_profile > TSX_ZSTD_PROFILE_1_5_7) return TSX_E_UNSUPPORTED;
     }
     if (n == 0) return TSX_OK;
-    uint32_t max_len; size_t in_bytes;
-    size_t out_bytes = dst_size;                                        // size of the output area the kernels see
-    if (packed) {
-        // the kernels still write one bound-sized slot per chunk - on the device; only the bytes produced cross PCIe, straight
-        // to their final place in the caller's buffer
-        uint32_t longest = 0;
-        for (uint32_t i = 0; i < n; i++) if (descs[i].src_len > longest) longest = descs[i].src_len;
-        const size_t slot = (tsx_transformed_bound(longest, flags) + 63) & ~(size_t)63;
-        if (slot >= ((size_t)1 << 32)) return TSX_E_INVAL;
-        for (uint32_t i = 0; i < n; i++) { descs[i].dst_off = (uint64_t)i * slot; descs[i].dst_cap = (uint32_t)slot; }
-        out_bytes = (size_t)n * slot;
+    if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
+    tsx_run r{};
+    r.c = c; r.params = params; r.descs = descs; r.n = n; r.src = src; r.dst = dst; r.dst_size = dst_size; r.mem_kind = mem_kind; r.mode = mode;
+    r.flags = flags; r.host = mem_kind != TSX_MEM_DEVICE; r.packed = packed;
+    r.enc = mode != 2 && (flags & TSX_ENCRYPT); r.comp = mode != 2 && (flags & TSX_COMPRESS);
+    r.fuse_stages = r.comp && !getenv("TSX_STAGES_SEPARATE");
+    const int rc = run_batch_inner(r);
+    // Whatever happened: nothing of this call is still in flight when it returns (the copies reference the caller's buffers), and
+    // the data key does not stay behind in a context that may serve another segment next (the native side zeroises its
+    // copy; the round keys and H powers are as good as the key).
+    if (r.enc) {
+        hipMemsetAsync(c->d_keyraw, 0, 128, c->st);
+        hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st);
     }
-    int rc = validate(descs, n, out_bytes, mode != 2, &max_len, &in_bytes);
-    if (rc) return rc;
-    const bool host = mem_kind != TSX_MEM_DEVICE;
-    rc = ctx_reserve(c, n, max_len, flags, host, in_bytes, out_bytes);
-    if (rc) return rc;
-    hipStream_t st = c->st;
-    bool fused = false;
-    memset(&c->timing, 0, sizeof c->timing);
-    const uint8_t* d_src = (const uint8_t*)src;
-    uint8_t* d_dst = (uint8_t*)dst;
-    HIPCHK(hipEventRecord(c->ev[0], st));
-    if (host) {
-        HIPCHK(hipMemcpyAsync(c->d_in, src, in_bytes, hipMemcpyHostToDevice, st));
-        d_src = c->d_in; d_dst = c->d_out;
-    }
-    HIPCHK(hipMemcpyAsync(c->d_descs, descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_status, n);
-    HIPCHK(hipEventRecord(c->ev[1], st));
-    const bool enc = flags & TSX_ENCRYPT, comp = flags & TSX_COMPRESS;
-    if (enc) {
-        HIPCHK(hipMemcpyAsync(c->d_keyraw, params->key, 32, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(c->d_keyraw + 32, params->aad, 64, hipMemcpyHostToDevice, st));
-        tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, params->aad_len, c->d_key);
-    }
-    if (mode == 2) {
-        tsx_launch_crc32c(st, c->dev->d_crc, d_src, c->d_descs, n, max_len, c->d_partials, 0);
-        HIPCHK(hipEventRecord(c->ev[2], st));
-        c->timing.crc_launches = 2;
-    } else if (mode == 0) {
-        // With compression the whole chain of a chunk runs in the wave that compresses it: CRC32C of the source chunk first, GCM over
-        // the finished frame last - one launch per batch.  The batch CRC / GCM kernels want 20 / 40 KiB of LDS per workgroup and, on
-        // a chip filled by the compressor waves of the batches in flight, sat hundreds of ms in the queue for a few ms of work.
-        // TSX_STAGES_SEPARATE=1 keeps one launch per stage (A/B measurements, tests of the stand-alone kernels).
-        const bool fuse_stages = comp && !getenv("TSX_STAGES_SEPARATE");
-        if ((flags & TSX_CRC) && !fuse_stages) { tsx_launch_crc32c(st, c->dev->d_crc, d_src, c->d_descs, n, max_len, c->d_partials, 0); c->timing.crc_launches = 2; }
-        HIPCHK(hipEventRecord(c->ev[2], st));
-        if (comp) {
-            fused = enc && fuse_stages;
-            tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr};
-            if (fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
-            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = d_dst; }
-            c->timing.zstd_launches = tsx_launch_zstd_compress(st, c->dev->d_zc, d_src, c->d_descs, n, max_len, c->d_mid, c->mid_stride,
-                                                              c->d_zlen, c->d_status, c->d_zwork, params->zstd_profile, fuse);
-        }
-        HIPCHK(hipEventRecord(c->ev[3], st));
-        if (fused) {
-        } else if (enc) {
-            hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_descs, n, (const uint32_t*)c->d_zlen,
-                               (uint64_t)c->mid_stride, comp ? 1 : 0, 0, 0, c->d_gchunks, c->d_status);
-            uint32_t glen = comp ? (uint32_t)tsx_transformed_bound(max_len, TSX_COMPRESS) : max_len;
-            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, c->d_gchunks, n, glen, comp ? c->d_mid : d_src, d_dst, c->d_partials, c->d_status, 0);
-            c->timing.gcm_launches = 2;
-        } else {
-            uint32_t bpc = max_len > (1u << 20) ? 16 : 1;
-            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, c->d_descs, (const uint32_t*)c->d_zlen,
-                               (uint64_t)c->mid_stride, comp ? 1 : 0, comp ? (const uint8_t*)c->d_mid : d_src, d_dst, c->d_status, bpc);
-        }
-        HIPCHK(hipEventRecord(c->ev[4], st));
-    } else {
-        HIPCHK(hipEventRecord(c->ev[2], st));
-        const uint8_t* zsrc = d_src;      // where the Zstd frames live when there is no encryption
-        if (enc) {
-            hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_descs, n, (const uint32_t*)c->d_zlen,
-                               (uint64_t)c->mid_stride, 0, 1, comp ? 1 : 0, c->d_gchunks, c->d_status);
-            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, c->d_gchunks, n, max_len, d_src, comp ? c->d_mid : d_dst, c->d_partials, c->d_status, 1);
-            c->timing.gcm_launches = 2;
-            zsrc = c->d_mid;
-        }
-        HIPCHK(hipEventRecord(c->ev[3], st));
-        if (comp) {
-            c->timing.unzstd_launches = tsx_launch_zstd_decompress(st, c->dev->d_zc, zsrc, enc ? 1 : 0, (uint64_t)c->mid_stride, c->d_descs, n,
-                                                                  d_dst, c->d_status, c->d_zwork);
-        } else if (!enc) {
-            uint32_t bpc = max_len > (1u << 20) ? 16 : 1;
-            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, c->d_descs, (const uint32_t*)c->d_zlen,
-                               (uint64_t)0, 0, d_src, d_dst, c->d_status, bpc);
-        }
-        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_descs, (const int32_t*)c->d_status, n);
-        HIPCHK(hipEventRecord(c->ev[4], st));
-        if (flags & TSX_CRC) {
-            // CRC of the restored bytes; upper bound of a restored chunk is its slot capacity
-            uint32_t max_out = 0;
-            for (uint32_t i = 0; i < n; i++) if (descs[i].dst_cap > max_out) max_out = descs[i].dst_cap;
-            tsx_launch_crc32c(st, c->dev->d_crc, d_dst, c->d_descs, n, max_out, c->d_partials, 1);
-            c->timing.crc_launches = 2;
-        }
-    }
-    if (mode != 1) hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_descs, (const int32_t*)c->d_status, n);
-    HIPCHK(hipEventRecord(c->ev[5], st));
-    HIPCHK(hipMemcpyAsync(descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
-    if (packed) {
-        HIPCHK(hipStreamSynchronize(st));                               // sizes first: they say where each chunk goes
-        size_t at = 0; bool full = false;
-        for (uint32_t i = 0; i < n; i++) {
-            const size_t slot_off = descs[i].dst_off;
-            descs[i].dst_off = at;
-            if (descs[i].status != TSX_OK) { descs[i].dst_len = 0; continue; }
-            if (full || at + descs[i].dst_len > dst_size) { full = true; descs[i].status = TSX_E_DST_TOO_SMALL; descs[i].dst_len = 0; continue; }
-            if (descs[i].dst_len) HIPCHK(hipMemcpyAsync((uint8_t*)dst + at, c->d_out + slot_off, descs[i].dst_len, hipMemcpyDeviceToHost, st));
-            at += descs[i].dst_len;
-        }
-    } else if (host && mode != 2) {
-        // only the bytes each chunk produced travel back (a compressed chunk fills ~1/3 of its slot): the descriptors
-        // first, then one copy per run of chunks whose outputs are adjacent in dst
-        HIPCHK(hipStreamSynchronize(st));
-        uint32_t i = 0;
-        while (i < n) {
-            if (descs[i].status != TSX_OK || descs[i].dst_len == 0) { i++; continue; }
-            size_t lo = descs[i].dst_off, hi = lo + descs[i].dst_len;
-            uint32_t j = i + 1;
-            while (j < n && descs[j].status == TSX_OK && descs[j].dst_off >= hi && descs[j].dst_off - hi <= 4096) { hi = descs[j].dst_off + descs[j].dst_len; j++; }
-            HIPCHK(hipMemcpyAsync((uint8_t*)dst + lo, c->d_out + lo, hi - lo, hipMemcpyDeviceToHost, st));
-            i = j;
-        }
-    }
-    HIPCHK(hipEventRecord(c->ev[6], st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
-    tsx_timing& t = c->timing;
-    t.h2d_ms = ev_ms(c->ev[0], c->ev[1]);
-    t.d2h_ms = ev_ms(c->ev[5], c->ev[6]);
-    t.total_ms = ev_ms(c->ev[0], c->ev[6]);
-    if (mode == 2) t.crc_ms = ev_ms(c->ev[1], c->ev[2]);
-    else if (mode == 0) {
-        t.crc_ms = (flags & TSX_CRC) ? ev_ms(c->ev[1], c->ev[2]) : 0;
-        t.zstd_ms = comp ? ev_ms(c->ev[2], c->ev[3]) : 0;
-        t.gcm_ms = ev_ms(c->ev[3], c->ev[4]);
-    } else {
-        t.gcm_ms = enc ? ev_ms(c->ev[2], c->ev[3]) : 0;
-        t.unzstd_ms = ev_ms(c->ev[3], c->ev[4]);
-        t.crc_ms = (flags & TSX_CRC) ? ev_ms(c->ev[4], c->ev[5]) : 0;
-    }
-    return TSX_OK;
+    hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
+    if (rc != TSX_OK) (void)hipGetLastError();
+    return rc;
 }
 
 static int with_ctx(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, void* dst,
@@ -523,6 +718,35 @@ extern "C" int tsx_detransform_batch(tsx_ctx* ctx, const tsx_batch_params* param
 
 extern "C" int tsx_crc32c_batch(tsx_ctx* ctx, tsx_chunk_desc* descs, uint32_t n, const void* src, int mem_kind) {
     return with_ctx(ctx, nullptr, descs, n, src, nullptr, 0, mem_kind, 2);
+}
+
+// Test hook (not part of the ABI in include/tsxform.h): OR of every byte of the context's key material on the device - 0 after
+// any batch, whatever its outcome.
+extern "C" int tsx_debug_key_residue(tsx_ctx* c) {
+    if (!c) return TSX_E_INVAL;
+    if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
+    std::vector<uint8_t> h(sizeof(tsx_gcm_key) + 128);
+    if (hipMemcpy(h.data(), c->d_key, sizeof(tsx_gcm_key), hipMemcpyDeviceToHost) != hipSuccess) return TSX_E_DEVICE;
+    if (hipMemcpy(h.data() + sizeof(tsx_gcm_key), c->d_keyraw, 128, hipMemcpyDeviceToHost) != hipSuccess) return TSX_E_DEVICE;
+    int acc = 0;
+    for (uint8_t b : h) acc |= b;
+    return acc;
+}
+
+// Pins a caller buffer that will be used for TSX_MEM_HOST / TSX_MEM_HOST_PACKED batches again and again (the JVM side registers its
+// per-thread direct ByteBuffers once): copies from / to it go by DMA and overlap fully instead of being staged by the runtime.
+extern "C" int tsx_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return TSX_E_INVAL;
+    { std::lock_guard<std::mutex> lk(g_mu); if (g_devs.empty()) return TSX_E_DEVICE; }
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { tsx_set_err("hipHostRegister", e); (void)hipGetLastError(); return TSX_E_DEVICE; }
+    return TSX_OK;
+}
+extern "C" int tsx_host_unregister(void* p) {
+    if (!p) return TSX_E_INVAL;
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { tsx_set_err("hipHostUnregister", e); (void)hipGetLastError(); return TSX_E_DEVICE; }
+    return TSX_OK;
 }
 
 // ---- device memory helpers -------------------------------------------------------------------------
