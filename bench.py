@@ -37,8 +37,19 @@ def parse():
                     help="caller threads, each with its own tsx_ctx + output buffer, that submit the steps concurrently (the reference "
                          "calls the path from >= 10 RLM upload threads; the Zstd kernel is latency bound, so batches in flight are its "
                          "latency cover).  1 = strictly one batch at a time")
+    ap.add_argument("--chunk-bytes", type=int, default=0, help="chunk size (default 4 MiB: the metric's configuration; smaller only with --rehearse)")
+    ap.add_argument("--chunks-per-segment", type=int, default=0, help="default 256 (1 GiB segments); smaller only with --rehearse")
+    ap.add_argument("--split-segments", action="store_true",
+                    help="segments < GPUs (BASELINE configs[4] tail): every segment is cut by chunk range over ALL ranks, the ranks all-gather the "
+                         "transformed sizes (the one exchange of the path, tsxform.shard) inside the timed step; total work fixed -> scaling strong")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU rehearsal of the multi-rank logic: the kernel sources compiled for the CPU emulator (tests/emu), host buffers, gloo. "
+                         "Exercises rank->segment mapping, IVs, barrier + max-over-ranks timing and the size exchange - NOT a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--verify-chunks", type=int, default=64, help="chunks compared byte for byte with the oracle after the timed region")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host->host (PCIe-inclusive) measurement after the timed region")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
     return ap.parse_args()
 
@@ -68,15 +79,52 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch  # before libtsxform: one shared HIP runtime
     import torch.distributed as dist
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    rehearse = args.rehearse
+    if rehearse:
+        assert args.backend == "gloo" or world == 1, "--rehearse runs on CPU: use --backend gloo"
+        os.environ["TSX_ALLOW_ANY_ARCH"] = "1"
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback; --rehearse is a logic rehearsal, not a measurement)"
+        torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # NCCL = RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     import tsxform
     from tsxform import synth
     nat = tsxform._native
-    N = nat.Native()
-    N.init(1, [local_rank])
+    if rehearse:
+        from tests.emu import emu_native                                   # test harness: same sources, compiled for the CPU emulator
+        N = emu_native.get()
+    else:
+        N = nat.Native()
+        N.init(1, [local_rank])
+    dev = None if rehearse else torch.device("cuda", local_rank)
+    MEM = nat.MEM_HOST if rehearse else nat.MEM_DEVICE
+
+    class Mem:                                                            # resident buffers: HBM tensors, or host arrays in a rehearsal
+        @staticmethod
+        def empty(nbytes):
+            return np.zeros(nbytes, np.uint8) if rehearse else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        @staticmethod
+        def ptr(b):
+            return b if rehearse else b.data_ptr()
+        @staticmethod
+        def host(b, lo, hi):
+            return b[lo:hi] if rehearse else b[lo:hi].cpu().numpy()
+        @staticmethod
+        def equal(a, b):
+            return bool(np.array_equal(a, b)) if rehearse else bool(torch.equal(a, b))
+        @staticmethod
+        def sync():
+            if not rehearse:
+                torch.cuda.synchronize()
+        @staticmethod
+        def max_over_ranks(x):
+            tt = torch.tensor([x], dtype=torch.float64, device=torch.device("cpu") if args.backend == "gloo" else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
     have_zstd = getattr(tsxform, "HAVE_ZSTD", False)
     workload = args.workload
     if workload == "auto":
@@ -181,7 +229,8 @@ def main():
     if rank == 0 and not args.no_verify:
         from oracle import oracle as o
         verified = 0
-        for i in sorted(set([0, 1, n // 2, n - 1])):
+        # 64 chunks spread over the batch (first, last, both sides of every segment boundary region): byte equality with libzstd + OpenSSL
+        for i in sorted(set([0, 1, n // 2, n - 1] + [int(k) for k in np.linspace(0, n - 1, min(args.verify_chunks, n))])):
             chunk = src[i * CH:(i + 1) * CH].cpu().numpy()
             assert d["crc32c"][i] == o.crc32c(chunk), "crc mismatch chunk %d" % i
             if workload != "crc":
@@ -219,6 +268,22 @@ def main():
                    "value": round(float(n) * CH * world / GiB / inv_s, 4), "unit": "GiB/s", "ms_per_batch": round(inv_s * 1e3, 3),
                    "stage_ms": {"gcm": round(tm.gcm_ms, 3), "unzstd": round(tm.unzstd_ms, 3), "crc": round(tm.crc_ms, 3)},
                    "round_trip_exact": exact}
+        # roofline of the inverse chain's dominant kernel (the frame decoder): algorithmic bytes = frame read + chunk written
+        alg_inv = float(n) * (CH + float(d["dst_len"].astype(np.int64).mean()) - (28 if flags & nat.ENCRYPT else 0))
+        dom_ms = max(tm.unzstd_ms, tm.gcm_ms, tm.crc_ms)
+        dom_k = "zstd_decompress_kernel" if dom_ms == tm.unzstd_ms else ("gcm_ctr_ghash_kernel" if dom_ms == tm.gcm_ms else "crc32c_partial_kernel")
+        inv_traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                rec = json.load(f).get("detransform/%s/%d" % (args.dist, n))
+            if rec:
+                inv_traffic = rec["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        ach = alg_inv / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        inverse["roofline"] = {"bound": "hbm", "kernel": dom_k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": inv_traffic, "ms_per_launch": round(dom_ms, 4),
+                               "algorithmic_bytes_per_launch": int(alg_inv)}
         del back
 
     # ---- roofline of the dominant kernel (HIP events on the library's own stream, per launch) ----------
@@ -263,21 +328,68 @@ def main():
                 "launches_in_flight": T, "achieved_aggregate": round(achieved * T, 2),
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage.items()}, "binding_resource": binding}
 
-    # ---- CPU baseline: the oracle port (libzstd + OpenSSL GCM + CRC32C), all host cores, bounded sample --
+    # ---- CPU baseline: the oracle port (libzstd + OpenSSL GCM + CRC32C) on 1, 10 and all usable host cores, bounded samples ---------
+    # (T = 1 is the per-thread rate of the reference's chain, T = 10 the reference's default RLM copier pool, "all" what the
+    # box could do if every core ran uploads).  The headline object is the all-cores leg.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as o
         cores = usable_cores()
-        # every usable host core gets work: 16 chunks per thread for the full chain (about 10 s of CPU work), one segment otherwise
-        sample = {"full": max(48, 16 * cores), "gcm_crc": 256, "crc": 256}[workload]
-        sample = min(sample, n)
-        host = src[:sample * CH].cpu().numpy()
-        ivs = np.ascontiguousarray(d["iv"][:sample]).reshape(-1)
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except (OSError, IndexError):
+            model = "unknown"
         of = ((o.COMPRESS if flags & nat.COMPRESS else 0) | (o.ENCRYPT if flags & nat.ENCRYPT else 0) | o.CRC | o.OPENSSL)
-        secs, _, _, _, _ = o.chain_run_threads(of, synth.KEY, synth.AAD, host, CH, ivs, cores)
-        cpu = {"value": round(sample * CH / GiB / secs, 4), "unit": "GiB/s", "cores": cores, "kind": "port",
+        per_thread = {"full": 12, "gcm_crc": 64, "crc": 256}[workload]          # chunks per thread: ~0.5-1 s of work each
+        legs = []
+        for T in sorted(set([1, min(10, cores), cores])):
+            sample = min(n, max(per_thread * T, 24 if workload == "full" else 256))
+            host = src[:sample * CH].cpu().numpy()
+            ivs = np.ascontiguousarray(d["iv"][:sample]).reshape(-1)
+            secs, _, _, _, _ = o.chain_run_threads(of, synth.KEY, synth.AAD, host, CH, ivs, T)
+            legs.append({"threads": T, "value": round(sample * CH / GiB / secs, 4), "unit": "GiB/s", "sample_chunks": sample,
+                         "MiB_per_s_per_thread": round(sample * CH / (1 << 20) / secs / T, 1)})
+        top = legs[-1]
+        cpu = {"value": top["value"], "unit": "GiB/s", "cores": top["threads"], "kind": "port",
                "sample": "%d x 4 MiB chunks (%s) through oracle/chain.c: libzstd %s level 3 + OpenSSL AES-256-GCM + CRC32C, %d threads"
-                         % (sample, args.dist, o.zstd_version() if flags & nat.COMPRESS else "n/a", cores)}
+                         % (top["sample_chunks"], args.dist, o.zstd_version() if flags & nat.COMPRESS else "n/a", top["threads"]),
+               "by_threads": legs, "nproc": os.cpu_count(), "usable_cores": cores, "cpu_model": model,
+               "libzstd": o.zstd_version() if flags & nat.COMPRESS else None}
+
+    # ---- end to end: the same batch host -> host through TSX_MEM_HOST / TSX_MEM_HOST_PACKED (what the JNI shim uses), PCIe included.
+    # Never `value`.  Pageable buffers first (the runtime stages them), then the same buffers pinned with tsx_host_register.
+    e2e = None
+    if rank == 0 and world == 1 and workload != "crc" and not args.no_end_to_end:
+        PCIE = 64.0                                                       # GB/s per direction, PCIe 5.0 x16
+        hsrc = src.cpu().numpy()
+        hdst = np.zeros(n * slot, np.uint8)
+        rows = []
+        for kind, label in ((nat.MEM_HOST, "slots"), (nat.MEM_HOST_PACKED, "packed")):
+            for pinned in (False, True):
+                if pinned:
+                    try:
+                        N.host_register(hsrc); N.host_register(hdst)
+                    except nat.TsxError:
+                        break
+                de = d.copy(); de["status"] = 0; de["dst_len"] = 0
+                best = None
+                for _ in range(2):
+                    t1 = time.perf_counter()
+                    N.transform_batch(params, de, hsrc, hdst, hdst.size, kind, ctx=ctx)
+                    el = time.perf_counter() - t1
+                    best = el if best is None else min(best, el)
+                tm = N.ctx_timing(ctx)
+                ok = bool((de["status"] == 0).all() and (de["dst_len"] == d["dst_len"]).all())
+                moved = (float(n) * CH + float(de["dst_len"].sum())) / 1e9
+                rows.append({"dst_layout": label, "host_memory": "registered" if pinned else "pageable", "ms": round(best * 1e3, 2),
+                             "gibs": round(float(n) * CH / GiB / best, 4), "pcie_frac": round(moved / best / (2 * PCIE), 4),
+                             "kernels_ms": round(tm.crc_ms + tm.zstd_ms + tm.gcm_ms, 2), "same_sizes_as_device_run": ok})
+                if pinned:
+                    N.host_unregister(hsrc); N.host_unregister(hdst)
+        e2e = {"metric": "GiB/s of original bytes, host buffers in -> host buffers out (PCIe inclusive), one batch at a time",
+               "chunks": n, "pcie_peak_GBs_per_direction": PCIE, "runs": rows,
+               "value": max(r["gibs"] for r in rows) if rows else None, "unit": "GiB/s"}
+        del hsrc, hdst
 
     if rank == 0:
         line = {
@@ -294,7 +406,7 @@ def main():
                        "parallelism": "segment-major shard, %d rank(s), no data-path collective" % world,
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
                        "verified_chunks_vs_oracle": verified},
-            "roofline": roofline, "cpu_baseline": cpu, "detransform": inverse,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "detransform": inverse,
         }
         print(json.dumps(line))
     for c in ctxs:

@@ -109,3 +109,34 @@ EDGE_SIZES = [0, 1, 2, 3, 5, 13, 15, 16, 17, 31, 32, 33, 255, 1024, 2048, 4095, 
 
 def edge_chunks(dist="R", sizes=EDGE_SIZES):
     return [synth.gen_chunk(dist, 7, 1, i, s) for i, s in enumerate(sizes)]
+
+
+def check_profile_1_5_6(N, o, named_chunks):
+    """The profile the reference would ship with (libzstd 1.5.6 inside zstd-jni 1.5.6-9, core/build.gradle:29) has no real library
+    to be compared with here.  What CAN be pinned: profile 0 is the profile-1 code minus 1.5.7's block pre-splitter, so
+      (a) its frames equal the serial restatement's (oracle/zstd_l3.c, profile 0) - always;
+      (b) wherever the pre-splitter changes nothing for an input (restatement: profile 0 == profile 1), its frame is byte-identical
+          to what the REAL libzstd 1.5.7 emits;
+      (c) where the splitter does cut, the two profiles' frames differ and the real library decodes both to the source.
+    Returns (#inputs pinned to the real library through (b), #inputs where the profiles differ)."""
+    names = list(named_chunks)
+    chunks = [named_chunks[n] for n in names]
+    outs0, d0 = run_transform(N, nat.COMPRESS, chunks, profile=nat.ZSTD_PROFILE_1_5_6)
+    outs1, d1 = run_transform(N, nat.COMPRESS, chunks, profile=nat.ZSTD_PROFILE_1_5_7)
+    real157 = o.zstd_version().startswith("1.5.7")
+    pinned = differ = 0
+    for i, n in enumerate(names):
+        raw = chunks[i].tobytes()
+        assert d0["status"][i] == 0 and d1["status"][i] == 0, n
+        r0, r1 = o.zstd_l3_compress(raw, 0), o.zstd_l3_compress(raw, 1)
+        assert outs0[i] == r0, "%s: profile 1.5.6 frame differs from the restatement" % n
+        assert outs1[i] == r1, "%s: profile 1.5.7 frame differs from the restatement" % n
+        assert o.zstd_decompress_chunk(outs0[i], len(raw)) == raw, n
+        if r0 == r1:
+            if real157:
+                assert outs0[i] == o.zstd_compress_chunk(raw), "%s: split-free input, yet profile 1.5.6 != real libzstd 1.5.7" % n
+                pinned += 1
+        else:
+            differ += 1
+            assert outs0[i] != outs1[i] and o.zstd_decompress_chunk(outs1[i], len(raw)) == raw, n
+    return pinned, differ

@@ -62,6 +62,19 @@ def test_profile_1_5_6_matches_restatement_and_decodes(emu, oracle):
         assert oracle.zstd_decompress_chunk(outs[i]) == CASES[n].tobytes()
 
 
+def test_profile_1_5_6_is_pinned_to_the_real_library_wherever_the_splitter_is_idle(emu, oracle):
+    """Every case of this file + 12 fuzzed inputs, both profiles (parity_cases.check_profile_1_5_6)."""
+    from tests import fuzz_cases
+    cases = dict(CASES)
+    rng = np.random.default_rng(20260923)
+    for k in range(12):
+        cases["fuzz%d" % k] = fuzz_cases.gen_case(rng)
+    pinned, differ = pc.check_profile_1_5_6(emu, oracle, cases)
+    assert differ >= 1, "no input made the pre-splitter cut: the test does not exercise the difference between the profiles"
+    if oracle.zstd_version().startswith("1.5.7"):
+        assert pinned >= len(cases) // 2
+
+
 @pytest.mark.parametrize("gcm", ["in_compressor_wave", "separate_kernels"])
 def test_full_chain_vs_oracle(emu, oracle, gcm, monkeypatch):
     """With compression, each compressor wave also checksums its source chunk (crc32c_wave) and encrypts its own frame

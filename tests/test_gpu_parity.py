@@ -142,6 +142,25 @@ def test_zstd_compressor_byte_identical_to_libzstd(gpu, oracle):
     assert outs[0] == oracle.zstd_l3_compress(cases["mixKR"].tobytes(), 0) and outs[1] == oracle.zstd_l3_compress(cases["K1M"].tobytes(), 0)
 
 
+def test_zstd_profile_1_5_6_whole_case_set_and_fuzz(gpu, oracle):
+    """the profile the Java class can ship (1.5.6) had two GPU assertions.  Here: every case of _zcases(), 40 fuzzed
+    inputs, the window-edge chunks and two full 4 MiB chunks through BOTH profiles - profile 0 equals the restatement everywhere and
+    the real libzstd 1.5.7 on every input the 1.5.7 pre-splitter leaves alone; where it cuts, the real library decodes both."""
+    from tests import fuzz_cases
+    cases = dict(_zcases())
+    rng = np.random.default_rng(20260923)
+    for k in range(40):
+        cases["fuzz%d" % k] = fuzz_cases.gen_case(rng)
+    for seed in fuzz_cases.WINDOW_EDGE_SEEDS[:3]:
+        cases["window_edge_%d" % seed] = fuzz_cases.window_edge_case(seed)
+    cases["K4M"] = synth.gen_chunk("K", 1000, 0, 7); cases["mix4M"] = np.concatenate([cases["far_repeat"], cases["mixKR"], cases["skewed"]])[:CHUNK]
+    pinned, differ = pc.check_profile_1_5_6(gpu, oracle, cases)
+    assert differ >= 1
+    if oracle.zstd_version().startswith("1.5.7"):
+        assert pinned >= len(cases) // 2
+    print("profile 1.5.6: %d of %d inputs byte-identical to the real libzstd 1.5.7, %d differ only through the pre-splitter" % (pinned, len(cases), differ))
+
+
 @pytest.mark.parametrize("gcm", ["in_compressor_wave", "separate_kernels"])
 def test_zstd_full_size_chunks_and_full_chain(gpu, oracle, gcm, monkeypatch):
     """With compression each compressor wave also checksums its chunk and encrypts its frame, unless TSX_STAGES_SEPARATE=1

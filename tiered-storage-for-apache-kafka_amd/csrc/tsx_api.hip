@@ -44,6 +44,8 @@ struct tsx_ctx {
     hipStream_t st_in = nullptr, st_out = nullptr; // H2D / D2H of the host-memory staging pipeline
     // device workspace (grown on demand)
     tsx_chunk_desc* d_descs = nullptr; size_t descs_cap = 0;
+    tsx_chunk_desc* h_descs = nullptr;             // pinned mirror of the descriptors: no pageable copy ever sits in a stream
+    uint8_t* h_keyraw = nullptr;                   // pinned 128 bytes: key + aad on their way in (wiped after the batch)
     tsx_gcm_chunk* d_gchunks = nullptr;
     int32_t* d_status = nullptr;
     uint32_t* d_zlen = nullptr;
@@ -171,6 +173,8 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     if (c->d_keyraw) hipMemset(c->d_keyraw, 0, 128);
     void* ptrs[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen, c->d_partials, c->d_key, c->d_keyraw, c->d_in, c->d_out, c->d_mid, c->d_zwork};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->h_descs) hipHostFree(c->h_descs);
+    if (c->h_keyraw) { memset(c->h_keyraw, 0, 128); hipHostFree(c->h_keyraw); }
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     for (auto& row : c->sub_ev) for (auto& e : row) if (e) hipEventDestroy(e);
     if (c->st) hipStreamDestroy(c->st);
@@ -206,9 +210,11 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
     if (n > c->descs_cap || !c->d_descs) {
         void* olds[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen};
         for (void* p : olds) if (p) hipFree(p);
-        c->d_descs = nullptr; c->d_gchunks = nullptr; c->d_status = nullptr; c->d_zlen = nullptr;
+        if (c->h_descs) hipHostFree(c->h_descs);
+        c->d_descs = nullptr; c->d_gchunks = nullptr; c->d_status = nullptr; c->d_zlen = nullptr; c->h_descs = nullptr;
         size_t cap = (size_t)n + n / 4 + 16;
         HIPCHK(hipMalloc((void**)&c->d_descs, cap * sizeof(tsx_chunk_desc)));
+        HIPCHK(hipHostMalloc((void**)&c->h_descs, cap * sizeof(tsx_chunk_desc), hipHostMallocDefault));
         HIPCHK(hipMalloc((void**)&c->d_gchunks, cap * sizeof(tsx_gcm_chunk)));
         HIPCHK(hipMalloc((void**)&c->d_status, cap * sizeof(int32_t)));
         HIPCHK(hipMalloc((void**)&c->d_zlen, cap * sizeof(uint32_t)));
@@ -247,6 +253,7 @@ static int ctx_init_device_objects(tsx_ctx* c) {
     for (auto& e : c->sub_ev[0]) HIPCHK(hipEventCreate(&e));      // the other rows are created by the first pipelined batch
     HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
     HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
+    HIPCHK(hipHostMalloc((void**)&c->h_keyraw, 128, hipHostMallocDefault));
     return TSX_OK;
 }
 
@@ -474,7 +481,8 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e) {
     uint8_t* dmid = c->d_mid ? c->d_mid + (size_t)lo * c->mid_stride : nullptr;
     void* dzw = c->d_zwork;                                            // per-chunk workspace is indexed from 0 in every launch
     tsx_timing& t = c->timing;
-    HIPCHK(hipMemcpyAsync(dd, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
+    memcpy(c->h_descs + lo, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc));
+    HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
     HIPCHK(hipEventRecord(e[0], st));
     if (r.mode == 2) {
@@ -540,8 +548,8 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e) {
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, c->d_partials, 1);
         t.crc_launches += 2;
     }
-    HIPCHK(hipMemcpyAsync(r.descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(e[4], st));
+    HIPCHK(hipMemcpyAsync(c->h_descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(e[4], st));                                   // the caller's descriptors are filled in when this event has passed
     return TSX_OK;
 }
 
@@ -598,10 +606,12 @@ static int run_batch_inner(tsx_run& r) {
         size_t budget = TSX_SUB_BYTES;
         if (const char* e = getenv("TSX_SUB_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }     // tests / tuning
         if (in_bytes / TSX_SUB_BYTES + 1 > TSX_MAX_SUBS) budget = in_bytes / TSX_MAX_SUBS + 1;
+        const uint32_t min_chunks = r.comp ? 512u : 1u;
         uint32_t lo = 0;
         while (lo < n) {
             uint32_t hi = lo; size_t bytes = 0;
-            while (hi < n && (bytes < budget || hi == lo) && subs.size() + 1 <= TSX_MAX_SUBS) { bytes += r.descs[hi].src_len; hi++; }
+            // the frame decoder is bound by per-chunk latency too (~30 ms however few chunks a launch has): its pieces are >= 512 chunks
+            while (hi < n && (bytes < budget || hi - lo < min_chunks) && subs.size() + 1 <= TSX_MAX_SUBS) { bytes += r.descs[hi].src_len; hi++; }
             if (subs.size() + 1 == TSX_MAX_SUBS) hi = n;
             subs.push_back({lo, hi - lo, (size_t)r.descs[lo].src_off, (size_t)(r.descs[hi - 1].src_off + r.descs[hi - 1].src_len)});
             lo = hi;
@@ -610,8 +620,8 @@ static int run_batch_inner(tsx_run& r) {
     for (size_t k = 1; k < subs.size(); k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipEventRecord(c->ev[0], st));
     if (r.enc) {
-        HIPCHK(hipMemcpyAsync(c->d_keyraw, r.params->key, 32, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(c->d_keyraw + 32, r.params->aad, 64, hipMemcpyHostToDevice, st));
+        memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
+        HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, st));
         tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
     }
     if (r.host) HIPCHK(hipEventRecord(c->ev[2], c->st_in));
@@ -632,10 +642,11 @@ static int run_batch_inner(tsx_run& r) {
             }
             if ((rc = launch_stages(r, sb, e))) return rc;
         }
-        if (k > 0 && r.host && r.mode != 2) {
+        if (k > 0) {
             const tsx_sub& sb = subs[k - 1];
             HIPCHK(hipEventSynchronize(c->sub_ev[k - 1][4]));          // descriptors of piece k - 1 are on the host
-            if ((rc = copy_back(r, sb, &packed_at, &packed_full))) return rc;
+            memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
+            if (r.host && r.mode != 2 && (rc = copy_back(r, sb, &packed_at, &packed_full))) return rc;
         }
     }
     if (r.host) HIPCHK(hipEventRecord(c->ev[3], c->st_out));
@@ -687,6 +698,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     // the data key does not stay behind in a context that may serve another segment next (the native side zeroises its
     // copy; the round keys and H powers are as good as the key).
     if (r.enc) {
+        memset(c->h_keyraw, 0, 128);
         hipMemsetAsync(c->d_keyraw, 0, 128, c->st);
         hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st);
     }
