@@ -131,50 +131,68 @@ def main():
         workload = "full" if have_zstd else "gcm_crc"
     flags = {"full": nat.COMPRESS | nat.ENCRYPT | nat.CRC, "gcm_crc": nat.ENCRYPT | nat.CRC, "crc": nat.CRC}[workload]
     nseg = args.segments or (8 if workload == "full" else 1)
-    CH = synth.CHUNK
-    cps = 256                                            # chunks per 1 GiB segment
-    n = nseg * cps
-    dev = torch.device("cuda", local_rank)
-
-    # ---- synthetic segments, generated directly in HBM; global segment id = rank * nseg + s ------------
-    src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
-    # weak scaling, segment-major (tsxform.shard): with world*nseg segments in the job, rank r owns segments r, r+world, ...
+    CH = args.chunk_bytes or synth.CHUNK
+    cps = args.chunks_per_segment or 256                 # chunks per segment (256 x 4 MiB = 1 GiB)
+    if (CH != synth.CHUNK or cps != 256) and not rehearse:
+        raise SystemExit("the metric is quoted on 1 GiB segments of 4 MiB chunks: --chunk-bytes / --chunks-per-segment need --rehearse")
     from tsxform import shard
-    my_segments = shard.segments_of_rank(world * nseg, rank, world)
-    for s in range(nseg):
-        gs = my_segments[s]
-        for c in range(cps):
-            i = s * cps + c
-            src[i * CH:(i + 1) * CH] = synth.gen_chunk(args.dist, 1000 + gs, gs, c, CH, device=dev)
+    split = args.split_segments
+    if split:
+        # segments < GPUs: the job has nseg segments in total, every one cut by chunk range over all ranks (strong scaling)
+        my_segments = list(range(nseg))
+        ranges = [shard.chunk_range_of_rank(cps, rank, world) for _ in range(nseg)]
+    else:
+        # weak scaling, segment-major: with world*nseg segments in the job, rank r owns segments r, r+world, ...
+        my_segments = shard.segments_of_rank(world * nseg, rank, world)
+        ranges = [(0, cps)] * nseg
+    work = [(s_, c) for s_, (lo, hi) in zip(range(nseg), ranges) for c in range(lo, hi)]     # (local segment slot, chunk id) of every chunk here
+    n = len(work)
+
+    # ---- synthetic segments, generated directly in HBM -------------------------------------------------
+    src = Mem.empty(max(n, 1) * CH)
+    for i, (s_, c) in enumerate(work):
+        gs = my_segments[s_]
+        src[i * CH:(i + 1) * CH] = synth.gen_chunk(args.dist, 1000 + gs, gs, c, CH, device=dev)
     slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
     T = max(1, min(args.inflight, args.steps)) if workload == "full" else 1
-    dsts = [torch.empty(n * slot if workload != "crc" else 64, dtype=torch.uint8, device=dev) for _ in range(T)]
+    if split:
+        T = 1                                            # the size exchange is a collective: one caller thread per rank
+    dsts = [Mem.empty(max(n, 1) * slot if workload != "crc" else 64) for _ in range(T)]
     dst = dsts[0]
     d = np.zeros(n, nat.DESC_DTYPE)
     d["src_off"] = np.arange(n, dtype=np.uint64) * CH
     d["src_len"] = CH
     d["dst_off"] = np.arange(n, dtype=np.uint64) * slot
     d["dst_cap"] = slot
-    for s in range(nseg):
-        for c in range(cps):
-            d["iv"][s * cps + c] = np.frombuffer(synth.iv_for(my_segments[s], c), np.uint8)
+    for i, (s_, c) in enumerate(work):
+        d["iv"][i] = np.frombuffer(synth.iv_for(my_segments[s_], c), np.uint8)      # IV = f(global segment, chunk id), whoever transforms it
     profile = nat.ZSTD_PROFILE_1_5_7 if args.profile == "1.5.7" else nat.ZSTD_PROFILE_1_5_6
     params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=profile)
-    ctxs = [N.ctx_create(0, n, CH) for _ in range(T)]
+    ctxs = [N.ctx_create(0, max(n, 1), CH) for _ in range(T)]
     ds = [d] + [d.copy() for _ in range(T - 1)]
     ctx = ctxs[0]
+    index = {}                                           # split mode: per segment (sizes, positions, base) after the exchange
 
     def step(t=0):
-        if workload == "crc":
-            N.crc32c_batch(ds[t], src.data_ptr(), nat.MEM_DEVICE, ctx=ctxs[t])
-        else:
-            N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+        if n:
+            if workload == "crc":
+                N.crc32c_batch(ds[t], Mem.ptr(src), MEM, ctx=ctxs[t])
+            else:
+                N.transform_batch(params, ds[t], Mem.ptr(src), Mem.ptr(dsts[t]), dsts[t].size if rehearse else dsts[t].numel(), MEM, ctx=ctxs[t])
+        if split and workload != "crc":
+            # the path's one exchange: every rank learns every chunk's transformed size, so that it can place its slice of the
+            # .log object and build the whole chunk index (AbstractChunkIndex.java:52-72)
+            at = 0
+            for s_, (lo, hi) in zip(range(nseg), ranges):
+                index[s_] = shard.exchange_transformed_sizes(ds[t]["dst_len"][at:at + hi - lo], cps, rank, world, dist if world > 1 else None,
+                                                             device="cpu" if args.backend == "gloo" else dev)
+                at += hi - lo
 
     def fence():
-        torch.cuda.synchronize()
+        Mem.sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        Mem.sync()
 
     import threading
     for w in range(max(args.warmup, 1) if T > 1 else args.warmup):
@@ -216,11 +234,11 @@ def main():
         fence()
         single = float(n) * CH * 2 / GiB / (time.perf_counter() - t1)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = Mem.max_over_ranks(elapsed)
     assert (d["status"] == 0).all(), "chunk failures: %s" % d["status"][d["status"] != 0][:8]
-    total_bytes = float(n) * CH * world * args.steps
+    # whole-job bytes: weak scaling - every rank has nseg segments; split mode - the job is nseg segments in total
+    job_chunks = nseg * cps if split else n * world
+    total_bytes = float(job_chunks) * CH * args.steps
     value = total_bytes / GiB / elapsed
     out_sizes = d["dst_len"].astype(np.int64) if workload != "crc" else np.zeros(n, np.int64)
 
@@ -230,11 +248,13 @@ def main():
         from oracle import oracle as o
         verified = 0
         # 64 chunks spread over the batch (first, last, both sides of every segment boundary region): byte equality with libzstd + OpenSSL
-        for i in sorted(set([0, 1, n // 2, n - 1] + [int(k) for k in np.linspace(0, n - 1, min(args.verify_chunks, n))])):
-            chunk = src[i * CH:(i + 1) * CH].cpu().numpy()
+        for i in sorted(set([0, 1, n // 2, n - 1] + [int(k) for k in np.linspace(0, n - 1, min(args.verify_chunks, n))])) if n else []:
+            if i >= n:
+                continue
+            chunk = Mem.host(src, i * CH, (i + 1) * CH)
             assert d["crc32c"][i] == o.crc32c(chunk), "crc mismatch chunk %d" % i
             if workload != "crc":
-                got = dst[i * slot:i * slot + int(d["dst_len"][i])].cpu().numpy().tobytes()
+                got = Mem.host(dst, i * slot, i * slot + int(d["dst_len"][i])).tobytes()
                 of = (o.COMPRESS if flags & nat.COMPRESS else 0) | o.ENCRYPT | o.OPENSSL
                 exp, _ = o.transform_chunk(of, synth.KEY, synth.AAD, d["iv"][i].tobytes(), chunk.tobytes())
                 assert got == exp, "transformed bytes differ from the oracle for chunk %d (libzstd %s)" % (i, o.zstd_version())
@@ -245,27 +265,30 @@ def main():
     # bytes), device resident like the forward step; restored bytes must equal the source segment byte for byte.
     inverse = None
     if workload != "crc" and not args.no_inverse:
-        back = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+        back = Mem.empty(max(n, 1) * CH)
         e = np.zeros(n, nat.DESC_DTYPE)
         e["src_off"] = d["dst_off"]; e["src_len"] = d["dst_len"]; e["iv"] = d["iv"]
         e["dst_off"] = np.arange(n, dtype=np.uint64) * CH; e["dst_cap"] = CH
-        N.detransform_batch(params, e, dst.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE, ctx=ctx)     # warm-up
+        bsz = back.size if rehearse else back.numel()
+        if n:
+            N.detransform_batch(params, e, Mem.ptr(dst), Mem.ptr(back), bsz, MEM, ctx=ctx)     # warm-up
         fence()
         reps = 3
         t1 = time.perf_counter()
         for _ in range(reps):
-            N.detransform_batch(params, e, dst.data_ptr(), back.data_ptr(), back.numel(), nat.MEM_DEVICE, ctx=ctx)
+            if n:
+                N.detransform_batch(params, e, Mem.ptr(dst), Mem.ptr(back), bsz, MEM, ctx=ctx)
         fence()
         inv_s = (time.perf_counter() - t1) / reps
         if world > 1:
-            tt = torch.tensor([inv_s], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            inv_s = float(tt.item())
+            inv_s = Mem.max_over_ranks(inv_s)
         tm = N.ctx_timing(ctx)
-        exact = bool((e["status"] == 0).all() and (e["dst_len"] == CH).all() and (e["crc32c"] == d["crc32c"]).all() and torch.equal(back, src))
+        exact = bool((e["status"] == 0).all() and (e["dst_len"] == CH).all() and (e["crc32c"] == d["crc32c"]).all() and Mem.equal(back, src))
+        if world > 1:
+            exact = Mem.max_over_ranks(0.0 if exact else 1.0) == 0.0                      # every rank's round trip
         # reported, not asserted: a fetch-side failure must not take the forward measurement's line with it
         inverse = {"metric": "GiB/s of restored bytes, tsx_detransform_batch (GCM verify+decrypt, Zstd decode, CRC32C), one batch at a time",
-                   "value": round(float(n) * CH * world / GiB / inv_s, 4), "unit": "GiB/s", "ms_per_batch": round(inv_s * 1e3, 3),
+                   "value": round(float(job_chunks) * CH / GiB / inv_s, 4), "unit": "GiB/s", "ms_per_batch": round(inv_s * 1e3, 3),
                    "stage_ms": {"gcm": round(tm.gcm_ms, 3), "unzstd": round(tm.unzstd_ms, 3), "crc": round(tm.crc_ms, 3)},
                    "round_trip_exact": exact}
         # roofline of the inverse chain's dominant kernel (the frame decoder): algorithmic bytes = frame read + chunk written
@@ -287,6 +310,8 @@ def main():
         del back
 
     # ---- roofline of the dominant kernel (HIP events on the library's own stream, per launch) ----------
+    if rehearse:
+        stage["zstd" if workload == "full" else workload.split("_")[0]] += 1e-9          # (HIP events of the emulator say nothing)
     dom = max(stage, key=lambda k: stage[k])
     ms = stage[dom] / max(launches[dom], 1)
     mean_out = float(out_sizes.mean()) if workload != "crc" else 0.0
@@ -332,7 +357,7 @@ def main():
     # (T = 1 is the per-thread rate of the reference's chain, T = 10 the reference's default RLM copier pool, "all" what the
     # box could do if every core ran uploads).  The headline object is the all-cores leg.
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not rehearse:
         from oracle import oracle as o
         cores = usable_cores()
         try:
@@ -359,7 +384,7 @@ def main():
     # ---- end to end: the same batch host -> host through TSX_MEM_HOST / TSX_MEM_HOST_PACKED (what the JNI shim uses), PCIe included.
     # Never `value`.  Pageable buffers first (the runtime stages them), then the same buffers pinned with tsx_host_register.
     e2e = None
-    if rank == 0 and world == 1 and workload != "crc" and not args.no_end_to_end:
+    if rank == 0 and world == 1 and workload != "crc" and not args.no_end_to_end and not rehearse:
         PCIE = 64.0                                                       # GB/s per direction, PCIe 5.0 x16
         hsrc = src.cpu().numpy()
         hdst = np.zeros(n * slot, np.uint8)
@@ -395,15 +420,20 @@ def main():
         line = {
             "metric": "GiB/s segment chunk transform (Zstd+AES+CRC), 4MiB chunks",
             "value": round(value, 4), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if split else "weak",
+            "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic" if not rehearse else "synthetic; REHEARSAL on the CPU emulator (tests/emu) - exercises the rank logic, measures nothing",
             "config": {"workload": {"full": "%dx1GiB segments/GPU, 4 MiB chunks, Zstd(L3)+AES-256-GCM+CRC32C (BASELINE configs[3])" % nseg,
                                     "gcm_crc": "1 GiB segment, 4 MiB chunks, AES-256-GCM+CRC32C (BASELINE configs[2])",
                                     "crc": "1 GiB segment, 4 MiB chunks, CRC32C only (BASELINE configs[1])"}[workload],
-                       "stages": workload, "segments_per_gpu": nseg, "chunks_per_gpu": n, "chunk_bytes": CH, "content": args.dist,
+                       "stages": workload, "segments_per_gpu": None if split else nseg, "segments_total": nseg if split else nseg * world, "chunks_per_gpu": n, "chunk_bytes": CH, "content": args.dist,
                        "zstd_profile": args.profile if flags & nat.COMPRESS else None,
                        "mean_transformed_chunk_bytes": round(mean_out, 1), "residency": "device (HBM) in/out",
-                       "parallelism": "segment-major shard, %d rank(s), no data-path collective" % world,
+                       "parallelism": ("chunk-range split of %d segment(s) over %d rank(s), all-gather of transformed sizes per step" % (nseg, world)) if split
+                                      else "segment-major shard, %d rank(s), no data-path collective" % world,
+                       "segments_of_rank0": [int(x) for x in my_segments], "chunks_of_rank0": n,
+                       "chunk_index_positions_sha": None if not index else __import__("hashlib").sha256(
+                           b"".join(np.asarray(index[k][1], np.int64).tobytes() for k in sorted(index))).hexdigest()[:16],
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
                        "verified_chunks_vs_oracle": verified},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "detransform": inverse,

@@ -1,0 +1,63 @@
+"""bench.py's N > 1 logic, rehearsed on CPU: the driver's own launch line (torch.distributed.run, one process per
+rank) with --rehearse --backend gloo - the kernel sources compiled for the CPU emulator, host buffers, tiny chunks.  Asserts the
+rank -> segment mapping, per-rank IVs (through the oracle check and the round trip), the barrier + max-over-ranks reduction (one JSON
+line from rank 0 with whole-job bytes) and, for segments < GPUs, the chunk-range split with the all-gather of transformed sizes."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _launch(world, extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--rehearse", "--backend", "gloo", "--workload", "full"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_two_ranks_segment_major(emu, oracle):
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    CH, cps, nseg = 20000, 3, 2
+    j = _launch(2, ["--chunk-bytes", str(CH), "--chunks-per-segment", str(cps), "--segments", str(nseg), "--inflight", "2"])
+    c = j["config"]
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and "REHEARSAL" in j["data"]
+    assert c["segments_of_rank0"] == [0, 2] and c["chunks_of_rank0"] == nseg * cps and c["segments_total"] == 4     # segment s -> rank s mod 2
+    assert c["verified_chunks_vs_oracle"] == nseg * cps              # rank 0's chunks equal libzstd + OpenSSL with IV(global segment, chunk)
+    assert j["detransform"]["round_trip_exact"] is True             # max-over-ranks of every rank's round trip
+    # value = whole-job bytes (both ranks) / max-over-ranks time
+    assert abs(j["value"] - 2 * nseg * cps * CH / 2**30 / (j["ms_per_step"] * 1e-3)) <= 5.1e-5 + 1e-3 * j["value"]      # (value is rounded to 4 places)
+    assert j["cpu_baseline"] is None and j["end_to_end"] is None
+
+
+def test_one_segment_split_over_two_ranks(emu, oracle):
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    from tsxform import synth
+    CH, cps = 20000, 5
+    j = _launch(2, ["--chunk-bytes", str(CH), "--chunks-per-segment", str(cps), "--segments", "1", "--split-segments"])
+    c = j["config"]
+    assert j["scaling"] == "strong" and c["segments_total"] == 1 and c["chunks_of_rank0"] == 2 and "chunk-range split" in c["parallelism"]
+    assert abs(j["value"] - cps * CH / 2**30 / (j["ms_per_step"] * 1e-3)) <= 5.1e-5 + 1e-3 * j["value"]          # the job is ONE segment
+    of = oracle.COMPRESS | oracle.ENCRYPT
+    sizes = [len(oracle.transform_chunk(of, synth.KEY, synth.AAD, synth.iv_for(0, k), synth.gen_chunk("K", 1000, 0, k, CH).tobytes())[0])
+             for k in range(cps)]
+    pos = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    assert c["chunk_index_positions_sha"] == hashlib.sha256(pos.tobytes()).hexdigest()[:16]     # rank 0 holds the whole chunk index
+    assert j["detransform"]["round_trip_exact"] is True
