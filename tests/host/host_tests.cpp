@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <atomic>
 #include <random>
+#include <thread>
 #include <string>
 
 #include "../../tiered-storage-for-apache-kafka_amd/host/tsxhost.hpp"
@@ -218,7 +220,7 @@ static const Bytes AAD = [] { Bytes k(32); for (int i = 0; i < 32; i++) k[(size_
 static IvSupplier countingIv() { auto n = std::make_shared<uint64_t>(0); return [n](uint8_t iv[12]) { memset(iv, 0, 12); uint64_t v = (*n)++; for (int i = 0; i < 8; i++) iv[11 - i] = (uint8_t)(v >> (8 * i)); }; }
 
 struct MemFetcher : ObjectFetcher {
-    Bytes object; int fetches = 0;
+    Bytes object; std::atomic<int> fetches{0};
     std::shared_ptr<InputStream> fetch(const std::string&, BytesRange r) override {
         fetches++;
         return std::make_shared<ByteArrayInputStream>(Bytes(object.begin() + r.from, object.begin() + r.to + 1));
@@ -417,6 +419,105 @@ static void backendTests(bool full) {
         const auto win = cm.getChunks("k.log", m, 1, 4);                                              // 4-chunk prefetch window: one ranged fetch, one batch
         CHECK(fetcher->fetches == 1 && win.size() == 4);
         for (int k = 0; k < 4; k++) { const Chunk& c = chunks[(size_t)(1 + k)]; CHECK(win[(size_t)k] == Bytes(text.begin() + c.originalPosition, text.begin() + c.originalPosition + c.originalSize)); }
+    });
+    // CT/manifest/SegmentManifestV1SerdeTest.java:40-133 - the three golden strings
+    run("SegmentManifestV1SerdeTest: withEncryption / withoutEncryption / withoutTxnIndex", [&] {
+        const std::string rlsm = "{\"remoteLogSegmentId\":{\"topicIdPartition\":{\"topicId\":\"lZ6vvmajTWKDBUTV6SQAtQ\",\"topicPartition\":"
+                                 "{\"topic\":\"topic1\",\"partition\":42}},\"id\":\"adh9f8BMS4anaUnD8KWfWg\"},\"startOffset\":0,\"endOffset\":1000,"
+                                 "\"maxTimestampMs\":1000000000,\"brokerId\":2,\"eventTimestampMs\":2000000000,"
+                                 "\"segmentLeaderEpochs\":{\"0\":100,\"1\":200,\"2\":300}}";
+        const std::string head = "{\"version\":\"1\",\"chunkIndex\":{\"type\":\"fixed\",\"originalChunkSize\":100,\"originalFileSize\":1000,"
+                                 "\"transformedChunkSize\":110,\"finalTransformedChunkSize\":110},\"segmentIndexes\":{\"offset\":{\"position\":0,\"size\":1},"
+                                 "\"timestamp\":{\"position\":1,\"size\":1},\"producerSnapshot\":{\"position\":2,\"size\":1},\"leaderEpoch\":{\"position\":3,\"size\":1},";
+        const std::string withoutEnc = head + "\"transaction\":{\"position\":4,\"size\":1}},\"compression\":false,\"remoteLogSegmentMetadata\":" + rlsm + "}";
+        const std::string withoutTxn = head + "\"transaction\":null},\"compression\":false,\"remoteLogSegmentMetadata\":" + rlsm + "}";
+        // with encryption the reference compares after removing the (random, RSA-wrapped) dataKey: what remains is {"aad":"CgsMDQ=="}
+        const std::string withEncNoKey = head + "\"transaction\":{\"position\":4,\"size\":1}},\"compression\":false,\"encryption\":{\"aad\":\"CgsMDQ==\"},"
+                                         "\"remoteLogSegmentMetadata\":" + rlsm + "}";
+        SegmentManifestV1 m;
+        m.chunkIndex = std::make_shared<FixedSizeChunkIndex>(100, 1000, 110, 110);
+        m.segmentIndexes = SegmentIndexesV1{{0, 1}, {1, 1}, {2, 1}, {3, 1}, SegmentIndexV1{4, 1}};
+        m.compression = false; m.remoteLogSegmentMetadataJson = rlsm;
+        CHECK(segmentManifestToJson(*be, m) == withoutEnc);
+        SegmentManifestV1 back = segmentManifestFromJson(*be, withoutEnc);
+        CHECK(back.chunkIndex->chunks() == m.chunkIndex->chunks() && !back.compression && !back.encryption && back.segmentIndexes.transaction.has_value());
+        CHECK(back.segmentIndexes.offset == (SegmentIndexV1{0, 1}) && back.segmentIndexes.leaderEpoch == (SegmentIndexV1{3, 1}) && *back.segmentIndexes.transaction == (SegmentIndexV1{4, 1}));
+        CHECK(segmentManifestToJson(*be, back) == withoutEnc);                                        // parse -> write is the identity on the golden
+        SegmentManifestV1 noTxn = m; noTxn.segmentIndexes.transaction.reset();
+        CHECK(segmentManifestToJson(*be, noTxn) == withoutTxn);
+        CHECK(!segmentManifestFromJson(*be, withoutTxn).segmentIndexes.transaction.has_value());
+        SegmentManifestV1 enc = m;
+        enc.encryption = SegmentEncryptionMetadata{Bytes{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}, Bytes{10, 11, 12, 13}, 12};       // DATA_KEY, AAD of the reference test
+        const std::string wrapped = "static-key-id:" + base64Encode(Bytes{9, 8, 7, 6});               // stands for RsaEncryptionProvider.encryptDataKey
+        const std::string ej = segmentManifestToJson(*be, enc, [&](const Bytes& k) { CHECK(k.size() == 10); return wrapped; });
+        const std::string keyProp = "\"dataKey\":\"" + wrapped + "\",";
+        const size_t at = ej.find(keyProp);
+        CHECK(at != std::string::npos);
+        std::string without = ej; without.erase(at, keyProp.size());
+        CHECK(without == withEncNoKey);
+        SegmentManifestV1 eb = segmentManifestFromJson(*be, ej, [&](const std::string& sk) { CHECK(sk == wrapped); return Bytes{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}; });
+        CHECK(eb.encryption && eb.encryption->aad == (Bytes{10, 11, 12, 13}) && eb.encryption->dataKey.size() == 10);
+        expectThrows<std::invalid_argument>([&] { segmentManifestToJson(*be, enc); }, "a data-key encryptor is required to serialise an encrypted segment's manifest");
+        expectThrows<std::invalid_argument>([&] { segmentManifestFromJson(*be, "{\"version\":\"2\"}"); }, "Could not resolve type id '2' as a subtype of SegmentManifest");
+        expectThrows<std::invalid_argument>([&] { segmentManifestFromJson(*be, "{\"version\":\"1\",\"chunkIndex\":{\"type\":\"fixed\",\"originalChunkSize\":1,\"originalFileSize\":1,\"transformedChunkSize\":1,\"finalTransformedChunkSize\":1}}"); },
+                                            "Missing required creator property 'segmentIndexes'");
+        // a variable index (compressed segment) inside a manifest: the index's Zstd frame goes through the device compressor
+        SegmentManifestV1 var = m; var.compression = true; var.chunkIndex = std::make_shared<VariableSizeChunkIndex>(100, 250, std::vector<int>{10, 20, 30});
+        const std::string vj = segmentManifestToJson(*be, var);
+        CHECK(vj.find("\"transformedChunks\":\"KLUv/SAPeQAAAAAAAwAAAAoBAAoAAAAe\"") != std::string::npos && vj.find("\"compression\":true") != std::string::npos);
+        CHECK(segmentManifestFromJson(*be, vj).chunkIndex->chunks() == var.chunkIndex->chunks());
+    });
+    // C/fetch/cache/ChunkCache.java:76-129,159-184 with the device in mind: a window is ONE fetch + ONE device batch
+    run("GpuChunkCache: prefetch window and concurrent misses coalesce into one fetch + one batch", [&] {
+        const int cs = 4096;
+        GpuTransformChunkEnumeration t(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), cs), true, DataKeyAndAAD{KEY, AAD}, countingIv(), 32);
+        TransformFinisher tf(std::shared_ptr<TransformChunkEnumeration>(&t, [](TransformChunkEnumeration*) {}), (int)text.size());
+        auto fetcher = std::make_shared<MemFetcher>(); fetcher->object = tf.toBytes();
+        SegmentManifest m; m.chunkIndex = tf.chunkIndex(); m.compression = true; m.encryption = SegmentEncryptionMetadata{KEY, AAD, 12};
+        const auto& chunks = m.chunkIndex->chunks();
+        auto plain = [&](int id) { const Chunk& c = chunks[(size_t)id]; return Bytes(text.begin() + c.originalPosition, text.begin() + c.originalPosition + c.originalSize); };
+        CHECK(chunks.size() >= 12);
+        {   // one caller, prefetch of 3 chunks: chunk 2 and chunks 3..5 leave as ONE getChunks; 3, 4, 5 are hits afterwards
+            GpuChunkCache cache(std::make_shared<GpuChunkManager>(be, fetcher), 3 * cs, (size_t)64 << 20, 10000, 0);
+            fetcher->fetches = 0;
+            CHECK(cache.getChunk("k.log", m, 2) == plain(2));
+            CHECK(fetcher->fetches == 1 && cache.stats().fetchCalls == 1 && cache.stats().chunksFetched == 4);
+            CHECK(cache.getChunk("k.log", m, 3) == plain(3) && cache.getChunk("k.log", m, 4) == plain(4));
+            // chunk 3 prefetched 6, chunk 4 prefetched 7: one chunk each, nothing beyond the window of the chunk asked for
+            cache.quiesce();
+            ChunkCacheStats s1 = cache.stats();
+            CHECK(s1.misses == 1 && s1.hits == 2 && s1.chunksFetched == 6);
+            CHECK(cache.getChunk("k.log", m, (int)chunks.size() - 1) == plain((int)chunks.size() - 1));      // last chunk: no window behind it
+        }
+        {   // 8 threads miss chunks 0..7 of the same object at once: they meet in one batch (a few at most), not in 8
+            GpuChunkCache cache(std::make_shared<GpuChunkManager>(be, fetcher), 0, (size_t)64 << 20, 10000, 50000);
+            fetcher->fetches = 0;
+            std::vector<std::thread> th; std::vector<int> ok(8, 0);
+            std::atomic<int> go{0};
+            for (int i = 0; i < 8; i++) th.emplace_back([&, i] {
+                go++; while (go.load() < 8) std::this_thread::yield();
+                std::this_thread::sleep_for(std::chrono::microseconds(300 * i));          // arrive in order, inside the leader's wait
+                ok[(size_t)i] = cache.getChunk("k.log", m, i) == plain(i);
+            });
+            for (auto& x : th) x.join();
+            CHECK(std::all_of(ok.begin(), ok.end(), [](int v) { return v == 1; }));
+            const ChunkCacheStats s2 = cache.stats();
+            CHECK(s2.misses == 8 && s2.chunksFetched == 8 && s2.fetchCalls <= 3 && fetcher->fetches == s2.fetchCalls && s2.joined >= 5);
+        }
+        {   // a forged chunk fails only its own callers: the window is retried chunk by chunk
+            auto bad = std::make_shared<MemFetcher>(); bad->object = fetcher->object;
+            bad->object[(size_t)chunks[5].transformedPosition + 20] ^= 1;
+            GpuChunkCache cache(std::make_shared<GpuChunkManager>(be, bad), 3 * cs, (size_t)64 << 20, 10000, 0);
+            CHECK(cache.getChunk("k.log", m, 4) == plain(4));                                        // window 4..7 contains the forged chunk 5
+            expectThrows<std::runtime_error>([&] { cache.getChunk("k.log", m, 5); }, "Tag mismatch");
+            CHECK(cache.getChunk("k.log", m, 6) == plain(6));
+        }
+        {   // eviction by weight: a cache of two chunks keeps two
+            GpuChunkCache cache(std::make_shared<GpuChunkManager>(be, fetcher), 0, (size_t)2 * cs, 10000, 0);
+            for (int i = 0; i < 5; i++) CHECK(cache.getChunk("k.log", m, i) == plain(i));
+            CHECK(cache.stats().evictions == 3);
+            CHECK(cache.getChunk("k.log", m, 4) == plain(4) && cache.stats().hits == 1);
+        }
     });
 }
 

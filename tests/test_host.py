@@ -34,10 +34,11 @@ def test_host_chain_over_emulated_kernels(host_tests, emu):
     from tests.emu import emu_native
     out = _run([host_tests, "backend", emu_native.EMU_LIB], env=dict(os.environ, TSX_ALLOW_ANY_ARCH="1"))
     assert "ChunkIndexSerializationTest" in out and "TransformsEndToEndTest.compressionAndEncryption" in out
+    assert "SegmentManifestV1SerdeTest" in out and "GpuChunkCache" in out
 
 
 @pytest.mark.gpu
 def test_host_chain_on_gpu(host_tests):
     import tsxform
     out = _run([host_tests, "backend", tsxform._native.LIB_PATH, "full"])
-    assert "gfx950" in out and "ChunkManager.getChunk" in out
+    assert "gfx950" in out and "ChunkManager.getChunk" in out and "SegmentManifestV1SerdeTest" in out and "GpuChunkCache" in out

@@ -8,6 +8,13 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <future>
+#include <list>
+#include <map>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 
@@ -225,7 +232,16 @@ struct Backend::Fns {
     decltype(&tsx_crc32c_batch) crc; decltype(&tsx_transformed_bound) bound; decltype(&tsx_strerror) strerr; decltype(&tsx_version) version; decltype(&tsx_abi_version) abi;
 };
 
-Backend::Backend(const std::string& libPath, int deviceIndex) : f_(new Fns) {
+struct Backend::Lock { std::mutex mu; };
+namespace {
+struct CtxLease {                    // the Backend's own context if it is free, else NULL = a pooled context of the library
+    CtxLease(std::mutex& m, tsx_ctx* own) : mu(m), got(m.try_lock()), ctx(got ? own : nullptr) {}
+    ~CtxLease() { if (got) mu.unlock(); }
+    std::mutex& mu; bool got; tsx_ctx* ctx;
+};
+}  // namespace
+
+Backend::Backend(const std::string& libPath, int deviceIndex) : f_(new Fns), lock_(new Lock) {
     handle_ = dlopen(libPath.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!handle_) throw std::runtime_error("tsxhost: cannot load " + libPath + ": " + dlerror() + " (there is no CPU fallback)");
     auto sym = [&](const char* n) { void* p = dlsym(handle_, n); if (!p) throw std::runtime_error(std::string("tsxhost: missing symbol ") + n); return p; };
@@ -246,15 +262,18 @@ Backend::~Backend() {
     // the library stays loaded: other Backends of the process share its device state
 }
 void Backend::transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
-    const int rc = f_->transform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
+    CtxLease lease(lock_->mu, ctx_);
+    const int rc = f_->transform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
     if (rc) throw std::runtime_error(std::string("tsx_transform_batch: ") + f_->strerr(rc));
 }
 void Backend::transformBatchPacked(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
-    const int rc = f_->transform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST_PACKED);
+    CtxLease lease(lock_->mu, ctx_);
+    const int rc = f_->transform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST_PACKED);
     if (rc) throw std::runtime_error(std::string("tsx_transform_batch: ") + f_->strerr(rc));
 }
 void Backend::detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
-    const int rc = f_->detransform(ctx_, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
+    CtxLease lease(lock_->mu, ctx_);
+    const int rc = f_->detransform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
     if (rc) throw std::runtime_error(std::string("tsx_detransform_batch: ") + f_->strerr(rc));
 }
 uint32_t Backend::crc32c(const uint8_t* data, size_t n) {
@@ -263,7 +282,8 @@ uint32_t Backend::crc32c(const uint8_t* data, size_t n) {
     tsx_chunk_desc d;
     memset(&d, 0, sizeof d);
     d.src_len = (uint32_t)n;
-    const int rc = f_->crc(ctx_, &d, 1, buf.data(), TSX_MEM_HOST);
+    CtxLease lease(lock_->mu, ctx_);
+    const int rc = f_->crc(lease.ctx, &d, 1, buf.data(), TSX_MEM_HOST);
     if (rc || d.status != TSX_OK) throw std::runtime_error(std::string("tsx_crc32c_batch: ") + f_->strerr(rc ? rc : d.status));
     return d.crc32c;
 }
@@ -676,6 +696,244 @@ std::vector<Bytes> GpuChunkManager::getChunks(const std::string& objectKey, cons
     std::vector<Bytes> out;
     while (e->hasMoreElements()) out.push_back(e->nextElement());
     return out;
+}
+
+
+// =====================================================================================================
+// SegmentManifestV1 JSON (manifest/SegmentManifestV1.java:30-132 through Jackson; goldens SegmentManifestV1SerdeTest.java:82-133)
+// =====================================================================================================
+namespace {
+// One level of a JSON object: (key, raw text of the value) in document order.  Strings may contain escapes; nesting is skipped by
+// depth counting outside strings.
+std::vector<std::pair<std::string, std::string>> jsonFields(const std::string& j) {
+    std::vector<std::pair<std::string, std::string>> out;
+    size_t i = 0;
+    auto ws = [&] { while (i < j.size() && (j[i] == ' ' || j[i] == '\n' || j[i] == '\t' || j[i] == '\r')) i++; };
+    auto str = [&]() -> std::string {
+        if (j[i] != '"') throw std::invalid_argument("malformed JSON: expected a string");
+        size_t b = ++i;
+        while (i < j.size() && j[i] != '"') i += (j[i] == '\\') ? 2 : 1;
+        if (i >= j.size()) throw std::invalid_argument("malformed JSON: unterminated string");
+        return j.substr(b, i++ - b);
+    };
+    ws();
+    if (i >= j.size() || j[i] != '{') throw std::invalid_argument("malformed JSON: expected an object");
+    i++; ws();
+    if (i < j.size() && j[i] == '}') return out;
+    for (;;) {
+        ws();
+        std::string key = str();
+        ws();
+        if (i >= j.size() || j[i] != ':') throw std::invalid_argument("malformed JSON: expected ':'");
+        i++; ws();
+        const size_t b = i;
+        int depth = 0;
+        for (; i < j.size(); i++) {
+            const char c = j[i];
+            if (c == '"') { i++; while (i < j.size() && j[i] != '"') i += (j[i] == '\\') ? 2 : 1; continue; }
+            if (c == '{' || c == '[') depth++;
+            else if (c == '}' || c == ']') { if (depth == 0) break; depth--; }
+            else if (c == ',' && depth == 0) break;
+        }
+        if (i >= j.size()) throw std::invalid_argument("malformed JSON: unterminated object");
+        size_t e = i;
+        while (e > b && (j[e - 1] == ' ' || j[e - 1] == '\n' || j[e - 1] == '\t' || j[e - 1] == '\r')) e--;
+        out.emplace_back(std::move(key), j.substr(b, e - b));
+        if (j[i] == '}') break;
+        i++;
+    }
+    return out;
+}
+const std::string* findField(const std::vector<std::pair<std::string, std::string>>& f, const char* name) {
+    for (const auto& kv : f) if (kv.first == name) return &kv.second;
+    return nullptr;
+}
+const std::string& needField(const std::vector<std::pair<std::string, std::string>>& f, const char* name) {
+    const std::string* v = findField(f, name);
+    if (!v) throw std::invalid_argument(std::string("Missing required creator property '") + name + "'");
+    return *v;
+}
+std::string unquote(const std::string& raw) {
+    if (raw.size() < 2 || raw.front() != '"' || raw.back() != '"') throw std::invalid_argument("malformed JSON: expected a string value");
+    return raw.substr(1, raw.size() - 2);
+}
+std::string indexJson(const SegmentIndexV1& x) { return "{\"position\":" + std::to_string(x.position) + ",\"size\":" + std::to_string(x.size) + "}"; }
+SegmentIndexV1 indexFromJson(const std::string& raw) {
+    const auto f = jsonFields(raw);
+    return SegmentIndexV1{std::stoi(needField(f, "position")), std::stoi(needField(f, "size"))};
+}
+}  // namespace
+
+std::string segmentManifestToJson(Backend& be, const SegmentManifestV1& m, const DataKeyEncryptor& wrapKey) {
+    if (!m.chunkIndex) throw std::invalid_argument("chunkIndex cannot be null");
+    std::string j = "{\"version\":\"1\",\"chunkIndex\":" + chunkIndexToJson(be, *m.chunkIndex) + ",\"segmentIndexes\":{";
+    const SegmentIndexesV1& si = m.segmentIndexes;
+    j += "\"offset\":" + indexJson(si.offset) + ",\"timestamp\":" + indexJson(si.timestamp) + ",\"producerSnapshot\":" + indexJson(si.producerSnapshot) +
+         ",\"leaderEpoch\":" + indexJson(si.leaderEpoch) + ",\"transaction\":" + (si.transaction ? indexJson(*si.transaction) : std::string("null")) + "}";
+    j += std::string(",\"compression\":") + (m.compression ? "true" : "false");
+    if (m.encryption) {                                                // @JsonInclude(NON_ABSENT): no property at all without encryption
+        if (!wrapKey) throw std::invalid_argument("a data-key encryptor is required to serialise an encrypted segment's manifest");
+        j += ",\"encryption\":{\"dataKey\":\"" + wrapKey(m.encryption->dataKey) + "\",\"aad\":\"" + base64Encode(m.encryption->aad) + "\"}";
+    }
+    if (!m.remoteLogSegmentMetadataJson.empty()) j += ",\"remoteLogSegmentMetadata\":" + m.remoteLogSegmentMetadataJson;
+    return j + "}";
+}
+
+SegmentManifestV1 segmentManifestFromJson(Backend& be, const std::string& json, const DataKeyDecryptor& unwrapKey) {
+    const auto f = jsonFields(json);
+    const std::string version = unquote(needField(f, "version"));
+    if (version != "1") throw std::invalid_argument("Could not resolve type id '" + version + "' as a subtype of SegmentManifest");
+    SegmentManifestV1 m;
+    m.chunkIndex = chunkIndexFromJson(be, needField(f, "chunkIndex"));
+    const auto si = jsonFields(needField(f, "segmentIndexes"));
+    m.segmentIndexes.offset = indexFromJson(needField(si, "offset"));
+    m.segmentIndexes.timestamp = indexFromJson(needField(si, "timestamp"));
+    m.segmentIndexes.producerSnapshot = indexFromJson(needField(si, "producerSnapshot"));
+    m.segmentIndexes.leaderEpoch = indexFromJson(needField(si, "leaderEpoch"));
+    const std::string& txn = needField(si, "transaction");            // required = true, value may be null
+    if (txn != "null") m.segmentIndexes.transaction = indexFromJson(txn);
+    const std::string& comp = needField(f, "compression");
+    if (comp != "true" && comp != "false") throw std::invalid_argument("compression must be a boolean");
+    m.compression = comp == "true";
+    if (const std::string* enc = findField(f, "encryption")) {
+        if (*enc != "null") {
+            const auto ef = jsonFields(*enc);
+            if (!unwrapKey) throw std::invalid_argument("a data-key decryptor is required to read an encrypted segment's manifest");
+            SegmentEncryptionMetadata e;
+            e.dataKey = unwrapKey(unquote(needField(ef, "dataKey")));
+            e.aad = base64Decode(unquote(needField(ef, "aad")));
+            m.encryption = e;
+        }
+    }
+    // remoteLogSegmentMetadata: written for humans and tooling, never read back (JsonProperty.Access.READ_ONLY); kept verbatim
+    if (const std::string* r = findField(f, "remoteLogSegmentMetadata")) m.remoteLogSegmentMetadataJson = *r;
+    return m;
+}
+
+// =====================================================================================================
+// GpuChunkCache
+// =====================================================================================================
+struct GpuChunkCache::Impl {
+    using Key = std::pair<std::string, int>;
+    struct Batch {                                                     // one getChunks call being put together / in flight
+        std::string object; int first = 0, count = 0;
+        bool open = true;                                              // still accepts adjacent chunks
+        std::vector<std::shared_ptr<std::promise<Bytes>>> slots;
+    };
+    std::shared_ptr<GpuChunkManager> mgr;
+    int prefetchingSize; size_t maxBytes; int getTimeoutMs, coalesceWaitMicros;
+    mutable std::mutex mu;
+    std::list<std::pair<Key, Bytes>> lru;                              // front = most recently used
+    std::map<Key, std::list<std::pair<Key, Bytes>>::iterator> cached;
+    std::map<Key, std::shared_future<Bytes>> pending;
+    std::map<std::string, std::shared_ptr<Batch>> openBatch;           // per object: the batch that can still grow at its end
+    std::vector<std::future<void>> helpers;                           // prefetch batches nobody is waiting for yet
+    size_t bytes = 0;
+    ChunkCacheStats st;
+
+    void insert(const Key& k, const Bytes& v) {                        // under mu
+        auto it = cached.find(k);
+        if (it != cached.end()) { bytes -= it->second->second.size(); lru.erase(it->second); cached.erase(it); }
+        lru.emplace_front(k, v); cached[k] = lru.begin(); bytes += v.size();
+        while (bytes > maxBytes && lru.size() > 1) { bytes -= lru.back().second.size(); cached.erase(lru.back().first); lru.pop_back(); st.evictions++; }
+    }
+    // Runs one batch: one ranged fetch + one device batch; on failure every chunk on its own, so that only the bad one fails.
+    void runBatch(const std::shared_ptr<Batch>& b, const SegmentManifest& manifest) {
+        std::vector<Bytes> got;
+        std::exception_ptr batchErr;
+        try { got = mgr->getChunks(b->object, manifest, b->first, b->count); } catch (...) { batchErr = std::current_exception(); }
+        { std::lock_guard<std::mutex> lk(mu); st.fetchCalls++; st.chunksFetched += b->count; }
+        for (int i = 0; i < b->count; i++) {
+            const Key k{b->object, b->first + i};
+            Bytes v;
+            std::exception_ptr err;
+            if (!batchErr) v = std::move(got[(size_t)i]);
+            else if (b->count == 1) err = batchErr;
+            else { try { v = mgr->getChunk(b->object, manifest, b->first + i); } catch (...) { err = std::current_exception(); } }
+            { std::lock_guard<std::mutex> lk(mu); if (!err) insert(k, v); pending.erase(k); }
+            if (err) b->slots[(size_t)i]->set_exception(err); else b->slots[(size_t)i]->set_value(std::move(v));
+        }
+    }
+};
+
+GpuChunkCache::GpuChunkCache(std::shared_ptr<GpuChunkManager> manager, int prefetchingSize, size_t maxBytes, int getTimeoutMs, int coalesceWaitMicros)
+    : impl_(new Impl) {
+    impl_->mgr = std::move(manager); impl_->prefetchingSize = prefetchingSize; impl_->maxBytes = maxBytes;
+    impl_->getTimeoutMs = getTimeoutMs; impl_->coalesceWaitMicros = coalesceWaitMicros;
+}
+GpuChunkCache::~GpuChunkCache() { quiesce(); }
+void GpuChunkCache::quiesce() {
+    std::vector<std::future<void>> hs;
+    { std::lock_guard<std::mutex> lk(impl_->mu); hs.swap(impl_->helpers); }
+    for (auto& h : hs) if (h.valid()) h.wait();
+}
+ChunkCacheStats GpuChunkCache::stats() const { std::lock_guard<std::mutex> lk(impl_->mu); return impl_->st; }
+
+Bytes GpuChunkCache::getChunk(const std::string& objectKey, const SegmentManifest& manifest, int chunkId) {
+    Impl& I = *impl_;
+    const std::vector<Chunk>& all = manifest.chunkIndex->chunks();
+    if (chunkId < 0 || (size_t)chunkId >= all.size()) throw std::out_of_range("chunk id out of range");
+    // the window this call may touch: the chunk itself + ChunkCache.startPrefetching's range behind it (never more)
+    int last = chunkId;
+    if (I.prefetchingSize > 0) {
+        const Chunk& cur = all[(size_t)chunkId];
+        const long long start = (long long)cur.originalPosition + cur.originalSize;
+        const long long end = std::min<long long>(start + I.prefetchingSize - 1, 2147483647LL);
+        if (start <= end) for (const Chunk& c : manifest.chunkIndex->chunksForRange(BytesRange{(int)start, (int)end})) last = std::max(last, c.id);
+    }
+    std::shared_future<Bytes> mine;
+    std::shared_ptr<Impl::Batch> lead;                                 // a batch this caller has to send off
+    {
+        std::unique_lock<std::mutex> lk(I.mu);
+        const Impl::Key k{objectKey, chunkId};
+        auto hit = I.cached.find(k);
+        bool have = false;
+        Bytes cachedCopy;
+        if (hit != I.cached.end()) { I.st.hits++; I.lru.splice(I.lru.begin(), I.lru, hit->second); cachedCopy = hit->second->second; have = true; }
+        else if (I.pending.count(k)) { I.st.hits++; mine = I.pending[k]; }
+        else I.st.misses++;
+        // what is neither cached nor on its way, as runs of consecutive ids; the run containing chunkId is waited for, the rest is prefetch
+        int i = chunkId;
+        while (i <= last) {
+            while (i <= last && (I.cached.count({objectKey, i}) || I.pending.count({objectKey, i}))) i++;
+            if (i > last) break;
+            int j = i;
+            while (j <= last && !I.cached.count({objectKey, j}) && !I.pending.count({objectKey, j})) j++;
+            // join the batch that is about to leave for this object if the run continues it, else open a new one
+            std::shared_ptr<Impl::Batch> b;
+            auto ob = I.openBatch.find(objectKey);
+            const bool joins = ob != I.openBatch.end() && ob->second->open && ob->second->first + ob->second->count == i;
+            if (joins) { b = ob->second; I.st.joined++; }
+            else { b = std::make_shared<Impl::Batch>(); b->object = objectKey; b->first = i; }
+            for (int c = i; c < j; c++) {
+                auto pr = std::make_shared<std::promise<Bytes>>();
+                b->slots.push_back(pr); b->count++;
+                I.pending[{objectKey, c}] = pr->get_future().share();
+            }
+            if (i <= chunkId && chunkId < j) mine = I.pending[k];
+            if (!joins) {
+                if (i <= chunkId && chunkId < j && !lead) { lead = b; I.openBatch[objectKey] = b; }
+                else {                                                  // pure prefetch run: sent from a helper thread, nobody waits here
+                    b->open = false;
+                    I.helpers.erase(std::remove_if(I.helpers.begin(), I.helpers.end(), [](std::future<void>& h) {
+                                        return h.wait_for(std::chrono::seconds(0)) == std::future_status::ready; }), I.helpers.end());
+                    const SegmentManifest copy = manifest;              // the helper may outlive the caller's object
+                    I.helpers.push_back(std::async(std::launch::async, [this, b, copy] { impl_->runBatch(b, copy); }));
+                }
+            }
+            i = j;
+        }
+        if (have) return cachedCopy;
+    }
+    if (lead) {
+        // give concurrent misses on the next chunks of this object a moment to join (bounded, microseconds against get.timeout.ms)
+        if (I.coalesceWaitMicros > 0) std::this_thread::sleep_for(std::chrono::microseconds(I.coalesceWaitMicros));
+        { std::lock_guard<std::mutex> lk(I.mu); lead->open = false; auto ob = I.openBatch.find(objectKey); if (ob != I.openBatch.end() && ob->second == lead) I.openBatch.erase(ob); }
+        I.runBatch(lead, manifest);
+    }
+    if (mine.wait_for(std::chrono::milliseconds(I.getTimeoutMs)) != std::future_status::ready)
+        throw std::runtime_error("java.util.concurrent.TimeoutException");       // ChunkCache.java:126-128: wrapped in a RuntimeException
+    return mine.get();
 }
 
 // =====================================================================================================

@@ -160,7 +160,9 @@ private:
     struct Fns;
     void* handle_ = nullptr;
     std::unique_ptr<Fns> f_;
-    tsx_ctx* ctx_ = nullptr;
+    tsx_ctx* ctx_ = nullptr;        // this Backend's own context; a second concurrent caller borrows a pooled one (ctx == NULL in the ABI)
+    struct Lock;
+    std::unique_ptr<Lock> lock_;
 };
 
 // TransformedChunksSerializer / Deserializer: codec -> one Zstd frame (GPU compressor: same bytes as the reference's
@@ -355,11 +357,30 @@ public:
     virtual std::shared_ptr<InputStream> fetch(const std::string& objectKey, BytesRange range) = 0;
 };
 
-struct SegmentManifest {                 // manifest/SegmentManifestV1 as far as the path needs it
+struct SegmentManifest {                 // manifest/SegmentManifest.java:36-46 as far as the fetch path needs it
     std::shared_ptr<ChunkIndex> chunkIndex;
     bool compression = false;
     std::optional<SegmentEncryptionMetadata> encryption;
 };
+
+// manifest/SegmentIndexV1.java:26-48, SegmentIndexesV1.java:26-82, SegmentManifestV1.java:30-132: the manifest object as it is
+// stored next to the .log object - the JSON a reference broker reads back (Jackson layout pinned by
+// CT/manifest/SegmentManifestV1SerdeTest.java:82-133).  Two pieces stay opaque strings because their producers stay Java: the
+// RSA-wrapped data key "<keyId>:<base64>" (EncryptedDataKey.serialize, DataKeySerializer.java:30-46) and Kafka's
+// RemoteLogSegmentMetadata (KafkaTypeSerdeModule; written, never read back: JsonProperty.Access.READ_ONLY).
+struct SegmentIndexV1 { int position = 0, size = 0; bool operator==(const SegmentIndexV1& o) const { return position == o.position && size == o.size; } };
+struct SegmentIndexesV1 {
+    SegmentIndexV1 offset, timestamp, producerSnapshot, leaderEpoch;
+    std::optional<SegmentIndexV1> transaction;                        // "transaction":null when the segment has no txn index
+};
+struct SegmentManifestV1 : SegmentManifest {
+    SegmentIndexesV1 segmentIndexes;
+    std::string remoteLogSegmentMetadataJson;                         // "" = property absent
+};
+using DataKeyEncryptor = std::function<std::string(const Bytes& dataKey)>;      // -> "<keyId>:<base64 of the RSA-wrapped key>"
+using DataKeyDecryptor = std::function<Bytes(const std::string& serialized)>;
+std::string segmentManifestToJson(Backend& be, const SegmentManifestV1& m, const DataKeyEncryptor& wrapKey = nullptr);
+SegmentManifestV1 segmentManifestFromJson(Backend& be, const std::string& json, const DataKeyDecryptor& unwrapKey = nullptr);
 
 class ChunkManager {
 public:
@@ -377,6 +398,29 @@ public:
 private:
     std::shared_ptr<Backend> be_;
     std::shared_ptr<ObjectFetcher> fetcher_;
+};
+
+// ---- fetch-side batching -------------------------------------------------------------------
+// ChunkCache.java:76-129 (getChunk) + 159-184 (startPrefetching) with the device in mind.  The reference turns a prefetch window
+// of k chunks into k single-chunk tasks, each one ranged fetch + one detransform; through a GPU that is k launches of a kernel
+// whose latency is per chunk.  Here the requested chunk and the not-yet-cached part of its prefetch window become ONE
+// GpuChunkManager::getChunks call (one ranged fetch, one device batch), and concurrent misses on adjacent chunks of the same object
+// that arrive within a short bounded wait (coalesceWait, far below get.timeout.ms) join the batch that is about to leave.  Kept from
+// the reference: nothing beyond the configured window is ever fetched (laziness), a cached chunk is returned as a
+// copy of its bytes (eviction cannot pull it from under a reader), a waiter gives up after getTimeout with a RuntimeException, and a
+// chunk that fails (tag mismatch, corrupt frame) fails only the callers that asked for that chunk - the batch is retried chunk by chunk.
+struct ChunkCacheStats { long hits = 0, misses = 0, fetchCalls = 0, chunksFetched = 0, joined = 0, evictions = 0; };
+class GpuChunkCache : public ChunkManager {
+public:
+    GpuChunkCache(std::shared_ptr<GpuChunkManager> manager, int prefetchingSize, size_t maxBytes, int getTimeoutMs = 10000, int coalesceWaitMicros = 300);
+    ~GpuChunkCache() override;
+    Bytes getChunk(const std::string& objectKey, const SegmentManifest& manifest, int chunkId) override;
+    ChunkCacheStats stats() const;
+    void quiesce();                    // waits for the prefetch batches nobody is waiting for (tests; orderly shutdown)
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
 };
 
 // ---- upload sink --------------------------------------------------------------------------
