@@ -271,3 +271,83 @@ def test_zstd_differential_fuzz_vs_libzstd(gpu, oracle):
             assert d["status"][i] == 0 and outs[i] == oracle.zstd_compress_chunk(c.tobytes()), "case %d (n=%d): frame differs from libzstd" % (lo + i, c.size)
             assert d2["status"][i] == 0 and back[i] == c.tobytes(), "case %d (n=%d): round trip" % (lo + i, c.size)
     pc.check_transform_vs_oracle(gpu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, cases[:64])
+
+
+# ---- the front end on the device (twins of tests/test_emu_boundary.py) ----------------------------------------
+def test_detransform_on_a_fresh_context_of_highly_compressible_chunks(gpu, oracle):
+    """160 all-zero 4 MiB chunks compress to ~150 bytes each; the CRC of the restored bytes runs over 4 MiB slots
+    (16 partial sums per chunk) on a context that has only ever seen those tiny inputs."""
+    import torch
+    n = 160
+    zero_frame = oracle.zstd_compress_chunk(bytes(CHUNK))
+    blob = oracle.gcm_encrypt_chunk(synth.KEY, synth.iv_for(0, 0), synth.AAD, zero_frame, openssl=True)
+    stride = (len(blob) + 15) // 16 * 16 + 16
+    src = np.zeros(n * stride, np.uint8)
+    for i in range(n):
+        src[i * stride:i * stride + len(blob)] = np.frombuffer(blob, np.uint8)
+    dsrc = torch.from_numpy(src).cuda()
+    back = torch.full((n * CHUNK,), 0x5A, dtype=torch.uint8, device="cuda")
+    guard = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")          # a neighbour allocation that must stay untouched
+    d = np.zeros(n, nat.DESC_DTYPE)
+    d["src_off"] = np.arange(n, dtype=np.uint64) * stride; d["src_len"] = len(blob)
+    d["dst_off"] = np.arange(n, dtype=np.uint64) * CHUNK; d["dst_cap"] = CHUNK
+    ctx = gpu.ctx_create(0, 0, 0)
+    try:
+        gpu.detransform_batch(nat.Native.make_params(nat.COMPRESS | nat.ENCRYPT | nat.CRC, synth.KEY, synth.AAD), d, dsrc.data_ptr(), back.data_ptr(),
+                              back.numel(), nat.MEM_DEVICE, ctx=ctx)
+        assert gpu.lib.tsx_debug_key_residue(ctx) == 0
+    finally:
+        gpu.ctx_destroy(ctx)
+    assert (d["status"] == 0).all() and (d["dst_len"] == CHUNK).all() and (d["crc32c"] == oracle.crc32c(bytes(CHUNK))).all()
+    assert int(back.max()) == 0 and int(guard.max()) == 0
+
+
+def test_forged_chunk_is_scrubbed_from_a_device_slot(gpu):
+    import torch
+    chunks = pc.edge_chunks("R", [3000, 2 << 20, 70001])
+    outs, _ = pc.run_transform(gpu, nat.ENCRYPT, chunks)
+    forged = bytearray(outs[1]); forged[1 << 20] ^= 1
+    blobs = [outs[0], bytes(forged), outs[2]]
+    soff, st = [], 0
+    for b in blobs:
+        soff.append(st); st += (len(b) + 15) // 16 * 16 + 16
+    src = np.zeros(st, np.uint8)
+    for b, o_ in zip(blobs, soff):
+        src[o_:o_ + len(b)] = np.frombuffer(b, np.uint8)
+    doff = [0, 4096, 4096 + (2 << 20) + 4096]
+    total = doff[2] + 70016
+    d = pc.make_descs([len(b) for b in blobs], soff, doff, [3008, (2 << 20) + 16, 70016])
+    dsrc = torch.from_numpy(src).cuda(); ddst = torch.full((total,), 0xAB, dtype=torch.uint8, device="cuda")
+    gpu.detransform_batch(nat.Native.make_params(nat.ENCRYPT, synth.KEY, synth.AAD), d, dsrc.data_ptr(), ddst.data_ptr(), total, nat.MEM_DEVICE)
+    back = ddst.cpu().numpy()
+    assert list(d["status"]) == [0, nat.E_TAG_MISMATCH, 0] and d["dst_len"][1] == 0
+    assert back[0:3000].tobytes() == chunks[0].tobytes() and back[doff[2]:doff[2] + 70001].tobytes() == chunks[2].tobytes()
+    assert not back[4096:4096 + (2 << 20)].any(), "unauthenticated plaintext left in the caller's device slot"
+
+
+@pytest.mark.parametrize("flags", [nat.ENCRYPT | nat.CRC, nat.COMPRESS | nat.ENCRYPT | nat.CRC])
+def test_staged_host_pipeline_on_the_device(gpu, oracle, flags, monkeypatch):
+    """Host-memory batches in pieces (three streams) = one shot = the oracle; pageable and registered buffers; packed output."""
+    chunks = [synth.gen_chunk("K", 11, 0, i, s) for i, s in enumerate([CHUNK, 1 << 20, 70001, 0, 17, CHUNK - 5, 300000, 1 << 16, 4096, 2 << 20, 12345, 1 << 20])]
+    monkeypatch.setenv("TSX_NO_PIPELINE", "1")
+    ref, dref = pc.run_transform(gpu, flags, chunks)
+    monkeypatch.delenv("TSX_NO_PIPELINE")
+    monkeypatch.setenv("TSX_SUB_BYTES", str(3 << 20))
+    got, dgot = pc.check_transform_vs_oracle(gpu, oracle, flags, chunks)
+    gotp, dpk = pc.run_transform(gpu, flags, chunks, mem="packed")
+    assert got == ref == gotp and (dgot["crc32c"] == dref["crc32c"]).all() and (dpk["dst_len"] == dref["dst_len"]).all()
+    back, d2 = pc.run_detransform(gpu, flags, got, [int(c.size) for c in chunks])
+    assert (d2["status"] == 0).all() and back == [c.tobytes() for c in chunks]
+    # the same through registered (pinned) buffers
+    sizes = [int(c.size) for c in chunks]
+    soff, doff, caps, st, dt = pc.layout(sizes, flags, gpu)
+    src = np.zeros(st, np.uint8); dst = np.zeros(dt, np.uint8)
+    for c, o_ in zip(chunks, soff):
+        src[o_:o_ + c.size] = c
+    gpu.host_register(src); gpu.host_register(dst)
+    try:
+        d = pc.make_descs(sizes, soff, doff, caps)
+        gpu.transform_batch(nat.Native.make_params(flags, synth.KEY, synth.AAD), d, src, dst, dst.size)
+        assert [dst[doff[i]:doff[i] + d["dst_len"][i]].tobytes() for i in range(len(sizes))] == ref
+    finally:
+        gpu.host_unregister(src); gpu.host_unregister(dst)
