@@ -351,3 +351,37 @@ def test_staged_host_pipeline_on_the_device(gpu, oracle, flags, monkeypatch):
         assert [dst[doff[i]:doff[i] + d["dst_len"][i]].tobytes() for i in range(len(sizes))] == ref
     finally:
         gpu.host_unregister(src); gpu.host_unregister(dst)
+
+
+def test_every_chunk_of_a_segment_equals_libzstd_and_openssl(gpu, oracle):
+    """at full size the oracle saw a handful of chunks.  Here every one of the 256 chunks of a 1 GiB Kafka-like
+    segment (+ 16 incompressible ones) through Zstd -> GCM -> CRC on the device is compared byte for byte with libzstd 1.5.7 + OpenSSL,
+    for BOTH Zstd profiles (the content never makes 1.5.7's pre-splitter cut, so profile 1.5.6 must give the same bytes)."""
+    import torch
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    n = 272
+    seg = torch.empty(n * CHUNK, dtype=torch.uint8, device="cuda")
+    for c in range(n):
+        seg[c * CHUNK:(c + 1) * CHUNK] = synth.gen_chunk("K" if c < 256 else "R", 1234, 3, c, CHUNK, device="cuda")
+    host = seg.cpu().numpy()
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    slot = (gpu.transformed_bound(CHUNK, flags) + 63) // 64 * 64
+    out = torch.empty(n * slot, dtype=torch.uint8, device="cuda")
+    of = oracle.COMPRESS | oracle.ENCRYPT | oracle.CRC | oracle.OPENSSL
+    expected = None
+    for profile in (nat.ZSTD_PROFILE_1_5_7, nat.ZSTD_PROFILE_1_5_6):
+        d = np.zeros(n, nat.DESC_DTYPE)
+        d["src_off"] = np.arange(n, dtype=np.uint64) * CHUNK; d["src_len"] = CHUNK
+        d["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d["dst_cap"] = slot
+        for c in range(n):
+            d["iv"][c] = np.frombuffer(synth.iv_for(3, c), np.uint8)
+        gpu.transform_batch(nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=profile), d, seg.data_ptr(), out.data_ptr(), out.numel(), nat.MEM_DEVICE)
+        assert (d["status"] == 0).all()
+        got = out.cpu().numpy()
+        if expected is None:
+            expected = [oracle.transform_chunk(of, synth.KEY, synth.AAD, synth.iv_for(3, c), host[c * CHUNK:(c + 1) * CHUNK].tobytes()) for c in range(n)]
+        for c in range(n):
+            exp, crc = expected[c]
+            assert d["crc32c"][c] == crc, c
+            assert got[c * slot:c * slot + int(d["dst_len"][c])].tobytes() == exp, "chunk %d, profile %d" % (c, profile)
