@@ -45,7 +45,10 @@ extern "C" {
  * ctx (not when compressing: that kernel wants the whole batch in flight and dwarfs the copies).  Any host memory works - pageable
  * buffers are staged by the HIP runtime; buffers pinned once with tsx_host_register() are copied by DMA without a staging pass. */
 #define TSX_MEM_HOST   0
-#define TSX_MEM_DEVICE 1 /* device pointers (same HIP runtime/process): no copies                    */
+/* device pointers (same HIP runtime / process): no copies.  The kernels run on the ctx's own streams: work the caller still has
+ * queued on other streams for these buffers (the kernel that fills src, a memset of dst) must be complete when the call is made,
+ * and the call returns when the library's work is complete. */
+#define TSX_MEM_DEVICE 1
 /* host pointers, transformed chunks written BACK TO BACK into dst in batch order - the bytes of the `.log` object (or of a
  * multipart part buffer) exactly as TransformFinisher.java:134-151 (SequenceInputStream over the chunks) hands them to
  * ObjectUploader.upload / S3MultiPartOutputStream.java:89-122, without the bound-sized slot per chunk and the gather copy

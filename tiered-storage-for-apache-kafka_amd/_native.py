@@ -178,6 +178,17 @@ class Native:
         p.zstd_profile = zstd_profile
         return p
 
+    @staticmethod
+    def _device_ready(mem_kind):
+        """TSX_MEM_DEVICE hands the library raw device pointers; its kernels run on the context's OWN streams and know nothing about
+        the stream that produced those buffers.  A Python caller's buffers are usually torch tensors: whatever torch still has queued
+        on its current stream (the kernel filling `src`, the memset of `dst`) must be complete first - include/tsxform.h says so."""
+        if mem_kind == MEM_DEVICE:
+            import sys
+            torch = sys.modules.get("torch")
+            if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.current_stream().synchronize()
+
     def _ptr(self, x):
         if x is None:
             return None
@@ -187,16 +198,19 @@ class Native:
 
     def transform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None):
         assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
+        self._device_ready(mem_kind)
         return self.check(self.lib.tsx_transform_batch(ctx, C.byref(params), descs.ctypes.data, len(descs), self._ptr(src),
                                                        self._ptr(dst), dst_size, mem_kind))
 
     def detransform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None):
         assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
+        self._device_ready(mem_kind)
         return self.check(self.lib.tsx_detransform_batch(ctx, C.byref(params), descs.ctypes.data, len(descs), self._ptr(src),
                                                          self._ptr(dst), dst_size, mem_kind))
 
     def crc32c_batch(self, descs, src, mem_kind=MEM_HOST, ctx=None):
         assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
+        self._device_ready(mem_kind)
         return self.check(self.lib.tsx_crc32c_batch(ctx, descs.ctypes.data, len(descs), self._ptr(src), mem_kind))
 
 

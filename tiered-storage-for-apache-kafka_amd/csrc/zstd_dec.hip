@@ -63,8 +63,10 @@ typedef uint32_t SeqD;
 #define SEQD_COUNTS(e_) (((e_) >> 9) & 0xFFFu)                        /* nbBits | (nbBits + extra bits) << 5 */
 #ifdef HIPEMU
 #define TSX_SCHED_BARRIER() do {} while (0)
+#define TSX_SETPRIO(p_) do {} while (0)
 #else
 #define TSX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define TSX_SETPRIO(p_) __builtin_amdgcn_s_setprio(p_)          /* issue priority of this wave among the SIMD's waves, 0..3 */
 #endif
 // row_shl:n - lane i reads lane i + n of its row of 16, 0 past the row's end
 #define DPP_SHL(v_, n_) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v_), 0x100 + (n_), 0xF, 0xF, true))
@@ -155,7 +157,11 @@ __device__ static uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint
     if (n < 1) return 0;
     // bounded forward bit reader over at most n bytes
     uint64_t bitpos = 0;
-    #define NC_PEEK(k) ({ uint32_t v_ = 0; for (int i_ = 0; i_ < 4; i_++) { uint64_t b_ = (bitpos >> 3) + i_; v_ |= (uint32_t)(b_ < n ? src[b_] : 0) << (8 * i_); } (v_ >> (bitpos & 7)) & ((1u << (k)) - 1); })
+    // 4 bytes at the bit cursor: one unaligned load while they are all inside the description, byte by byte (zeros past its end) otherwise
+    #define NC_PEEK(k) ({ uint32_t v_ = 0; const uint64_t b0_ = bitpos >> 3; \
+                          if (b0_ + 4 <= n) __builtin_memcpy(&v_, src + b0_, 4); \
+                          else for (int i_ = 0; i_ < 4; i_++) { const uint64_t b_ = b0_ + i_; v_ |= (uint32_t)(b_ < n ? src[b_] : 0) << (8 * i_); } \
+                          (v_ >> (bitpos & 7)) & ((1u << (k)) - 1); })
     const uint32_t tableLog = NC_PEEK(4) + 5; bitpos += 4;
     if (tableLog > maxLogAllowed) return 0;
     int remaining = (1 << tableLog) + 1, threshold = 1 << tableLog, nbBits = (int)tableLog + 1;
@@ -239,7 +245,7 @@ __device__ static bool fse_buildSeqTable_wave(SeqD* dt, DecLds& L, uint32_t maxS
     const bool lowp = nv == -1;
     uint32_t incl = c;
     for (uint32_t o = 1; o < LANES; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    const uint32_t total = __shfl(incl, LANES - 1);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(incl, LANES - 1);
     const unsigned long long lowMask = __ballot(lowp);
     const uint32_t nLow = (uint32_t)__popcll(lowMask);
     if (total + nLow != size) return false;
@@ -271,9 +277,9 @@ __device__ static bool fse_buildSeqTable_wave(SeqD* dt, DecLds& L, uint32_t maxS
         uint32_t ns = 1;
         unsigned long long rem = __ballot(active);
         while (rem) {
-            const uint32_t cur = __shfl(sym, __ffsll((long long)rem) - 1);
+            const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane(sym, __ffsll((long long)rem) - 1);     // v_readlane: no LDS round trip
             const unsigned long long m = __ballot(active && sym == cur);
-            const uint32_t first = __shfl(next, (int)cur);
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(next, (int)cur);
             if (active && sym == cur) ns = first + (uint32_t)__popcll(m & ((1ull << lane) - 1));
             if (lane == cur) next += (uint32_t)__popcll(m);
             rem &= ~m;
@@ -409,8 +415,10 @@ __device__ static __forceinline__ void exec_copies(uint8_t* dst, const uint8_t* 
     while (bigm) {
         const int i = __ffsll((long long)bigm) - 1;
         bigm &= bigm - 1;
-        const uint64_t d = __shfl(d64, i), s_ = __shfl(s64, i);
-        copy_wave((uint8_t*)d, (const uint8_t*)s_, (uint32_t)__shfl(n, i), lane);
+        // readlane returns int: every half goes through uint32_t before it is widened (an OR-ed int sign-extends)
+        const uint64_t d = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(d64 >> 32), i) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)d64, i);
+        const uint64_t s_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(s64 >> 32), i) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)s64, i);
+        copy_wave((uint8_t*)d, (const uint8_t*)s_, (uint32_t)__builtin_amdgcn_readlane(n, i), lane);
     }
 }
 
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                                     const uint32_t myTop = hdone ? 0 : (Bh >> 3) + 8;                                // bytes past the stream's end are zeros
                                     const uint32_t myWb = myTop > ZS_HWIN ? (myTop - ZS_HWIN + 15) & ~15u : 0;     // top - wb <= ZS_HWIN = one 16-byte piece per lane
                                     for (uint32_t s_ = 0; s_ < streams; s_++) {
-                                        const uint32_t top = __shfl(myTop, s_), wb = __shfl(myWb, s_), beg = __shfl(sbeg, s_), n_ = __shfl(sn, s_);
+                                        const uint32_t top = (uint32_t)__builtin_amdgcn_readlane(myTop, (int)s_), wb = (uint32_t)__builtin_amdgcn_readlane(myWb, (int)s_), beg = (uint32_t)__builtin_amdgcn_readlane(sbeg, (int)s_), n_ = (uint32_t)__builtin_amdgcn_readlane(sn, (int)s_);
                                         const uint32_t k = lane * 16;
                                         if (wb + k < top) {
                                             uint4 v;
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                                 const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
                                 if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
                             }
-                            const uint32_t groupLit = __shfl(litIncl, LANES - 1), groupTot = __shfl(totIncl, LANES - 1);
+                            const uint32_t groupLit = (uint32_t)__builtin_amdgcn_readlane(litIncl, LANES - 1), groupTot = (uint32_t)__builtin_amdgcn_readlane(totIncl, LANES - 1);
                             if (lp + groupLit > litSize || (uint64_t)opos + groupTot > contentSize) RFAIL(DERR_FRAME);
                             const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
                             if (__any(valid && ml && (off == 0 || off > mOut))) RFAIL(DERR_FRAME);
@@ -805,6 +813,7 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                             if (lastByte == 0) RFAIL(DERR_FRAME);
                             B = 8 * (n - 1) + dhb32(lastByte);
                         }
+                        TSX_SETPRIO(3);                                         // the sequence stage is the chunk's critical path: its chain goes first
                         for (uint32_t g = 0; g < nbSeq; g += LANES) {
                             const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
                             // 64 sequences read at most 64 * 89 bits = 712 bytes below the cursor; every read is an 8-byte load at
@@ -934,6 +943,7 @@ __global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6)
                             if (valid) { sLL[g + lane] = ll; sML[g + lane] = ml; sOF[g + lane] = off; }
                             DLT(2);                                                 // 2: FSE sequence decode
                         }
+                        TSX_SETPRIO(0);
                         if (nbSeq && B != 0) RFAIL(DERR_FRAME);                     // BIT_endOfDStream: every bit of the stream was used
                     }
                     if (lane == 0) L.nseq[(it - 1) & 1] = nbSeq;

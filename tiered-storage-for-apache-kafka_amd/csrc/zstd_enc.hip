@@ -29,6 +29,9 @@
 //    batch; separate CRC / GCM launches starve for LDS on a chip full of compressor waves.
 // This is byte-stream work: no MFMA.  Algorithmic traffic per chunk: N bytes read + transformed bytes written.
 #include "zstd_common.h"
+#ifdef ZS_DBG
+#include <stdio.h>
+#endif
 #include "gcm_dev.h"
 #include "crc_dev.h"
 
@@ -51,7 +54,9 @@ struct __attribute__((packed)) zs_u32u { uint32_t v; };
 __device__ static inline uint64_t gld64(gbytes_t p) { return reinterpret_cast<const ZS_GLOBAL zs_u64u*>(p)->v; }
 __device__ static inline uint32_t gld32(gbytes_t p) { return reinterpret_cast<const ZS_GLOBAL zs_u32u*>(p)->v; }
 __device__ static inline uint4 ld128a(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }     // 16-byte aligned
-#ifndef HIPEMU
+#ifdef HIPEMU
+struct alignas(16) zs_u32x4 { uint32_t x, y, z, w; };
+#else
 typedef uint32_t zs_u32x4 __attribute__((ext_vector_type(4)));
 __device__ static inline uint4 ld128a(gbytes_t p) { const zs_u32x4 t = *reinterpret_cast<const ZS_GLOBAL zs_u32x4*>(p); return make_uint4(t.x, t.y, t.z, t.w); }
 #endif
@@ -653,6 +658,24 @@ __device__ __forceinline__ static unsigned long long eq_mask(const gbytes_t src,
 }
 __device__ static inline uint32_t cto64(unsigned long long m) { return m == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m) - 1; }
 
+#if ZS_LONG32
+// The 28 bytes [p - 4, p + 24) of the chunk around a position, as the seven words a long-table entry carries behind its index word.
+struct Ctx28 { uint32_t w[7]; };
+// number of leading equal bytes of two little-endian 8-byte groups XOR-ed into x (8 = all equal)
+__device__ static inline uint32_t eq8(uint64_t x) { return x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8u; }
+// forward: equal bytes of [p, p + 24) (0..24); backward: equal bytes walking down from p - 1 (0..4)
+__device__ static inline uint32_t ctx_fwd(const Ctx28& a, const Ctx28& b) {
+    const uint64_t x0 = ((uint64_t)(a.w[2] ^ b.w[2]) << 32) | (a.w[1] ^ b.w[1]), x1 = ((uint64_t)(a.w[4] ^ b.w[4]) << 32) | (a.w[3] ^ b.w[3]),
+                   x2 = ((uint64_t)(a.w[6] ^ b.w[6]) << 32) | (a.w[5] ^ b.w[5]);
+    const uint32_t n0 = eq8(x0), n1 = eq8(x1), n2 = eq8(x2);
+    return n0 < 8 ? n0 : n1 < 8 ? 8 + n1 : 16 + n2;
+}
+__device__ static inline uint32_t ctx_back(const Ctx28& a, const Ctx28& b) {
+    const uint32_t x = a.w[0] ^ b.w[0];
+    return x ? (uint32_t)__clz((int)x) >> 3 : 4u;
+}
+#endif
+
 __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src, const uint32_t srcSize_, const uint32_t blockStart,
                                                     const uint32_t blockSize_, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
                                                     const zs_cparams cp, const uint32_t dictLimitIn, uint32_t* rep, zs_seq* __restrict__ seqs,
@@ -677,6 +700,14 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
     }
     Win w; w.lo = w.hi = 0;
     (void)fwbuf;
+#if ZS_LONG32
+    // long-table entry e: words [8e .. 8e + 8) = index word | the inserting position's 28 context bytes
+#define GL_INSERT(h_, e_, c_) do { const gwords_t q_ = gL + (size_t)(h_) * 8; \
+        *reinterpret_cast<ZS_GLOBAL zs_u32x4*>(q_) = zs_u32x4{(e_), (c_).w[0], (c_).w[1], (c_).w[2]}; \
+        *reinterpret_cast<ZS_GLOBAL zs_u32x4*>(q_ + 4) = zs_u32x4{(c_).w[3], (c_).w[4], (c_).w[5], (c_).w[6]}; } while (0)
+#else
+#define GL_INSERT(h_, e_, c_) do { gL[h_] = (e_); } while (0)
+#endif
 #define STORE_SEQ(ll_, lp_, ob_, ml_) do { if (lane == 0) zs_put_seq(&gseqs[nbSeq], (ob_), (ll_), (ml_) - 3, (lp_)); \
                                            litSize += (ll_); nbSeq++; } while (0)
     if (blockSize >= 8) {
@@ -712,9 +743,38 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             const bool lane3 = lane == 3;                             // ip itself: searched (K > 0) or only checked for the immediate repcode
             const bool mayUse = compL || compS || (lane >= 3 && lane <= 3 + K);
             const uint32_t spos = mayUse ? pos : ip;                  // an address every lane may read
+#if ZS_LONG32
+            const bool posWin = ip + K * step + 24 <= w.hi && ip >= w.lo + 6 && (!comp || X >= w.lo + 4);
+#else
             const bool posWin = ip + K * step + 8 <= w.hi && (!comp || (X >= w.lo && ip >= w.lo + 2));
+#endif
             uint64_t d8;
             if (posWin) d8 = ring8(ring, spos); else { d8 = gld64(gsrc + spos); LOADED64(d8); }
+#if ZS_LONG32
+            Ctx28 own;                                                // this lane's position: what its insertion stores, what its candidates are compared with
+            if (posWin) {
+                const uint64_t u1 = ring8(ring, spos + 8), u2 = ring8(ring, spos + 16);
+                own.w[0] = ring4(ring, spos - 4);
+                own.w[3] = (uint32_t)u1; own.w[4] = (uint32_t)(u1 >> 32); own.w[5] = (uint32_t)u2; own.w[6] = (uint32_t)(u2 >> 32);
+            } else {                                                  // rare: read around spos from the chunk itself, never beyond its ends
+                uint64_t u1 = 0, u2 = 0;
+                if (spos >= 4) own.w[0] = gld32(gsrc + spos - 4);
+                else {                                                // the chunk's first bytes: what exists of [p - 4, p) goes to the top, byte p - 1 first
+                    uint32_t v = 0;
+                    for (uint32_t b = 0; b < spos; b++) v |= (uint32_t)gsrc[b] << (8 * (4 - spos + b));
+                    own.w[0] = v;
+                }
+                if (spos + 16 <= srcSize) u1 = gld64(gsrc + spos + 8);
+                else for (uint32_t b = 0; spos + 8 + b < srcSize; b++) u1 |= (uint64_t)gsrc[spos + 8 + b] << (8 * b);      // the chunk's last bytes, one by one
+                if (spos + 24 <= srcSize) u2 = gld64(gsrc + spos + 16);
+                else for (uint32_t b = 0; b < 8 && spos + 16 + b < srcSize; b++) u2 |= (uint64_t)gsrc[spos + 16 + b] << (8 * b);
+                LOADED64(u1); LOADED64(u2);
+                own.w[3] = (uint32_t)u1; own.w[4] = (uint32_t)(u1 >> 32); own.w[5] = (uint32_t)u2; own.w[6] = (uint32_t)(u2 >> 32);
+            }
+            own.w[1] = (uint32_t)d8; own.w[2] = (uint32_t)(d8 >> 32);
+#else
+            const int own = 0; (void)own;
+#endif
             const uint32_t hl = hash8(d8, hBitsL), hs = hashS(d8, hBitsS, mls);
             const uint32_t tL = tag8(d8, hBitsL, tagBits), tS = tag4((uint32_t)d8, tagBits);
             const uint32_t eL = ((tL << 1) << (idxBits - 1)) | (pos + 2), eS = ((tS << 1) << (idxBits - 1)) | (pos + 2);
@@ -753,8 +813,8 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                     const uint32_t t = (uint32_t)__ffsll((long long)fb) - 1;
                     if (t == 3) {
                         // ip itself shares a slot with a complementary insertion: make those first, then search
-                        if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
-                        if (lane == 1) gL[hl] = eL;
+                        if (lane == 0) { if (!shadowL0) GL_INSERT(hl, eL, own); if (!shadowS0) gS[hs] = eS; }
+                        if (lane == 1) GL_INSERT(hl, eL, own);
                         if (lane == 2) gS[hs] = eS;
                         comp = false;
                         PCNT(19, 1);
@@ -771,10 +831,21 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             const bool probeL = K > 0 && lane >= 3 && lane <= look, probeS = searching;
             const uint32_t hl3 = __builtin_amdgcn_readlane(hl, 3), hs3 = __builtin_amdgcn_readlane(hs, 3);
             uint32_t cL = 0, cS = 0;
+#if ZS_LONG32
+            Ctx28 cand;                                               // the long candidate's bytes, straight from its table entry
+            for (int k = 0; k < 7; k++) cand.w[k] = 0;
+            if (K > 0) {
+                const gwords_t q = gL + (size_t)(probeL ? hl : hl3) * 8;
+                const zs_u32x4 qa = *reinterpret_cast<const ZS_GLOBAL zs_u32x4*>(q), qb = *reinterpret_cast<const ZS_GLOBAL zs_u32x4*>(q + 4);
+                cL = qa.x; cand.w[0] = qa.y; cand.w[1] = qa.z; cand.w[2] = qa.w; cand.w[3] = qb.x; cand.w[4] = qb.y; cand.w[5] = qb.z; cand.w[6] = qb.w;
+                cS = gS[probeS ? hs : hs3];
+            }
+#else
             if (K > 0) {
                 cL = gL[probeL ? hl : hl3];
                 cS = gS[probeS ? hs : hs3];
             }
+#endif
             const bool r2Near = afterMatch && posWin && ip >= w.lo + off2;
             const bool needFar = (K > 0 && off1 > 0 && !r1Near) || (afterMatch && !r2Near);
             uint32_t rfar = 0;
@@ -797,13 +868,13 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                     const uint32_t rlen = 4 + n;
                     const uint32_t t = off2; off2 = off1; off1 = t;
                     if (comp) {
-                        if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
-                        if (lane == 1) gL[hl] = eL;
+                        if (lane == 0) { if (!shadowL0) GL_INSERT(hl, eL, own); if (!shadowS0) gS[hs] = eS; }
+                        if (lane == 1) GL_INSERT(hl, eL, own);
                         if (lane == 2) gS[hs] = eS;
                         comp = false;
                     }
                     WAVE_MEM_SYNC();                                  // (emulator) the insertion at ip comes after the complementary ones
-                    if (lane3) { gS[hs] = eS; gL[hl] = eL; }
+                    if (lane3) { gS[hs] = eS; GL_INSERT(hl, eL, own); }
                     STORE_SEQ(0, ip, 1, rlen);
                     ip += rlen; anchor = ip;
                     PCNT(13, 1);
@@ -816,11 +887,22 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             if (flagLook) {
                 const uint32_t hk = __builtin_amdgcn_readlane(hl, look);
                 const unsigned long long em = __ballot((compL || searching) && hl == hk && !(lane == 0 && shadowL0));
-                if (em) { const uint32_t e = 63u - (uint32_t)__clzll((long long)em); const uint32_t ee = __builtin_amdgcn_readlane(eL, e); if (lane == look) cL = ee; }
+                if (em) {
+                    const uint32_t e = 63u - (uint32_t)__clzll((long long)em); const uint32_t ee = __builtin_amdgcn_readlane(eL, e);
+                    if (lane == look) cL = ee;
+#if ZS_LONG32
+                    for (int k = 0; k < 7; k++) { const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane(own.w[k], e); if (lane == look) cand.w[k] = cw; }
+#endif
+                }
             }
             // ---- events ----
             const uint32_t iL = cL & idxMask, iS = cS & idxMask;
+#if ZS_LONG32
+            const uint32_t fwdL = ctx_fwd(own, cand), backL = ctx_back(own, cand);
+            bool vL = probeL && iL >= plowIdx && fwdL >= 8;                          // in the window and the 8 bytes ARE equal (no tag needed)
+#else
             bool vL = probeL && iL >= plowIdx && ((cL ^ eL) & ~idxMask) == 0;        // in the window and same tag
+#endif
             bool vS = probeS && iS >= plowIdx && ((cS ^ eS) & ~idxMask) == 0;
             const bool repOK = searching && off1 > 0 && r1 == (uint32_t)(d8 >> 8);
             int f = -1;
@@ -845,6 +927,22 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                 if (evf == 2) {                                       // long match at posf
                     uint32_t mpos = __builtin_amdgcn_readlane(iL, f) - 2;
                     uint32_t lim = posf - anchor; if (mpos - lowPos < lim) lim = mpos - lowPos;
+#if ZS_LONG32
+                    {   // verified already; both extensions from the entry's bytes, the chunk is only read when they run out
+                        uint32_t fwd = (uint32_t)__builtin_amdgcn_readlane(fwdL, f), back = (uint32_t)__builtin_amdgcn_readlane(backL, f);
+                        if (fwd == 24 && posf + 24 < iend) fwd += UNI(count_more(src, ring, w, posf + 24, mpos + 24, iend, lane));
+                        if (posf + fwd > iend) fwd = iend - posf;
+#ifdef ZS_DBG
+                        { const uint32_t o0_ = (uint32_t)__builtin_amdgcn_readlane(own.w[0], f), c0_ = (uint32_t)__builtin_amdgcn_readlane(cand.w[0], f);
+                          if (lane == 0) fprintf(stderr, "L ev posf %u mpos %u fwd %u back %u lim %u anchor %u ownw0 %08x candw0 %08x posWin %d\n", posf, mpos, fwd, back, lim, anchor, o0_, c0_, (int)posWin); }
+#endif
+                        if (back > lim) back = lim;
+                        if (back == 4 && lim > 4) back += UNI(count_more_back(src, ring, w, posf - 4, mpos - 4, anchor, lowPos, lane));
+                        start = posf - back; mpos -= back; mlen = fwd + back;
+                        offBase = start - mpos + 3;
+                        break;
+                    }
+#endif
                     const bool valid = lane < 8 ? (8 - lane) <= lim : posf + (lane - 8) < iend;
                     const unsigned long long m = eq_mask(gsrc, ring, w, posf, mpos, 8, valid, lane);
                     if (((m >> 8) & 0xFF) != 0xFF) { if (lane == (uint32_t)f) vL = false; PCNT(21, 1); continue; }     // a tag's false positive
@@ -865,9 +963,35 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                     uint32_t fwd = cto64(m >> 8);
                     if (fwd == 56) fwd += UNI(count_more(src, ring, w, posf + 56, mpos + 56, iend, lane));
                     uint32_t sp = posf;
+#if ZS_LONG32
+                    bool tookLong1 = false;
+                    uint32_t back1 = 0;
                     if (__builtin_amdgcn_readlane((uint32_t)vL, f + 1)) {
                         const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(iL, f + 1) - 2;
                         uint32_t lim1 = p1 - anchor; if (m1 - lowPos < lim1) lim1 = m1 - lowPos;
+                        uint32_t f1 = (uint32_t)__builtin_amdgcn_readlane(fwdL, f + 1);
+                        if (f1 == 24 && p1 + 24 < iend) f1 += UNI(count_more(src, ring, w, p1 + 24, m1 + 24, iend, lane));
+                        if (p1 + f1 > iend) f1 = iend - p1;
+                        if (f1 > fwd) {
+                            sp = p1; mpos = m1; fwd = f1; lim = lim1; tookLong1 = true;
+                            back1 = (uint32_t)__builtin_amdgcn_readlane(backL, f + 1);
+                            if (back1 > lim1) back1 = lim1;
+                            if (back1 == 4 && lim1 > 4) back1 += UNI(count_more_back(src, ring, w, p1 - 4, m1 - 4, anchor, lowPos, lane));
+                        }
+                    }
+                    if (tookLong1) {
+                        start = sp - back1; mpos -= back1; mlen = fwd + back1;
+                        offBase = start - mpos + 3;
+                        break;
+                    }
+                    if (false) {
+                        const uint32_t p1 = posf + step, m1 = 0;
+                        uint32_t lim1 = 0;
+#else
+                    if (__builtin_amdgcn_readlane((uint32_t)vL, f + 1)) {
+                        const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(iL, f + 1) - 2;
+                        uint32_t lim1 = p1 - anchor; if (m1 - lowPos < lim1) lim1 = m1 - lowPos;
+#endif
                         const bool valid1 = lane < 8 ? (8 - lane) <= lim1 : p1 + (lane - 8) < iend;
                         const unsigned long long mm = eq_mask(gsrc, ring, w, p1, m1, 8, valid1, lane);
                         if (((mm >> 8) & 0xFF) == 0xFF) {
@@ -885,10 +1009,10 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             }
             // ---- commit: the visited positions insert themselves, then the pending complementary insertions ----
             const uint32_t lastIns = f >= 0 ? (uint32_t)f : 2 + K;
-            if (lane >= 3 && lane <= lastIns) { gL[hl] = eL; gS[hs] = eS; }
+            if (lane >= 3 && lane <= lastIns) { GL_INSERT(hl, eL, own); gS[hs] = eS; }
             if (comp) {
-                if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
-                if (lane == 1) gL[hl] = eL;
+                if (lane == 0) { if (!shadowL0) GL_INSERT(hl, eL, own); if (!shadowS0) gS[hs] = eS; }
+                if (lane == 1) GL_INSERT(hl, eL, own);
                 if (lane == 2) gS[hs] = eS;
                 comp = false;
             }
@@ -903,7 +1027,7 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             if (!isRep) {
                 off2 = off1; off1 = offBase - 3;
                 WAVE_MEM_SYNC();                                      // (emulator) ... after the insertions of the visited positions
-                if (step < 4 && lane == (uint32_t)f + 1) gL[hl] = eL;              // hashLong[hl1] = ip1
+                if (step < 4 && lane == (uint32_t)f + 1) GL_INSERT(hl, eL, own);              // hashLong[hl1] = ip1
             }
             STORE_SEQ(start - anchor, anchor, offBase, mlen);
             X = ip + ((uint32_t)f - 3) * step + 2;                    // curr + 2
@@ -921,6 +1045,7 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
     ms.nbSeq = nbSeq; ms.lastLL = iend - anchor; ms.anchor = anchor;
     ms.litSize = litSize + ms.lastLL;
 #undef STORE_SEQ
+#undef GL_INSERT
     PT(4);
 }
 
@@ -1813,7 +1938,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
     {   // fresh tables (ZSTD_reset_matchState): zero hashLong[1 << hashLog] and hashSmall[1 << chainLog]
         uint4 z; z.x = z.y = z.z = z.w = 0;
         uint4* a = (uint4*)hashLong; uint4* b = (uint4*)hashSmall;
-        for (uint32_t i = lane; i < (1u << cp.hashLog) / 4; i += LANES) a[i] = z;
+        for (uint32_t i = lane; i < ((1u << cp.hashLog) / 4) * ZS_LONG_ENTRY_WORDS; i += LANES) a[i] = z;
         for (uint32_t i = lane; i < (1u << cp.chainLog) / 4; i += LANES) b[i] = z;
     }
     // ---- frame header (ZSTD_writeFrameHeader: content size known, no checksum, no dictID) ----
@@ -1861,6 +1986,9 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
         if (blockSize >= 7) {
             uint32_t rep[3] = {repc[0], repc[1], repc[2]};
             MfState ms;
+#if ZS_LONG32 && ZS_PARSER != 2
+#error "ZS_LONG32 is implemented by the second form of the parser only"
+#endif
 #if ZS_PARSER == 2
             match_block2(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane);
 #else
