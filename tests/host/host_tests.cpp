@@ -227,6 +227,59 @@ struct MemFetcher : ObjectFetcher {
     }
 };
 
+struct StubChunkManager : ChunkManager {                  // every chunk is "0123456789" (FetchChunkEnumerationTest.java:58)
+    std::vector<int> asked;
+    Bytes getChunk(const std::string&, const SegmentManifest&, int chunkId) override {
+        asked.push_back(chunkId);
+        const char* c = "0123456789";
+        return Bytes(c, c + 10);
+    }
+};
+
+static void fetchEnumerationTests() {
+    // CT/fetch/FetchChunkEnumerationTest.java:46-160: 10 chunks of 10 bytes (fixed index 10 / 100 / 12 / 12)
+    SegmentManifest m; m.chunkIndex = std::make_shared<FixedSizeChunkIndex>(10, 100, 12, 12);
+    auto str = [](const Bytes& b) { return std::string(b.begin(), b.end()); };
+    run("FetchChunkEnumerationTest.failsWhenLargerStartPosition", [&] {
+        auto cm = std::make_shared<StubChunkManager>();
+        expectThrows<std::invalid_argument>([&] { FetchChunkEnumeration e(cm, "topic/segment", m, BytesRange{1000, 1001}); }, "Invalid start position 1000 in segment path topic/segment");
+    });
+    run("FetchChunkEnumerationTest.endPositionIsWithinIndex / endPositionIsOutsideIndex", [&] {
+        auto cm = std::make_shared<StubChunkManager>();
+        FetchChunkEnumeration a(cm, "topic/segment", m, BytesRange{0, 80});
+        CHECK(a.startChunkId() == 0 && a.lastChunkId() == 8);
+        FetchChunkEnumeration b(cm, "topic/segment", m, BytesRange{0, 110});
+        CHECK(b.startChunkId() == 0 && b.lastChunkId() == 9);
+        CHECK(cm->asked.empty());                                                        // construction fetches nothing
+    });
+    run("FetchChunkEnumerationTest.shouldReturnRangeFromSingleChunk", [&] {
+        auto cm = std::make_shared<StubChunkManager>();
+        FetchChunkEnumeration e(cm, "topic/segment", m, BytesRange{32, 34});
+        CHECK(e.startChunkId() == e.lastChunkId());
+        CHECK(str(e.nextElement()) == "234");
+        CHECK(!e.hasMoreElements());
+        expectThrows<std::out_of_range>([&] { e.nextElement(); }, nullptr);
+    });
+    run("FetchChunkEnumerationTest.shouldReturnRangeFromMultipleChunks + laziness (close early asks for nothing more)", [&] {
+        auto cm = std::make_shared<StubChunkManager>();
+        FetchChunkEnumeration e(cm, "topic/segment", m, BytesRange{15, 34});
+        CHECK(e.startChunkId() != e.lastChunkId());
+        CHECK(str(e.nextElement()) == "56789");
+        CHECK((cm->asked == std::vector<int>{1}));                                       // one chunk read, one chunk asked for
+        CHECK(str(e.nextElement()) == "0123456789");
+        CHECK(str(e.nextElement()) == "01234");
+        CHECK(!e.hasMoreElements());
+        expectThrows<std::out_of_range>([&] { e.nextElement(); }, nullptr);
+        auto cm2 = std::make_shared<StubChunkManager>();
+        FetchChunkEnumeration lazy(cm2, "topic/segment", m, BytesRange{5, 95});
+        CHECK(str(lazy.nextElement()) == "56789");
+        lazy.close();
+        CHECK(!lazy.hasMoreElements() && (cm2->asked == std::vector<int>{0}));
+        FetchChunkEnumeration all(std::make_shared<StubChunkManager>(), "topic/segment", m, BytesRange{7, 1000});
+        CHECK(all.readAll().size() == 93);
+    });
+}
+
 static void backendTests(bool full) {
     auto be = std::make_shared<Backend>(g_lib);
     printf("  backend: %s\n", be->version().c_str());
@@ -512,6 +565,22 @@ static void backendTests(bool full) {
             expectThrows<std::runtime_error>([&] { cache.getChunk("k.log", m, 5); }, "Tag mismatch");
             CHECK(cache.getChunk("k.log", m, 6) == plain(6));
         }
+        {   // fetchLogSegment's caller on top: an original-offset range through FetchChunkEnumeration -> GpuChunkCache -> GpuChunkManager
+            // gives exactly those bytes, and a reader that closes early has caused nothing beyond its chunk's window to be fetched
+            auto cache = std::make_shared<GpuChunkCache>(std::make_shared<GpuChunkManager>(be, fetcher), 2 * cs, (size_t)64 << 20, 10000, 0);
+            const int from = cs + 100, to = 5 * cs + 17;
+            FetchChunkEnumeration e(cache, "k.log", m, BytesRange{from, to});
+            CHECK(e.startChunkId() == 1 && e.lastChunkId() == 5);
+            CHECK(e.readAll() == Bytes(text.begin() + from, text.begin() + to + 1));
+            cache->quiesce();
+            CHECK(cache->stats().chunksFetched <= 8);                                    // chunks 1..5 + at most the 2-chunk window behind chunk 5
+            auto cache2 = std::make_shared<GpuChunkCache>(std::make_shared<GpuChunkManager>(be, fetcher), 2 * cs, (size_t)64 << 20, 10000, 0);
+            FetchChunkEnumeration early(cache2, "k.log", m, BytesRange{0, (int)text.size() - 1});
+            CHECK(early.nextElement() == plain(0));
+            early.close();
+            cache2->quiesce();
+            CHECK(!early.hasMoreElements() && cache2->stats().chunksFetched == 3);       // chunk 0 + its window (1, 2): nothing further
+        }
         {   // eviction by weight: a cache of two chunks keeps two
             GpuChunkCache cache(std::make_shared<GpuChunkManager>(be, fetcher), 0, (size_t)2 * cs, 10000, 0);
             for (int i = 0; i < 5; i++) CHECK(cache.getChunk("k.log", m, i) == plain(i));
@@ -524,7 +593,7 @@ static void backendTests(bool full) {
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     if (argc < 2) { printf("usage: host_tests cpu | backend <libtsxform path> [full]\n"); return 2; }
-    if (std::string(argv[1]) == "cpu") cpuTests();
+    if (std::string(argv[1]) == "cpu") { cpuTests(); fetchEnumerationTests(); }
     else { if (argc < 3) return 2; g_lib = argv[2]; try { backendTests(argc > 3 && std::string(argv[3]) == "full"); } catch (const std::exception& e) { printf("  FAIL backend: %s\n", e.what()); g_failed++; } }
     printf("%d run, %d failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;

@@ -27,7 +27,7 @@ def _run(args, env=None):
 
 def test_host_logic_matches_reference_tests(host_tests):
     out = _run([host_tests, "cpu"])
-    assert "FixedSizeChunkIndexBuilderTest.threeChunks" in out and "ChunkSizesBinaryCodecTest" in out
+    assert "FixedSizeChunkIndexBuilderTest.threeChunks" in out and "ChunkSizesBinaryCodecTest" in out and "FetchChunkEnumerationTest" in out
 
 
 def test_host_chain_over_emulated_kernels(host_tests, emu):

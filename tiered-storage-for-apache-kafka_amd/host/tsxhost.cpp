@@ -937,6 +937,43 @@ Bytes GpuChunkCache::getChunk(const std::string& objectKey, const SegmentManifes
 }
 
 // =====================================================================================================
+// FetchChunkEnumeration (fetch/FetchChunkEnumeration.java:53-138)
+// =====================================================================================================
+FetchChunkEnumeration::FetchChunkEnumeration(std::shared_ptr<ChunkManager> chunkManager, std::string objectKey, SegmentManifest manifest, BytesRange range)
+    : chunkManager_(std::move(chunkManager)), objectKey_(std::move(objectKey)), manifest_(std::move(manifest)), range_(range) {
+    if (!chunkManager_) throw std::invalid_argument("chunkManager cannot be null");
+    if (!manifest_.chunkIndex) throw std::invalid_argument("manifest cannot be null");
+    if (range_.to < range_.from) throw std::invalid_argument("range cannot be empty");
+    const auto first = manifest_.chunkIndex->findChunkForOriginalOffset(range_.from);
+    if (!first) throw std::invalid_argument("Invalid start position " + std::to_string(range_.from) + " in segment path " + objectKey_);
+    startChunkId_ = currentChunkId_ = first->id;
+    const auto last = manifest_.chunkIndex->findChunkForOriginalOffset(range_.to);
+    lastChunkId_ = last ? last->id : manifest_.chunkIndex->chunks().back().id;
+}
+
+Bytes FetchChunkEnumeration::nextElement() {
+    if (!hasMoreElements()) throw std::out_of_range("NoSuchElementException");
+    Bytes content = chunkManager_->getChunk(objectKey_, manifest_, currentChunkId_);
+    const Chunk& cur = manifest_.chunkIndex->chunks()[(size_t)currentChunkId_];
+    const bool first = currentChunkId_ == startChunkId_, last = currentChunkId_ == lastChunkId_;
+    size_t skip = first ? (size_t)(range_.from - cur.originalPosition) : 0;             // InputStream.skip
+    if (skip > content.size()) skip = content.size();
+    size_t end = content.size();
+    if (last) {                                                                          // BoundedInputStream
+        const size_t bound = first ? (size_t)range_.size() : (size_t)(range_.to - cur.originalPosition + 1);
+        end = std::min(end, skip + bound);
+    }
+    currentChunkId_++;
+    return Bytes(content.begin() + (long)skip, content.begin() + (long)end);
+}
+
+Bytes FetchChunkEnumeration::readAll() {
+    Bytes out;
+    while (hasMoreElements()) { const Bytes c = nextElement(); out.insert(out.end(), c.begin(), c.end()); }
+    return out;
+}
+
+// =====================================================================================================
 // upload sink
 // =====================================================================================================
 namespace {

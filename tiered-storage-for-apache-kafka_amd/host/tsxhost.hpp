@@ -423,6 +423,30 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
+// fetch/FetchChunkEnumeration.java:40-178: the caller of ChunkManager.getChunk on fetchLogSegment().  An original-offset range
+// [from, to] (inclusive; to beyond the end is clamped to the last chunk) becomes the chunks that cover it, the first one skipped to
+// `from`, the last one bounded at `to`.  Lazy: a chunk is asked of the ChunkManager only when nextElement() reaches it, and after
+// close() nothing more is asked for - with a GpuChunkCache underneath that means: nothing beyond the cache's configured window.
+class FetchChunkEnumeration {
+public:
+    FetchChunkEnumeration(std::shared_ptr<ChunkManager> chunkManager, std::string objectKey, SegmentManifest manifest, BytesRange range);
+    bool hasMoreElements() const { return !closed_ && currentChunkId_ <= lastChunkId_; }
+    Bytes nextElement();                      // the part of the next chunk that lies inside the range; std::out_of_range (NoSuchElementException) at the end
+    Bytes readAll();                          // toInputStream().readAllBytes()
+    void close() { closed_ = true; }
+    int startChunkId() const { return startChunkId_; }
+    int lastChunkId() const { return lastChunkId_; }
+    int currentChunkId() const { return currentChunkId_; }
+
+private:
+    std::shared_ptr<ChunkManager> chunkManager_;
+    std::string objectKey_;
+    SegmentManifest manifest_;
+    BytesRange range_;
+    int startChunkId_ = 0, lastChunkId_ = 0, currentChunkId_ = 0;
+    bool closed_ = false;
+};
+
 // ---- upload sink --------------------------------------------------------------------------
 // io.github.bucket4j.Bucket as RateLimitedInputStream.rateLimitBucket builds it (RateLimitedInputStream.java:46-55):
 // capacity = rate tokens, greedy refill of `rate` tokens per second, starts full.
