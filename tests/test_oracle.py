@@ -136,3 +136,19 @@ def test_threaded_chain_matches_single(oracle):
     for c in range(6):
         exp, crc = oracle.transform_chunk(flags & ~oracle.OPENSSL, synth.KEY, synth.AAD, synth.iv_for(0, c), src[c * 65536:(c + 1) * 65536].tobytes())
         assert dst[c * stride:c * stride + sizes[c]].tobytes() == exp and crcs[c] == crc
+
+
+def test_two_independent_builds_of_libzstd_1_5_7_agree(oracle):
+    """The parity library is the libzstd 1.5.7 bundled with Pillow (an unoptimised build: ~30 MiB/s at level 3).  pyarrow carries its
+    own, optimised, statically linked 1.5.7: its level-3 frames must be the same bytes - the checker is not an artefact of one build."""
+    pa = pytest.importorskip("pyarrow")
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    from tsxform import synth
+    rng = np.random.default_rng(5)
+    cases = [synth.gen_chunk("K", 5, 0, 0, 1 << 20), synth.gen_chunk("R", 5, 0, 1, 300000), synth.gen_chunk("K", 5, 0, 2, 70001),
+             np.concatenate([synth.gen_chunk("K", 6, 0, 0, 200000), synth.gen_chunk("R", 6, 0, 1, 150000), np.zeros(70000, np.uint8), synth.gen_chunk("K", 6, 0, 2, 300000)]),
+             rng.integers(0, 4, 500000, dtype=np.uint8), np.frombuffer(bytes.fromhex("000000030000000A01000A0000001E"), np.uint8)]
+    codec = pa.Codec("zstd", compression_level=3)
+    for c in cases:
+        assert codec.compress(c.tobytes(), asbytes=True) == oracle.zstd_compress_chunk(c.tobytes()), c.size
