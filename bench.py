@@ -344,7 +344,7 @@ def main():
                 rate = req * args.steps / elapsed / 1e9
                 binding = {"resource": "random 64-B line accesses L2<->HBM (table probes + insertions)", "requests_per_launch": int(req),
                            "achieved": round(rate, 2), "peak": 44.0, "unit": "G lines/s", "frac": round(rate / 44.0, 3),
-                           "peak_source": "profiles/r01_ubench_mix.txt (measured, same 58/42 read/write-back mix)"}
+                           "peak_source": "profiles/r02_ubench_mix_same_box_as_pmc.txt (waves that do nothing else, 58/42 read/write-back mix; 36-46 by box and run)"}
     except (OSError, ValueError, KeyError):
         pass
     roofline = {"bound": "hbm", "kernel": {"crc": "crc32c_partial_kernel", "gcm": "gcm_ctr_ghash_kernel", "zstd": "zstd_compress_kernel"}[dom],

@@ -48,6 +48,18 @@ def test_compressor_is_byte_identical_to_libzstd(emu, oracle):
         assert outs[i] == oracle.zstd_compress_chunk(CASES[n].tobytes()), "%s: frame differs from libzstd %s" % (n, oracle.zstd_version())
 
 
+@pytest.mark.parametrize("sched", ["1,1", "2,16", "7,59", "59,59"])
+def test_speculation_schedule_never_changes_the_bytes(emu, oracle, sched, monkeypatch):
+    """How many positions a step of the parser evaluates speculatively (default 4 after a match, then 32, then 59; TSX_ZSTD_SCHED=k0,k1
+    overrides it for measurements) decides what a search run costs, never what it finds: identical frames, identical to libzstd."""
+    _need157(oracle)
+    monkeypatch.setenv("TSX_ZSTD_SCHED", sched)
+    names = ["K70000", "K200000", "mixKR", "farmatch", "jumps", "period7", "lowent"]
+    outs, d = pc.run_transform(emu, nat.COMPRESS, [CASES[n] for n in names])
+    for i, n in enumerate(names):
+        assert outs[i] == oracle.zstd_compress_chunk(CASES[n].tobytes()), (n, sched)
+
+
 def test_reference_golden_frame(emu):
     # CT/manifest/index/ChunkIndexSerializationTest.java:39-61
     outs, _ = pc.run_transform(emu, nat.COMPRESS, [CASES["golden15"]])

@@ -502,8 +502,13 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e) {
             tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr};
             if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
             if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = r.d_dst; }
+            uint32_t sched = 0;                                              // the kernel's default speculation schedule
+            if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1": explicit schedule (measurements; same bytes)
+                unsigned a = 0, b = 0;
+                if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) sched = a | b << 8;
+            }
             t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
-                                                       r.params->zstd_profile, fuse);
+                                                       r.params->zstd_profile, sched, fuse);
         }
         HIPCHK(hipEventRecord(e[2], st));
         if (fused) {

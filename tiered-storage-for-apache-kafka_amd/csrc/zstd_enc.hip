@@ -618,7 +618,7 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
 //     the complementary insertions at ip - 2 / ip - 1, lanes 3.. the K search positions, lane 3 + K the look-ahead for the "long
 //     match at +1" rule, lane 63 fetches the bytes of the immediate-repcode check): the complementary insertions of the previous
 //     match share the hash computation, the collision check and the store instructions of the next step;
-//   * K starts at ZS_K0 (2) after a match and widens (ZS_K1, then doubling) only while nothing is found;
+//   * K starts at ZS_K0 (4) after a match and widens (ZS_K1 = 32, then 59) only while nothing is found;
 //   * two lanes of a step that touch the same bucket are not patched up but avoided: a byte scoreboard in LDS (converging to the
 //     lowest lane id per slot) finds the first lane with an earlier partner and the step is cut in front of it - before the table
 //     loads are issued, so a cut costs no memory traffic; only the look-ahead lane is resolved exactly (one ballot);
@@ -627,10 +627,10 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
 //     tag's false positive (1/512) is struck out and the next event of the same step taken.
 // ---------------------------------------------------------------------------------------------------
 #ifndef ZS_K0
-#define ZS_K0 2u              /* search positions of the first step after a match */
+#define ZS_K0 4u              /* search positions of the first step after a match */
 #endif
 #ifndef ZS_K1
-#define ZS_K1 16u             /* ... of the second step; doubling from there */
+#define ZS_K1 32u             /* ... of the second step; doubling from there */
 #endif
 #define ZS_KMAX 59u
 // the rare continuations (matches longer than the 64 bytes the first comparison covers) stay out of line
@@ -679,7 +679,13 @@ __device__ static inline uint32_t ctx_back(const Ctx28& a, const Ctx28& b) {
 __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src, const uint32_t srcSize_, const uint32_t blockStart,
                                                     const uint32_t blockSize_, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
                                                     const zs_cparams cp, const uint32_t dictLimitIn, uint32_t* rep, zs_seq* __restrict__ seqs,
-                                                    MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane) {
+                                                    MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane, const uint32_t sched) {
+    // Speculation schedule (never changes the output, only what a search run costs): positions of the first step after a match, of the
+    // second step; doubling from there.  sched = K0 | K1 << 8, 0 in a field = the compile-time default (4, 32).  Measured with 18-step
+    // runs, three batches in flight / one at a time (profiles/r02_sweep_k_schedule.txt): (2,16) 17.6-17.9 GiB/s / 762 ms, (3,24) 18.5-18.6 /
+    // 729-735, (4,32) 18.8 / 719, (4,48) 18.8 / 725, (6,32) 18.75 / 723: the dependent round trips a wider step saves are worth more than
+    // the table lines it wastes, on a full chip too.  (Sweeps of 6 steps had said the opposite - their start-up transient dominates.)
+    const uint32_t kFirst = (UNI(sched) & 0xFF) ? (UNI(sched) & 0xFF) : ZS_K0, kSecond = ((UNI(sched) >> 8) & 0xFF) ? ((UNI(sched) >> 8) & 0xFF) : ZS_K1;
     const gbytes_t gsrc = (gbytes_t)uni_ptr(src);
     const gwords_t gL = (gwords_t)uni_ptr(hashLong), gS = (gwords_t)uni_ptr(hashSmall);
     ZS_GLOBAL zs_seq* const gseqs = (ZS_GLOBAL zs_seq*)uni_ptr(seqs);
@@ -715,9 +721,9 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
         bool afterMatch = false;          // the immediate-repcode check (offset_2 at ip) of the match just stored is still due
         bool comp = false;                // ... and so are its complementary insertions (X = curr + 2, ip - 2, ip - 1)
         bool runStart = true;
-        uint32_t X = 0, step = 1, nextStep = 0, width = ZS_K0;
+        uint32_t X = 0, step = 1, nextStep = 0, width = kFirst;
         for (;;) {                                                    // one iteration per wave step
-            if (runStart) { step = 1; nextStep = ip + 256; width = ZS_K0; runStart = false; }
+            if (runStart) { step = 1; nextStep = ip + 256; width = kFirst; runStart = false; }
             uint32_t K = 0;
             const bool tail = ip + step > ilimit;
             if (tail) {
@@ -1021,7 +1027,7 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                 const bool inc = ip + K * step >= nextStep;
                 ip += K * step;
                 if (inc) { step++; nextStep += 256; }
-                width = width < ZS_K1 ? ZS_K1 : (width * 2 > ZS_KMAX ? ZS_KMAX : width * 2);
+                width = width < kSecond ? kSecond : (width * 2 > ZS_KMAX ? ZS_KMAX : width * 2);
                 continue;
             }
             if (!isRep) {
@@ -1905,7 +1911,7 @@ __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ des
 
 __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
                                                               uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
-                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile,
+                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
                                                               const tsx_chain_fuse fuse
 #ifdef TSX_PROF
                                                               , unsigned long long* __restrict__ prof_out
@@ -1990,7 +1996,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
 #error "ZS_LONG32 is implemented by the second form of the parser only"
 #endif
 #if ZS_PARSER == 2
-            match_block2(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane);
+            match_block2(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane, sched);
 #else
             match_block(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane);
 #endif
@@ -2064,10 +2070,10 @@ size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size
 
 uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* src, tsx_chunk_desc* d_descs, uint32_t n,
                                   uint32_t /*max_len*/, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status, void* d_work,
-                                  uint32_t profile, tsx_chain_fuse fuse) {
+                                  uint32_t profile, uint32_t sched, tsx_chain_fuse fuse) {
     if (!n) return 0;
     hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
-                       (uint8_t*)d_work, profile, fuse
+                       (uint8_t*)d_work, profile, sched, fuse
 #ifdef TSX_PROF
                        , g_prof_out
 #endif

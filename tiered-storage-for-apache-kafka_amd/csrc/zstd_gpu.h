@@ -14,7 +14,7 @@ size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t max_len);
 // TSX_E_DST_TOO_SMALL in d_status when the slot is too small).  Returns the number of kernel launches.
 uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* src, tsx_chunk_desc* d_descs,
                                   uint32_t n, uint32_t max_len, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status,
-                                  void* d_work, uint32_t profile, tsx_chain_fuse fuse);
+                                  void* d_work, uint32_t profile, uint32_t sched /* 0 lean, 1 wide speculation: zstd_enc.hip */, tsx_chain_fuse fuse);
 // Inverse (DecompressionChunkEnumeration.java:39-46): frame i at (from_mid ? frames + i*mid_stride :
 // frames + descs[i].src_off), length descs[i].src_len - (from_mid ? 28 : 0); output to dst + descs[i].dst_off,
 // descs[i].dst_len set; status TSX_E_BAD_SIZE / TSX_E_BAD_FRAME / TSX_E_DST_TOO_SMALL on failure.

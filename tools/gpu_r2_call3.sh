@@ -3,11 +3,11 @@
 # (current build) and - for the first time - of the frame decoder, the line-rate wall (tools/ubench/mix) on the same box.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2c3; mkdir -p $O
+O=$R/gpurun_out/r2final; rm -rf $O; mkdir -p $O
 cd $R
-timeout 500 python bench.py --steps 9 --warmup 1 2> $O/bench.err | tail -1 > $O/bench_full.json
+timeout 500 python bench.py --steps 18 --warmup 1 2> $O/bench.err | tail -1 > $O/bench_full.json
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python $R/bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-verify --no-end-to-end > $O/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python $R/bench.py --steps 12 --warmup 1 --no-cpu-baseline --no-verify --no-end-to-end > $O/stats.log 2>&1
 find $O/stats -name "*kernel_trace.csv" -delete; find $O/stats -name "*agent_info.csv" -delete; tail -c 3000 $O/stats.log > $O/stats.log.tail; rm -f $O/stats.log
 python $R/tools/prof_zstd.py --chunks 256 --lib libtsxform.so --data /tmp/k256.npy > /dev/null 2>&1
 CMD="python $R/tools/prof_zstd.py --chunks 2048 --dist K --chain --lib libtsxform.so --data /tmp/k256.npy"
