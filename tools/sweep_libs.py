@@ -15,10 +15,12 @@ ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--chunks", type=int, default=2048)
 ap.add_argument("--inflight", type=int, default=3)
 ap.add_argument("--dist", default="K")
+ap.add_argument("--prealloc-gib", type=int, default=0, help="allocate (and keep) this much device memory before anything else: placement experiment")
 ap.add_argument("libs", nargs="+")
 a = ap.parse_args()
 n, CH, T = a.chunks, synth.CHUNK, a.inflight
 dev = torch.device("cuda", 0)
+_dummy = torch.empty(a.prealloc_gib << 30, dtype=torch.uint8, device=dev) if a.prealloc_gib else None
 src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
 cache = "/tmp/%s256.npy" % a.dist.lower()
 if os.path.exists(cache):
