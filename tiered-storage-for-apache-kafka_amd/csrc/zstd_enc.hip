@@ -1,4 +1,4 @@
-// Zstandard level-3 frame compressor — gfx950, one 64-lane wavefront per chunk, up to 20 chunks resident per CU.
+// Zstandard level-3 frame compressor — gfx950, one 64-lane wavefront per chunk, up to 24 chunks resident per CU.
 //
 // Replaces zstd-jni's  new ZstdCompressCtx(); setPledgedSrcSize(n); setContentSize(true); compress(chunk)
 //   core/src/main/java/io/aiven/kafka/tieredstorage/transform/CompressionChunkEnumeration.java:50-63
@@ -19,7 +19,7 @@
 //    near ip (LDS ring of the chunk around ip), never reads a candidate that cannot match (tags in the table entries),
 //    fetches a far candidate together with the 48 bytes both extensions need, and keeps its state in SGPRs.
 //  * Chunks are independent (fresh context per chunk in the reference); the kernel is latency bound per chunk and
-//    HBM-random-access bound in aggregate, so it is shaped for residency: 96 VGPRs, 8 KiB LDS (parse-stage and
+//    HBM-random-access bound in aggregate, so it is shaped for residency: 80 VGPRs, 6.5 KiB LDS (parse-stage and
 //    entropy-stage LDS alias), and callers keep several batches in flight.
 //  * The entropy stage of each block: histograms, Huffman bit packing, literal gathering and the FSE sequence bit stream
 //    run on all lanes (the three FSE state machines on three lanes, then prefix-summed bit packing); only the table
@@ -78,7 +78,7 @@ template <class T> __device__ static inline T* uni_ptr(T* p) {
 #define ZS_FILL 2048u         /* refill granule */
 #define ZS_SAFE 384u          /* the parser may touch [ip, ip + ZS_SAFE) between two refill checks */
 #ifndef ZS_WAVES_PER_SIMD
-#define ZS_WAVES_PER_SIMD 5   /* occupancy target: 96 VGPRs, <= 8 KiB LDS -> 20 chunks per CU */
+#define ZS_WAVES_PER_SIMD 6   /* occupancy target: 80 VGPRs, <= 6826 B of LDS -> 24 chunks per CU */
 #endif
 #define ZS_SCR 1024u          /* slots of the intra-step hash-collision detector (per table) */
 // cold, register-hungry scalar stages are kept out of line so the speculative match loop keeps its occupancy
@@ -163,12 +163,16 @@ struct NodeElt { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; 
 // in LDS: LDS per wave is what bounds how many chunks a CU can hold, and occupancy is this kernel's only latency cover.
 struct HufScratch { NodeElt nodes[514]; uint16_t rankBase[192], rankCurr[192]; };
 struct EncLds {
-    HufTable huf[2];            // [cur] = table of the previous compressed-literals block, [cur ^ 1] = candidate
     int hufRepeat[2];           // 0 none, 1 check
     uint32_t scal[16];          // lane-0 -> wave broadcast slots
     union alignas(16) {
         struct {                // entropy stage of a block
-            FseTable ll, of;
+            // The two Huffman tables of the literal stage ([cur] = table of the previous compressed-literals block, [cur ^ 1] =
+            // candidate) are dead while the sequences are coded and the LL table is dead while the literals are: they share their
+            // bytes, and between two blocks the Huffman tables wait in the chunk's workspace (ZS_WS_HUFSAVE).  That is what brings
+            // the wave's LDS under 160 KiB / 24: six chunks per SIMD instead of five.
+            union { FseTable ll; HufTable huf[2]; };
+            FseTable of;        // (the literal stage borrows it to FSE-code the Huffman weights)
             union {
                 FseTable ml;            // sequence stage
                 uint32_t hist[256];     // literal stage (and the pre-splitter): byte histogram, dead before ml is built
@@ -1447,15 +1451,15 @@ __device__ ZS_NOINLINE static uint32_t huf_writeCTable(uint8_t* dst, const HufTa
                 const uint32_t tableLog = fse_optimalTableLog(6, wtSize, maxSV, 2);
                 if (fse_normalizeCount(L.norm, tableLog, cnt, wtSize, maxSV, false) < 0) return 0xFFFFFFFFu;
                 op += fse_writeNCount(op, L.norm, maxSV, tableLog);
-                fse_buildCTable(L.ll, L.norm, maxSV, tableLog, L.cumul, L.tableSymbol);     // L.ll is free until the sequence stage
+                fse_buildCTable(L.of, L.norm, maxSV, tableLog, L.cumul, L.tableSymbol);     // L.of is free until the sequence stage
                 // FSE_compress_usingCTable: two interleaved states, from the last weight to the first
                 if (wtSize <= 2) hSize = 0;
                 else {
                     BitW b; bw_init(b, op, op + 512);
                     const uint8_t* ip = hw + wtSize; uint32_t s1, s2;
-                    if (wtSize & 1) { s1 = fse_init2(L.ll, *--ip); s2 = fse_init2(L.ll, *--ip); fse_encode(b, L.ll, s1, *--ip); }
-                    else { s2 = fse_init2(L.ll, *--ip); s1 = fse_init2(L.ll, *--ip); }
-                    while (ip > hw) { fse_encode(b, L.ll, s2, *--ip); if (ip > hw) fse_encode(b, L.ll, s1, *--ip); }
+                    if (wtSize & 1) { s1 = fse_init2(L.of, *--ip); s2 = fse_init2(L.of, *--ip); fse_encode(b, L.of, s1, *--ip); }
+                    else { s2 = fse_init2(L.of, *--ip); s1 = fse_init2(L.of, *--ip); }
+                    while (ip > hw) { fse_encode(b, L.of, s2, *--ip); if (ip > hw) fse_encode(b, L.of, s1, *--ip); }
                     bw_add(b, s2, tableLog); bw_add(b, s1, tableLog);
                     op += bw_close(b);
                     hSize = (uint32_t)(op - (dst + 1));
@@ -1909,6 +1913,7 @@ __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ des
     if (lane == 0) descs[chunk].dst_len = flen + 28;
 }
 
+static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
 __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
                                                               uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
                                                               int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
@@ -1968,7 +1973,12 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
         finish_frame(descs, chunk, frame, hdr + 3, zlen, status, fuse, L, lane);
         return;
     }
+    uint32_t* const hufSave = (uint32_t*)(ws + ZS_WS_HUFSAVE);
+    static_assert(sizeof(L.huf) % 4 == 0 && sizeof(L.huf) <= 2048, "Huffman tables fit their place in the workspace");
     if (lane == 0) { L.hufRepeat[0] = 0; L.hufRepeat[1] = 0; L.huf[0].maxSym = 0; L.huf[1].maxSym = 0; }
+    __syncthreads();
+    for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) hufSave[i] = reinterpret_cast<const uint32_t*>(&L.huf[0])[i];
+    __threadfence_block();
     __syncthreads();
     PT(0);
     uint32_t repc[3] = {1, 4, 8};                                       // confirmed repcode history
@@ -2013,7 +2023,13 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
             if (lane == 0) L.scal[8] = 0;
             __syncthreads();
             const bool suspect = ms.nbSeq == 0 || (ms.litSize / ms.nbSeq >= 20);
+            for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) reinterpret_cast<uint32_t*>(&L.huf[0])[i] = hufSave[i];     // back from the workspace
+            __threadfence_block();
+            __syncthreads();
             uint32_t litBytes = UNI(compress_literals(blockout, lit, ms.litSize, L, cur, suspect, huftmp, (HufScratch*)(codes + 3 * ZS_WS_CODE_STRIDE), lane));
+            __threadfence_block();
+            __syncthreads();
+            for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) hufSave[i] = reinterpret_cast<const uint32_t*>(&L.huf[0])[i];     // the LL table takes their place
             __threadfence_block();
             __syncthreads();
             uint32_t seqBytes = UNI(compress_sequences(blockout + litBytes, blockout + (255u << 10), seqs, ms.nbSeq, codes, L, huftmp, (ZS_BLOCKOUT_CAP - (256u << 10)) - 64, lane));
