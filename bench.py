@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9)
+    ap.add_argument("--steps", type=int, default=18)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="auto", choices=["auto", "full", "gcm_crc", "crc"])
     ap.add_argument("--segments", type=int, default=0, help="1 GiB segments per GPU (default: 8 for full, 1 otherwise)")
