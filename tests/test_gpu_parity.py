@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP library on a real MI355X, through the C ABI, against the CPU oracle.
 Bit-exact everywhere (integer/byte work)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -385,3 +387,39 @@ def test_every_chunk_of_a_segment_equals_libzstd_and_openssl(gpu, oracle):
             exp, crc = expected[c]
             assert d["crc32c"][c] == crc, c
             assert got[c * slot:c * slot + int(d["dst_len"][c])].tobytes() == exp, "chunk %d, profile %d" % (c, profile)
+
+
+def test_concurrent_ctxless_host_batches(gpu, oracle):
+    """The JVM case in small: 8 threads, no context of their own (ctx == NULL -> pooled contexts), host buffers, full chain and
+    encrypt-only batches interleaved, the staged pipeline cut into small pieces - every result equals the single-threaded one."""
+    import threading
+    os.environ["TSX_SUB_BYTES"] = str(2 << 20)
+    try:
+        sets = {}
+        for flags in (nat.ENCRYPT | nat.CRC, nat.COMPRESS | nat.ENCRYPT | nat.CRC):
+            chunks = [synth.gen_chunk("K", 21, 0, i, s) for i, s in enumerate([1 << 20, 70001, 1 << 19, 17, 0, 300000, 1 << 20, 4096] * 4)]
+            sets[flags] = (chunks, pc.run_transform(gpu, flags, chunks)[0])
+        errors = []
+
+        def worker(k):
+            try:
+                for rep in range(4):
+                    flags = (nat.ENCRYPT | nat.CRC) if (k + rep) % 2 else (nat.COMPRESS | nat.ENCRYPT | nat.CRC)
+                    chunks, ref = sets[flags]
+                    outs, d = pc.run_transform(gpu, flags, chunks, mem="packed" if rep % 2 else None)
+                    if outs != ref or (d["status"] != 0).any():
+                        errors.append((k, rep, "transform"))
+                    back, d2 = pc.run_detransform(gpu, flags, outs, [int(c.size) for c in chunks])
+                    if back != [c.tobytes() for c in chunks] or (d2["status"] != 0).any():
+                        errors.append((k, rep, "detransform"))
+            except Exception as e:                                    # noqa: BLE001 - reported through the list
+                errors.append((k, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errors, errors[:5]
+        s = gpu.pool_stats(0)
+        assert s["in_use"] == 0 and 1 <= s["idle"] <= 8
+    finally:
+        os.environ.pop("TSX_SUB_BYTES", None)
