@@ -236,6 +236,25 @@ struct StubChunkManager : ChunkManager {                  // every chunk is "012
     }
 };
 
+static void segmentIndexesBuilderTests() {
+    // CT/manifest/SegmentIndexesV1BuilderTest.java:30-95
+    run("SegmentIndexesV1BuilderTest: failures and both layouts", [] {
+        expectThrows<std::logic_error>([] { SegmentIndexesV1Builder().build(); }, "Not enough indexes have been added; at least 4 required. Indexes included: []");
+        expectThrows<std::logic_error>([] { SegmentIndexesV1Builder().add(IndexType::OFFSET, 1).add(IndexType::TIMESTAMP, 1).build(); },
+                                       "Not enough indexes have been added; at least 4 required. Indexes included: [OFFSET, TIMESTAMP]");
+        expectThrows<std::logic_error>([] { SegmentIndexesV1Builder().add(IndexType::OFFSET, 1).add(IndexType::OFFSET, 1); }, "Index OFFSET is already added");
+        expectThrows<std::logic_error>([] { SegmentIndexesV1Builder().add(IndexType::OFFSET, 1).add(IndexType::TIMESTAMP, 1).add(IndexType::PRODUCER_SNAPSHOT, 1)
+                                                .add(IndexType::TRANSACTION, 1).build(); }, "OFFSET, TIMESTAMP, PRODUCER_SNAPSHOT, and LEADER_EPOCH indexes are required");
+        const SegmentIndexesV1 a = SegmentIndexesV1Builder().add(IndexType::OFFSET, 1).add(IndexType::TIMESTAMP, 1).add(IndexType::PRODUCER_SNAPSHOT, 1)
+                                       .add(IndexType::LEADER_EPOCH, 1).add(IndexType::TRANSACTION, 1).build();
+        CHECK(a.offset == (SegmentIndexV1{0, 1}) && a.timestamp == (SegmentIndexV1{1, 1}) && a.producerSnapshot == (SegmentIndexV1{2, 1}) &&
+              a.leaderEpoch == (SegmentIndexV1{3, 1}) && a.transaction && *a.transaction == (SegmentIndexV1{4, 1}));
+        const SegmentIndexesV1 b = SegmentIndexesV1Builder().add(IndexType::OFFSET, 10).add(IndexType::TIMESTAMP, 20).add(IndexType::PRODUCER_SNAPSHOT, 0)
+                                       .add(IndexType::LEADER_EPOCH, 7).build();
+        CHECK(b.timestamp == (SegmentIndexV1{10, 20}) && b.producerSnapshot == (SegmentIndexV1{30, 0}) && b.leaderEpoch == (SegmentIndexV1{30, 7}) && !b.transaction);
+    });
+}
+
 static void fetchEnumerationTests() {
     // CT/fetch/FetchChunkEnumerationTest.java:46-160: 10 chunks of 10 bytes (fixed index 10 / 100 / 12 / 12)
     SegmentManifest m; m.chunkIndex = std::make_shared<FixedSizeChunkIndex>(10, 100, 12, 12);
@@ -593,7 +612,7 @@ static void backendTests(bool full) {
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
     if (argc < 2) { printf("usage: host_tests cpu | backend <libtsxform path> [full]\n"); return 2; }
-    if (std::string(argv[1]) == "cpu") { cpuTests(); fetchEnumerationTests(); }
+    if (std::string(argv[1]) == "cpu") { cpuTests(); segmentIndexesBuilderTests(); fetchEnumerationTests(); }
     else { if (argc < 3) return 2; g_lib = argv[2]; try { backendTests(argc > 3 && std::string(argv[3]) == "full"); } catch (const std::exception& e) { printf("  FAIL backend: %s\n", e.what()); g_failed++; } }
     printf("%d run, %d failed\n", g_run, g_failed);
     return g_failed ? 1 : 0;

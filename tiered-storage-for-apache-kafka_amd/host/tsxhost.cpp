@@ -764,6 +764,43 @@ SegmentIndexV1 indexFromJson(const std::string& raw) {
 }
 }  // namespace
 
+namespace {
+const char* indexTypeName(IndexType t) {
+    switch (t) {
+        case IndexType::OFFSET: return "OFFSET"; case IndexType::TIMESTAMP: return "TIMESTAMP"; case IndexType::PRODUCER_SNAPSHOT: return "PRODUCER_SNAPSHOT";
+        case IndexType::TRANSACTION: return "TRANSACTION"; default: return "LEADER_EPOCH";
+    }
+}
+}  // namespace
+
+SegmentIndexesV1Builder& SegmentIndexesV1Builder::add(IndexType type, int size) {
+    for (const auto& a : added_) if (a.first == type) throw std::logic_error(std::string("Index ") + indexTypeName(type) + " is already added");
+    added_.emplace_back(type, SegmentIndexV1{currentPosition_, size});
+    currentPosition_ += size;
+    return *this;
+}
+std::vector<IndexType> SegmentIndexesV1Builder::indexes() const {
+    std::vector<IndexType> v;
+    for (const auto& a : added_) v.push_back(a.first);
+    std::sort(v.begin(), v.end());
+    return v;
+}
+SegmentIndexesV1 SegmentIndexesV1Builder::build() const {
+    auto has = [&](IndexType t) { for (const auto& a : added_) if (a.first == t) return true; return false; };
+    auto get = [&](IndexType t) { for (const auto& a : added_) if (a.first == t) return a.second; return SegmentIndexV1{}; };
+    if (added_.size() < 4) {
+        std::string list;
+        for (IndexType t : indexes()) { if (!list.empty()) list += ", "; list += indexTypeName(t); }
+        throw std::logic_error("Not enough indexes have been added; at least 4 required. Indexes included: [" + list + "]");
+    }
+    if (added_.size() == 4 && has(IndexType::TRANSACTION)) throw std::logic_error("OFFSET, TIMESTAMP, PRODUCER_SNAPSHOT, and LEADER_EPOCH indexes are required");
+    SegmentIndexesV1 out;
+    out.offset = get(IndexType::OFFSET); out.timestamp = get(IndexType::TIMESTAMP); out.producerSnapshot = get(IndexType::PRODUCER_SNAPSHOT);
+    out.leaderEpoch = get(IndexType::LEADER_EPOCH);
+    if (has(IndexType::TRANSACTION)) out.transaction = get(IndexType::TRANSACTION);
+    return out;
+}
+
 std::string segmentManifestToJson(Backend& be, const SegmentManifestV1& m, const DataKeyEncryptor& wrapKey) {
     if (!m.chunkIndex) throw std::invalid_argument("chunkIndex cannot be null");
     std::string j = "{\"version\":\"1\",\"chunkIndex\":" + chunkIndexToJson(be, *m.chunkIndex) + ",\"segmentIndexes\":{";

@@ -373,6 +373,19 @@ struct SegmentIndexesV1 {
     SegmentIndexV1 offset, timestamp, producerSnapshot, leaderEpoch;
     std::optional<SegmentIndexV1> transaction;                        // "transaction":null when the segment has no txn index
 };
+// manifest/SegmentIndexesV1Builder.java:27-66: the index files of a segment follow one another in the `.indexes` object (each one ONE
+// encrypt-only chunk, transformIndex below); add() records (running position, transformed size) per index type.
+enum class IndexType { OFFSET = 0, TIMESTAMP = 1, PRODUCER_SNAPSHOT = 2, TRANSACTION = 3, LEADER_EPOCH = 4 };   // Kafka's RemoteStorageManager.IndexType order
+class SegmentIndexesV1Builder {
+public:
+    SegmentIndexesV1Builder& add(IndexType type, int size);       // std::logic_error("Index OFFSET is already added")
+    std::vector<IndexType> indexes() const;                        // sorted, for messages
+    SegmentIndexesV1 build() const;                                // the reference's two IllegalStateException messages
+private:
+    std::vector<std::pair<IndexType, SegmentIndexV1>> added_;
+    int currentPosition_ = 0;
+};
+
 struct SegmentManifestV1 : SegmentManifest {
     SegmentIndexesV1 segmentIndexes;
     std::string remoteLogSegmentMetadataJson;                         // "" = property absent
