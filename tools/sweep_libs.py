@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """A/B of compressor builds on one box (GPU): the same 2048-chunk K batch (256 distinct chunks x 8) through every library given,
 three caller threads in flight as in bench.py, plus one batch at a time.  Outputs of all libraries must be identical.
+METHOD (learnt the hard way in round 2): give ONE library per process and alternate processes - whatever is loaded second into a
+process measures 15-20 % lower with batches in flight - and use >= 18 steps: shorter runs are dominated by the simultaneous start
+of the callers' first batches.  Several libraries in one call are still useful for the digest comparison.
     python tools/sweep_libs.py [--steps 6] tools/_libs/libtsxform_a.so tools/_libs/libtsxform_b.so ..."""
 import argparse, hashlib, json, os, sys, threading, time
 import numpy as np
@@ -11,7 +14,7 @@ import tsxform
 from tsxform import synth
 nat = tsxform._native
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--steps", type=int, default=18)
 ap.add_argument("--chunks", type=int, default=2048)
 ap.add_argument("--inflight", type=int, default=3)
 ap.add_argument("--dist", default="K")
