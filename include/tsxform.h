@@ -118,6 +118,8 @@ const char* tsx_strerror(int code);
 /* device_ids == NULL: use devices 0..device_count-1; device_count <= 0: all visible devices.
  * Returns the number of devices in use (>0) or TSX_E_DEVICE. */
 int  tsx_init(int device_count, const int* device_ids);
+/* Every tsx_ctx must have been destroyed and no batch may be in flight.  No entry point of this library changes the calling
+ * thread's current HIP device: each one that selects a device puts the previous one back before it returns. */
 void tsx_shutdown(void);
 int  tsx_device_count(void);
 

@@ -35,7 +35,7 @@ typedef struct hipemu_stream* hipStream_t;
 typedef struct hipemu_event* hipEvent_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0, hipHostRegisterDefault = 0, hipEventDisableTiming = 2 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0, hipHostRegisterDefault = 0, hipHostRegisterPortable = 1, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
 
 namespace hipemu {

@@ -1,6 +1,7 @@
 // TEST HARNESS ONLY — scheduler / runtime half of the HIP emulator declared in hip/hip_runtime.h.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <mutex>
@@ -176,7 +177,17 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->totalGlobalMem = (size_t)8 << 30;
     return hipSuccess;
 }
-hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// Fault injection for the front end's out-of-memory paths: hipemu_fail_alloc_at(k) makes the k-th allocation from now on (device
+// or pinned host, k >= 1) fail once; 0 disarms.  hipemu_alloc_calls() counts allocations since the last arming.
+static std::atomic<long> g_fail_at{0}, g_alloc_calls{0};
+extern "C" void hipemu_fail_alloc_at(long k) { g_alloc_calls = 0; g_fail_at = k; }
+extern "C" long hipemu_alloc_calls() { return g_alloc_calls; }
+hipError_t hipMalloc(void** p, size_t n) {
+    const long k = ++g_alloc_calls;
+    if (g_fail_at > 0 && k == g_fail_at) { g_fail_at = 0; *p = nullptr; return hipErrorOutOfMemory; }
+    *p = aligned_alloc(256, (n + 255) & ~(size_t)255);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }

@@ -30,3 +30,17 @@ def test_decoder_is_memory_safe_on_damaged_frames():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "asan_decode_check.py"), LIB, "60", "23"],
                        env=env, capture_output=True, text=True, timeout=850)
     assert r.returncode == 0 and "asan decode check ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.timeout(900)
+def test_front_end_survives_every_failed_allocation():
+    """tsx_api.hip's out-of-memory paths (workspace growth of a context, context creation, pooled contexts): each allocation of a
+    batch fails once; no double free, no dangling pointer (ASan), and the context serves the batch on the next try."""
+    asan = _libasan()
+    if asan is None:
+        pytest.skip("no libasan in this toolchain")
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emu-asan"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_stack_use_after_return=0:detect_leaks=0:halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "asan_alloc_faults.py"), LIB],
+                       env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0 and "asan alloc faults ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -49,6 +49,10 @@ def test_ctxless_calls_use_every_device(emu):
         except nat.TsxError as e:
             assert e.code == nat.E_INVAL
         c = N.ctx_create(1); assert N.ctx_device(c) == 1; N.ctx_destroy(c)
+        # the calling thread's current device is the caller's business: every entry point puts it back
+        import ctypes
+        cur = ctypes.c_int(-1); get = N.lib._Z12hipGetDevicePi; get.argtypes = [ctypes.POINTER(ctypes.c_int)]
+        get(ctypes.byref(cur)); assert cur.value == 0, cur.value
         th = [threading.Thread(target=lambda: [crc() for _ in range(3)]) for _ in range(24)]
         [t.start() for t in th]; [t.join() for t in th]
         s = [N.pool_stats(i) for i in (0, 1)]

@@ -19,6 +19,16 @@ static void tsx_set_err(const char* what, hipError_t e) {
     if (getenv("TSX_DEBUG")) fprintf(stderr, "[tsxform] %s\n", g_last_err);
 }
 
+// Every entry point that selects a device puts the calling thread's current device back on the way out: the caller may share
+// the thread with another HIP user (a torch process, another JNI library) whose notion of "current device" is not ours to change.
+struct tsx_device_scope {
+    int prev = -1;
+    tsx_device_scope() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+    ~tsx_device_scope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    tsx_device_scope(const tsx_device_scope&) = delete;
+    tsx_device_scope& operator=(const tsx_device_scope&) = delete;
+};
+
 struct tsx_ctx;
 struct tsx_device {
     int hip_id = -1;
@@ -131,6 +141,7 @@ static int init_devices(std::vector<tsx_device>& devs, int want, const int* devi
 extern "C" int tsx_init(int device_count, const int* device_ids) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_devs.empty()) return (int)g_devs.size();
+    tsx_device_scope keep;
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
         snprintf(g_last_err, sizeof g_last_err, "no HIP device visible");
@@ -184,6 +195,7 @@ static void ctx_free_device_mem(tsx_ctx* c) {
 
 extern "C" void tsx_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
+    tsx_device_scope keep;
     for (auto& d : g_devs) {
         for (tsx_ctx* c : d.idle) { ctx_free_device_mem(c); delete c; }
         d.idle.clear();
@@ -212,6 +224,7 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
         for (void* p : olds) if (p) hipFree(p);
         if (c->h_descs) hipHostFree(c->h_descs);
         c->d_descs = nullptr; c->d_gchunks = nullptr; c->d_status = nullptr; c->d_zlen = nullptr; c->h_descs = nullptr;
+        c->descs_cap = 0;                                    // a failure below leaves a context that reallocates, not one with holes
         size_t cap = (size_t)n + n / 4 + 16;
         HIPCHK(hipMalloc((void**)&c->d_descs, cap * sizeof(tsx_chunk_desc)));
         HIPCHK(hipHostMalloc((void**)&c->h_descs, cap * sizeof(tsx_chunk_desc), hipHostMallocDefault));
@@ -238,8 +251,9 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
         c->mid_stride = stride;
         size_t zw = tsx_zstd_workspace_bytes(n, max_len);
         uint8_t* zp = (uint8_t*)c->d_zwork;
-        if ((rc = grow(&zp, &c->zwork_cap, zw))) return rc;
-        c->d_zwork = zp;
+        rc = grow(&zp, &c->zwork_cap, zw);
+        c->d_zwork = zp;                                     // also when grow failed: it has freed the old block
+        if (rc) return rc;
     }
     return TSX_OK;
 }
@@ -268,6 +282,7 @@ extern "C" int tsx_ctx_create(int device_index, uint32_t max_chunks, uint32_t ma
     }
     tsx_ctx* c = new (std::nothrow) tsx_ctx;
     if (!c) return TSX_E_NOMEM;
+    tsx_device_scope keep;
     c->dev_index = device_index; c->dev = dev;
     int rc = ctx_init_device_objects(c);
     if (rc == TSX_OK && max_chunks && max_chunk_size) rc = ctx_reserve(c, max_chunks, max_chunk_size, max_chunk_size, 0, false, 0, 0);
@@ -278,6 +293,7 @@ extern "C" int tsx_ctx_create(int device_index, uint32_t max_chunks, uint32_t ma
 
 extern "C" void tsx_ctx_destroy(tsx_ctx* c) {
     if (!c) return;
+    tsx_device_scope keep;
     ctx_free_device_mem(c);
     delete c;
 }
@@ -342,6 +358,7 @@ static void pool_release(tsx_ctx* c) {
         d.in_use--;
         if (d.idle.size() < TSX_POOL_MAX_IDLE) { d.idle.push_back(c); return; }
     }
+    tsx_device_scope keep;
     ctx_free_device_mem(c);                                            // a burst of callers does not pin its workspaces forever
     delete c;
 }
@@ -692,6 +709,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
         if ((flags & TSX_COMPRESS) && params->zstd_profile > TSX_ZSTD_PROFILE_1_5_7) return TSX_E_UNSUPPORTED;
     }
     if (n == 0) return TSX_OK;
+    tsx_device_scope keep;
     if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
     tsx_run r{};
     r.c = c; r.params = params; r.descs = descs; r.n = n; r.src = src; r.dst = dst; r.dst_size = dst_size; r.mem_kind = mem_kind; r.mode = mode;
@@ -741,6 +759,7 @@ extern "C" int tsx_crc32c_batch(tsx_ctx* ctx, tsx_chunk_desc* descs, uint32_t n,
 // any batch, whatever its outcome.
 extern "C" int tsx_debug_key_residue(tsx_ctx* c) {
     if (!c) return TSX_E_INVAL;
+    tsx_device_scope keep;
     if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
     std::vector<uint8_t> h(sizeof(tsx_gcm_key) + 128);
     if (hipMemcpy(h.data(), c->d_key, sizeof(tsx_gcm_key), hipMemcpyDeviceToHost) != hipSuccess) return TSX_E_DEVICE;
@@ -752,10 +771,11 @@ extern "C" int tsx_debug_key_residue(tsx_ctx* c) {
 
 // Pins a caller buffer that will be used for TSX_MEM_HOST / TSX_MEM_HOST_PACKED batches again and again (the JVM side registers its
 // per-thread direct ByteBuffers once): copies from / to it go by DMA and overlap fully instead of being staged by the runtime.
+// Portable: the pinning holds for every device of the node, whichever one the pool picks for a batch.
 extern "C" int tsx_host_register(void* p, size_t bytes) {
     if (!p || !bytes) return TSX_E_INVAL;
     { std::lock_guard<std::mutex> lk(g_mu); if (g_devs.empty()) return TSX_E_DEVICE; }
-    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) { tsx_set_err("hipHostRegister", e); (void)hipGetLastError(); return TSX_E_DEVICE; }
     return TSX_OK;
 }
@@ -774,18 +794,22 @@ static int set_dev(int device_index) {
 }
 extern "C" int tsx_device_malloc(int device_index, size_t bytes, void** out) {
     if (!out) return TSX_E_INVAL;
+    tsx_device_scope keep;
     int rc = set_dev(device_index); if (rc) return rc;
     return hipMalloc(out, bytes) == hipSuccess ? TSX_OK : TSX_E_NOMEM;
 }
 extern "C" int tsx_device_free(int device_index, void* p) {
+    tsx_device_scope keep;
     int rc = set_dev(device_index); if (rc) return rc;
     return hipFree(p) == hipSuccess ? TSX_OK : TSX_E_DEVICE;
 }
 extern "C" int tsx_memcpy_h2d(int device_index, void* d, const void* s, size_t bytes) {
+    tsx_device_scope keep;
     int rc = set_dev(device_index); if (rc) return rc;
     return hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) == hipSuccess ? TSX_OK : TSX_E_DEVICE;
 }
 extern "C" int tsx_memcpy_d2h(int device_index, void* d, const void* s, size_t bytes) {
+    tsx_device_scope keep;
     int rc = set_dev(device_index); if (rc) return rc;
     return hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TSX_OK : TSX_E_DEVICE;
 }
