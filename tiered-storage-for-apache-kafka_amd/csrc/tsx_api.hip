@@ -78,7 +78,7 @@ static std::vector<tsx_device> g_devs;
 static uint32_t g_rr = 0;
 static thread_local int t_dev_hint = -1;
 static const char kUninitVersion[] = "tsxform 0.2 (gfx950 HIP; uninitialised)";
-static char g_version_buf[2][384];
+static char g_version_buf[2][512];
 static unsigned g_version_gen = 0;
 static std::atomic<const char*> g_version{kUninitVersion};
 
