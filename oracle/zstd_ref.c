@@ -56,7 +56,7 @@ static const char* k_candidates[] = {
 };
 
 static int try_open(const char* p) {
-    void* h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+    void* h = dlopen(p, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);   /* its internal calls bind to ITSELF even when the process (a profiler) has another libzstd loaded globally */
     if (!h) return -1;
     Z.h = h;
     Z.createCCtx = (fn_createCCtx)dlsym(h, "ZSTD_createCCtx");
