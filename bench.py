@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--verify-chunks", type=int, default=64, help="chunks compared byte for byte with the oracle after the timed region")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the continuously-fed measurement (5 callers, 10 batches each) after the timed region")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host->host (PCIe-inclusive) measurement after the timed region")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
@@ -233,6 +234,49 @@ def main():
             step(0)
         fence()
         single = float(n) * CH * 2 / GiB / (time.perf_counter() - t1)
+    # ---- a continuously fed device (outside the timed region, never `value`) ---------------------------------------------
+    # The timed region is K steps from a barrier: the callers start at the same instant and each waits for its whole batch - the
+    # stragglers of a batch hold its slots while nothing is queued behind them.  A broker's >= 10 upload threads (README.md:221 of
+    # the reference) keep work queued: 5 callers, started a quarter of a second apart, 10 batches each; the rate is the slope of
+    # (batches completed) over time across the middle 60 % of the run, i.e. without the ramp at either end.
+    sustained = None
+    if rank == 0 and world == 1 and workload == "full" and T > 1 and not split and not args.no_sustained:
+        TS, BS, stag = (5, 10, 0.25) if not rehearse else (5, 3, 0.01)
+        nbytes = (lambda b: b.size) if rehearse else (lambda b: b.numel())
+        xctx = [N.ctx_create(0, n, CH) for _ in range(TS - T)]
+        xdst = [Mem.empty(n * slot) for _ in range(TS - T)]
+        sctx, sdst, sds = ctxs + xctx, dsts + xdst, ds + [d.copy() for _ in range(TS - T)]
+        for t in range(T, TS):                             # their workspaces exist before the clock starts
+            N.transform_batch(params, sds[t], Mem.ptr(src), Mem.ptr(sdst[t]), nbytes(sdst[t]), MEM, ctx=sctx[t])
+        fence()
+        stamps = [[] for _ in range(TS)]
+
+        def feeder(t):
+            time.sleep(t * stag)
+            for _ in range(BS):
+                N.transform_batch(params, sds[t], Mem.ptr(src), Mem.ptr(sdst[t]), nbytes(sdst[t]), MEM, ctx=sctx[t])
+                stamps[t].append(time.perf_counter())
+
+        ts0 = time.perf_counter()
+        th = [threading.Thread(target=feeder, args=(t,)) for t in range(TS)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        fence()
+        whole = time.perf_counter() - ts0
+        for t in range(TS):
+            assert (sds[t]["status"] == 0).all() and (sds[t]["dst_len"] == d["dst_len"]).all() and (sds[t]["crc32c"] == d["crc32c"]).all()
+        done_at = np.sort(np.concatenate([np.asarray(x) for x in stamps])) - ts0
+        k0, k1 = int(len(done_at) * 0.2), int(len(done_at) * 0.8)
+        slope = float(np.polyfit(done_at[k0:k1], np.arange(k0, k1), 1)[0])
+        batch_gib = float(n) * CH / GiB
+        sustained = {"metric": "GiB/s of original bytes with work always queued (%d callers %.2f s apart, %d batches of %d chunks each)" % (TS, stag, BS, n),
+                     "value": round(slope * batch_gib, 4), "unit": "GiB/s", "callers": TS, "batches": TS * BS,
+                     "method": "least-squares slope of batches completed over time, completions %d..%d of %d (no ramp-up, no drain)" % (k0, k1 - 1, len(done_at)),
+                     "whole_run_gibs_incl_ramp_and_drain": round(TS * BS * batch_gib / whole, 4),
+                     "ms_between_completions": round(1e3 / slope, 2)}
+        for c in xctx:
+            N.ctx_destroy(c)
+        del xdst, sdst
     if world > 1:
         elapsed = Mem.max_over_ranks(elapsed)
     assert (d["status"] == 0).all(), "chunk failures: %s" % d["status"][d["status"] != 0][:8]
@@ -521,7 +565,7 @@ def main():
                            b"".join(np.asarray(index[k][1], np.int64).tobytes() for k in sorted(index))).hexdigest()[:16],
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
                        "verified_chunks_vs_oracle": verified},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "detransform": inverse,
+            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "end_to_end": e2e, "detransform": inverse,
         }
         print(json.dumps(line))
     for c in ctxs:

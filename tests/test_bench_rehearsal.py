@@ -61,3 +61,21 @@ def test_one_segment_split_over_two_ranks(emu, oracle):
     pos = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
     assert c["chunk_index_positions_sha"] == hashlib.sha256(pos.tobytes()).hexdigest()[:16]     # rank 0 holds the whole chunk index
     assert j["detransform"]["round_trip_exact"] is True
+
+
+def test_single_rank_line_has_every_leg(emu, oracle):
+    """N = 1 as the driver runs it at round end (plain `python bench.py ...`, no launcher): one JSON line whose legs outside the
+    timed region are all present - here on the emulator, where they measure nothing but must run."""
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--rehearse", "--backend", "gloo",
+           "--chunk-bytes", "8192", "--chunks-per-segment", "3", "--segments", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["config"]["batches_in_flight"] == 3 and j["config"]["verified_chunks_vs_oracle"] == 6
+    s = j["sustained"]
+    assert s["callers"] == 5 and s["batches"] == 15 and s["value"] >= 0 and "slope" in s["method"]
+    assert j["detransform"]["round_trip_exact"] is True and j["roofline"]["bound"] == "hbm"

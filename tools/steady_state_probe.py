@@ -52,5 +52,9 @@ lo = max(d[1] for d in done); hi = min(d[-1] for d in done)
 cnt = sum(1 for d in done for x in d if lo < x <= hi)
 assert all((d["status"] == 0).all() for d in descs)
 per = np.mean([np.diff(d).mean() for d in done])
-print("T=%d B=%d n=%d stagger=%4.0f ms: whole run %.2f GiB/s | steady window %.2f s, %d batches -> %.2f GiB/s | batch period %.0f ms"
-      % (T, B, n, stagger * 1e3, T * B * gib / el, hi - lo, cnt, cnt * gib / (hi - lo) if hi > lo else 0, per * 1e3), flush=True)
+# sustained rate without the window's batch quantisation: slope of (completions so far) over time, middle 60 % of the run
+ts = np.sort(np.concatenate([np.array(d) for d in done])) - t0
+k0, k1 = int(len(ts) * 0.2), int(len(ts) * 0.8)
+slope = np.polyfit(ts[k0:k1], np.arange(k0, k1), 1)[0] if k1 - k0 >= 4 else 0.0
+print("T=%d B=%d n=%d stagger=%4.0f ms: whole run %.2f GiB/s | steady window %.2f s, %d batches -> %.2f GiB/s | batch period %.0f ms | slope of the middle 60 %% %.2f GiB/s"
+      % (T, B, n, stagger * 1e3, T * B * gib / el, hi - lo, cnt, cnt * gib / (hi - lo) if hi > lo else 0, per * 1e3, slope * gib), flush=True)
