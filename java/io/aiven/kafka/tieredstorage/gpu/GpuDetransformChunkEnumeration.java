@@ -10,6 +10,7 @@ package io.aiven.kafka.tieredstorage.gpu;
 import java.nio.ByteBuffer;
 import java.util.ArrayDeque;
 import java.util.ArrayList;
+import java.util.Arrays;
 import java.util.List;
 import java.util.NoSuchElementException;
 import java.util.Objects;
@@ -97,9 +98,15 @@ public class GpuDetransformChunkEnumeration implements DetransformChunkEnumerati
             src.position((int) descs.getLong(i * TsxNative.DESC_BYTES + TsxNative.DESC_SRC_OFF));
             src.put(in.get(i));
         }
-        final int rc = TsxNative.detransformBatch(flags,
-            encryption != null ? encryption.dataKey().getEncoded() : null,
-            encryption != null ? encryption.aad() : null, descs, in.size(), src, dst);
+        final byte[] key = encryption != null ? encryption.dataKey().getEncoded() : null;   // a copy (SecretKeySpec.getEncoded clones)
+        final int rc;
+        try {
+            rc = TsxNative.detransformBatch(flags, key, encryption != null ? encryption.aad() : null, descs, in.size(), src, dst);
+        } finally {
+            if (key != null) {
+                Arrays.fill(key, (byte) 0);            // the copy does not wait for the garbage collector
+            }
+        }
         if (rc != TsxNative.OK) {
             throw new RuntimeException(TsxNative.strerror(rc));
         }

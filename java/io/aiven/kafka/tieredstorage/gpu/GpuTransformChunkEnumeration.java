@@ -13,6 +13,7 @@ import java.nio.ByteBuffer;
 import java.security.SecureRandom;
 import java.util.ArrayDeque;
 import java.util.ArrayList;
+import java.util.Arrays;
 import java.util.List;
 import java.util.NoSuchElementException;
 import java.util.Objects;
@@ -140,9 +141,15 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
             src.put(in.get(i));
         }
         TsxNative.setThreadDevice(device);
-        final int rc = TsxNative.transformBatch(flags,
-            keyAndAad != null ? keyAndAad.dataKey.getEncoded() : null,
-            keyAndAad != null ? keyAndAad.aad : null, zstdProfile, descs, in.size(), src, dst);
+        final byte[] key = keyAndAad != null ? keyAndAad.dataKey.getEncoded() : null;   // a copy (SecretKeySpec.getEncoded clones)
+        final int rc;
+        try {
+            rc = TsxNative.transformBatch(flags, key, keyAndAad != null ? keyAndAad.aad : null, zstdProfile, descs, in.size(), src, dst);
+        } finally {
+            if (key != null) {
+                Arrays.fill(key, (byte) 0);            // the copy does not wait for the garbage collector
+            }
+        }
         if (rc != TsxNative.OK) {
             throw new RuntimeException(TsxNative.strerror(rc));
         }

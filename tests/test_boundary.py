@@ -95,3 +95,37 @@ def test_product_never_touches_the_oracle_or_the_emulator():
     assert not bad, bad
     linked = subprocess.run(["ldd", nat.LIB_PATH], capture_output=True, text=True).stdout
     assert "zstd" not in linked and "crypto" not in linked and "oracle" not in linked
+
+
+def test_java_binding_agrees_with_the_header_and_the_shim():
+    """The Java side cannot be compiled in this image (no JDK): what can be checked is that TsxNative.java's constants are the
+    C header's, and that every `native` method has its JNI entry point in java/jni/tsx_jni.c with the same number of arguments
+    (and the other way round)."""
+    jdir = os.path.join(ROOT, "java", "io", "aiven", "kafka", "tieredstorage", "gpu")
+    src = open(os.path.join(jdir, "TsxNative.java")).read()
+    consts = {k: int(v, 0) for k, v in re.findall(r"public static final int (\w+) = (-?(?:0x)?[0-9A-Fa-f]+);", src)}
+    assert consts["DESC_BYTES"] == ctypes.sizeof(nat.ChunkDesc)
+    for jname, field in [("DESC_SRC_OFF", "src_off"), ("DESC_DST_OFF", "dst_off"), ("DESC_SRC_LEN", "src_len"), ("DESC_DST_CAP", "dst_cap"),
+                         ("DESC_DST_LEN", "dst_len"), ("DESC_CRC32C", "crc32c"), ("DESC_STATUS", "status"), ("DESC_IV", "iv")]:
+        assert consts[jname] == getattr(nat.ChunkDesc, field).offset, jname
+    assert (consts["COMPRESS"], consts["ENCRYPT"], consts["CRC"]) == (nat.COMPRESS, nat.ENCRYPT, nat.CRC)
+    assert (consts["OK"], consts["E_TAG_MISMATCH"], consts["E_BAD_FRAME"], consts["E_BAD_SIZE"]) == (0, nat.E_TAG_MISMATCH, nat.E_BAD_FRAME, nat.E_BAD_SIZE)
+    assert (consts["ZSTD_PROFILE_1_5_6"], consts["ZSTD_PROFILE_1_5_7"]) == (nat.ZSTD_PROFILE_1_5_6, nat.ZSTD_PROFILE_1_5_7)
+    h = open(os.path.join(ROOT, "include", "tsxform.h")).read()
+    for cname, jname in [("TSX_E_TAG_MISMATCH", "E_TAG_MISMATCH"), ("TSX_E_BAD_FRAME", "E_BAD_FRAME"), ("TSX_E_BAD_SIZE", "E_BAD_SIZE")]:
+        m = re.search(r"#define\s+%s\s+\(?(-?\d+)\)?" % cname, h) or re.search(r"%s\s*=\s*(-?\d+)" % cname, h)
+        assert m and int(m.group(1)) == consts[jname], cname
+    # native methods <-> JNI entry points (JNIEnv*, jclass + the Java parameters)
+    natives = {}
+    for m in re.finditer(r"native\s+\w+(?:\[\])?\s+(\w+)\s*\(([^)]*)\)", src, flags=re.S):
+        params = [p for p in m.group(2).split(",") if p.strip()]
+        natives[m.group(1)] = len(params)
+    shim = open(os.path.join(ROOT, "java", "jni", "tsx_jni.c")).read()
+    entries = {}
+    for m in re.finditer(r"Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_(\w+)\s*\(([^)]*)\)", shim, flags=re.S):
+        entries[m.group(1)] = len([p for p in m.group(2).split(",") if p.strip()]) - 2
+    assert natives == entries, (natives, entries)
+    # every class that calls into TsxNative uses methods that exist
+    for f in os.listdir(jdir):
+        for ref in re.findall(r"TsxNative\.(\w+)", open(os.path.join(jdir, f)).read()):
+            assert ref in natives or ref in consts or ref == "Buffers", (f, ref)
