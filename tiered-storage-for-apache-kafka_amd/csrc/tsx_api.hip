@@ -520,9 +520,11 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e) {
             if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
             if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = r.d_dst; }
             uint32_t sched = 0;                                              // the kernel's default speculation schedule
-            if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1": explicit schedule (measurements; same bytes)
-                unsigned a = 0, b = 0;
-                if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) sched = a | b << 8;
+            if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1[,p]": explicit schedule (measurements; same bytes)
+                unsigned a = 0, b = 0, pm = 0;                               // optional third field: block priority mode (zs_block_priority)
+                const int got = sscanf(e, "%u,%u,%u", &a, &b, &pm);
+                // third field as the user writes it: absent = the kernel's default, 0 = no priorities, 1..4 = that mode
+                if (got >= 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59 && pm <= 4) sched = a | b << 8 | (got == 3 ? (pm ? pm : 5u) : 0u) << 16;
             }
             t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
                                                        r.params->zstd_profile, sched, fuse);

@@ -1913,6 +1913,35 @@ __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ des
     if (lane == 0) descs[chunk].dst_len = flen + 28;
 }
 
+// Issue priority of this chunk's wave for the coming block (sched bits 16-19; scheduling only, never the output).  Measured
+// (tools/chunk_time_spread.py, profiles/r02_chunk_time_spread.txt): the workgroups of the later half of a grid - the younger wave
+// on every SIMD - run 5-8 % slower than the first half, because the SIMD's arbiter serves its oldest wave first; a batch is over
+// when its slowest chunk is, so with three batches in flight 11-17 % of the slot-time goes to chunks that have already finished.
+//   1 later half of the grid above the first (over-compensates: the order flips)   2 the halves alternate block by block
+//   (quarters of the grid within 2 %, slowest chunk 12 % earlier, a lone batch 3 % faster)   3 pseudo-random per (chunk, block)
+//   4 graded by position in the grid (worse)   5 none   0 = the default.
+// The default stays NONE: with priorities the three-batches-in-flight rate came out at 17.2-17.7 GiB/s in five processes out of five,
+// without them 17.4-17.5 in two and 19.3 in one (same boxes, same hour) - the callers never fell in step - and in flight is the headline.
+#define ZS_PRIO_DEFAULT 5u
+__device__ static __forceinline__ void zs_block_priority(uint32_t mode, uint32_t chunk, uint32_t nChunks, uint32_t blk) {
+#ifndef HIPEMU
+    uint32_t p = 0;
+    const uint32_t later = (2 * chunk >= nChunks) ? 1u : 0u;
+    if (mode == 0) mode = ZS_PRIO_DEFAULT;
+    if (mode == 1) p = later;
+    else if (mode == 2) p = later ^ (blk & 1);
+    else if (mode == 3) p = ((chunk * 0x9E3779B1u + blk * 0x85EBCA77u) >> 30);
+    else if (mode == 4) p = (uint32_t)(((uint64_t)chunk * 4) / (nChunks ? nChunks : 1));
+    else return;
+    p = UNI(p);
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#else
+    (void)mode; (void)chunk; (void)nChunks; (void)blk;
+#endif
+}
 static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
 __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
                                                               uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
@@ -1987,7 +2016,10 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
     int64_t savings = 0;
     int cur = 0;                 // index of the confirmed Huffman table (L.huf[cur]); a candidate is built in L.huf[cur ^ 1]
     bool first = true;
+    const uint32_t prioMode = (UNI(sched) >> 16) & 0xF;
+    uint32_t blk = 0;
     while (remaining) {
+        zs_block_priority(prioMode, chunk, gridDim.x, blk++);
         // ---- block size (ZSTD_optimalBlockSize) ----
         uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
         if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
