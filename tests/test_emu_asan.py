@@ -44,3 +44,17 @@ def test_front_end_survives_every_failed_allocation():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "asan_alloc_faults.py"), LIB],
                        env=env, capture_output=True, text=True, timeout=850)
     assert r.returncode == 0 and "asan alloc faults ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.timeout(900)
+def test_compressor_is_memory_safe_and_exact_on_structured_inputs():
+    """The compressor with its fused CRC head / GCM tail under AddressSanitizer: structured random inputs and the edge sizes, both
+    Zstd profiles; frames equal libzstd's / the restatement's, the round trip is exact, no access leaves its buffer."""
+    asan = _libasan()
+    if asan is None:
+        pytest.skip("no libasan in this toolchain")
+    subprocess.check_call(["make", "-s", "-C", CSRC, "emu-asan"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_stack_use_after_return=0:detect_leaks=0:halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "asan_compress_check.py"), LIB, "8", "11"],
+                       env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0 and "asan compress check ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
