@@ -17,6 +17,10 @@ import java.util.Arrays;
 import java.util.List;
 import java.util.NoSuchElementException;
 import java.util.Objects;
+import java.util.concurrent.CompletableFuture;
+import java.util.concurrent.CompletionException;
+import java.util.concurrent.ExecutorService;
+import java.util.concurrent.Executors;
 
 import io.aiven.kafka.tieredstorage.security.DataKeyAndAAD;
 import io.aiven.kafka.tieredstorage.transform.TransformChunkEnumeration;
@@ -34,6 +38,21 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
     private final int device;
     private final Integer transformedChunkSize;
     private final ArrayDeque<byte[]> ready = new ArrayDeque<>();
+    private final boolean readAhead;
+    /** The batch behind {@code ready}, being transformed by a helper; while it is set, only the helper touches {@code inner}. */
+    private CompletableFuture<List<byte[]>> ahead;
+    private boolean exhausted;
+
+    /**
+     * Long-lived helper threads (their pinned per-thread {@link TsxNative.Buffers} live as long as they do); as many as the
+     * broker has upload threads by default (remote.log.manager.thread.pool.size = 10).
+     */
+    private static final ExecutorService HELPERS = Executors.newFixedThreadPool(
+        Integer.getInteger("tsx.readahead.threads", 10), r -> {
+            final Thread t = new Thread(r, "tsx-read-ahead");
+            t.setDaemon(true);
+            return t;
+        });
 
     /**
      * @param zstdProfile TsxNative.ZSTD_PROFILE_1_5_6 (the libzstd inside the reference's zstd-jni 1.5.6-9, core/build.gradle:29)
@@ -41,10 +60,15 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
      *                    profile has been compared with
      * @param segmentHash any stable hash of the segment (e.g. of its RemoteLogSegmentId): its batches go to GPU
      *                    floorMod(segmentHash, deviceCount) so that the node's GPUs are all used and one segment stays on one
+     * @param readAhead   while the consumer (TransformFinisher -> the uploader) drains batch k, batch k + 1 is already read
+     *                    from {@code inner} and on the device: an upload thread keeps two batches in flight and its uploads
+     *                    overlap the device.  Chunks, IVs and failures keep their order.  false: {@code inner} is read exactly
+     *                    when the reference would read it.  (C++ twin, tested: tsx::GpuTransformChunkEnumeration, readAhead.)
      */
     public GpuTransformChunkEnumeration(final TransformChunkEnumeration inner, final boolean compress,
                                         final DataKeyAndAAD keyAndAad, final int batchChunks,
-                                        final SecureRandom random, final int zstdProfile, final int segmentHash) {
+                                        final SecureRandom random, final int zstdProfile, final int segmentHash,
+                                        final boolean readAhead) {
         this.inner = Objects.requireNonNull(inner, "inner cannot be null");
         this.compress = compress;
         this.keyAndAad = keyAndAad;
@@ -54,6 +78,7 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
             throw new IllegalArgumentException("unknown Zstd profile " + zstdProfile);
         }
         this.zstdProfile = zstdProfile;
+        this.readAhead = readAhead;
         this.device = Math.floorMod(segmentHash, TsxNative.deviceCount());
         // src and dst of a batch live in one direct ByteBuffer each (< 2 GiB)
         final long perChunk = TsxNative.transformedBound(inner.originalChunkSize(),
@@ -100,15 +125,43 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
     }
 
     private void fillBatchIfNeeded() {
-        if (!ready.isEmpty()) {
+        if (!ready.isEmpty() || exhausted) {
             return;
         }
+        final List<byte[]> batch;
+        if (ahead != null) {
+            final CompletableFuture<List<byte[]>> f = ahead;
+            ahead = null;
+            try {
+                batch = f.join();              // the helper's failure surfaces here, where its first chunk is asked for
+            } catch (final CompletionException e) {
+                if (e.getCause() instanceof RuntimeException) {
+                    throw (RuntimeException) e.getCause();
+                }
+                throw e;
+            }
+        } else {
+            batch = transformNextBatch();
+        }
+        if (batch.isEmpty()) {
+            exhausted = true;
+            return;
+        }
+        ready.addAll(batch);
+        if (readAhead) {
+            ahead = CompletableFuture.supplyAsync(this::transformNextBatch, HELPERS);
+        }
+    }
+
+    /** Up to batchChunks chunks of {@code inner} through the device; empty when {@code inner} is exhausted. */
+    private List<byte[]> transformNextBatch() {
+        final List<byte[]> out = new ArrayList<>();
         final List<byte[]> in = new ArrayList<>();
         while (in.size() < batchChunks && inner.hasMoreElements()) {
             in.add(inner.nextElement());
         }
         if (in.isEmpty()) {
-            return;
+            return out;
         }
         final int flags = (compress ? TsxNative.COMPRESS : 0) | (keyAndAad != null ? TsxNative.ENCRYPT : 0);
         final TsxNative.Buffers buffers = TsxNative.Buffers.get();     // per-thread, reused, pinned
@@ -159,10 +212,11 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
             if (status != TsxNative.OK) {
                 throw new RuntimeException(TsxNative.strerror(status));   // as EncryptionChunkEnumeration.java:76-78
             }
-            final byte[] out = new byte[descs.getInt(base + TsxNative.DESC_DST_LEN)];   // fresh array per chunk, owned by the caller
+            final byte[] chunk = new byte[descs.getInt(base + TsxNative.DESC_DST_LEN)];   // fresh array per chunk, owned by the caller
             dst.position((int) descs.getLong(base + TsxNative.DESC_DST_OFF));
-            dst.get(out);
-            ready.add(out);
+            dst.get(chunk);
+            out.add(chunk);
         }
+        return out;
     }
 }

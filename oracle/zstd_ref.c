@@ -58,7 +58,7 @@ static const char* k_candidates[] = {
 static int try_open(const char* p) {
     /* DEEPBIND: the library's internal calls bind to ITSELF even when the process (a profiler) has another libzstd loaded globally -
      * under rocprofv3 they went to the profiler's own copy and crashed.  The sanitizer runtime refuses DEEPBIND, and needs none. */
-    const int deep = dlsym(RTLD_DEFAULT, "__asan_init") ? 0 : RTLD_DEEPBIND;
+    const int deep = (dlsym(RTLD_DEFAULT, "__asan_init") || dlsym(RTLD_DEFAULT, "__tsan_init") || dlsym(RTLD_DEFAULT, "__msan_init")) ? 0 : RTLD_DEEPBIND;
     void* h = dlopen(p, RTLD_NOW | RTLD_LOCAL | deep);
     if (!h) return -1;
     Z.h = h;

@@ -363,6 +363,36 @@ static void backendTests(bool full) {
         exp.resize(m);
         CHECK(c0 == exp);                                                                            // ciphertext + tag bit-exact vs the oracle
     });
+    // read-ahead: batch k + 1 is on the device while the consumer drains batch k - same chunks, same IV order, same CRC list, the
+    // same chunk index; a failure in batch k + 1 surfaces only after batch k has been handed out; an enumeration dropped with its
+    // helper still running goes away cleanly
+    run("GpuTransformChunkEnumeration read-ahead: same object, same index, failures in order", [&] {
+        for (int mode = 1; mode < 4; mode++) {
+            const bool comp = (mode & 1) != 0, enc = (mode & 2) != 0;
+            auto make = [&](bool ahead) {
+                return std::make_shared<GpuTransformChunkEnumeration>(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), 4096 + 3), comp,
+                    enc ? std::optional<DataKeyAndAAD>(DataKeyAndAAD{KEY, AAD}) : std::nullopt, countingIv(), 5, true, TSX_ZSTD_PROFILE_1_5_7, ahead);
+            };
+            auto a = make(false), b = make(true);
+            TransformFinisher fa(a, (int)text.size()), fb(b, (int)text.size());
+            CHECK(fa.toBytes() == fb.toBytes());
+            CHECK(a->crc32cOfOriginalChunks() == b->crc32cOfOriginalChunks() && !a->crc32cOfOriginalChunks().empty());
+            auto ia = fa.chunkIndex(), ib = fb.chunkIndex();
+            CHECK(ia->chunks().size() == ib->chunks().size());
+            for (size_t i = 0; i < ia->chunks().size(); i++) CHECK(ia->chunks()[i].transformedSize == ib->chunks()[i].transformedSize);
+        }
+        auto n = std::make_shared<int>(0);
+        IvSupplier failing = [n](uint8_t iv[12]) { if ((*n)++ == 4) throw std::runtime_error("entropy source failed"); memset(iv, 7, 12); };
+        GpuTransformChunkEnumeration e(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), 4096), false, DataKeyAndAAD{KEY, AAD}, failing, 3, false,
+                                       TSX_ZSTD_PROFILE_1_5_7, true);
+        for (int i = 0; i < 3; i++) { CHECK(e.hasMoreElements()); CHECK(e.nextElement().size() == 4096 + 28); }     // batch 0 (IVs 0..2) is whole
+        expectThrows<std::runtime_error>([&] { e.hasMoreElements(); }, "entropy source failed");                   // batch 1 (IV 4) is not
+        {
+            GpuTransformChunkEnumeration dropped(be, std::make_shared<BaseTransformChunkEnumeration>(stream(text), 4096), true, DataKeyAndAAD{KEY, AAD}, countingIv(), 4, false,
+                                                 TSX_ZSTD_PROFILE_1_5_7, true);
+            CHECK(dropped.nextElement().size() > 28);                                                               // the helper is working on batch 1 now
+        }
+    });
     run("full chain bytes == oracle chain (Zstd frame + GCM) for the supplier's IVs", [&] {
         if (std::string(orc_zstd_version()).rfind("1.5.7", 0) != 0) { printf("    (skipped: libzstd 1.5.7 not available)\n"); return; }
         const int cs = full ? 1 << 20 : 20000;

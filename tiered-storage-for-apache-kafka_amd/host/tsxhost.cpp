@@ -454,9 +454,9 @@ Bytes BaseTransformChunkEnumeration::nextElement() {
 }
 
 GpuTransformChunkEnumeration::GpuTransformChunkEnumeration(std::shared_ptr<Backend> be, std::shared_ptr<TransformChunkEnumeration> inner, bool compress,
-                                                           std::optional<DataKeyAndAAD> enc, IvSupplier iv, int batchChunks, bool withCrc, uint32_t profile)
+                                                           std::optional<DataKeyAndAAD> enc, IvSupplier iv, int batchChunks, bool withCrc, uint32_t profile, bool readAhead)
     : be_(std::move(be)), inner_(std::move(inner)), compress_(compress), enc_(std::move(enc)), iv_(std::move(iv)), batch_(batchChunks), withCrc_(withCrc),
-      profile_(profile) {
+      profile_(profile), readAhead_(readAhead) {
     if (!inner_) throw std::invalid_argument("inner cannot be null");
     if (batch_ < 1) throw std::invalid_argument("batchChunks must be positive");
     if (enc_ && enc_->dataKey.size() != 32) throw std::invalid_argument("AES-256 data key must be 32 bytes");
@@ -465,15 +465,17 @@ GpuTransformChunkEnumeration::GpuTransformChunkEnumeration(std::shared_ptr<Backe
     if (compress_ || !innerSize) transformedChunkSize_ = std::nullopt;
     else transformedChunkSize_ = enc_ ? *innerSize + IV_SIZE + GCM_TAG_BYTES : *innerSize;
 }
+GpuTransformChunkEnumeration::~GpuTransformChunkEnumeration() {
+    if (ahead_.valid()) { try { ahead_.get(); } catch (...) {} }       // the helper uses this object: it is gone before the members are
+}
 
-void GpuTransformChunkEnumeration::fillBatchIfNeeded() {
-    if (next_ < ready_.size()) return;
-    ready_.clear(); next_ = 0;
+GpuTransformChunkEnumeration::Batch GpuTransformChunkEnumeration::transformNextBatch() {
+    Batch out;
     std::vector<Bytes> in;
     while ((int)in.size() < batch_ && inner_->hasMoreElements()) in.push_back(inner_->nextElement());
-    if (in.empty()) return;
+    if (in.empty()) return out;
     const uint32_t flags = (compress_ ? TSX_COMPRESS : 0u) | (enc_ ? TSX_ENCRYPT : 0u) | (withCrc_ ? TSX_CRC : 0u);
-    if ((flags & (TSX_COMPRESS | TSX_ENCRYPT)) == 0 && !withCrc_) { ready_ = std::move(in); return; }     // pure base: nothing to do
+    if ((flags & (TSX_COMPRESS | TSX_ENCRYPT)) == 0 && !withCrc_) { out.chunks = std::move(in); return out; }     // pure base: nothing to do
     std::vector<tsx_chunk_desc> d(in.size());
     size_t so = 0, dofs = 0;
     for (size_t i = 0; i < in.size(); i++) {
@@ -489,12 +491,24 @@ void GpuTransformChunkEnumeration::fillBatchIfNeeded() {
     be_->transformBatch(p, d, src.data(), dst.data(), dst.size());
     for (size_t i = 0; i < in.size(); i++) {
         if (d[i].status != TSX_OK) throw std::runtime_error(be_->strerror(d[i].status));        // the reference wraps crypto failures in RuntimeException
-        if (withCrc_) crcs_.push_back(d[i].crc32c);
-        ready_.emplace_back(dst.begin() + (long)d[i].dst_off, dst.begin() + (long)(d[i].dst_off + d[i].dst_len));
+        if (withCrc_) out.crcs.push_back(d[i].crc32c);
+        out.chunks.emplace_back(dst.begin() + (long)d[i].dst_off, dst.begin() + (long)(d[i].dst_off + d[i].dst_len));
     }
+    return out;
+}
+
+void GpuTransformChunkEnumeration::fillBatchIfNeeded() {
+    if (next_ < ready_.size() || exhausted_) return;
+    ready_.clear(); next_ = 0;
+    // the batch the helper has been working on (its failure surfaces here, where its first chunk is asked for), else a fresh one
+    Batch b = ahead_.valid() ? ahead_.get() : transformNextBatch();
+    if (b.chunks.empty()) { exhausted_ = true; return; }
+    ready_ = std::move(b.chunks);
+    crcs_.insert(crcs_.end(), b.crcs.begin(), b.crcs.end());
+    if (readAhead_) ahead_ = std::async(std::launch::async, [this] { return transformNextBatch(); });
 }
 size_t GpuTransformChunkEnumeration::appendNextBatchPacked(Bytes& object, std::vector<int>& sizes) {
-    if (next_ < ready_.size()) throw std::logic_error("appendNextBatchPacked after nextElement inside a batch");
+    if (next_ < ready_.size() || ahead_.valid()) throw std::logic_error("appendNextBatchPacked after nextElement inside a batch");
     std::vector<Bytes> in;
     while ((int)in.size() < batch_ && inner_->hasMoreElements()) in.push_back(inner_->nextElement());
     if (in.empty()) return 0;

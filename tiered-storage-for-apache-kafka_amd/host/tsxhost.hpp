@@ -18,6 +18,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <future>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -239,9 +240,14 @@ private:
 // them out in order.  transformedChunkSize(): unknown when compressing, else inner + 28 when encrypting.
 class GpuTransformChunkEnumeration : public TransformChunkEnumeration {
 public:
+    // readAhead: while the consumer drains batch k (TransformFinisher hands its chunks to the uploader one by one), batch k + 1 is
+    // already read from `inner` and on the device (one helper thread per enumeration; chunks, IVs and failures keep their order).
+    // An upload thread then keeps two batches in flight instead of one and its uploads overlap the device - what keeps a GPU
+    // fed by a handful of threads ("stragglers").  Off: `inner` is read exactly when the reference would read it.
     GpuTransformChunkEnumeration(std::shared_ptr<Backend> backend, std::shared_ptr<TransformChunkEnumeration> inner, bool compress,
                                  std::optional<DataKeyAndAAD> encryption, IvSupplier ivSupplier = secureRandomIvSupplier(),
-                                 int batchChunks = 64, bool withCrc = false, uint32_t zstdProfile = TSX_ZSTD_PROFILE_1_5_7);
+                                 int batchChunks = 64, bool withCrc = false, uint32_t zstdProfile = TSX_ZSTD_PROFILE_1_5_7, bool readAhead = false);
+    ~GpuTransformChunkEnumeration() override;
     int originalChunkSize() const override { return inner_->originalChunkSize(); }
     std::optional<int> transformedChunkSize() const override { return transformedChunkSize_; }
     bool hasMoreElements() override;
@@ -254,6 +260,8 @@ public:
     size_t appendNextBatchPacked(Bytes& object, std::vector<int>& sizes);
 
 private:
+    struct Batch { std::vector<Bytes> chunks; std::vector<uint32_t> crcs; };
+    Batch transformNextBatch();                        // pulls up to batch_ chunks from inner_; empty when inner_ is exhausted
     void fillBatchIfNeeded();
     std::shared_ptr<Backend> be_;
     std::shared_ptr<TransformChunkEnumeration> inner_;
@@ -263,10 +271,13 @@ private:
     int batch_;
     bool withCrc_;
     uint32_t profile_;
+    bool readAhead_;
     std::optional<int> transformedChunkSize_;
     std::vector<Bytes> ready_;
     size_t next_ = 0;
     std::vector<uint32_t> crcs_;
+    std::future<Batch> ahead_;                         // the batch behind ready_, being transformed (readAhead_); the only toucher of inner_ while valid
+    bool exhausted_ = false;
 };
 
 class TransformFinisher {
