@@ -37,6 +37,20 @@ def test_host_chain_over_emulated_kernels(host_tests, emu):
     assert "SegmentManifestV1SerdeTest" in out and "GpuChunkCache" in out
 
 
+def test_host_layer_threads_under_thread_sanitizer(host_tests, emu):
+    """GpuChunkCache (helper threads, joined batches, eviction) and the read-ahead helper of GpuTransformChunkEnumeration over the
+    emulated kernels, ThreadSanitizer build: no data race reported, every test still passes."""
+    tsan = subprocess.run(["gcc", "-print-file-name=libtsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(tsan) and os.path.exists(tsan)):
+        pytest.skip("no libtsan in this toolchain")
+    subprocess.check_call(["make", "-s", "-C", HOST_DIR, "tsan"])
+    from tests.emu import emu_native
+    p = subprocess.run([BIN + "_tsan", "backend", emu_native.EMU_LIB], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       env=dict(os.environ, TSX_ALLOW_ANY_ARCH="1", TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+    assert "WARNING: ThreadSanitizer" not in p.stdout, p.stdout[-6000:]
+    assert p.returncode == 0 and " 0 failed" in p.stdout and "read-ahead" in p.stdout and "GpuChunkCache" in p.stdout, p.stdout[-4000:]
+
+
 @pytest.mark.gpu
 def test_host_chain_on_gpu(host_tests):
     import tsxform
