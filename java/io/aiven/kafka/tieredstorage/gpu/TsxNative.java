@@ -106,6 +106,24 @@ public final class TsxNative {
             descs = grow(descs, (long) n * DESC_BYTES, false);
             return descs;
         }
+
+        /**
+         * For a thread that is about to end (the broker's upload / fetch threads and the read-ahead helpers never do): the
+         * pinning must be undone before the garbage collector frees the buffers' memory.
+         */
+        public static void release() {
+            final Buffers b = LOCAL.get();
+            if (b.src != null) {
+                hostUnregister(b.src);
+            }
+            if (b.dst != null) {
+                hostUnregister(b.dst);
+            }
+            b.src = null;
+            b.dst = null;
+            b.descs = null;
+            LOCAL.remove();
+        }
     }
 
     /** tsx_transformed_bound. */
