@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--verify-chunks", type=int, default=64, help="chunks compared byte for byte with the oracle after the timed region")
+    ap.add_argument("--gather-object", action="store_true",
+                    help="with --split-segments: rank 0 (the owner of the upload stream) also receives every rank's slice of the transformed object inside the step (send / recv)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the continuously-fed measurement (5 callers, 10 batches each) after the timed region")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host->host (PCIe-inclusive) measurement after the timed region")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
@@ -173,6 +175,7 @@ def main():
     ds = [d] + [d.copy() for _ in range(T - 1)]
     ctx = ctxs[0]
     index = {}                                           # split mode: per segment (sizes, positions, base) after the exchange
+    objects = {}                                         # split mode with --gather-object: the whole transformed object of each segment, on rank 0
 
     def step(t=0):
         if n:
@@ -187,6 +190,11 @@ def main():
             for s_, (lo, hi) in zip(range(nseg), ranges):
                 index[s_] = shard.exchange_transformed_sizes(ds[t]["dst_len"][at:at + hi - lo], cps, rank, world, dist if world > 1 else None,
                                                              device="cpu" if args.backend == "gloo" else dev)
+                if args.gather_object:
+                    # the optional second exchange: this rank's slice, packed, straight into its place on the owner rank
+                    mine = shard.pack_slice(dsts[t], ds[t]["dst_off"][at:at + hi - lo], ds[t]["dst_len"][at:at + hi - lo])
+                    objects[s_] = shard.gather_object_to_owner(mine, index[s_][0], cps, rank, world, 0, dist if world > 1 else None,
+                                                               device="cpu" if args.backend == "gloo" else dev)
                 at += hi - lo
 
     def fence():
@@ -563,6 +571,8 @@ def main():
                        "segments_of_rank0": [int(x) for x in my_segments], "chunks_of_rank0": n,
                        "chunk_index_positions_sha": None if not index else __import__("hashlib").sha256(
                            b"".join(np.asarray(index[k][1], np.int64).tobytes() for k in sorted(index))).hexdigest()[:16],
+                       "object_gathered_on_rank0_sha": None if not objects else __import__("hashlib").sha256(
+                           b"".join((objects[k].cpu().numpy() if hasattr(objects[k], "cpu") else np.asarray(objects[k])).tobytes() for k in sorted(objects))).hexdigest()[:16],
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
                        "verified_chunks_vs_oracle": verified},
             "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "end_to_end": e2e, "detransform": inverse,

@@ -51,7 +51,7 @@ def test_one_segment_split_over_two_ranks(emu, oracle):
         pytest.skip("libzstd 1.5.7 not available")
     from tsxform import synth
     CH, cps = 20000, 5
-    j = _launch(2, ["--chunk-bytes", str(CH), "--chunks-per-segment", str(cps), "--segments", "1", "--split-segments"])
+    j = _launch(2, ["--chunk-bytes", str(CH), "--chunks-per-segment", str(cps), "--segments", "1", "--split-segments", "--gather-object"])
     c = j["config"]
     assert j["scaling"] == "strong" and c["segments_total"] == 1 and c["chunks_of_rank0"] == 2 and "chunk-range split" in c["parallelism"]
     assert abs(j["value"] - cps * CH / 2**30 / (j["ms_per_step"] * 1e-3)) <= 5.1e-5 + 1e-3 * j["value"]          # the job is ONE segment
@@ -60,6 +60,8 @@ def test_one_segment_split_over_two_ranks(emu, oracle):
              for k in range(cps)]
     pos = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
     assert c["chunk_index_positions_sha"] == hashlib.sha256(pos.tobytes()).hexdigest()[:16]     # rank 0 holds the whole chunk index
+    whole = b"".join(oracle.transform_chunk(of, synth.KEY, synth.AAD, synth.iv_for(0, k), synth.gen_chunk("K", 1000, 0, k, CH).tobytes())[0] for k in range(cps))
+    assert c["object_gathered_on_rank0_sha"] == hashlib.sha256(whole).hexdigest()[:16]          # ... and, with --gather-object, the whole .log object
     assert j["detransform"]["round_trip_exact"] is True
 
 

@@ -45,6 +45,14 @@ def _rank_main(rank, world, port, n_chunks, chunk_size, tmpdir):
     all_sizes, positions, base = shard.exchange_transformed_sizes(d["dst_len"], n_chunks, rank, world, dist)
     mine = b"".join(dst[doff[i]:doff[i] + d["dst_len"][i]].tobytes() for i in range(hi - lo))
     assert base == positions[lo] if hi > lo else True
+    # the optional second exchange: the owner of the upload stream (rank 0) receives the other slices in place
+    packed = shard.pack_slice(dst, [doff[i] for i in range(hi - lo)], d["dst_len"])
+    assert packed.tobytes() == mine
+    obj = shard.gather_object_to_owner(packed, all_sizes, n_chunks, rank, world, 0, dist)
+    assert (obj is None) == (rank != 0)
+    if rank == 0:
+        with open(os.path.join(tmpdir, "object.bin"), "wb") as f:
+            f.write(obj.numpy().tobytes())
     np.save(os.path.join(tmpdir, "sizes_%d.npy" % rank), all_sizes)
     with open(os.path.join(tmpdir, "slice_%d.bin" % rank), "wb") as f:
         f.write(base.to_bytes(8, "little") + mine)
@@ -71,6 +79,7 @@ def test_two_ranks_split_a_segment_and_agree_on_the_chunk_index(oracle, emu, tmp
         base = int.from_bytes(raw[:8], "little")
         obj[base:base + len(raw) - 8] = raw[8:]                                      # slices land at their exchanged bases
     assert bytes(obj) == b"".join(expected)
+    assert (tmp_path / "object.bin").read_bytes() == b"".join(expected)               # ... and the owner rank holds exactly that object
 
 
 def test_partition_helpers():

@@ -49,3 +49,49 @@ def exchange_transformed_sizes(local_sizes, n_chunks: int, rank: int, world: int
         sizes = np.concatenate(parts).astype(np.int64)
     positions = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
     return sizes, positions, int(positions[lo]) if hi > lo else int(sizes.sum())
+
+
+def pack_slice(dst, dst_offs, dst_lens):
+    """This rank's transformed chunks back to back - its contiguous slice of the .log object - from the slotted output buffer
+    (torch tensor on the device, or numpy array): one narrow copy per chunk, no host round trip for device tensors."""
+    lens = [int(x) for x in dst_lens]
+    total = sum(lens)
+    if isinstance(dst, np.ndarray):
+        out = np.empty(total, np.uint8)
+        at = 0
+        for o, n in zip(dst_offs, lens):
+            out[at:at + n] = dst[int(o):int(o) + n]; at += n
+        return out
+    import torch
+    out = torch.empty(total, dtype=torch.uint8, device=dst.device)
+    at = 0
+    for o, n in zip(dst_offs, lens):
+        out[at:at + n] = dst[int(o):int(o) + n]; at += n
+    return out
+
+
+def gather_object_to_owner(my_slice, sizes, n_chunks: int, rank: int, world: int, owner: int = 0, dist=None, device="cpu"):
+    """The optional second exchange of a split segment: the rank that owns the upload stream receives every other rank's
+    slice straight into its place in the transformed object (point-to-point send / recv - RCCL over xGMI on GPUs, gloo in the CPU
+    tests; the object is the concatenation of the chunks in id order, AbstractChunkIndex.java:52-72).  `sizes` is the all-gathered
+    size list of exchange_transformed_sizes.  Returns the whole object (uint8 tensor) on `owner`, None elsewhere."""
+    import torch
+    sizes = np.asarray(sizes, dtype=np.int64)
+    bounds = [chunk_range_of_rank(n_chunks, r, world) for r in range(world)]
+    slice_bytes = [int(sizes[a:b].sum()) for a, b in bounds]
+    bases = np.concatenate([[0], np.cumsum(slice_bytes)[:-1]]).astype(np.int64)
+    mine = my_slice if isinstance(my_slice, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(my_slice)).to(device)
+    assert mine.numel() == slice_bytes[rank], (mine.numel(), slice_bytes[rank])
+    if world == 1:
+        return mine
+    if rank != owner:
+        if slice_bytes[rank]:
+            dist.send(mine.contiguous(), dst=owner)
+        return None
+    obj = torch.empty(int(sizes.sum()), dtype=torch.uint8, device=mine.device)
+    obj[int(bases[rank]):int(bases[rank]) + slice_bytes[rank]] = mine
+    for r in range(world):
+        if r == owner or slice_bytes[r] == 0:
+            continue
+        dist.recv(obj[int(bases[r]):int(bases[r]) + slice_bytes[r]], src=r)        # a contiguous view: received in place
+    return obj
