@@ -30,6 +30,9 @@
 #define ORC_STAT_IMMREP() do {} while (0)
 #define ORC_STAT_CAND(isLong, inwin, dist, eq) do {} while (0)
 #endif
+#ifndef ORC_TRACE           /* table-access trace of the parse (tools/stats/step_sim.c); no-op in the oracle build */
+#define ORC_TRACE(kind, a, b, c) do {} while (0)
+#endif
 
 typedef uint8_t BYTE; typedef uint16_t U16; typedef uint32_t U32; typedef uint64_t U64; typedef int64_t S64;
 
@@ -188,6 +191,7 @@ static size_t compressBlock_doubleFast(matchstate_t* ms, seqstore_t* ss, U32 rep
     if (srcSize < HASH_READ_SIZE) goto _cleanup;   /* ilimit would precede istart: nothing searchable */
     while (1) {
         step = 1; nextStep = ip + kStepIncr; ip1 = ip + step;
+        ORC_TRACE('R', (U32)(ip - base), 0, 0);
         if (ip1 > ilimit) goto _cleanup;
         hl0 = hashPtr(ip, hBitsL, 8); idxl0 = hashLong[hl0]; matchl0 = base + idxl0;
         do {
@@ -197,12 +201,14 @@ static size_t compressBlock_doubleFast(matchstate_t* ms, seqstore_t* ss, U32 rep
             matchs0 = base + idxs0;
             hashLong[hl0] = hashSmall[hs0] = curr;
             ORC_STAT_VISIT();
+            ORC_TRACE('V', curr, (U32)hl0, (U32)hs0);
             ORC_STAT_CAND(1, idxl0 >= prefixLowestIndex, (U32)(ip - matchl0), idxl0 >= prefixLowestIndex && rd64(matchl0) == rd64(ip));
             ORC_STAT_CAND(0, idxs0 >= prefixLowestIndex, (U32)(ip - matchs0), idxs0 >= prefixLowestIndex && rd32(matchs0) == rd32(ip));
             if ((offset_1 > 0) & (rd32(ip + 1 - offset_1) == rd32(ip + 1))) {
                 mLength = count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
                 ip++;
                 ORC_STAT_EVENT(1, offset_1);
+                ORC_TRACE('E', 1, offset_1, (U32)mLength);
                 storeSeq(ss, (size_t)(ip - anchor), anchor, 1 /* REPCODE1_TO_OFFBASE */, mLength);
                 goto _match_stored;
             }
@@ -214,6 +220,7 @@ static size_t compressBlock_doubleFast(matchstate_t* ms, seqstore_t* ss, U32 rep
                     mLength = count(ip + 8, matchl0 + 8, iend) + 8;
                     offset = (U32)(ip - matchl0);
                     ORC_STAT_EVENT(2, offset);
+                    ORC_TRACE('E', 2, offset, (U32)mLength);
                     while (((ip > anchor) & (matchl0 > prefixLowest)) && (ip[-1] == matchl0[-1])) { ip--; matchl0--; mLength++; }
                     goto _match_found;
                 }
@@ -237,13 +244,13 @@ _search_next_long:
         offset = (U32)(ip - matchs0);
         if ((idxl1 >= prefixLowestIndex) && (rd64(matchl1) == rd64(ip1))) {
             size_t const l1len = count(ip1 + 8, matchl1 + 8, iend) + 8;
-            if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (U32)(ip - matchl1); matchs0 = matchl1; ORC_STAT_EVENT(4, offset); }
-            else ORC_STAT_EVENT(3, offset);
-        } else ORC_STAT_EVENT(3, offset);
+            if (l1len > mLength) { ip = ip1; mLength = l1len; offset = (U32)(ip - matchl1); matchs0 = matchl1; ORC_STAT_EVENT(4, offset); ORC_TRACE('E', 4, offset, (U32)mLength); }
+            else { ORC_STAT_EVENT(3, offset); ORC_TRACE('E', 3, offset, (U32)mLength); }
+        } else { ORC_STAT_EVENT(3, offset); ORC_TRACE('E', 3, offset, (U32)mLength); }
         while (((ip > anchor) & (matchs0 > prefixLowest)) && (ip[-1] == matchs0[-1])) { ip--; matchs0--; mLength++; }
 _match_found:
         offset_2 = offset_1; offset_1 = offset;
-        if (step < 4) hashLong[hl1] = (U32)(ip1 - base);
+        if (step < 4) { hashLong[hl1] = (U32)(ip1 - base); ORC_TRACE('1', (U32)(ip1 - base), (U32)hl1, 0); }
         storeSeq(ss, (size_t)(ip - anchor), anchor, offset + ZSTD_REP_NUM, mLength);
 _match_stored:
         ip += mLength; anchor = ip;
@@ -253,6 +260,8 @@ _match_stored:
                 hashLong[hashPtr(ip - 2, hBitsL, 8)] = (U32)(ip - 2 - base);
                 hashSmall[hashPtr(base + indexToInsert, hBitsS, mls)] = indexToInsert;
                 hashSmall[hashPtr(ip - 1, hBitsS, mls)] = (U32)(ip - 1 - base);
+                ORC_TRACE('C', indexToInsert, (U32)hashPtr(base + indexToInsert, hBitsL, 8), (U32)hashPtr(base + indexToInsert, hBitsS, mls));
+                ORC_TRACE('D', (U32)(ip - base), (U32)hashPtr(ip - 2, hBitsL, 8), (U32)hashPtr(ip - 1, hBitsS, mls));
             }
             while ((ip <= ilimit) && ((offset_2 > 0) & (rd32(ip) == rd32(ip - offset_2)))) {
                 size_t const rLength = count(ip + 4, ip + 4 - offset_2, iend) + 4;
@@ -260,6 +269,7 @@ _match_stored:
                 hashSmall[hashPtr(ip, hBitsS, mls)] = (U32)(ip - base);
                 hashLong[hashPtr(ip, hBitsL, 8)] = (U32)(ip - base);
                 ORC_STAT_IMMREP();
+                ORC_TRACE('I', (U32)(ip - base), (U32)hashPtr(ip, hBitsL, 8), (U32)hashPtr(ip, hBitsS, mls));
                 storeSeq(ss, 0, anchor, 1, rLength);
                 ip += rLength; anchor = ip;
             }

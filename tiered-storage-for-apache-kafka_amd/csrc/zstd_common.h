@@ -21,17 +21,8 @@ struct tsx_zstd_consts { uint32_t abi; uint32_t pad[3]; };
 struct zs_seq { uint32_t offBase, litLength, mlBase, litPos; };   /* litPos: chunk offset of the literal run (encoder) */
 
 // ---- per-chunk workspace (global memory) --------------------------------------------------------------
-// ZS_LONG32: an entry of the long table is 32 bytes - libzstd's index word (+ tag) followed by the 28 bytes [p - 4, p + 24) of the
-// chunk around the position.  A probe then brings the candidate's bytes with it (same 32-byte sector, same line request) and the
-// match is verified and extended in registers: 94 % of the far matches of log-like content are <= 24 bytes, so the second
-// dependent HBM round trip of most sequences disappears.  Costs capacity only (4 MiB instead of 512 KiB per chunk: 288 GB of HBM
-// is what this chip has plenty of); the bucket geometry, i.e. what the parse sees, is unchanged.
-#ifndef ZS_LONG32
-#define ZS_LONG32 0
-#endif
-#define ZS_LONG_ENTRY_WORDS (ZS_LONG32 ? 8u : 1u)
-#define ZS_WS_HASHLONG 0u                                             /* u32[1 << 17] x entry words         */
-#define ZS_WS_HASHSMALL (ZS_WS_HASHLONG + (4u << 17) * ZS_LONG_ENTRY_WORDS) /* u32[1 << 16]                 */
+#define ZS_WS_HASHLONG 0u                                             /* u32[1 << 17]                       */
+#define ZS_WS_HASHSMALL (ZS_WS_HASHLONG + (4u << 17))                 /* u32[1 << 16]                       */
 #define ZS_WS_SEQS (ZS_WS_HASHSMALL + (4u << 16))                     /* zs_seq[ZS_MAX_SEQ + 64]            */
 #define ZS_WS_LIT (ZS_WS_SEQS + 16u * (ZS_MAX_SEQ + 64))              /* literals of the current block      */
 #define ZS_WS_CODES (ZS_WS_LIT + ZS_BLOCK_MAX + 256)                  /* llCode | ofCode | mlCode           */

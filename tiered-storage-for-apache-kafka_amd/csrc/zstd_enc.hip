@@ -9,15 +9,14 @@
 //
 //  * Match finding is an inherently serial greedy parse (every decision updates two hash tables and the repcode
 //    history), so parallelism inside a chunk is SPECULATION: the wave evaluates K consecutive search positions at once
-//    (K = 8, doubling to 63 while nothing matches) — each lane hashes its position, probes both tables (global memory:
-//    512 KiB + 256 KiB per chunk cannot shrink into LDS without changing the output), sees the insertions EARLIER lanes
-//    of the same step would have made (LDS scoreboard detects shared buckets, lane broadcasts resolve them), checks its
-//    candidates and classifies repcode / long / short match.  A ballot picks the first lane with a match — everything
-//    before it is exactly what the serial loop would have done — its table inserts are committed and the match is
-//    extended with wave-wide 8-byte compares.
+//    (K = 4 after a match, then 32, then 59 while nothing matches) - each lane hashes its position and probes both tables
+//    (global memory: 512 KiB + 256 KiB per chunk cannot shrink into LDS without changing the output); a step whose lanes
+//    share a bucket is cut in front of the second one (LDS scoreboard), a ballot picks the first lane with a match -
+//    everything before it is exactly what the serial loop would have done - its table inserts are committed and the match
+//    is verified and extended with one wave-wide 64-byte compare.
 //  * A dependent global round trip costs a wave 1300-2000 cycles here, so the parser never reads global memory for bytes
 //    near ip (LDS ring of the chunk around ip), never reads a candidate that cannot match (tags in the table entries),
-//    fetches a far candidate together with the 48 bytes both extensions need, and keeps its state in SGPRs.
+//    verifies a far candidate and runs both extensions in one round trip, and keeps its state in SGPRs.
 //  * Chunks are independent (fresh context per chunk in the reference); the kernel is latency bound per chunk and
 //    HBM-random-access bound in aggregate, so it is shaped for residency: 80 VGPRs, 6.5 KiB LDS (parse-stage and
 //    entropy-stage LDS alias), and callers keep several batches in flight.
@@ -187,7 +186,6 @@ struct EncLds {
         struct {                // parse stage of a block (re-primed per block): source window + collision scoreboard
             uint32_t ring[ZS_RING / 4 + 4];     // + 16-byte mirror of the first bytes
             uint8_t scr[2 * ZS_SCR];
-            alignas(16) uint8_t fwbuf[96];      // two far windows of 48 bytes (winner, long candidate at +1)
         } p;
         struct {                // GCM tail over the finished frame (gcm_encrypt_wave)
             tsx_gf128 tab[256];
@@ -263,30 +261,19 @@ template <class SP> __device__ __forceinline__ static void win_ensure(SP src, ui
     while (ip + ZS_SAFE > w.hi && w.hi < srcCeil) win_append(src, lastPiece, ring, w, lane);
 }
 
-// A match candidate older than the ring costs one global round trip to verify; its extension (forward and backward) would
-// cost two more.  So a lane probing such a candidate loads 48 bytes around it at once ([p - 16, p + 32)); the winner parks
-// them in a small LDS "far window" and the extension compares ring bytes against it.
-struct FarWin { uint32_t lo, hi; const uint8_t* buf; };   // chunk bytes [lo, hi) at buf[0 ..); lo == hi: none (wave-uniform)
-__device__ static inline uint64_t far8(const FarWin fw, uint32_t p) { uint64_t v; __builtin_memcpy(&v, fw.buf + (p - fw.lo), 8); return v; }
-
-// number of equal bytes of src[a..] and src[b..] (b < a), not reading a-side bytes at or beyond iend
-__device__ static uint32_t wave_count(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, const FarWin fw, uint32_t a, uint32_t b,
-                                      uint32_t iend, uint32_t lane) {
-    uint32_t total = 0, width = 8;
-    if (b >= fw.lo && b + 8 <= fw.hi) width = (fw.hi - b) >> 3;      // first pass: what the far window holds
+// number of equal bytes of src[a..] and src[b..] (b < a), not reading a-side bytes at or beyond iend: the continuation of a
+// match beyond the 64 bytes the step's first comparison covers (rare; 64 lanes x 8 bytes per pass)
+__device__ static uint32_t wave_count(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, uint32_t a, uint32_t b, uint32_t iend, uint32_t lane) {
+    uint32_t total = 0;
     for (;;) {
         const uint32_t off = total + 8 * lane;
-        const bool active = lane < width;
         uint32_t n = 8;
-        if (a + total + 8 * width <= iend) {                         // every active lane compares 8 whole bytes
-            uint64_t x = 0;
-            const bool aRing = a + total >= w.lo && a + total + 8 * width <= w.hi;
-            const uint32_t o = active ? off : total;
-            if (aRing && b + total >= w.lo) x = ring8(ring, a + o) ^ ring8(ring, b + o);
-            else if (aRing && b + total >= fw.lo && b + total + 8 * width <= fw.hi) x = ring8(ring, a + o) ^ far8(fw, b + o);
-            else { PCNT(21, 1); if (active) x = ld64(src + a + off) ^ ld64(src + b + off); }
-            if (active) n = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
-        } else if (active) {
+        if (a + total + 8 * LANES <= iend) {                         // every lane compares 8 whole bytes
+            uint64_t x;
+            if (a + total >= w.lo && a + total + 8 * LANES <= w.hi && b + total >= w.lo) x = ring8(ring, a + off) ^ ring8(ring, b + off);
+            else { PCNT(21, 1); x = ld64(src + a + off) ^ ld64(src + b + off); }
+            n = x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8;
+        } else {
             const uint32_t avail = (a + off < iend) ? iend - (a + off) : 0;
             if (avail >= 8) {
                 uint64_t x = ld64(src + a + off) ^ ld64(src + b + off);
@@ -296,37 +283,31 @@ __device__ static uint32_t wave_count(const uint8_t* __restrict__ src, const uin
                 while (n < avail && src[a + off + n] == src[b + off + n]) n++;
             }
         }
-        const unsigned long long m = __ballot(active && n < 8);
+        const unsigned long long m = __ballot(n < 8);
         if (m) {
             const int fl = __ffsll((long long)m) - 1;
             return total + 8 * (uint32_t)fl + __builtin_amdgcn_readlane(n, fl);
         }
-        total += 8 * width;
-        width = LANES;
+        total += 8 * LANES;
     }
 }
 
 // backward extension: while (ip > anchor && match > low && src[ip-1] == src[match-1])
-__device__ static uint32_t wave_count_back(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, const FarWin fw, uint32_t ip, uint32_t match,
-                                           uint32_t anchor, uint32_t low, uint32_t lane) {
+__device__ static uint32_t wave_count_back(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, uint32_t ip, uint32_t match, uint32_t anchor,
+                                           uint32_t low, uint32_t lane) {
     uint32_t lim = ip - anchor;
     if (match - low < lim) lim = match - low;
     if (lim == 0) return 0;
-    uint32_t done = 0, width = LANES;
-    if (match > fw.lo && match <= fw.hi) width = match - fw.lo;      // first pass: the bytes the far window holds below the match
+    uint32_t done = 0;
     for (;;) {
         const uint32_t i = done + lane;
-        const bool active = lane < width;
         bool ok = i < lim;
-        const uint32_t j = (ok && active) ? i : done;
-        const bool aRing = ip <= w.hi && ip - done >= w.lo + width;
-        if (aRing && match - done >= w.lo + width) ok = ok && ring1(ring, ip - 1 - j) == ring1(ring, match - 1 - j);
-        else if (aRing && match - done <= fw.hi && match - done >= fw.lo + width) ok = ok && ring1(ring, ip - 1 - j) == fw.buf[match - 1 - j - fw.lo];
-        else if (active) ok = ok && src[ip - 1 - i] == src[match - 1 - i];
-        const unsigned long long m = __ballot(active && !ok);
+        const uint32_t j = ok ? i : done;
+        if (ip <= w.hi && ip - done >= w.lo + LANES && match - done >= w.lo + LANES) ok = ok && ring1(ring, ip - 1 - j) == ring1(ring, match - 1 - j);
+        else ok = ok && src[ip - 1 - i] == src[match - 1 - i];
+        const unsigned long long m = __ballot(!ok);
         if (m) return done + (uint32_t)(__ffsll((long long)m) - 1);
-        done += width;
-        width = LANES;
+        done += LANES;
     }
 }
 
@@ -334,290 +315,13 @@ struct MfState { uint32_t nbSeq, litSize, lastLL, anchor; };
 
 // The parser keeps the literals where they are: a sequence records where its literal run starts in the chunk and the
 // entropy stage gathers them with all lanes (gather_literals) instead of copying on the serial critical path.
-__device__ static inline void store_seq(zs_seq* __restrict__ seqs, MfState& s, uint32_t litLen, uint32_t litPos, uint32_t offBase,
-                                        uint32_t mlen, uint32_t lane) {
-    if (lane == 0) { zs_seq q; q.offBase = offBase; q.litLength = litLen; q.mlBase = mlen - 3; q.litPos = litPos; seqs[s.nbSeq] = q; }
-    s.litSize += litLen; s.nbSeq++;
-}
-
-#ifndef ZS_PARSER
-#define ZS_PARSER 2           /* 1: first form of the parser (match_block), 2: match_block2 */
-#endif
-#ifndef ZS_W0
-#define ZS_W0 8u              /* first speculation width of a search run */
-#endif
 
 // ---------------------------------------------------------------------------------------------------
-// double-fast match finder for one block (ZSTD_compressBlock_doubleFast_noDict_generic, speculative form)
-// all "positions" are offsets within the chunk; table values are libzstd's indices = position + 2.
-// rep[] updated as the serial code does.  Everything that is the same for all lanes (ip, anchor, offsets, step...) is
-// derived from ballots / readlanes so it lives in SGPRs and the control flow is scalar.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ static void match_block(const uint8_t* __restrict__ src, const uint32_t srcSize, const uint32_t blockStart,
-                                                   const uint32_t blockSize, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
-                                                   const zs_cparams cp, const uint32_t dictLimitIn, uint32_t* rep, zs_seq* __restrict__ seqs,
-                                                   MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane) {
-    // ZSTD_getLowestPrefixIndex(ms, endIndex, windowLog): the window was slid to the block's START (dictLimit), match candidates
-    // are bounded from the block's END; a candidate AT the bound is valid (>=) - both pinned by tests/golden/fuzz_regress/window_*.bin
-    const uint32_t iend = UNI(blockStart + blockSize), dictLimit = UNI(dictLimitIn), maxDist = 1u << UNI(cp.windowLog);
-    const uint32_t plowIdx = (iend + 2 - dictLimit > maxDist) ? iend + 2 - maxDist : dictLimit;
-    const uint32_t hBitsL = UNI(cp.hashLog), hBitsS = UNI(cp.chainLog), mls = UNI(cp.minMatch);
-    const uint32_t srcCeil = (srcSize + ZS_FILL - 1) & ~(ZS_FILL - 1), lastPiece = (srcSize - 1) & ~15u;
-    const uint32_t idxBits = 32u - (uint32_t)__clz((int)(srcSize + 2)), tagBits = 32u - idxBits, idxMask = (uint32_t)((1ull << idxBits) - 1);
-    uint32_t ip = UNI(blockStart), anchor = ip;
-    uint32_t off1 = UNI(rep[0]), off2 = UNI(rep[1]), sav1 = 0, sav2 = 0;
-    ms.nbSeq = 0; ms.litSize = 0;
-    if (ip + 2 == plowIdx) ip++;
-    {   const uint32_t cur = ip + 2, windowLow = (cur - dictLimit > maxDist) ? cur - maxDist : dictLimit, maxRep = cur - windowLow;
-        if (off2 > maxRep) { sav2 = off2; off2 = 0; }
-        if (off1 > maxRep) { sav1 = off1; off1 = 0; }
-    }
-    Win w; w.lo = w.hi = 0;                                           // empty: the first win_ensure primes the ring
-    FarWin FW0; FW0.lo = FW0.hi = 0; FW0.buf = fwbuf;                 // "no far window"
-    LT_DECL
-    if (blockSize >= 8) {
-        const uint32_t ilimit = iend - 8;
-        // The serial code checks an "immediate repcode" (offset_2 at the new ip) right after every stored match.  Its far
-        // read src[ip - off2] rides with the table loads of the next search step instead of costing a round trip of its own.
-        bool afterMatch = false;
-        for (;;) {                                                    // one iteration per stored match
-            uint32_t step = 1, nextStep = ip + 256;
-            if (ip + step > ilimit) {
-                if (afterMatch && ip <= ilimit) {                     // ip == ilimit: no search step left, only the repcode check
-                    if (ip + ZS_SAFE > w.hi || ip < w.lo) win_ensure(src, srcCeil, lastPiece, ring, w, ip, lane);
-                    const uint64_t dr = ring8(ring, ip);
-                    if ((uint32_t)dr == ld32(src + ip - off2)) {
-                        const uint32_t rlen = 4 + wave_count(src, ring, w, FW0, ip + 4, ip + 4 - off2, iend, lane);
-                        const uint32_t t = off2; off2 = off1; off1 = t;
-                        store_seq(seqs, ms, 0, ip, 1, rlen, lane);    // (its table insertions can no longer be probed in this block... but later blocks can)
-                        if (lane == 0) {
-                            hashSmall[hashS(dr, hBitsS, mls)] = ((tag4((uint32_t)dr, tagBits) << 1) << (idxBits - 1)) | (ip + 2);
-                            hashLong[hash8(dr, hBitsL)] = ((tag8(dr, hBitsL, tagBits) << 1) << (idxBits - 1)) | (ip + 2);
-                        }
-                        ip += rlen; anchor = ip;
-                        PCNT(13, 1);
-                    }
-                }
-                break;
-            }
-            uint32_t width = ZS_W0;
-            bool done = false;
-            for (;;) {                                                // one iteration per speculative wave step
-                // K search positions ip + k*step (k < K) evaluated at once; lane K only provides the look-ahead
-                uint32_t K;
-                if (step == 1) {
-                    K = ilimit - ip;                                  // positions p with p + 1 <= ilimit
-                    const uint32_t K1 = nextStep > ip + 1 ? nextStep - ip : 1;
-                    if (K1 < K) K = K1;
-                } else {
-                    uint32_t K1 = 1;
-                    if (nextStep > ip + step) K1 = (nextStep - ip - 1) / step + 1;
-                    K = (ilimit - step - ip) / step + 1;
-                    if (K1 < K) K = K1;
-                }
-                if (width < K) K = width;
-                LT(0);                                                // 0: everything between steps (post-match work, loop control)
-                if (ip + ZS_SAFE > w.hi || ip < w.lo) win_ensure(src, srcCeil, lastPiece, ring, w, ip, lane);
-                const bool inRange = lane <= K;
-                const bool searching = lane < K;
-                const uint32_t pos = ip + lane * step;
-                const uint32_t spos = inRange ? pos : ip;            // an address every lane may read
-                const bool posWin = ip + K * step + 8 <= w.hi;        // all position reads hit the ring (ip >= w.lo holds)
-                uint64_t d8;
-                if (posWin) d8 = ring8(ring, spos); else { d8 = ld64(src + spos); LOADED64(d8); }
-                PTW(16);
-                LT_USE(d8); LT(1);                                    // 1: window upkeep + position bytes
-                const uint32_t hl = hash8(d8, hBitsL), hs = hashS(d8, hBitsS, mls);
-                const uint32_t tL = tag8(d8, hBitsL, tagBits), tS = tag4((uint32_t)d8, tagBits);
-                const uint32_t eL = ((tL << 1) << (idxBits - 1)) | (pos + 2), eS = ((tS << 1) << (idxBits - 1)) | (pos + 2);   // what this position inserts
-                WAVE_MEM_SYNC();
-                // The repcode check of a position (bytes at pos + 1 - off1) precedes its table checks, and everything behind the
-                // step's first event is discarded: when those bytes are in the ring the first repcode hit is known BEFORE the table
-                // loads go out, and the lanes behind it need no probes (they re-read lane 0's entries: same lines, no extra HBM
-                // requests).  The hit lane itself still probes the long table (the "long match at +1" rule of the lane before it);
-                // lane K only provides that look-ahead and never needs the short table.
-                const uint32_t ra = off1 > 0 ? spos + 1 - off1 : spos;
-                const bool r1Near = posWin && ip + 1 >= w.lo + off1;
-                uint32_t r1 = 0, firstRep = LANES;
-                if (r1Near) {
-                    r1 = ring4(ring, ra);
-                    const unsigned long long rb = __ballot(searching && off1 > 0 && r1 == (uint32_t)(d8 >> 8));
-                    if (rb) firstRep = (uint32_t)__ffsll((long long)rb) - 1;
-                }
-                const bool probeL = inRange && lane <= firstRep, probeS = searching && lane < firstRep;
-                const uint32_t hl0 = __builtin_amdgcn_readfirstlane(hl), hs0 = __builtin_amdgcn_readfirstlane(hs);
-                uint32_t cL = hashLong[probeL ? hl : hl0];           // lanes beyond the step read (harmlessly) too: no branches
-                uint32_t cS = hashSmall[probeS ? hs : hs0];
-                if (!r1Near) r1 = ld32(src + ra);
-                if (afterMatch) {                                     // immediate repcode at ip (lane 0's position), wave-uniform
-                    afterMatch = false;
-                    const uint32_t r2 = (posWin && ip >= w.lo + off2) ? ring4(ring, ip - off2) : ld32(src + ip - off2);
-                    const uint32_t d0 = __builtin_amdgcn_readfirstlane((uint32_t)d8);
-                    if (__builtin_amdgcn_readfirstlane(r2) == d0) {
-                        const uint32_t rlen = 4 + wave_count(src, ring, w, FW0, ip + 4, ip + 4 - off2, iend, lane);
-                        const uint32_t t = off2; off2 = off1; off1 = t;
-                        if (lane == 0) { hashSmall[hs] = eS; hashLong[hl] = eL; }
-                        store_seq(seqs, ms, 0, ip, 1, rlen, lane);
-                        ip += rlen; anchor = ip;
-                        PCNT(13, 1);
-                        afterMatch = ip <= ilimit && off2 > 0;
-                        break;                                        // restart the search at the new ip (step = 1)
-                    }
-                }
-                uint32_t nextL = LANES, nextS = LANES;               // first later searching lane with my hash
-                PTW(17);
-                LT_USE(cL); LT_USE(cS); LT_USE(r1); LT(2);            // 2: hashing + table round trip (+ immediate repcode)
-                {   // Two lanes of one step with the same hash see each other's insertions.  Detect (conservatively) through
-                    // an LDS scoreboard: every lane posts its id under its hash, a lane that reads back another id collides.
-                    const uint32_t sl = hl & (ZS_SCR - 1), ss = ZS_SCR + (hs & (ZS_SCR - 1));
-                    if (inRange) scr[sl] = (uint8_t)lane;
-                    if (searching) scr[ss] = (uint8_t)lane;
-                    WAVE_MEM_SYNC();
-                    const bool coll = (inRange && scr[sl] != (uint8_t)lane) || (searching && scr[ss] != (uint8_t)lane);
-                    if (__any(coll)) {
-                        PCNT(19, 1);
-                        for (uint32_t i = 0; i < K; i++) {
-                            const uint32_t hli = __builtin_amdgcn_readlane(hl, i), hsi = __builtin_amdgcn_readlane(hs, i);
-                            const uint32_t eLi = __builtin_amdgcn_readlane(eL, i), eSi = __builtin_amdgcn_readlane(eS, i);
-                            if (hl == hli) { if (lane > i) cL = eLi; else if (lane < i && nextL == LANES) nextL = i; }
-                            if (hs == hsi) { if (lane > i) cS = eSi; else if (lane < i && nextS == LANES) nextS = i; }
-                        }
-                    }
-                }
-                PTW(18);
-                LT(3);                                                // 3: collision scoreboard
-                // candidates: from the ring when recent enough, else one global load each - all issued before any is used
-                const uint32_t iL = cL & idxMask, iS = cS & idxMask;
-                const bool vL = probeL && iL >= plowIdx && ((cL ^ eL) & ~idxMask) == 0;       // in the window and same tag
-                const bool vS = probeS && iS >= plowIdx && ((cS ^ eS) & ~idxMask) == 0;
-                const uint32_t pL = vL ? iL - 2 : w.lo, pS = vS ? iS - 2 : w.lo;
-                const bool nL = pL >= w.lo && pL + 8 <= w.hi, nS = pS >= w.lo && pS + 4 <= w.hi;
-                // far candidates: 48 bytes around each in one go (verification + both extensions); the rare ones too close to the
-                // chunk's ends for that read just their 8 / 4 bytes
-                const bool wL = vL && !nL && pL >= 16 && pL + 32 <= srcSize, wS = vS && !nS && pS >= 16 && pS + 32 <= srcSize;
-                uint64_t gL = 0, kL = 0; uint32_t gS = 0, kS = 0;
-                uint4 L0, L1, L2, S0, S1, S2;
-                L0 = L1 = L2 = S0 = S1 = S2 = make_uint4(0, 0, 0, 0);
-                if (__any(wL || wS)) {                                // all six loads go out back to back (lanes without one re-read byte 0)
-                    const uint8_t* qL = src + (wL ? pL - 16 : 0); const uint8_t* qS = src + (wS ? pS - 16 : 0);
-                    L0 = ld128(qL); L1 = ld128(qL + 16); L2 = ld128(qL + 32);
-                    S0 = ld128(qS); S1 = ld128(qS + 16); S2 = ld128(qS + 32);
-                    PCNT(20, 1);
-                }
-                if (__any((vL && !nL && !wL) || (vS && !nS && !wS))) {
-                    gL = ld64(src + ((nL || wL) ? ip : pL));
-                    gS = ld32(src + ((nS || wS) ? ip : pS));
-                }
-                if (__any(vL && nL)) kL = ring8(ring, nL ? pL : w.lo);               // most steps have no live candidate of a kind:
-                if (__any(vS && nS)) kS = ring4(ring, nS ? pS : w.lo);               // skip the reads wave-uniformly
-                const uint64_t fL = wL ? (((uint64_t)L1.y << 32) | L1.x) : gL;
-                const uint32_t fS = wS ? S1.x : gS;
-                const bool longOK = vL && (nL ? kL : fL) == d8;
-                const bool shortOK = vS && (nS ? kS : fS) == (uint32_t)d8;
-                const bool repOK = searching && off1 > 0 && r1 == (uint32_t)(d8 >> 8);
-                const uint32_t ev = !searching ? 0u : repOK ? 1u : longOK ? 2u : shortOK ? 3u : 0u;
-                const unsigned long long bm = __ballot(ev != 0);
-                const int f = bm ? __ffsll((long long)bm) - 1 : -1;
-                PT(2); PCNT(12, 1); PCNT(15, K);
-                LT(4);                                                // 4: candidate fetch + verdict
-                const uint32_t lastIns = f >= 0 ? (uint32_t)f : K - 1;
-                if (lane <= lastIns) {                                // the visited positions insert themselves
-                    if (nextL > lastIns) hashLong[hl] = eL;
-                    if (nextS > lastIns) hashSmall[hs] = eS;
-                }
-                if (f < 0) {
-                    const bool inc = ip + K * step >= nextStep;
-                    ip += K * step;
-                    if (inc) { step++; nextStep += 256; }
-                    if (ip + step > ilimit) { done = true; break; }
-                    width = width >= 32 ? 63 : width * 2;
-                    continue;
-                }
-                const uint32_t evf = __builtin_amdgcn_readlane(ev, f);
-                const uint32_t posf = ip + (uint32_t)f * step;
-                uint32_t start, mlen;
-                FarWin FW; FW.lo = FW.hi = 0; FW.buf = fwbuf;
-                FarWin FW1; FW1.lo = FW1.hi = 0; FW1.buf = fwbuf + 48;
-                if (evf == 1) {                                       // repcode at posf + 1
-                    start = posf + 1;
-                    mlen = 4 + wave_count(src, ring, w, FW, start + 4, start + 4 - off1, iend, lane);
-                    store_seq(seqs, ms, start - anchor, anchor, 1, mlen, lane);
-                } else {
-                    uint32_t mpos;
-                    if (evf == 2) {                                   // long match at posf
-                        start = posf; mpos = __builtin_amdgcn_readlane(iL, f) - 2;
-                        if (__builtin_amdgcn_readlane((uint32_t)wL, f)) {
-                            if (lane == (uint32_t)f) { uint4* o = reinterpret_cast<uint4*>(fwbuf); o[0] = L0; o[1] = L1; o[2] = L2; }
-                            WAVE_MEM_SYNC();
-                            FW.lo = mpos - 16; FW.hi = mpos + 32;
-                        }
-                        mlen = 8 + wave_count(src, ring, w, FW, start + 8, mpos + 8, iend, lane);
-                    } else {                                          // short match; a strictly longer long match at +1 wins
-                        start = posf; mpos = __builtin_amdgcn_readlane(iS, f) - 2;
-                        const bool long1 = __builtin_amdgcn_readlane((uint32_t)longOK, f + 1) != 0;
-                        const bool far0 = __builtin_amdgcn_readlane((uint32_t)wS, f) != 0;
-                        const bool far1 = long1 && __builtin_amdgcn_readlane((uint32_t)wL, f + 1) != 0;
-                        if (far0 || far1) {
-                            if (far0 && lane == (uint32_t)f) { uint4* o = reinterpret_cast<uint4*>(fwbuf); o[0] = S0; o[1] = S1; o[2] = S2; }
-                            if (far1 && lane == (uint32_t)f + 1) { uint4* o = reinterpret_cast<uint4*>(fwbuf + 48); o[0] = L0; o[1] = L1; o[2] = L2; }
-                            WAVE_MEM_SYNC();
-                            if (far0) { FW.lo = mpos - 16; FW.hi = mpos + 32; }
-                        }
-                        mlen = 4 + wave_count(src, ring, w, FW, start + 4, mpos + 4, iend, lane);
-                        if (long1) {
-                            const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(iL, f + 1) - 2;
-                            if (far1) { FW1.lo = m1 - 16; FW1.hi = m1 + 32; }
-                            const uint32_t l1 = 8 + wave_count(src, ring, w, FW1, p1 + 8, m1 + 8, iend, lane);
-                            if (l1 > mlen) { start = p1; mpos = m1; mlen = l1; FW = FW1; }
-                        }
-                    }
-                    const uint32_t back = wave_count_back(src, ring, w, FW, start, mpos, anchor, plowIdx - 2, lane);
-                    start -= back; mpos -= back; mlen += back;
-                    off2 = off1; off1 = start - mpos;
-                    if (step < 4 && lane == (uint32_t)f + 1) hashLong[hl] = eL;          // hashLong[hl1] = ip1
-                    store_seq(seqs, ms, start - anchor, anchor, off1 + 3, mlen, lane);
-                }
-                ip = UNI(start + mlen); anchor = ip;
-                off1 = UNI(off1); off2 = UNI(off2);
-                PT(3); PCNT(13, 1);
-                LT_USE(ip); LT(5);                                    // 5: inserts + extension + sequence store
-                if (ip <= ilimit) {
-                    if (ip + ZS_SAFE > w.hi || ip < w.lo) win_ensure(src, srcCeil, lastPiece, ring, w, ip, lane);
-                    {   // complementary insertion: long[curr+2], long[ip-2], small[curr+2], small[ip-1] (in that order)
-                        const uint32_t p = lane == 0 || lane == 2 ? posf + 2 : lane == 1 ? ip - 2 : ip - 1;
-                        const uint32_t sp = lane < 4 ? p : ip;
-                        const uint64_t d = posf + 2 >= w.lo ? ring8(ring, sp) : ld64(src + sp);
-                        const uint32_t h = lane < 2 ? hash8(d, hBitsL) : hashS(d, hBitsS, mls);
-                        const uint32_t t = lane < 2 ? tag8(d, hBitsL, tagBits) : tag4((uint32_t)d, tagBits);
-                        const uint32_t e = ((t << 1) << (idxBits - 1)) | (p + 2);
-                        const uint32_t hn = __shfl(h, lane + 1);
-                        const bool shadowed = (lane == 0 || lane == 2) && hn == h;      // the later write of the pair wins
-                        if (lane < 2 && !shadowed) hashLong[h] = e;
-                        if ((lane == 2 || lane == 3) && !shadowed) hashSmall[h] = e;
-                    }
-                    afterMatch = off2 > 0;
-                }
-                PT(4);
-                break;
-            }
-            if (done) break;
-        }
-    }
-    sav2 = (sav1 != 0 && off1 != 0) ? sav1 : sav2;
-    rep[0] = off1 ? off1 : sav1;
-    rep[1] = off2 ? off2 : sav2;
-    ms.lastLL = iend - anchor; ms.anchor = anchor;
-    ms.litSize += ms.lastLL;
-    PT(4);
-    LT(0); LT_FLUSH();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Parser, second form (ZS_PARSER == 2).  Same serial algorithm, same tables, same output; what changed is what a step costs.
-// The first form spends ~700 instructions and 2K+1 table lines per step on speculation that the content seldom honours: on
-// log-like data 54 % of all sequences start at the FIRST position searched after the previous match and 69 % within two
-// (tools/stats/parse_stats.c), so K = 8 first steps read 17 table lines to use 2-4, and every lane fetched 96 bytes around both
-// of its candidates although only the step's first event is ever used.  Here:
+// double-fast match finder for one block (ZSTD_compressBlock_doubleFast_noDict_generic, speculative form).
+// All "positions" are offsets within the chunk; table values are libzstd's indices = position + 2; rep[] is updated as the serial
+// code does.  Everything that is the same for all lanes (ip, anchor, offsets, step...) is derived from ballots / readlanes so it
+// lives in SGPRs and the control flow is scalar.  On log-like data 54 % of all sequences start at the FIRST position searched after
+// the previous match and 69 % within two (tools/stats/parse_stats.c), and only a step's first event is ever used, hence:
 //   * lane roles: lane 0 = the complementary insertion at curr + 2, lanes 1.. = consecutive positions from ip - 2 (lanes 1, 2 are
 //     the complementary insertions at ip - 2 / ip - 1, lanes 3.. the K search positions, lane 3 + K the look-ahead for the "long
 //     match at +1" rule, lane 63 fetches the bytes of the immediate-repcode check): the complementary insertions of the previous
@@ -636,17 +340,15 @@ __device__ __forceinline__ static void match_block(const uint8_t* __restrict__ s
 #ifndef ZS_K1
 #define ZS_K1 32u             /* ... of the second step; doubling from there */
 #endif
-#define ZS_KMAX 59u
+#define ZS_KMAX 59u           /* lanes 3..61 search, 62 looks ahead, 63 serves the immediate repcode */
 // the rare continuations (matches longer than the 64 bytes the first comparison covers) stay out of line
 __device__ ZS_NOINLINE static uint32_t count_more(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, uint32_t a, uint32_t b, uint32_t iend, uint32_t lane) {
-    FarWin fw; fw.lo = fw.hi = 0; fw.buf = nullptr;
-    return wave_count(src, ring, w, fw, a, b, iend, lane);
+    return wave_count(src, ring, w, a, b, iend, lane);
 }
 __device__ ZS_NOINLINE static uint32_t count_more_back(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, uint32_t ip, uint32_t match, uint32_t anchor,
                                                        uint32_t low, uint32_t lane) {
-    FarWin fw; fw.lo = fw.hi = 0; fw.buf = nullptr;
-    return wave_count_back(src, ring, w, fw, ip, match, anchor, low, lane);
-}           /* lanes 3..61 search, 62 looks ahead, 63 serves the immediate repcode */
+    return wave_count_back(src, ring, w, ip, match, anchor, low, lane);
+}
 
 // bit i = lane i is valid and chunk byte pa + i - nb equals byte pb + i - nb (pb < pa).  Bytes come from the ring when the whole
 // 64-byte span is resident, else from global memory (valid lanes only touch [0, srcSize)).
@@ -662,28 +364,11 @@ __device__ __forceinline__ static unsigned long long eq_mask(const gbytes_t src,
 }
 __device__ static inline uint32_t cto64(unsigned long long m) { return m == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m) - 1; }
 
-#if ZS_LONG32
-// The 28 bytes [p - 4, p + 24) of the chunk around a position, as the seven words a long-table entry carries behind its index word.
-struct Ctx28 { uint32_t w[7]; };
-// number of leading equal bytes of two little-endian 8-byte groups XOR-ed into x (8 = all equal)
-__device__ static inline uint32_t eq8(uint64_t x) { return x ? (uint32_t)(__ffsll((long long)x) - 1) >> 3 : 8u; }
-// forward: equal bytes of [p, p + 24) (0..24); backward: equal bytes walking down from p - 1 (0..4)
-__device__ static inline uint32_t ctx_fwd(const Ctx28& a, const Ctx28& b) {
-    const uint64_t x0 = ((uint64_t)(a.w[2] ^ b.w[2]) << 32) | (a.w[1] ^ b.w[1]), x1 = ((uint64_t)(a.w[4] ^ b.w[4]) << 32) | (a.w[3] ^ b.w[3]),
-                   x2 = ((uint64_t)(a.w[6] ^ b.w[6]) << 32) | (a.w[5] ^ b.w[5]);
-    const uint32_t n0 = eq8(x0), n1 = eq8(x1), n2 = eq8(x2);
-    return n0 < 8 ? n0 : n1 < 8 ? 8 + n1 : 16 + n2;
-}
-__device__ static inline uint32_t ctx_back(const Ctx28& a, const Ctx28& b) {
-    const uint32_t x = a.w[0] ^ b.w[0];
-    return x ? (uint32_t)__clz((int)x) >> 3 : 4u;
-}
-#endif
 
-__device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src, const uint32_t srcSize_, const uint32_t blockStart,
+__device__ ZS_NOINLINE static void match_block(const uint8_t* __restrict__ src, const uint32_t srcSize_, const uint32_t blockStart,
                                                     const uint32_t blockSize_, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
                                                     const zs_cparams cp, const uint32_t dictLimitIn, uint32_t* rep, zs_seq* __restrict__ seqs,
-                                                    MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* fwbuf, const uint32_t lane, const uint32_t sched) {
+                                                    MfState& ms, uint32_t* ring, uint8_t* scr, const uint32_t lane, const uint32_t sched) {
     // Speculation schedule (never changes the output, only what a search run costs): positions of the first step after a match, of the
     // second step; doubling from there.  sched = K0 | K1 << 8, 0 in a field = the compile-time default (4, 32).  Measured with 18-step
     // runs, three batches in flight / one at a time (profiles/r02_sweep_k_schedule.txt): (2,16) 17.6-17.9 GiB/s / 762 ms, (3,24) 18.5-18.6 /
@@ -709,15 +394,6 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
         if (off1 > maxRep) { sav1 = off1; off1 = 0; }
     }
     Win w; w.lo = w.hi = 0;
-    (void)fwbuf;
-#if ZS_LONG32
-    // long-table entry e: words [8e .. 8e + 8) = index word | the inserting position's 28 context bytes
-#define GL_INSERT(h_, e_, c_) do { const gwords_t q_ = gL + (size_t)(h_) * 8; \
-        *reinterpret_cast<ZS_GLOBAL zs_u32x4*>(q_) = zs_u32x4{(e_), (c_).w[0], (c_).w[1], (c_).w[2]}; \
-        *reinterpret_cast<ZS_GLOBAL zs_u32x4*>(q_ + 4) = zs_u32x4{(c_).w[3], (c_).w[4], (c_).w[5], (c_).w[6]}; } while (0)
-#else
-#define GL_INSERT(h_, e_, c_) do { gL[h_] = (e_); } while (0)
-#endif
 #define STORE_SEQ(ll_, lp_, ob_, ml_) do { if (lane == 0) zs_put_seq(&gseqs[nbSeq], (ob_), (ll_), (ml_) - 3, (lp_)); \
                                            litSize += (ll_); nbSeq++; } while (0)
     if (blockSize >= 8) {
@@ -753,38 +429,9 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             const bool lane3 = lane == 3;                             // ip itself: searched (K > 0) or only checked for the immediate repcode
             const bool mayUse = compL || compS || (lane >= 3 && lane <= 3 + K);
             const uint32_t spos = mayUse ? pos : ip;                  // an address every lane may read
-#if ZS_LONG32
-            const bool posWin = ip + K * step + 24 <= w.hi && ip >= w.lo + 6 && (!comp || X >= w.lo + 4);
-#else
             const bool posWin = ip + K * step + 8 <= w.hi && (!comp || (X >= w.lo && ip >= w.lo + 2));
-#endif
             uint64_t d8;
             if (posWin) d8 = ring8(ring, spos); else { d8 = gld64(gsrc + spos); LOADED64(d8); }
-#if ZS_LONG32
-            Ctx28 own;                                                // this lane's position: what its insertion stores, what its candidates are compared with
-            if (posWin) {
-                const uint64_t u1 = ring8(ring, spos + 8), u2 = ring8(ring, spos + 16);
-                own.w[0] = ring4(ring, spos - 4);
-                own.w[3] = (uint32_t)u1; own.w[4] = (uint32_t)(u1 >> 32); own.w[5] = (uint32_t)u2; own.w[6] = (uint32_t)(u2 >> 32);
-            } else {                                                  // rare: read around spos from the chunk itself, never beyond its ends
-                uint64_t u1 = 0, u2 = 0;
-                if (spos >= 4) own.w[0] = gld32(gsrc + spos - 4);
-                else {                                                // the chunk's first bytes: what exists of [p - 4, p) goes to the top, byte p - 1 first
-                    uint32_t v = 0;
-                    for (uint32_t b = 0; b < spos; b++) v |= (uint32_t)gsrc[b] << (8 * (4 - spos + b));
-                    own.w[0] = v;
-                }
-                if (spos + 16 <= srcSize) u1 = gld64(gsrc + spos + 8);
-                else for (uint32_t b = 0; spos + 8 + b < srcSize; b++) u1 |= (uint64_t)gsrc[spos + 8 + b] << (8 * b);      // the chunk's last bytes, one by one
-                if (spos + 24 <= srcSize) u2 = gld64(gsrc + spos + 16);
-                else for (uint32_t b = 0; b < 8 && spos + 16 + b < srcSize; b++) u2 |= (uint64_t)gsrc[spos + 16 + b] << (8 * b);
-                LOADED64(u1); LOADED64(u2);
-                own.w[3] = (uint32_t)u1; own.w[4] = (uint32_t)(u1 >> 32); own.w[5] = (uint32_t)u2; own.w[6] = (uint32_t)(u2 >> 32);
-            }
-            own.w[1] = (uint32_t)d8; own.w[2] = (uint32_t)(d8 >> 32);
-#else
-            const int own = 0; (void)own;
-#endif
             const uint32_t hl = hash8(d8, hBitsL), hs = hashS(d8, hBitsS, mls);
             const uint32_t tL = tag8(d8, hBitsL, tagBits), tS = tag4((uint32_t)d8, tagBits);
             const uint32_t eL = ((tL << 1) << (idxBits - 1)) | (pos + 2), eS = ((tS << 1) << (idxBits - 1)) | (pos + 2);
@@ -823,8 +470,8 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                     const uint32_t t = (uint32_t)__ffsll((long long)fb) - 1;
                     if (t == 3) {
                         // ip itself shares a slot with a complementary insertion: make those first, then search
-                        if (lane == 0) { if (!shadowL0) GL_INSERT(hl, eL, own); if (!shadowS0) gS[hs] = eS; }
-                        if (lane == 1) GL_INSERT(hl, eL, own);
+                        if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
+                        if (lane == 1) gL[hl] = eL;
                         if (lane == 2) gS[hs] = eS;
                         comp = false;
                         PCNT(19, 1);
@@ -841,21 +488,10 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             const bool probeL = K > 0 && lane >= 3 && lane <= look, probeS = searching;
             const uint32_t hl3 = __builtin_amdgcn_readlane(hl, 3), hs3 = __builtin_amdgcn_readlane(hs, 3);
             uint32_t cL = 0, cS = 0;
-#if ZS_LONG32
-            Ctx28 cand;                                               // the long candidate's bytes, straight from its table entry
-            for (int k = 0; k < 7; k++) cand.w[k] = 0;
-            if (K > 0) {
-                const gwords_t q = gL + (size_t)(probeL ? hl : hl3) * 8;
-                const zs_u32x4 qa = *reinterpret_cast<const ZS_GLOBAL zs_u32x4*>(q), qb = *reinterpret_cast<const ZS_GLOBAL zs_u32x4*>(q + 4);
-                cL = qa.x; cand.w[0] = qa.y; cand.w[1] = qa.z; cand.w[2] = qa.w; cand.w[3] = qb.x; cand.w[4] = qb.y; cand.w[5] = qb.z; cand.w[6] = qb.w;
-                cS = gS[probeS ? hs : hs3];
-            }
-#else
             if (K > 0) {
                 cL = gL[probeL ? hl : hl3];
                 cS = gS[probeS ? hs : hs3];
             }
-#endif
             const bool r2Near = afterMatch && posWin && ip >= w.lo + off2;
             const bool needFar = (K > 0 && off1 > 0 && !r1Near) || (afterMatch && !r2Near);
             uint32_t rfar = 0;
@@ -878,13 +514,13 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                     const uint32_t rlen = 4 + n;
                     const uint32_t t = off2; off2 = off1; off1 = t;
                     if (comp) {
-                        if (lane == 0) { if (!shadowL0) GL_INSERT(hl, eL, own); if (!shadowS0) gS[hs] = eS; }
-                        if (lane == 1) GL_INSERT(hl, eL, own);
+                        if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
+                        if (lane == 1) gL[hl] = eL;
                         if (lane == 2) gS[hs] = eS;
                         comp = false;
                     }
                     WAVE_MEM_SYNC();                                  // (emulator) the insertion at ip comes after the complementary ones
-                    if (lane3) { gS[hs] = eS; GL_INSERT(hl, eL, own); }
+                    if (lane3) { gS[hs] = eS; gL[hl] = eL; }
                     STORE_SEQ(0, ip, 1, rlen);
                     ip += rlen; anchor = ip;
                     PCNT(13, 1);
@@ -900,19 +536,11 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                 if (em) {
                     const uint32_t e = 63u - (uint32_t)__clzll((long long)em); const uint32_t ee = __builtin_amdgcn_readlane(eL, e);
                     if (lane == look) cL = ee;
-#if ZS_LONG32
-                    for (int k = 0; k < 7; k++) { const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane(own.w[k], e); if (lane == look) cand.w[k] = cw; }
-#endif
                 }
             }
             // ---- events ----
             const uint32_t iL = cL & idxMask, iS = cS & idxMask;
-#if ZS_LONG32
-            const uint32_t fwdL = ctx_fwd(own, cand), backL = ctx_back(own, cand);
-            bool vL = probeL && iL >= plowIdx && fwdL >= 8;                          // in the window and the 8 bytes ARE equal (no tag needed)
-#else
             bool vL = probeL && iL >= plowIdx && ((cL ^ eL) & ~idxMask) == 0;        // in the window and same tag
-#endif
             bool vS = probeS && iS >= plowIdx && ((cS ^ eS) & ~idxMask) == 0;
             const bool repOK = searching && off1 > 0 && r1 == (uint32_t)(d8 >> 8);
             int f = -1;
@@ -937,22 +565,6 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                 if (evf == 2) {                                       // long match at posf
                     uint32_t mpos = __builtin_amdgcn_readlane(iL, f) - 2;
                     uint32_t lim = posf - anchor; if (mpos - lowPos < lim) lim = mpos - lowPos;
-#if ZS_LONG32
-                    {   // verified already; both extensions from the entry's bytes, the chunk is only read when they run out
-                        uint32_t fwd = (uint32_t)__builtin_amdgcn_readlane(fwdL, f), back = (uint32_t)__builtin_amdgcn_readlane(backL, f);
-                        if (fwd == 24 && posf + 24 < iend) fwd += UNI(count_more(src, ring, w, posf + 24, mpos + 24, iend, lane));
-                        if (posf + fwd > iend) fwd = iend - posf;
-#ifdef ZS_DBG
-                        { const uint32_t o0_ = (uint32_t)__builtin_amdgcn_readlane(own.w[0], f), c0_ = (uint32_t)__builtin_amdgcn_readlane(cand.w[0], f);
-                          if (lane == 0) fprintf(stderr, "L ev posf %u mpos %u fwd %u back %u lim %u anchor %u ownw0 %08x candw0 %08x posWin %d\n", posf, mpos, fwd, back, lim, anchor, o0_, c0_, (int)posWin); }
-#endif
-                        if (back > lim) back = lim;
-                        if (back == 4 && lim > 4) back += UNI(count_more_back(src, ring, w, posf - 4, mpos - 4, anchor, lowPos, lane));
-                        start = posf - back; mpos -= back; mlen = fwd + back;
-                        offBase = start - mpos + 3;
-                        break;
-                    }
-#endif
                     const bool valid = lane < 8 ? (8 - lane) <= lim : posf + (lane - 8) < iend;
                     const unsigned long long m = eq_mask(gsrc, ring, w, posf, mpos, 8, valid, lane);
                     if (((m >> 8) & 0xFF) != 0xFF) { if (lane == (uint32_t)f) vL = false; PCNT(21, 1); continue; }     // a tag's false positive
@@ -973,35 +585,9 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
                     uint32_t fwd = cto64(m >> 8);
                     if (fwd == 56) fwd += UNI(count_more(src, ring, w, posf + 56, mpos + 56, iend, lane));
                     uint32_t sp = posf;
-#if ZS_LONG32
-                    bool tookLong1 = false;
-                    uint32_t back1 = 0;
                     if (__builtin_amdgcn_readlane((uint32_t)vL, f + 1)) {
                         const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(iL, f + 1) - 2;
                         uint32_t lim1 = p1 - anchor; if (m1 - lowPos < lim1) lim1 = m1 - lowPos;
-                        uint32_t f1 = (uint32_t)__builtin_amdgcn_readlane(fwdL, f + 1);
-                        if (f1 == 24 && p1 + 24 < iend) f1 += UNI(count_more(src, ring, w, p1 + 24, m1 + 24, iend, lane));
-                        if (p1 + f1 > iend) f1 = iend - p1;
-                        if (f1 > fwd) {
-                            sp = p1; mpos = m1; fwd = f1; lim = lim1; tookLong1 = true;
-                            back1 = (uint32_t)__builtin_amdgcn_readlane(backL, f + 1);
-                            if (back1 > lim1) back1 = lim1;
-                            if (back1 == 4 && lim1 > 4) back1 += UNI(count_more_back(src, ring, w, p1 - 4, m1 - 4, anchor, lowPos, lane));
-                        }
-                    }
-                    if (tookLong1) {
-                        start = sp - back1; mpos -= back1; mlen = fwd + back1;
-                        offBase = start - mpos + 3;
-                        break;
-                    }
-                    if (false) {
-                        const uint32_t p1 = posf + step, m1 = 0;
-                        uint32_t lim1 = 0;
-#else
-                    if (__builtin_amdgcn_readlane((uint32_t)vL, f + 1)) {
-                        const uint32_t p1 = posf + step, m1 = __builtin_amdgcn_readlane(iL, f + 1) - 2;
-                        uint32_t lim1 = p1 - anchor; if (m1 - lowPos < lim1) lim1 = m1 - lowPos;
-#endif
                         const bool valid1 = lane < 8 ? (8 - lane) <= lim1 : p1 + (lane - 8) < iend;
                         const unsigned long long mm = eq_mask(gsrc, ring, w, p1, m1, 8, valid1, lane);
                         if (((mm >> 8) & 0xFF) == 0xFF) {
@@ -1019,10 +605,10 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             }
             // ---- commit: the visited positions insert themselves, then the pending complementary insertions ----
             const uint32_t lastIns = f >= 0 ? (uint32_t)f : 2 + K;
-            if (lane >= 3 && lane <= lastIns) { GL_INSERT(hl, eL, own); gS[hs] = eS; }
+            if (lane >= 3 && lane <= lastIns) { gL[hl] = eL; gS[hs] = eS; }
             if (comp) {
-                if (lane == 0) { if (!shadowL0) GL_INSERT(hl, eL, own); if (!shadowS0) gS[hs] = eS; }
-                if (lane == 1) GL_INSERT(hl, eL, own);
+                if (lane == 0) { if (!shadowL0) gL[hl] = eL; if (!shadowS0) gS[hs] = eS; }
+                if (lane == 1) gL[hl] = eL;
                 if (lane == 2) gS[hs] = eS;
                 comp = false;
             }
@@ -1037,7 +623,7 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
             if (!isRep) {
                 off2 = off1; off1 = offBase - 3;
                 WAVE_MEM_SYNC();                                      // (emulator) ... after the insertions of the visited positions
-                if (step < 4 && lane == (uint32_t)f + 1) GL_INSERT(hl, eL, own);              // hashLong[hl1] = ip1
+                if (step < 4 && lane == (uint32_t)f + 1) gL[hl] = eL;              // hashLong[hl1] = ip1
             }
             STORE_SEQ(start - anchor, anchor, offBase, mlen);
             X = ip + ((uint32_t)f - 3) * step + 2;                    // curr + 2
@@ -1055,7 +641,6 @@ __device__ ZS_NOINLINE static void match_block2(const uint8_t* __restrict__ src,
     ms.nbSeq = nbSeq; ms.lastLL = iend - anchor; ms.anchor = anchor;
     ms.litSize = litSize + ms.lastLL;
 #undef STORE_SEQ
-#undef GL_INSERT
     PT(4);
 }
 
@@ -1978,7 +1563,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
     {   // fresh tables (ZSTD_reset_matchState): zero hashLong[1 << hashLog] and hashSmall[1 << chainLog]
         uint4 z; z.x = z.y = z.z = z.w = 0;
         uint4* a = (uint4*)hashLong; uint4* b = (uint4*)hashSmall;
-        for (uint32_t i = lane; i < ((1u << cp.hashLog) / 4) * ZS_LONG_ENTRY_WORDS; i += LANES) a[i] = z;
+        for (uint32_t i = lane; i < (1u << cp.hashLog) / 4; i += LANES) a[i] = z;
         for (uint32_t i = lane; i < (1u << cp.chainLog) / 4; i += LANES) b[i] = z;
     }
     // ---- frame header (ZSTD_writeFrameHeader: content size known, no checksum, no dictID) ----
@@ -2034,19 +1619,9 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
         if (blockSize >= 7) {
             uint32_t rep[3] = {repc[0], repc[1], repc[2]};
             MfState ms;
-#if ZS_LONG32 && ZS_PARSER != 2
-#error "ZS_LONG32 is implemented by the second form of the parser only"
-#endif
-#if ZS_PARSER == 2
-            match_block2(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane, sched);
-#else
-            match_block(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.fwbuf, lane);
-#endif
+            match_block(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, lane, sched);
             __threadfence_block();
             __syncthreads();
-#ifdef ZS_ABL_PARSE_ONLY
-            { cSize = 0; repc[0] = rep[0]; repc[1] = rep[1]; repc[2] = rep[2]; if (lane == 0) zlen[chunk] += ms.nbSeq; goto abl_next; }
-#endif
             gather_literals(lit, src, seqs, ms.nbSeq, ms.anchor, ms.lastLL, lane);
             __threadfence_block();
             __syncthreads();
@@ -2092,18 +1667,11 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
             cSize += 3;
         }
         PT(11);
-#ifdef ZS_ABL_PARSE_ONLY
-        abl_next:
-#endif
         savings += (int64_t)blockSize - (int64_t)cSize;
         ipos += blockSize; remaining -= blockSize; op += cSize; first = false;
         __syncthreads();
     }
-#ifdef ZS_ABL_PARSE_ONLY
-    if (lane == 0) zlen[chunk] = (uint32_t)(op - frame);
-#else
     finish_frame(descs, chunk, frame, (uint32_t)(op - frame), zlen, status, fuse, L, lane);
-#endif
 #ifdef TSX_PROF
     if (lane == 0 && prof_out) { g_prof[14] = (unsigned long long)clock64() - g_prof[22]; for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i]; }
 #endif
