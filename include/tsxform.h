@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define TSX_ABI_VERSION 2 /* 2: ctx-less calls spread over all initialised devices; tsx_set_thread_device, tsx_host_register */
+#define TSX_ABI_VERSION 3 /* 2: ctx-less calls spread over all initialised devices; tsx_set_thread_device, tsx_host_register
+                             3: the batch entry points take src_size and reject descriptors that reach beyond it */
 
 /* flags: which stages of the chain run.  Replaces the reference's chain construction
  * RemoteStorageManager.transformation(), core/.../RemoteStorageManager.java:434-453
@@ -147,19 +148,21 @@ size_t tsx_transformed_bound(size_t n, uint32_t flags);
 
 /* Forward chain over a batch of n chunks: [Zstd frame] -> [IV||AES-256-GCM(C)||TAG], CRC32C(original).
  * Replaces CompressionChunkEnumeration.nextElement + EncryptionChunkEnumeration.nextElement for the
- * whole batch.  ctx == NULL borrows a pooled context: on the device the calling thread chose with tsx_set_thread_device(),
+ * whole batch.  src_size / dst_size are the sizes of the caller's buffers: a descriptor whose [src_off, src_off + src_len) or
+ * [dst_off, dst_off + dst_cap) reaches beyond them fails the call with TSX_E_INVAL before anything is touched (ABI 3; the chunk
+ * bounds of the reference are the array lengths of its byte[] chunks).  ctx == NULL borrows a pooled context: on the device the calling thread chose with tsx_set_thread_device(),
  * else on the initialised device with the fewest batches in flight (one JVM drives all GPUs of the node from >= 10 RLM
  * threads, README.md:218-222). */
 int tsx_transform_batch(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n,
-                        const void* src, void* dst, size_t dst_size, int mem_kind);
+                        const void* src, size_t src_size, void* dst, size_t dst_size, int mem_kind);
 
 /* Inverse chain: [verify tag + AES-256-GCM decrypt] -> [Zstd decode], CRC32C(restored).
  * Replaces DecryptionChunkEnumeration.nextElement + DecompressionChunkEnumeration.nextElement. */
 int tsx_detransform_batch(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n,
-                          const void* src, void* dst, size_t dst_size, int mem_kind);
+                          const void* src, size_t src_size, void* dst, size_t dst_size, int mem_kind);
 
 /* CRC32C only (BASELINE.json configs[1]); equals java.util.zip.CRC32C over each chunk. */
-int tsx_crc32c_batch(tsx_ctx* ctx, tsx_chunk_desc* descs, uint32_t n, const void* src, int mem_kind);
+int tsx_crc32c_batch(tsx_ctx* ctx, tsx_chunk_desc* descs, uint32_t n, const void* src, size_t src_size, int mem_kind);
 
 /* ---- device memory helpers for hosts that do not link HIP themselves (the JNI shim) --------- */
 int tsx_device_malloc(int device_index, size_t bytes, void** out);

@@ -81,12 +81,10 @@ static jint run(JNIEnv* env, int detransform, int mem_kind, jint flags, jbyteArr
         const jlong cap = (*env)->GetDirectBufferCapacity(env, dst);
         const jlong scap = (*env)->GetDirectBufferCapacity(env, src);
         if (n < 0 || !d || !s || !o || (*env)->GetDirectBufferCapacity(env, descs) < (jlong)n * (jlong)sizeof(tsx_chunk_desc)) rc = TSX_E_INVAL;
-        /* the C ABI trusts src_off + src_len (it has no src_size): the shim is where a Java caller's buffer bound is known */
-        for (jint i = 0; rc == TSX_OK && i < n; i++)
-            if (d[i].src_off > (uint64_t)scap || d[i].src_len > (uint64_t)scap - d[i].src_off) rc = TSX_E_INVAL;
+        /* the capacities of the two direct buffers are the bounds the library validates every descriptor against (ABI 3) */
         if (rc == TSX_OK)
-            rc = detransform ? tsx_detransform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, mem_kind)
-                             : tsx_transform_batch(NULL, &p, d, (uint32_t)n, s, o, (size_t)cap, mem_kind);
+            rc = detransform ? tsx_detransform_batch(NULL, &p, d, (uint32_t)n, s, (size_t)scap, o, (size_t)cap, mem_kind)
+                             : tsx_transform_batch(NULL, &p, d, (uint32_t)n, s, (size_t)scap, o, (size_t)cap, mem_kind);
     }
     explicit_bzero(&p, sizeof p);         /* the key does not outlive the call (ownership); not a dead store */
     return rc;

@@ -144,6 +144,34 @@ def test_validation_is_overflow_safe_and_leaves_descriptors_alone(emu):
     assert list(d["dst_off"]) == [777, 999] and list(d["dst_cap"]) == [5, 6]
 
 
+def test_descriptors_beyond_the_source_buffer_are_rejected(emu):
+    """ABI 3: every batch entry point takes src_size; a chunk that reaches beyond it (or whose src_off + src_len wraps) fails the call
+    with TSX_E_INVAL and nothing is touched - the array bounds of the reference's byte[] chunks."""
+    src = np.zeros(4096, np.uint8); dst = np.zeros(8192, np.uint8)
+    p = nat.Native.make_params(nat.ENCRYPT | nat.CRC, synth.KEY, synth.AAD)
+    for off, ln in ((4096 - 32, 64), (4096 + 16, 0), ((1 << 64) - 16, 64)):
+        d = pc.make_descs([ln], [off], [0], [256]); d["status"] = -7; d["dst_len"] = 5
+        for call in (lambda: emu.transform_batch(p, d, src, dst, dst.size), lambda: emu.detransform_batch(p, d, src, dst, dst.size),
+                     lambda: emu.crc32c_batch(d, src)):
+            with pytest.raises(nat.TsxError) as e:
+                call()
+            assert e.value.code == nat.E_INVAL and d["status"][0] == -7 and d["dst_len"][0] == 5
+    d = pc.make_descs([64], [4096 - 64], [0], [256])                # ends exactly at the end of src: fine
+    emu.transform_batch(p, d, src, dst, dst.size)
+    assert d["status"][0] == 0
+    d = pc.make_descs([64], [0], [0], [256])                        # the caller states a smaller source than the array: that bound counts
+    with pytest.raises(nat.TsxError):
+        emu.transform_batch(p, d, src, dst, dst.size, src_size=32)
+
+
+def test_crc_only_batches_publish_their_status(emu):
+    """A descriptor that comes back from tsx_crc32c_batch says TSX_OK whatever it said before (callers reuse descriptors)."""
+    buf = np.zeros(64, np.uint8); buf[:9] = np.frombuffer(b"123456789", np.uint8)
+    d = pc.make_descs([9, 0], [0, 16], [0, 0], [0, 0]); d["status"] = -7
+    emu.crc32c_batch(d, buf)
+    assert list(d["status"]) == [0, 0] and d["crc32c"][0] == 0xE3069283 and d["crc32c"][1] == 0
+
+
 @pytest.mark.parametrize("flags", [nat.ENCRYPT | nat.CRC, nat.CRC, 0])
 def test_staged_pipeline_equals_single_shot(emu, flags, monkeypatch):
     """TSX_MEM_HOST batches are cut into pieces (copy-in / kernels / copy-out overlapped); forced down to 4 KiB pieces here so that 23

@@ -73,8 +73,8 @@ class Native:
         L.tsx_transformed_bound.restype = sz; L.tsx_transformed_bound.argtypes = [sz, u32]
         for name in ("tsx_transform_batch", "tsx_detransform_batch"):
             f = getattr(L, name); f.restype = C.c_int
-            f.argtypes = [vp, C.POINTER(BatchParams), vp, u32, vp, vp, sz, C.c_int]
-        L.tsx_crc32c_batch.restype = C.c_int; L.tsx_crc32c_batch.argtypes = [vp, vp, u32, vp, C.c_int]
+            f.argtypes = [vp, C.POINTER(BatchParams), vp, u32, vp, sz, vp, sz, C.c_int]
+        L.tsx_crc32c_batch.restype = C.c_int; L.tsx_crc32c_batch.argtypes = [vp, vp, u32, vp, sz, C.c_int]
         L.tsx_device_malloc.restype = C.c_int; L.tsx_device_malloc.argtypes = [C.c_int, sz, C.POINTER(vp)]
         L.tsx_device_free.restype = C.c_int; L.tsx_device_free.argtypes = [C.c_int, vp]
         L.tsx_memcpy_h2d.restype = C.c_int; L.tsx_memcpy_h2d.argtypes = [C.c_int, vp, vp, sz]
@@ -196,22 +196,32 @@ class Native:
             return x.ctypes.data
         return x  # raw device pointer (int)
 
-    def transform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None):
+    @staticmethod
+    def _src_size(descs, src, src_size):
+        """Size of the caller's source buffer (ABI 3).  A numpy array knows its own; for a raw device pointer the caller states it,
+        or - src_size None - vouches that the descriptors lie inside the allocation (their extent is passed)."""
+        if src_size is not None:
+            return int(src_size)
+        if isinstance(src, np.ndarray):
+            return src.nbytes
+        return int((descs["src_off"] + descs["src_len"]).max()) if len(descs) else 0
+
+    def transform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None, src_size=None):
         assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
         self._device_ready(mem_kind)
         return self.check(self.lib.tsx_transform_batch(ctx, C.byref(params), descs.ctypes.data, len(descs), self._ptr(src),
-                                                       self._ptr(dst), dst_size, mem_kind))
+                                                       self._src_size(descs, src, src_size), self._ptr(dst), dst_size, mem_kind))
 
-    def detransform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None):
+    def detransform_batch(self, params, descs, src, dst, dst_size, mem_kind=MEM_HOST, ctx=None, src_size=None):
         assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
         self._device_ready(mem_kind)
         return self.check(self.lib.tsx_detransform_batch(ctx, C.byref(params), descs.ctypes.data, len(descs), self._ptr(src),
-                                                         self._ptr(dst), dst_size, mem_kind))
+                                                         self._src_size(descs, src, src_size), self._ptr(dst), dst_size, mem_kind))
 
-    def crc32c_batch(self, descs, src, mem_kind=MEM_HOST, ctx=None):
+    def crc32c_batch(self, descs, src, mem_kind=MEM_HOST, ctx=None, src_size=None):
         assert descs.dtype == DESC_DTYPE and descs.flags["C_CONTIGUOUS"]
         self._device_ready(mem_kind)
-        return self.check(self.lib.tsx_crc32c_batch(ctx, descs.ctypes.data, len(descs), self._ptr(src), mem_kind))
+        return self.check(self.lib.tsx_crc32c_batch(ctx, descs.ctypes.data, len(descs), self._ptr(src), self._src_size(descs, src, src_size), mem_kind))
 
 
 _native = None

@@ -77,7 +77,7 @@ static std::mutex g_mu;
 static std::vector<tsx_device> g_devs;
 static uint32_t g_rr = 0;
 static thread_local int t_dev_hint = -1;
-static const char kUninitVersion[] = "tsxform 0.2 (gfx950 HIP; uninitialised)";
+static const char kUninitVersion[] = "tsxform 0.3 (gfx950 HIP; uninitialised)";
 static char g_version_buf[2][512];
 static unsigned g_version_gen = 0;
 static std::atomic<const char*> g_version{kUninitVersion};
@@ -166,7 +166,7 @@ extern "C" int tsx_init(int device_count, const int* device_ids) {
     g_devs.swap(devs);
     char* vb = g_version_buf[g_version_gen++ & 1];
     snprintf(vb, sizeof g_version_buf[0],
-             "tsxform 0.2 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; %d device(s): %s)",
+             "tsxform 0.3 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; %d device(s): %s)",
              (int)g_devs.size(), g_devs[0].name);
     g_version.store(vb, std::memory_order_release);
     return (int)g_devs.size();
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void scrub_failed_kernel(const tsx_chunk_desc*
 }
 
 // ---- batch drivers ---------------------------------------------------------------------------------
-static int validate(const tsx_chunk_desc* descs, uint32_t n, size_t dst_size, bool need_dst, uint32_t* max_len, uint32_t* max_out,
+static int validate(const tsx_chunk_desc* descs, uint32_t n, size_t src_size, size_t dst_size, bool need_dst, uint32_t* max_len, uint32_t* max_out,
                     size_t* in_bytes, bool* monotonic) {
     *max_len = 0; *max_out = 0; *in_bytes = 0; *monotonic = true;
     uint64_t prev_src_end = 0, prev_dst_end = 0;
@@ -465,7 +465,7 @@ static int validate(const tsx_chunk_desc* descs, uint32_t n, size_t dst_size, bo
         if ((d.src_off & 15) || (need_dst && (d.dst_off & 15))) return TSX_E_INVAL;       // 16-byte aligned slots
         if (need_dst && (d.dst_off > dst_size || d.dst_cap > dst_size - d.dst_off)) return TSX_E_INVAL;   // no wrap-around
         if (d.src_len >= (1u << 30) + 4096) return TSX_E_INVAL;                             // chunk.size <= 2^30 - 1 (RemoteStorageManagerConfig.java:122-130)
-        if (d.src_off > ((uint64_t)1 << 62)) return TSX_E_INVAL;
+        if (d.src_off > src_size || d.src_len > src_size - d.src_off) return TSX_E_INVAL;    // inside the caller's source buffer, no wrap-around
         if (d.src_len > *max_len) *max_len = d.src_len;
         if (need_dst && d.dst_cap > *max_out) *max_out = d.dst_cap;
         if (d.src_off + d.src_len > *in_bytes) *in_bytes = d.src_off + d.src_len;
@@ -481,7 +481,7 @@ static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTi
 struct tsx_sub { uint32_t lo, n; size_t in_lo, in_hi; };     // chunks [lo, lo + n), their input bytes [in_lo, in_hi) of src
 
 struct tsx_run {                                              // what one batch needs everywhere below
-    tsx_ctx* c; const tsx_batch_params* params; tsx_chunk_desc* descs; uint32_t n; const void* src; void* dst; size_t dst_size;
+    tsx_ctx* c; const tsx_batch_params* params; tsx_chunk_desc* descs; uint32_t n; const void* src; void* dst; size_t src_size, dst_size;
     int mem_kind, mode; uint32_t flags, max_len, max_out; bool host, packed, enc, comp, fuse_stages;
     const uint8_t* d_src; uint8_t* d_dst;
 };
@@ -506,6 +506,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e) {
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, c->d_partials, 0);
         HIPCHK(hipEventRecord(e[1], st)); HIPCHK(hipEventRecord(e[2], st));
         t.crc_launches += 2;
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);      // a reused descriptor must not keep an old status
     } else if (r.mode == 0) {
         // With compression the whole chain of a chunk runs in the wave that compresses it: CRC32C of the source chunk first, GCM over
         // the finished frame last - one launch per batch.  The batch CRC / GCM kernels want 20 / 40 KiB of LDS per workgroup and, on
@@ -603,7 +604,7 @@ static int run_batch_inner(tsx_run& r) {
     const uint32_t n = r.n;
     uint32_t max_len, max_out; size_t in_bytes; bool monotonic;
     // src-side validation first: nothing of the caller's descriptors is touched by a call that fails with TSX_E_INVAL
-    int rc = validate(r.descs, n, r.dst_size, r.mode != 2 && !r.packed, &max_len, &max_out, &in_bytes, &monotonic);
+    int rc = validate(r.descs, n, r.src_size, r.dst_size, r.mode != 2 && !r.packed, &max_len, &max_out, &in_bytes, &monotonic);
     if (rc) return rc;
     size_t out_bytes = r.dst_size;                                      // size of the output area the kernels see
     if (r.packed) {
@@ -697,7 +698,7 @@ static int run_batch_inner(tsx_run& r) {
     return TSX_OK;
 }
 
-static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, void* dst,
+static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, size_t src_size, void* dst,
                      size_t dst_size, int mem_kind, int mode /*0 transform, 1 detransform, 2 crc only*/) {
     if (!descs || (n && !src) || (mode != 2 && (!params || (n && !dst)))) return TSX_E_INVAL;
     if (mem_kind != TSX_MEM_HOST && mem_kind != TSX_MEM_DEVICE && mem_kind != TSX_MEM_HOST_PACKED) return TSX_E_INVAL;
@@ -714,7 +715,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     tsx_device_scope keep;
     if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
     tsx_run r{};
-    r.c = c; r.params = params; r.descs = descs; r.n = n; r.src = src; r.dst = dst; r.dst_size = dst_size; r.mem_kind = mem_kind; r.mode = mode;
+    r.c = c; r.params = params; r.descs = descs; r.n = n; r.src = src; r.dst = dst; r.src_size = src_size; r.dst_size = dst_size; r.mem_kind = mem_kind; r.mode = mode;
     r.flags = flags; r.host = mem_kind != TSX_MEM_DEVICE; r.packed = packed;
     r.enc = mode != 2 && (flags & TSX_ENCRYPT); r.comp = mode != 2 && (flags & TSX_COMPRESS);
     r.fuse_stages = r.comp && !getenv("TSX_STAGES_SEPARATE");
@@ -732,29 +733,29 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     return rc;
 }
 
-static int with_ctx(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, void* dst,
+static int with_ctx(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, size_t src_size, void* dst,
                     size_t dst_size, int mem_kind, int mode) {
-    if (ctx) return run_batch(ctx, params, descs, n, src, dst, dst_size, mem_kind, mode);
+    if (ctx) return run_batch(ctx, params, descs, n, src, src_size, dst, dst_size, mem_kind, mode);
     int rc = TSX_OK;
     tsx_ctx* c = pool_acquire(&rc);
     if (!c) return rc;
-    rc = run_batch(c, params, descs, n, src, dst, dst_size, mem_kind, mode);
+    rc = run_batch(c, params, descs, n, src, src_size, dst, dst_size, mem_kind, mode);
     pool_release(c);
     return rc;
 }
 
 extern "C" int tsx_transform_batch(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src,
-                                   void* dst, size_t dst_size, int mem_kind) {
-    return with_ctx(ctx, params, descs, n, src, dst, dst_size, mem_kind, 0);
+                                   size_t src_size, void* dst, size_t dst_size, int mem_kind) {
+    return with_ctx(ctx, params, descs, n, src, src_size, dst, dst_size, mem_kind, 0);
 }
 
 extern "C" int tsx_detransform_batch(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src,
-                                     void* dst, size_t dst_size, int mem_kind) {
-    return with_ctx(ctx, params, descs, n, src, dst, dst_size, mem_kind, 1);
+                                     size_t src_size, void* dst, size_t dst_size, int mem_kind) {
+    return with_ctx(ctx, params, descs, n, src, src_size, dst, dst_size, mem_kind, 1);
 }
 
-extern "C" int tsx_crc32c_batch(tsx_ctx* ctx, tsx_chunk_desc* descs, uint32_t n, const void* src, int mem_kind) {
-    return with_ctx(ctx, nullptr, descs, n, src, nullptr, 0, mem_kind, 2);
+extern "C" int tsx_crc32c_batch(tsx_ctx* ctx, tsx_chunk_desc* descs, uint32_t n, const void* src, size_t src_size, int mem_kind) {
+    return with_ctx(ctx, nullptr, descs, n, src, src_size, nullptr, 0, mem_kind, 2);
 }
 
 // Test hook (not part of the ABI in include/tsxform.h): OR of every byte of the context's key material on the device - 0 after

@@ -261,19 +261,19 @@ Backend::~Backend() {
     if (ctx_) f_->ctx_destroy(ctx_);
     // the library stays loaded: other Backends of the process share its device state
 }
-void Backend::transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
+void Backend::transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, size_t srcSize, uint8_t* dst, size_t dstSize) {
     CtxLease lease(lock_->mu, ctx_);
-    const int rc = f_->transform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
+    const int rc = f_->transform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, srcSize, dst, dstSize, TSX_MEM_HOST);
     if (rc) throw std::runtime_error(std::string("tsx_transform_batch: ") + f_->strerr(rc));
 }
-void Backend::transformBatchPacked(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
+void Backend::transformBatchPacked(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, size_t srcSize, uint8_t* dst, size_t dstSize) {
     CtxLease lease(lock_->mu, ctx_);
-    const int rc = f_->transform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST_PACKED);
+    const int rc = f_->transform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, srcSize, dst, dstSize, TSX_MEM_HOST_PACKED);
     if (rc) throw std::runtime_error(std::string("tsx_transform_batch: ") + f_->strerr(rc));
 }
-void Backend::detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, uint8_t* dst, size_t dstSize) {
+void Backend::detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& d, const uint8_t* src, size_t srcSize, uint8_t* dst, size_t dstSize) {
     CtxLease lease(lock_->mu, ctx_);
-    const int rc = f_->detransform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, dst, dstSize, TSX_MEM_HOST);
+    const int rc = f_->detransform(lease.ctx, &p, d.data(), (uint32_t)d.size(), src, srcSize, dst, dstSize, TSX_MEM_HOST);
     if (rc) throw std::runtime_error(std::string("tsx_detransform_batch: ") + f_->strerr(rc));
 }
 uint32_t Backend::crc32c(const uint8_t* data, size_t n) {
@@ -283,7 +283,7 @@ uint32_t Backend::crc32c(const uint8_t* data, size_t n) {
     memset(&d, 0, sizeof d);
     d.src_len = (uint32_t)n;
     CtxLease lease(lock_->mu, ctx_);
-    const int rc = f_->crc(lease.ctx, &d, 1, buf.data(), TSX_MEM_HOST);
+    const int rc = f_->crc(lease.ctx, &d, 1, buf.data(), buf.size(), TSX_MEM_HOST);
     if (rc || d.status != TSX_OK) throw std::runtime_error(std::string("tsx_crc32c_batch: ") + f_->strerr(rc ? rc : d.status));
     return d.crc32c;
 }
@@ -333,7 +333,7 @@ std::string serializeTransformedChunks(Backend& be, const std::vector<int>& valu
     memset(d.data(), 0, sizeof(tsx_chunk_desc));
     d[0].src_len = (uint32_t)bin.size(); d[0].dst_cap = (uint32_t)cap;
     const tsx_batch_params p = makeParams(TSX_COMPRESS, nullptr, nullptr, profile);
-    be.transformBatch(p, d, src.data(), dst.data(), dst.size());
+    be.transformBatch(p, d, src.data(), src.size(), dst.data(), dst.size());
     if (d[0].status != TSX_OK) throw std::runtime_error("index compression failed: " + be.strerror(d[0].status));
     dst.resize(d[0].dst_len);
     return base64Encode(dst);
@@ -350,7 +350,7 @@ std::vector<int> deserializeTransformedChunks(Backend& be, const std::string& ba
     memset(d.data(), 0, sizeof(tsx_chunk_desc));
     d[0].src_len = (uint32_t)frame.size(); d[0].dst_cap = (uint32_t)size;
     const tsx_batch_params p = makeParams(TSX_COMPRESS, nullptr, nullptr, TSX_ZSTD_PROFILE_1_5_7);
-    be.detransformBatch(p, d, src.data(), dst.data(), dst.size());
+    be.detransformBatch(p, d, src.data(), src.size(), dst.data(), dst.size());
     if (d[0].status != TSX_OK) throw std::runtime_error("index decompression failed: " + be.strerror(d[0].status));
     dst.resize(d[0].dst_len);
     return ChunkSizesBinaryCodec::decode(dst);
@@ -488,7 +488,7 @@ GpuTransformChunkEnumeration::Batch GpuTransformChunkEnumeration::transformNextB
     Bytes src(so + 16), dst(dofs + 16);
     for (size_t i = 0; i < in.size(); i++) memcpy(src.data() + d[i].src_off, in[i].data(), in[i].size());
     const tsx_batch_params p = makeParams(flags, enc_ ? &enc_->dataKey : nullptr, enc_ ? &enc_->aad : nullptr, profile_);
-    be_->transformBatch(p, d, src.data(), dst.data(), dst.size());
+    be_->transformBatch(p, d, src.data(), src.size(), dst.data(), dst.size());
     for (size_t i = 0; i < in.size(); i++) {
         if (d[i].status != TSX_OK) throw std::runtime_error(be_->strerror(d[i].status));        // the reference wraps crypto failures in RuntimeException
         if (withCrc_) out.crcs.push_back(d[i].crc32c);
@@ -535,7 +535,7 @@ size_t GpuTransformChunkEnumeration::appendNextBatchPacked(Bytes& object, std::v
     for (size_t i = 0; i < in.size(); i++) if (!in[i].empty()) memcpy(src.data() + d[i].src_off, in[i].data(), in[i].size());
     const tsx_batch_params p = makeParams(flags, enc_ ? &enc_->dataKey : nullptr, enc_ ? &enc_->aad : nullptr, profile_);
     object.resize(at + bound);                                         // room for the worst case, trimmed to what was produced
-    be_->transformBatchPacked(p, d, src.data(), object.data() + at, bound);
+    be_->transformBatchPacked(p, d, src.data(), src.size(), object.data() + at, bound);
     for (size_t i = 0; i < in.size(); i++) {
         if (d[i].status != TSX_OK) { object.resize(at); throw std::runtime_error(be_->strerror(d[i].status)); }
         if (withCrc_) crcs_.push_back(d[i].crc32c);
@@ -664,7 +664,7 @@ void GpuDetransformChunkEnumeration::fillBatchIfNeeded() {
     Bytes src(so + 16), dst(dofs + 16);
     for (size_t i = 0; i < in.size(); i++) memcpy(src.data() + d[i].src_off, in[i].data(), in[i].size());
     const tsx_batch_params p = makeParams(flags, enc_ ? &enc_->dataKey : nullptr, enc_ ? &enc_->aad : nullptr, TSX_ZSTD_PROFILE_1_5_7);
-    be_->detransformBatch(p, d, src.data(), dst.data(), dst.size());
+    be_->detransformBatch(p, d, src.data(), src.size(), dst.data(), dst.size());
     for (size_t i = 0; i < in.size(); i++) {
         if (d[i].status != TSX_OK) {
             // the failure belongs to chunk i: everything before it is still handed out, the exception surfaces when i is reached

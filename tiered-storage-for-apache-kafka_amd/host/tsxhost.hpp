@@ -148,10 +148,10 @@ public:
     Backend(const Backend&) = delete;
     Backend& operator=(const Backend&) = delete;
     // one batch over host buffers; throws std::runtime_error on a batch-level failure, per-chunk status stays in descs
-    void transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
+    void transformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, size_t srcSize, uint8_t* dst, size_t dstSize);
     // the same with TSX_MEM_HOST_PACKED: transformed chunks back to back in dst, offsets and sizes returned in descs
-    void transformBatchPacked(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
-    void detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, uint8_t* dst, size_t dstSize);
+    void transformBatchPacked(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, size_t srcSize, uint8_t* dst, size_t dstSize);
+    void detransformBatch(const tsx_batch_params& p, std::vector<tsx_chunk_desc>& descs, const uint8_t* src, size_t srcSize, uint8_t* dst, size_t dstSize);
     uint32_t crc32c(const uint8_t* data, size_t n);              // java.util.zip.CRC32C of one byte range (tsx_crc32c_batch)
     size_t transformedBound(size_t n, uint32_t flags) const;
     std::string strerror(int code) const;

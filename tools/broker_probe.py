@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""The shape a broker drives the forward chain in: T caller threads (RLM upload threads, reference README.md:218-222,
+RemoteStorageManager.java:400-432), each submitting B-chunk batches back to back.  Prints one JSON line per configuration.
+
+  --mem device   resident buffers (what bench.py's `value` is quoted on)
+  --mem host     TSX_MEM_HOST_PACKED from / to tsx_host_register'ed host buffers (what the JNI shim passes)
+  --ctxless      pooled contexts (tsx_transform_batch(ctx = NULL)), as GpuTransformChunkEnumeration calls
+Each configuration is "threads x batch": e.g.  --configs 10x256,20x256,3x2048
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GiB = float(1 << 30)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="10x256,20x256,3x2048")
+    ap.add_argument("--mem", default="device", choices=["device", "host"])
+    ap.add_argument("--ctxless", action="store_true")
+    ap.add_argument("--seconds", type=float, default=6.0, help="approximate run time per configuration")
+    ap.add_argument("--pool-chunks", type=int, default=2048, help="distinct source chunks generated (threads take slices)")
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    import torch
+    import tsxform
+    from tsxform import synth
+    nat = tsxform._native
+    N = nat.Native()
+    N.init(1, [0])
+    dev = torch.device("cuda", 0)
+    CH = synth.CHUNK
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
+    P = args.pool_chunks
+    src = torch.empty(P * CH, dtype=torch.uint8, device=dev)
+    for i in range(P):
+        src[i * CH:(i + 1) * CH] = synth.gen_chunk("K", 1000 + i // 256, i // 256, i % 256, CH, device=dev)
+    torch.cuda.synchronize()
+    hsrc = None
+    if args.mem == "host":
+        hsrc = src.cpu().numpy()
+        N.host_register(hsrc)
+    params = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    for cfg in args.configs.split(","):
+        T, B = (int(x) for x in cfg.split("x"))
+        descs, dsts, ctxs, offs = [], [], [], []
+        for t in range(T):
+            lo = (t * B) % max(P - B + 1, 1)
+            d = np.zeros(B, nat.DESC_DTYPE)
+            d["src_off"] = (np.arange(B, dtype=np.uint64) + np.uint64(lo)) * np.uint64(CH)
+            d["src_len"] = CH
+            d["dst_off"] = np.arange(B, dtype=np.uint64) * np.uint64(slot)
+            d["dst_cap"] = slot
+            for i in range(B):
+                d["iv"][i] = np.frombuffer(synth.iv_for(t, i), np.uint8)
+            descs.append(d)
+            if args.mem == "device":
+                dsts.append(torch.empty(B * slot, dtype=torch.uint8, device=dev))
+            else:
+                h = np.zeros(B * slot, np.uint8)
+                N.host_register(h)
+                dsts.append(h)
+            ctxs.append(None if args.ctxless else N.ctx_create(0, B, CH))
+
+        def call(t):
+            if args.mem == "device":
+                N.transform_batch(params, descs[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+            else:
+                N.transform_batch(params, descs[t], hsrc, dsts[t], dsts[t].size, nat.MEM_HOST_PACKED, ctx=ctxs[t])
+
+        for t in range(min(T, 4)):                       # workspaces / pools exist before the clock starts
+            call(t)
+        torch.cuda.synchronize()
+        done = [0] * T
+        lat = [[] for _ in range(T)]
+        stop_at = [0.0]
+
+        def worker(t):
+            while time.perf_counter() < stop_at[0]:
+                a = time.perf_counter()
+                call(t)
+                lat[t].append(time.perf_counter() - a)
+                done[t] += 1
+
+        t0 = time.perf_counter()
+        stop_at[0] = t0 + args.seconds
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ok = all(bool((d["status"] == 0).all()) for d in descs)
+        allat = np.concatenate([np.asarray(x) for x in lat]) if sum(done) else np.zeros(1)
+        print(json.dumps({"tag": args.tag, "threads": T, "batch_chunks": B, "mem": args.mem, "ctxless": args.ctxless,
+                          "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "batches": int(sum(done)), "seconds": round(el, 3),
+                          "gibs": round(sum(done) * B * CH / GiB / el, 3), "ms_per_call_median": round(float(np.median(allat)) * 1e3, 1),
+                          "ms_per_call_p95": round(float(np.percentile(allat, 95)) * 1e3, 1), "ok": ok}), flush=True)
+        for c in ctxs:
+            if c is not None:
+                N.ctx_destroy(c)
+        if args.mem == "host":
+            for h in dsts:
+                N.host_unregister(h)
+        del dsts
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
