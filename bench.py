@@ -75,11 +75,28 @@ def usable_cores():
     return n
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: become the launch line the contract names (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1) instead of silently measuring one rank."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args)                                     # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line would misreport n_gpus" % (args.gpus, world))
     import torch  # before libtsxform: one shared HIP runtime
     import torch.distributed as dist
     rehearse = args.rehearse

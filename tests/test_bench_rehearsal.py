@@ -46,6 +46,28 @@ def test_two_ranks_segment_major(emu, oracle):
     assert j["cpu_baseline"] is None and j["end_to_end"] is None
 
 
+def test_gpus_2_without_a_launcher_starts_two_ranks(emu, oracle):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run: two ranks, the
+    process group, the barrier and the max-over-ranks reduction really run, and the line says n_gpus 2 (it used to run ONE
+    rank and print n_gpus 1).  A launcher whose WORLD_SIZE disagrees with --gpus is refused."""
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse", "--backend", "gloo",
+           "--workload", "full", "--chunk-bytes", "20000", "--chunks-per-segment", "3", "--segments", "2", "--inflight", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["segments_of_rank0"] == [0, 2] and j["config"]["segments_total"] == 4
+    assert j["detransform"]["round_trip_exact"] is True
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse", "--backend", "gloo"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 4" in (r.stdout + r.stderr)
+
+
 def test_one_segment_split_over_two_ranks(emu, oracle):
     if not oracle.zstd_version().startswith("1.5.7"):
         pytest.skip("libzstd 1.5.7 not available")
