@@ -111,6 +111,36 @@ def edge_chunks(dist="R", sizes=EDGE_SIZES):
     return [synth.gen_chunk(dist, 7, 1, i, s) for i, s in enumerate(sizes)]
 
 
+MiB = 1 << 20
+
+
+def big_chunk(kind):
+    """Chunks beyond 4 MiB: the reference allows chunk.size up to 2^30 - 1 (RemoteStorageManagerConfig.java:122-130), disables chunking
+    with size 0 (BaseTransformChunkEnumeration.java:85-89: the whole segment is ONE chunk) and its integration matrix transforms a
+    10 MiB segment as one chunk (RemoteStorageManagerTest.java:190-242).  Beyond 4 MiB the 2 MiB match window slides several times, the
+    table entries keep fewer tag bits (9 at 4 MiB, 8 at 10 MiB, 5 at 64 MiB) and the frame is no longer single-segment."""
+    R = synth.gen_chunk("R", 11, 0, 0, 4 * MiB); K = synth.gen_chunk("K", 11, 0, 1, 4 * MiB)
+    Z = np.zeros(MiB // 2, np.uint8)
+    if kind == "K6":                 # Kafka-like throughout (the bench content), 6 MiB
+        return np.concatenate([K, synth.gen_chunk("K", 11, 0, 2, 2 * MiB)])
+    if kind == "K10":
+        return np.concatenate([K, synth.gen_chunk("K", 11, 0, 2, 4 * MiB), synth.gen_chunk("K", 11, 0, 3, 2 * MiB)])
+    if kind == "mixed6":             # K / R pieces; the 1 MiB of K at the start comes back 1.5 MiB later (inside the window) and 4 MiB later (outside)
+        return np.concatenate([K[:MiB], R[:MiB // 2], K[:MiB], R[MiB:2 * MiB], Z, K[MiB:2 * MiB], K[:MiB]])[:6 * MiB]
+    if kind == "mixed10":            # far repeats at 1.5 / 3 / 7 MiB distance over five window slides, raw (R) and RLE (zeros) blocks between compressed ones
+        parts = [K[:MiB], R[:MiB // 2], K[:MiB // 2], R[MiB:2 * MiB], K[MiB:2 * MiB], R[:MiB // 2], Z, K[:MiB], R[2 * MiB:3 * MiB],
+                 K[2 * MiB:3 * MiB + MiB // 2], R[:MiB], K[:MiB]]
+        return np.concatenate(parts)[:10 * MiB]
+    if kind == "sparse64":           # 64 MiB: mostly incompressible with repeats 1 MiB (in the window) and 3+ MiB (outside) apart, zeros, some K
+        parts = []
+        for i in range(16):
+            parts += [R[:2 * MiB], R[MiB // 2:MiB // 2 + MiB], Z, K[i * 65536:(i + 4) * 65536], R[3 * MiB:3 * MiB + MiB // 4]]
+        return np.concatenate([np.concatenate(parts), R])[:64 * MiB]
+    if kind == "K64":                # the bench content as ONE 64 MiB chunk (a segment with chunking disabled)
+        return np.concatenate([synth.gen_chunk("K", 12, 0, c, 4 * MiB) for c in range(16)])
+    raise ValueError(kind)
+
+
 def check_profile_1_5_6(N, o, named_chunks):
     """The profile the reference would ship with (libzstd 1.5.6 inside zstd-jni 1.5.6-9, core/build.gradle:29) has no real library
     to be compared with here.  What CAN be pinned: profile 0 is the profile-1 code minus 1.5.7's block pre-splitter, so

@@ -60,6 +60,18 @@ def test_speculation_schedule_never_changes_the_bytes(emu, oracle, sched, monkey
         assert outs[i] == oracle.zstd_compress_chunk(CASES[n].tobytes()), (n, sched)
 
 
+@pytest.mark.parametrize("kind", ["mixed10", "sparse64"])
+def test_chunks_beyond_4_MiB(emu, oracle, kind):
+    """chunk.size above 4 MiB (up to a whole segment as one chunk): frames equal libzstd's and decode back.  Content chosen so that the
+    emulator finishes in about a minute per case; the Kafka-like 6 / 10 / 64 MiB chunks run on the device (tests/test_gpu_parity.py)."""
+    _need157(oracle)
+    x = pc.big_chunk(kind)
+    outs, d = pc.run_transform(emu, nat.COMPRESS, [x])
+    assert d["status"][0] == 0 and outs[0] == oracle.zstd_compress_chunk(x.tobytes()), kind
+    back, d2 = pc.run_detransform(emu, nat.COMPRESS, outs, [int(x.size)])
+    assert d2["status"][0] == 0 and back[0] == x.tobytes()
+
+
 def test_reference_golden_frame(emu):
     # CT/manifest/index/ChunkIndexSerializationTest.java:39-61
     outs, _ = pc.run_transform(emu, nat.COMPRESS, [CASES["golden15"]])

@@ -355,6 +355,44 @@ def test_staged_host_pipeline_on_the_device(gpu, oracle, flags, monkeypatch):
         gpu.host_unregister(src); gpu.host_unregister(dst)
 
 
+@pytest.mark.parametrize("kind", ["K6", "K10", "mixed6", "mixed10", "sparse64", "K64"])
+def test_chunks_beyond_4_MiB(gpu, oracle, kind, monkeypatch):
+    """chunk.size above 4 MiB - up to a whole segment as ONE chunk (RemoteStorageManagerConfig.java:122-130, chunk.size = 0 in
+    BaseTransformChunkEnumeration.java:85-89; the reference's integration matrix has a 10 MiB segment as one chunk): the full chain
+    equals libzstd 1.5.7 + OpenSSL for both Zstd profiles (wherever 1.5.7's pre-splitter is idle), decodes back, and the host-memory
+    pipeline cut into pieces gives the same bytes."""
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    x = pc.big_chunk(kind)
+    small = synth.gen_chunk("K", 13, 0, 1, 300000)                     # a small neighbour in the same batch
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    outs, d = pc.check_transform_vs_oracle(gpu, oracle, flags, [x, small])
+    back, d2 = pc.run_detransform(gpu, flags, outs, [int(x.size), int(small.size)])
+    assert (d2["status"] == 0).all() and back[0] == x.tobytes() and back[1] == small.tobytes() and d2["crc32c"][0] == d["crc32c"][0]
+    pinned, differ = pc.check_profile_1_5_6(gpu, oracle, {kind: x})
+    monkeypatch.setenv("TSX_SUB_BYTES", str(3 << 20))                  # pieces smaller than the chunk: one chunk never straddles two
+    outs2, _ = pc.run_transform(gpu, flags, [x, small], mem="packed")
+    assert outs2 == outs
+    dev, _ = pc.run_transform(gpu, flags, [x, small], mem="device")
+    assert dev == outs
+
+
+def test_descriptors_beyond_the_source_buffer_are_rejected_on_the_device(gpu):
+    """ABI 3 on the product library: src_size bounds every descriptor; CRC-only batches publish their statuses."""
+    src = np.zeros(4096, np.uint8); dst = np.zeros(8192, np.uint8)
+    p = nat.Native.make_params(nat.ENCRYPT | nat.CRC, synth.KEY, synth.AAD)
+    d = pc.make_descs([64], [4096 - 32], [0], [256]); d["status"] = -7
+    for call in (lambda: gpu.transform_batch(p, d, src, dst, dst.size), lambda: gpu.detransform_batch(p, d, src, dst, dst.size),
+                 lambda: gpu.crc32c_batch(d, src)):
+        with pytest.raises(nat.TsxError) as e:
+            call()
+        assert e.value.code == nat.E_INVAL and d["status"][0] == -7
+    src[:9] = np.frombuffer(b"123456789", np.uint8)
+    d = pc.make_descs([9, 0], [0, 16], [0, 0], [0, 0]); d["status"] = -7
+    gpu.crc32c_batch(d, src)
+    assert list(d["status"]) == [0, 0] and d["crc32c"][0] == 0xE3069283
+
+
 def test_every_chunk_of_a_segment_equals_libzstd_and_openssl(gpu, oracle):
     """at full size the oracle saw a handful of chunks.  Here every one of the 256 chunks of a 1 GiB Kafka-like
     segment (+ 16 incompressible ones) through Zstd -> GCM -> CRC on the device is compared byte for byte with libzstd 1.5.7 + OpenSSL,
