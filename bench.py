@@ -52,9 +52,34 @@ def parse():
                     help="with --split-segments: rank 0 (the owner of the upload stream) also receives every rank's slice of the transformed object inside the step (send / recv)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the continuously-fed measurement (5 callers, 10 batches each) after the timed region")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host->host (PCIe-inclusive) measurement after the timed region")
+    ap.add_argument("--no-broker", action="store_true", help="skip the broker-shaped leg of end_to_end (10 / 20 callers x 256-chunk segments, pooled contexts, registered buffers)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
     return ap.parse_args()
+
+
+def kernel_source_sha(names):
+    """sha256 (16 hex) over the kernel sources a PMC record was measured on (tools/pmc_traffic.py writes the same)."""
+    import hashlib
+    h = hashlib.sha256()
+    for nm in names:
+        with open(os.path.join(ROOT, "tiered-storage-for-apache-kafka_amd", "csrc", nm), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(key):
+    """(record, fresh): the committed PMC pass for this workload, and whether the kernel source is still the one it was measured on.
+    A stale record is not quoted: `traffic` is null until tools/pmc_zstd.sh + tools/pmc_traffic.py have run on the new kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(key)
+        if not rec:
+            return None, False
+        fresh = "kernel_source_sha" in rec and rec["kernel_source_sha"] == kernel_source_sha(rec.get("kernel_sources", []))
+        return rec, fresh
+    except (OSError, ValueError, KeyError):
+        return None, False
 
 
 def usable_cores():
@@ -364,17 +389,13 @@ def main():
         alg_inv = float(n) * (CH + float(d["dst_len"].astype(np.int64).mean()) - (28 if flags & nat.ENCRYPT else 0))
         dom_ms = max(tm.unzstd_ms, tm.gcm_ms, tm.crc_ms)
         dom_k = "zstd_decompress_kernel" if dom_ms == tm.unzstd_ms else ("gcm_ctr_ghash_kernel" if dom_ms == tm.gcm_ms else "crc32c_partial_kernel")
-        inv_traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                rec = json.load(f).get("detransform/%s/%d" % (args.dist, n))
-            if rec:
-                inv_traffic = rec["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        rec, fresh = pmc_record("detransform/%s/%d" % (args.dist, n))
+        inv_traffic = rec["hbm_bytes_per_launch"] if rec and fresh else None
         ach = alg_inv / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         inverse["roofline"] = {"bound": "hbm", "kernel": dom_k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": inv_traffic, "ms_per_launch": round(dom_ms, 4),
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": inv_traffic,
+                               "traffic_source": None if not rec else (rec.get("source") if fresh else "STALE: %s was measured on another build of the kernel" % rec.get("source")),
+                               "ms_per_launch": round(dom_ms, 4),
                                "algorithmic_bytes_per_launch": int(alg_inv)}
         del back
 
@@ -398,27 +419,26 @@ def main():
     # FETCH_SIZE + WRITE_SIZE of the same kernel build and workload); null when no such measurement is recorded
     traffic = None
     binding = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get("%s/%s/%d" % (workload, args.dist, n))
-        if rec:
-            traffic = rec["hbm_bytes_per_launch"]
-            if dom == "zstd" and "tcc_ea_rdreq" in rec:
-                # The resource that actually binds the hash-table parser: 64-B lines moved between L2 and memory at random
-                # addresses (one per 4-byte table probe / insertion).  Requests per launch from the committed PMC passes
-                # (TCC_EA0_RDREQ + WRREQ), rate over the whole timed region (all launches, as they overlapped), ceiling =
-                # what the chip sustains for the same read / write-back mix with waves that do nothing else
-                # (tools/ubench/mix.hip, profiles/r01_ubench_mix.txt: 44 G lines/s at 4096-5120 waves).
-                req = float(rec["tcc_ea_rdreq"] + rec["tcc_ea_wrreq"])
-                rate = req * args.steps / elapsed / 1e9
-                binding = {"resource": "random 64-B line accesses L2<->HBM (table probes + insertions)", "requests_per_launch": int(req),
-                           "achieved": round(rate, 2), "peak": 44.0, "unit": "G lines/s", "frac": round(rate / 44.0, 3),
-                           "peak_source": "profiles/r02_ubench_mix_same_box_as_pmc.txt (waves that do nothing else, 58/42 read/write-back mix; 36-46 by box and run)"}
-    except (OSError, ValueError, KeyError):
-        pass
+    rec, fresh = pmc_record("%s/%s/%d" % (workload, args.dist, n))
+    if rec and fresh:
+        traffic = rec["hbm_bytes_per_launch"]
+        if dom == "zstd" and "tcc_ea_rdreq" in rec:
+            # The resource that actually binds the hash-table parser: 64-B lines moved between L2 and memory at random addresses (one
+            # per 4-byte table probe / insertion).  Requests per launch from the committed PMC passes (TCC_EA0_RDREQ + WRREQ), rate over
+            # the whole timed region (all launches, as they overlapped).  The ceiling is what the chip sustains for the same mix with
+            # waves that do nothing else (tools/ubench/mix.hip): 36-46 G lines/s by box and run - a band, so this is a diagnosis,
+            # not a roofline; the roofline above is the contract's (HBM streaming peak).
+            req = float(rec["tcc_ea_rdreq"] + rec["tcc_ea_wrreq"])
+            rate = req * args.steps / elapsed / 1e9
+            binding = {"resource": "random 64-B line accesses L2<->HBM (table probes + insertions)", "requests_per_launch": int(req),
+                       "requests_per_sequence": rec.get("requests_per_sequence"),
+                       "achieved": round(rate, 2), "peak_band": [36.0, 46.0], "unit": "G lines/s", "frac_band": [round(rate / 46.0, 3), round(rate / 36.0, 3)],
+                       "peak_source": "profiles/r02_ubench_mix_same_box_as_pmc.txt, r02_ubench_mix4_placement.txt (waves that do nothing else, 58/42 read / write-back mix)"}
     roofline = {"bound": "hbm", "kernel": {"crc": "crc32c_partial_kernel", "gcm": "gcm_ctr_ghash_kernel", "zstd": "zstd_compress_kernel"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
+                "traffic": traffic,
+                "traffic_source": None if not rec else (rec.get("source") if fresh else "STALE: %s was measured on another build of the kernel - rerun tools/pmc_zstd.sh + tools/pmc_traffic.py" % rec.get("source")),
+                "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
                 "launches_in_flight": T, "achieved_aggregate": round(achieved * T, 2),
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage.items()}, "binding_resource": binding}
 
@@ -456,14 +476,20 @@ def main():
             timed_lib, timed_ver = best[1], best[2]
             o.zstd_open(timed_lib)
         legs = []
+        # BASELINE configs[0] times the reference "to filesystem backend": the transformed chunks also go to a file on tmpfs (what
+        # FileSystemStorage.upload does with the transformed stream), in-memory rate next to it
+        sink_dir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        sink = os.path.join(sink_dir, "tsx_cpu_baseline_%d.log" % os.getpid()) if sink_dir else None
         try:
             for nthr in sorted(set([1, min(10, cores), cores])):
                 sample = min(n, max(per_thread * nthr, 24 if workload == "full" else 256))
                 host = src[:sample * CH].cpu().numpy()
                 ivs = np.ascontiguousarray(d["iv"][:sample]).reshape(-1)
-                secs, _, _, _, _ = o.chain_run_threads(of, synth.KEY, synth.AAD, host, CH, ivs, nthr)
+                secs_mem, _, _, _, _ = o.chain_run_threads(of, synth.KEY, synth.AAD, host, CH, ivs, nthr)
+                secs = o.chain_run_threads(of, synth.KEY, synth.AAD, host, CH, ivs, nthr, sink=sink)[0] if sink else secs_mem
                 legs.append({"threads": nthr, "value": round(sample * CH / GiB / secs, 4), "unit": "GiB/s", "sample_chunks": sample,
-                             "MiB_per_s_per_thread": round(sample * CH / (1 << 20) / secs / nthr, 1)})
+                             "MiB_per_s_per_thread": round(sample * CH / (1 << 20) / secs / nthr, 1),
+                             "in_memory_only_gibs": round(sample * CH / GiB / secs_mem, 4)})
         finally:
             if flags & nat.COMPRESS:
                 o.zstd_open(None)                                         # parity checks go back to 1.5.7
@@ -488,8 +514,10 @@ def main():
                 zstd157 = {"error": str(e)[:200]}
         top = legs[-1]
         cpu = {"value": top["value"], "unit": "GiB/s", "cores": top["threads"], "kind": "port",
-               "sample": "%d x 4 MiB chunks (%s) through oracle/chain.c: libzstd %s level 3 + OpenSSL AES-256-GCM + CRC32C, %d threads"
-                         % (top["sample_chunks"], args.dist, timed_ver if flags & nat.COMPRESS else "n/a", top["threads"]),
+               "sample": "%d x 4 MiB chunks (%s) through oracle/chain.c: libzstd %s level 3 + OpenSSL AES-256-GCM + CRC32C, %d threads, transformed chunks written to %s"
+                         % (top["sample_chunks"], args.dist, timed_ver if flags & nat.COMPRESS else "n/a", top["threads"], "a tmpfs file (/dev/shm)" if sink else "memory only (no tmpfs)"),
+               "sink": "tmpfs file" if sink else "memory", "jvm_on_box": __import__("shutil").which("java"),
+               "not_the_reference_java_chain": "no JDK in this image or on the GPU box (java not on PATH): a C port of the chain with the real libzstd / OpenSSL stands in",
                "by_threads": legs, "nproc": os.cpu_count(), "usable_cores": cores, "cpu_model": model,
                "libzstd_timed": timed_ver, "libzstd_timed_path": timed_lib or "parity library", "libzstd_parity": o.zstd_version() if flags & nat.COMPRESS else None,
                "libzstd_one_chunk_probe_MiB_per_s": probe, "zstd_stage_alone_optimised_1_5_7": zstd157}
@@ -565,9 +593,59 @@ def main():
                 for c_ in cx[len(ctxs):]:
                     N.ctx_destroy(c_)
                 del hdsts
+        # ... and in the broker's real shape (reference README.md:218-222, RemoteStorageManager.java:400-432: >= 10 RLM upload threads, one
+        # segment each): `callers` threads, every call ONE 256-chunk segment, context-less (pooled contexts, as the JNI shim calls),
+        # TSX_MEM_HOST_PACKED from a registered source into a registered per-thread output buffer - what GpuTransformChunkEnumeration
+        # issues (20 callers = 10 threads with one batch of read-ahead each).
+        broker = None
+        if T > 1 and n >= 256 and not args.no_broker:
+            broker = []
+            B = 256
+            cap = B * (2 << 20)                                           # packed output of one segment: 0.33 GiB at r = 0.31, 0.5 GiB of room
+            N.host_register(hsrc)
+            bufs = []
+            try:
+                for callers in (10, 20):
+                    while len(bufs) < callers:
+                        hb = np.zeros(cap, np.uint8); N.host_register(hb); bufs.append(hb)
+                    segs = [hsrc[(t % (n // B)) * B * CH:((t % (n // B)) + 1) * B * CH] for t in range(callers)]
+                    des = []
+                    for t in range(callers):
+                        dd = np.zeros(B, nat.DESC_DTYPE)
+                        dd["src_off"] = np.arange(B, dtype=np.uint64) * CH; dd["src_len"] = CH
+                        dd["iv"] = d["iv"][(t % (n // B)) * B:((t % (n // B)) + 1) * B]
+                        des.append(dd)
+                    reps = 4
+                    lat = [[] for _ in range(callers)]
+
+                    def bworker(t, k):
+                        for _ in range(k):
+                            a = time.perf_counter()
+                            N.transform_batch(params, des[t], segs[t], bufs[t], cap, nat.MEM_HOST_PACKED, ctx=None)
+                            lat[t].append(time.perf_counter() - a)
+
+                    th = [threading.Thread(target=bworker, args=(t, 1)) for t in range(callers)]     # pooled contexts and their workspaces exist
+                    [x.start() for x in th]; [x.join() for x in th]
+                    lat = [[] for _ in range(callers)]
+                    t1 = time.perf_counter()
+                    th = [threading.Thread(target=bworker, args=(t, reps)) for t in range(callers)]
+                    [x.start() for x in th]; [x.join() for x in th]
+                    el = time.perf_counter() - t1
+                    ok = all(bool((dd["status"] == 0).all()) and bool((dd["dst_len"] == d["dst_len"][(t % (n // B)) * B:((t % (n // B)) + 1) * B]).all())
+                             for t, dd in enumerate(des))
+                    gibs = float(callers * reps * B) * CH / GiB / el
+                    broker.append({"callers": callers, "batch_chunks": B, "calls": callers * reps, "context": "pooled (ctx = NULL)", "dst_layout": "packed",
+                                   "host_memory": "source and outputs registered", "gibs": round(gibs, 4), "frac_of_device_resident_value": round(gibs / value, 3),
+                                   "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat]))) * 1e3, 1),
+                                   "same_sizes_as_device_run": ok})
+            finally:
+                for hb in bufs:
+                    N.host_unregister(hb)
+                N.host_unregister(hsrc)
+            del bufs
         e2e = {"metric": "GiB/s of original bytes, host buffers in -> host buffers out (PCIe inclusive)",
-               "chunks": n, "pcie_peak_GBs_per_direction": PCIE, "one_batch_at_a_time": rows, "batches_in_flight": conc,
-               "value": max([r["gibs"] for r in rows] + [c_["gibs"] for c_ in (conc or [])]) if rows else None, "unit": "GiB/s"}
+               "chunks": n, "pcie_peak_GBs_per_direction": PCIE, "one_batch_at_a_time": rows, "batches_in_flight": conc, "broker": broker,
+               "value": max([r["gibs"] for r in rows] + [c_["gibs"] for c_ in (conc or [])] + [b_["gibs"] for b_ in (broker or [])]) if rows else None, "unit": "GiB/s"}
         del hsrc, hdst
 
     if rank == 0:

@@ -42,8 +42,9 @@ extern "C" {
 #define TSX_CRC      0x4u /* CRC32C of the ORIGINAL chunk bytes, out of band       */
 
 /* where src/dst live */
-/* host pointers.  The batch is cut into pieces of >= 64 MiB whose H2D copy, kernels and D2H copy overlap on three streams of the
- * ctx (not when compressing: that kernel wants the whole batch in flight and dwarfs the copies).  Any host memory works - pageable
+/* host pointers.  The batch is cut into pieces whose H2D copy, kernels and D2H copy overlap: pieces of >= 64 MiB in order on three
+ * streams of the ctx; when compressing, up to 4 co-resident pieces with a compute stream each (a chunk is ~0.6 s of one wave whatever
+ * the batch size: piece k starts when its share of the input has landed, its output travels while later pieces run).  Any host memory works - pageable
  * buffers are staged by the HIP runtime; buffers pinned once with tsx_host_register() are copied by DMA without a staging pass. */
 #define TSX_MEM_HOST   0
 /* device pointers (same HIP runtime / process): no copies.  The kernels run on the ctx's own streams: work the caller still has
@@ -134,7 +135,8 @@ int  tsx_ctx_device(const tsx_ctx* ctx);                /* device index (0 .. ts
 /* Device of the calling thread's ctx-less calls: 0 .. tsx_device_count()-1, or -1 = automatic (least loaded).  The JVM side
  * passes  segment hash % devices  so that the chunks of one segment stay on one GPU (segment s -> GPU s mod N). */
 int  tsx_set_thread_device(int device_index);
-/* Pool of the ctx-less calls on one device: idle contexts kept (at most 8), contexts out right now, batches served so far. */
+/* Pool of the ctx-less calls on one device: idle contexts kept (at most 32, and at most 96 GiB of device workspace between them),
+ * contexts out right now, batches served so far. */
 int  tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use, uint64_t* batches);
 
 /* Pin / unpin a host buffer that is reused for TSX_MEM_HOST(_PACKED) batches (hipHostRegister): optional, see TSX_MEM_HOST. */

@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/types.h>
 
 uint32_t orc_crc32c(const uint8_t* p, size_t n);
 size_t orc_gcm_encrypt_chunk(const uint8_t key[32], const uint8_t iv[12], const uint8_t* aad, size_t aad_len,
@@ -137,7 +140,17 @@ typedef struct {
     const uint8_t* src; size_t chunk; size_t nchunks; const uint8_t* ivs;
     uint8_t* dst; size_t dst_stride; uint32_t* sizes; uint32_t* crcs;
     int tid, nthreads; volatile long* next;
+    int fd;                  /* >= 0: every transformed chunk is also written to this file (BASELINE configs[0]: "to filesystem backend") */
 } job_t;
+
+/* Sink of the threaded baseline: a file (tmpfs on the bench box) that receives the transformed chunks at slot offsets, as the
+ * reference's FileSystemStorage receives the `.log` object (storage/filesystem/.../FileSystemStorage.java: Files.copy of the
+ * transformed stream).  NULL / "" = in memory only. */
+static char g_sink_path[512];
+void orc_chain_set_sink(const char* path) {
+    if (!path) { g_sink_path[0] = 0; return; }
+    strncpy(g_sink_path, path, sizeof g_sink_path - 1); g_sink_path[sizeof g_sink_path - 1] = 0;
+}
 
 static void* worker(void* arg) {
     job_t* j = (job_t*)arg;
@@ -151,6 +164,14 @@ static void* worker(void* arg) {
                                        j->dst + (size_t)i * j->dst_stride, j->dst_stride, scratch, &crc);
         j->sizes[i] = (uint32_t)r;
         j->crcs[i] = crc;
+        if (j->fd >= 0 && r != (size_t)-1) {
+            size_t done = 0;
+            while (done < r) {
+                ssize_t w = pwrite(j->fd, j->dst + (size_t)i * j->dst_stride + done, r - done, (off_t)((size_t)i * j->dst_stride + done));
+                if (w <= 0) break;
+                done += (size_t)w;
+            }
+        }
     }
     free(scratch);
     return NULL;
@@ -166,13 +187,17 @@ double orc_chain_run_threads(unsigned flags, const uint8_t key[32], const uint8_
     volatile long next = 0;
     struct timespec t0, t1;
     orc_zstd_compress_bound(1);            /* force dlopen outside the timed region */
+    int fd = -1;
+    if (g_sink_path[0]) fd = open(g_sink_path, O_CREAT | O_TRUNC | O_WRONLY, 0600);
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < nthreads; t++) {
-        jobs[t] = (job_t){flags, key, aad, aad_len, src, chunk, nchunks, ivs, dst, dst_stride, sizes, crcs, t, nthreads, &next};
+        jobs[t] = (job_t){flags, key, aad, aad_len, src, chunk, nchunks, ivs, dst, dst_stride, sizes, crcs, t, nthreads, &next, fd};
         pthread_create(&th[t], NULL, worker, &jobs[t]);
     }
     for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    if (fd >= 0) close(fd);                /* inside the timed region, like the copy's close() */
     clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (fd >= 0) unlink(g_sink_path);
     free(th); free(jobs);
     return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
 }

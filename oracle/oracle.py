@@ -60,6 +60,7 @@ def lib():
         L.orc_detransform_chunk.argtypes = [C.c_uint, u8p, u8p, sz, u8p, sz, u8p, sz, u8p, C.POINTER(u32)]
         L.orc_chain_run_threads.restype = C.c_double
         L.orc_chain_run_threads.argtypes = [C.c_uint, u8p, u8p, sz, u8p, sz, sz, u8p, u8p, sz, u8p, u8p, C.c_int]
+        L.orc_chain_set_sink.restype = None; L.orc_chain_set_sink.argtypes = [C.c_char_p]
         L.orc_l3_compress.restype = sz; L.orc_l3_compress.argtypes = [u8p, sz, u8p, sz, C.c_int]
         L.orc_l3_compress_bound.restype = sz; L.orc_l3_compress_bound.argtypes = [sz]
         L.orc_l3_cparams.restype = None; L.orc_l3_cparams.argtypes = [C.c_uint64, C.POINTER(C.c_uint32 * 7)]
@@ -189,8 +190,10 @@ def detransform_chunk(flags, key, aad, data):
     return out, crc
 
 
-def chain_run_threads(flags, key, aad, src: np.ndarray, chunk: int, ivs: np.ndarray, nthreads: int):
-    """cpu_baseline leg: returns (seconds, sizes, crcs, dst, stride)."""
+def chain_run_threads(flags, key, aad, src: np.ndarray, chunk: int, ivs: np.ndarray, nthreads: int, sink=None):
+    """cpu_baseline leg: returns (seconds, sizes, crcs, dst, stride).  sink: path of a file that also receives every transformed chunk
+    (BASELINE configs[0] "to filesystem backend": tmpfs on the bench box); None = in memory only."""
+    lib().orc_chain_set_sink(sink.encode() if sink else None)
     n = src.size // chunk
     stride = lib().orc_chain_bound(chunk, flags)
     dst = np.empty(n * stride, np.uint8)

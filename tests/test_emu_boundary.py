@@ -26,7 +26,7 @@ def _run_py(code, **env):
 
 def test_ctxless_calls_use_every_device(emu):
     """tsx_init(2): ctx-less batches alternate between the devices (least loaded, ties round-robin), a thread's device hint pins
-    them, a burst of callers leaves at most 8 idle contexts per device (VERDICT r1 #3: a broker JVM must reach all 8 GPUs)."""
+    them, a burst of callers leaves at most 32 idle contexts per device (and at most 96 GiB of idle workspaces) (VERDICT r1 #3: a broker JVM must reach all 8 GPUs)."""
     out = _run_py("""
         import threading, numpy as np
         import tsxform
@@ -53,11 +53,11 @@ def test_ctxless_calls_use_every_device(emu):
         import ctypes
         cur = ctypes.c_int(-1); get = N.lib._Z12hipGetDevicePi; get.argtypes = [ctypes.POINTER(ctypes.c_int)]
         get(ctypes.byref(cur)); assert cur.value == 0, cur.value
-        th = [threading.Thread(target=lambda: [crc() for _ in range(3)]) for _ in range(24)]
+        th = [threading.Thread(target=lambda: [crc() for _ in range(3)]) for _ in range(80)]
         [t.start() for t in th]; [t.join() for t in th]
         s = [N.pool_stats(i) for i in (0, 1)]
-        assert all(x["in_use"] == 0 and 1 <= x["idle"] <= 8 for x in s), s
-        assert s[0]["batches"] + s[1]["batches"] == 10 + 72 and min(x["batches"] for x in s) >= 20, s
+        assert all(x["in_use"] == 0 and 1 <= x["idle"] <= 32 for x in s), s
+        assert s[0]["batches"] + s[1]["batches"] == 10 + 240 and min(x["batches"] for x in s) >= 60, s
         N.shutdown()
         assert "uninitialised" in N.version()
         print("ok")
@@ -172,10 +172,11 @@ def test_crc_only_batches_publish_their_status(emu):
     assert list(d["status"]) == [0, 0] and d["crc32c"][0] == 0xE3069283 and d["crc32c"][1] == 0
 
 
-@pytest.mark.parametrize("flags", [nat.ENCRYPT | nat.CRC, nat.CRC, 0])
+@pytest.mark.parametrize("flags", [nat.ENCRYPT | nat.CRC, nat.CRC, 0, nat.COMPRESS | nat.ENCRYPT | nat.CRC, nat.COMPRESS])
 def test_staged_pipeline_equals_single_shot(emu, flags, monkeypatch):
     """TSX_MEM_HOST batches are cut into pieces (copy-in / kernels / copy-out overlapped); forced down to 4 KiB pieces here so that 23
-    chunks make ~20 of them.  Outputs, descriptors and the inverse must equal the un-pipelined run."""
+    chunks make ~20 of them (with compression: 4 co-resident pieces, one compute stream each).  Outputs, descriptors and the inverse
+    must equal the un-pipelined run."""
     chunks = pc.edge_chunks("K", [0, 1, 17, 300, 4096, 5000, 65537, 12, 70001, 33, 2048, 9000, 100, 4097, 1, 31000, 16, 15, 8191, 8192, 8193, 700, 64])
     monkeypatch.setenv("TSX_NO_PIPELINE", "1")
     ref, dref = pc.run_transform(emu, flags, chunks)

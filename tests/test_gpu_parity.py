@@ -458,6 +458,6 @@ def test_concurrent_ctxless_host_batches(gpu, oracle):
         [t.join() for t in th]
         assert not errors, errors[:5]
         s = gpu.pool_stats(0)
-        assert s["in_use"] == 0 and 1 <= s["idle"] <= 8
+        assert s["in_use"] == 0 and 1 <= s["idle"] <= 32
     finally:
         os.environ.pop("TSX_SUB_BYTES", None)

@@ -39,19 +39,24 @@ struct tsx_device {
     char arch[256] = {0};
     // pooled contexts of the ctx-less calls: idle ones, how many are out, batches served (all under g_mu)
     std::vector<tsx_ctx*> idle;
+    size_t idle_bytes = 0;
     uint32_t in_use = 0;
     uint64_t batches = 0;
 };
 
 #define TSX_MAX_SUBS 64                 /* sub-batches of one host-memory batch (staging pipeline) */
 #define TSX_SUB_BYTES ((size_t)64 << 20) /* input bytes per sub-batch: >= 1000 workgroups of the GCM / CRC kernels */
-#define TSX_POOL_MAX_IDLE 8             /* idle pooled contexts kept per device; the rest are destroyed on release */
+#define TSX_POOL_MAX_IDLE 32            /* idle pooled contexts kept per device (a broker: >= 10 RLM threads + read-ahead helpers + the fetch pool) ... */
+#define TSX_POOL_MAX_IDLE_BYTES ((size_t)96 << 30) /* ... as long as their workspaces together stay under a third of the 288 GB; the rest are destroyed on release */
+#define TSX_COMP_PIECES 4               /* pieces of a host-memory batch on the compress path: one compute stream each (they must co-reside) */
 
 struct tsx_ctx {
     int dev_index = 0;
     tsx_device* dev = nullptr;
     hipStream_t st = nullptr;                      // kernels (+ descriptor copies)
     hipStream_t st_in = nullptr, st_out = nullptr; // H2D / D2H of the host-memory staging pipeline
+    hipStream_t st_pc[TSX_COMP_PIECES - 1] = {nullptr}; // compute streams of pieces 1.. of a compressing host batch (created on first use)
+    hipEvent_t ev_key = nullptr;                   // key schedule ready (the piece streams wait for it)
     // device workspace (grown on demand)
     tsx_chunk_desc* d_descs = nullptr; size_t descs_cap = 0;
     tsx_chunk_desc* h_descs = nullptr;             // pinned mirror of the descriptors: no pageable copy ever sits in a stream
@@ -191,6 +196,8 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     if (c->st) hipStreamDestroy(c->st);
     if (c->st_in) hipStreamDestroy(c->st_in);
     if (c->st_out) hipStreamDestroy(c->st_out);
+    for (auto& q : c->st_pc) if (q) hipStreamDestroy(q);
+    if (c->ev_key) hipEventDestroy(c->ev_key);
 }
 
 extern "C" void tsx_shutdown(void) {
@@ -198,7 +205,7 @@ extern "C" void tsx_shutdown(void) {
     tsx_device_scope keep;
     for (auto& d : g_devs) {
         for (tsx_ctx* c : d.idle) { ctx_free_device_mem(c); delete c; }
-        d.idle.clear();
+        d.idle.clear(); d.idle_bytes = 0;
         device_free_consts(d);
     }
     g_devs.clear();
@@ -264,6 +271,7 @@ static int ctx_init_device_objects(tsx_ctx* c) {
     HIPCHK(hipStreamCreateWithFlags(&c->st_in, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->st_out, hipStreamNonBlocking));
     for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventCreate(&c->ev_key));
     for (auto& e : c->sub_ev[0]) HIPCHK(hipEventCreate(&e));      // the other rows are created by the first pipelined batch
     HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
     HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
@@ -329,6 +337,10 @@ extern "C" int tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use
     return TSX_OK;
 }
 
+static size_t ctx_workspace_bytes(const tsx_ctx* c) {
+    return c->descs_cap * (sizeof(tsx_chunk_desc) + sizeof(tsx_gcm_chunk) + 8) + c->partials_cap * 4 + c->in_cap + c->out_cap + c->mid_cap + c->zwork_cap;
+}
+
 static tsx_ctx* pool_acquire(int* rc) {
     int di = -1;
     {
@@ -343,7 +355,7 @@ static tsx_ctx* pool_acquire(int* rc) {
         }
         tsx_device& d = g_devs[di];
         d.in_use++; d.batches++;
-        if (!d.idle.empty()) { tsx_ctx* c = d.idle.back(); d.idle.pop_back(); return c; }
+        if (!d.idle.empty()) { tsx_ctx* c = d.idle.back(); d.idle.pop_back(); d.idle_bytes -= ctx_workspace_bytes(c); return c; }
     }
     tsx_ctx* c = nullptr;
     *rc = tsx_ctx_create(di, 0, 0, &c);
@@ -356,7 +368,8 @@ static void pool_release(tsx_ctx* c) {
         std::lock_guard<std::mutex> lk(g_mu);
         tsx_device& d = *c->dev;
         d.in_use--;
-        if (d.idle.size() < TSX_POOL_MAX_IDLE) { d.idle.push_back(c); return; }
+        const size_t b = ctx_workspace_bytes(c);
+        if (d.idle.size() < TSX_POOL_MAX_IDLE && (d.idle.empty() || d.idle_bytes + b <= TSX_POOL_MAX_IDLE_BYTES)) { d.idle.push_back(c); d.idle_bytes += b; return; }
     }
     tsx_device_scope keep;
     ctx_free_device_mem(c);                                            // a burst of callers does not pin its workspaces forever
@@ -486,17 +499,17 @@ struct tsx_run {                                              // what one batch 
     const uint8_t* d_src; uint8_t* d_dst;
 };
 
-// Enqueues the kernels of chunks [lo, lo + n) on the context's compute stream; e[0..3] are recorded at the stage boundaries.
-static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e) {
+// Enqueues the kernels of chunks [lo, lo + n) on compute stream st; e[0..3] are recorded at the stage boundaries.
+static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st) {
     tsx_ctx* c = r.c;
-    hipStream_t st = c->st;
     const uint32_t n = sb.n, lo = sb.lo, flags = r.flags;
     tsx_chunk_desc* dd = c->d_descs + lo;
     int32_t* ds = c->d_status + lo;
     uint32_t* dz = c->d_zlen + lo;
     tsx_gcm_chunk* dg = c->d_gchunks + lo;
     uint8_t* dmid = c->d_mid ? c->d_mid + (size_t)lo * c->mid_stride : nullptr;
-    void* dzw = c->d_zwork;                                            // per-chunk workspace is indexed from 0 in every launch
+    // the Zstd workspace of chunk i is slot i of the batch, whichever piece it travels in: pieces of one batch co-reside
+    void* dzw = c->d_zwork ? (uint8_t*)c->d_zwork + (size_t)lo * tsx_zstd_workspace_bytes(1, 0) : nullptr;
     tsx_timing& t = c->timing;
     memcpy(c->h_descs + lo, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc));
     HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
@@ -622,56 +635,79 @@ static int run_batch_inner(tsx_run& r) {
     r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
     hipStream_t st = c->st;
     memset(&c->timing, 0, sizeof c->timing);
-    // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap (three streams).  Not
-    // with compression on the way in: that kernel is bound by per-chunk latency and wants every chunk of the batch in flight at
-    // once, and its ~0.5 s dwarf the copies.  Device-memory batches have nothing to overlap.
+    // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap.  Device-memory batches
+    // have nothing to overlap.  Two shapes:
+    //  * short kernels (no compression, or the inverse chain): many pieces of >= 64 MiB in order on ONE compute stream, three streams
+    //    in all (the frame decoder is bound by per-chunk latency - ~30 ms however few chunks a launch has: its pieces are >= 512 chunks);
+    //  * the compressing chain: every chunk is ~0.6 s of one wave whatever the batch size, so the pieces must CO-RESIDE - at most
+    //    TSX_COMP_PIECES of them, each on its own compute stream, all copies and launches queued before the host waits for anything.
+    //    Piece k's waves start when its share of the input has landed instead of when the whole batch has, and its output travels
+    //    back while the later pieces still run; what stays serial is the input copy of the whole batch + one piece's kernel + one
+    //    piece's output copy.
     std::vector<tsx_sub> subs;
-    const bool pipelined = r.host && monotonic && !(r.mode == 0 && r.comp) && !getenv("TSX_NO_PIPELINE");
+    const bool comp_fwd = r.mode == 0 && r.comp;
+    const bool pipelined = r.host && monotonic && !(comp_fwd && !r.fuse_stages) && !getenv("TSX_NO_PIPELINE");
     if (pipelined) {
         size_t budget = TSX_SUB_BYTES;
+        size_t max_subs = TSX_MAX_SUBS;
+        if (comp_fwd) { max_subs = TSX_COMP_PIECES; budget = in_bytes / TSX_COMP_PIECES + 1; if (budget < TSX_SUB_BYTES) budget = TSX_SUB_BYTES; }
         if (const char* e = getenv("TSX_SUB_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }     // tests / tuning
-        if (in_bytes / TSX_SUB_BYTES + 1 > TSX_MAX_SUBS) budget = in_bytes / TSX_MAX_SUBS + 1;
-        const uint32_t min_chunks = r.comp ? 512u : 1u;
+        if (in_bytes / budget + 1 > max_subs) budget = in_bytes / max_subs + 1;
+        const uint32_t min_chunks = (r.comp && !comp_fwd) ? 512u : 1u;
         uint32_t lo = 0;
         while (lo < n) {
             uint32_t hi = lo; size_t bytes = 0;
-            // the frame decoder is bound by per-chunk latency too (~30 ms however few chunks a launch has): its pieces are >= 512 chunks
-            while (hi < n && (bytes < budget || hi - lo < min_chunks) && subs.size() + 1 <= TSX_MAX_SUBS) { bytes += r.descs[hi].src_len; hi++; }
-            if (subs.size() + 1 == TSX_MAX_SUBS) hi = n;
+            while (hi < n && (bytes < budget || hi - lo < min_chunks) && subs.size() + 1 <= max_subs) { bytes += r.descs[hi].src_len; hi++; }
+            if (subs.size() + 1 == max_subs) hi = n;
             subs.push_back({lo, hi - lo, (size_t)r.descs[lo].src_off, (size_t)(r.descs[hi - 1].src_off + r.descs[hi - 1].src_len)});
             lo = hi;
         }
     } else subs.push_back({0, n, 0, in_bytes});
-    for (size_t k = 1; k < subs.size(); k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
+    const size_t ns = subs.size();
+    const bool multi = comp_fwd && ns > 1;                              // one compute stream per piece
+    for (size_t k = 1; k < ns; k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
+    if (multi) for (size_t k = 1; k < ns; k++) if (!c->st_pc[k - 1]) HIPCHK(hipStreamCreateWithFlags(&c->st_pc[k - 1], hipStreamNonBlocking));
+    auto stream_of = [&](size_t k) { return (multi && k > 0) ? c->st_pc[k - 1] : st; };
     HIPCHK(hipEventRecord(c->ev[0], st));
     if (r.enc) {
         memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
         HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, st));
         tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
+        if (multi) HIPCHK(hipEventRecord(c->ev_key, st));
     }
     if (r.host) HIPCHK(hipEventRecord(c->ev[2], c->st_in));
     size_t packed_at = 0; bool packed_full = false;
-    const size_t ns = subs.size();
-    // software pipeline on the host: copy-in + kernels of piece k are queued before the host waits for piece k - 1's descriptors
-    // (they say how many bytes each chunk produced) and queues its copy-out
-    for (size_t k = 0; k <= ns; k++) {
-        if (k < ns) {
-            const tsx_sub& sb = subs[k];
-            hipEvent_t* e = c->sub_ev[k];
-            if (r.host) {
-                // pageable memory is staged by the runtime (the call returns when the source has been read); memory pinned with
-                // tsx_host_register goes by DMA and the call returns at once - either way the copy overlaps the kernels of piece k - 1
-                if (sb.in_hi > sb.in_lo) HIPCHK(hipMemcpyAsync(c->d_in + sb.in_lo, (const uint8_t*)r.src + sb.in_lo, sb.in_hi - sb.in_lo, hipMemcpyHostToDevice, c->st_in));
-                HIPCHK(hipEventRecord(e[5], c->st_in));
-                HIPCHK(hipStreamWaitEvent(st, e[5], 0));
-            }
-            if ((rc = launch_stages(r, sb, e))) return rc;
+    auto enqueue_piece = [&](size_t k) -> int {
+        const tsx_sub& sb = subs[k];
+        hipEvent_t* e = c->sub_ev[k];
+        hipStream_t ks = stream_of(k);
+        if (r.host) {
+            // pageable memory is staged by the runtime (the call returns when the source has been read); memory pinned with
+            // tsx_host_register goes by DMA and the call returns at once - either way the copy overlaps the kernels of earlier pieces
+            if (sb.in_hi > sb.in_lo) HIPCHK(hipMemcpyAsync(c->d_in + sb.in_lo, (const uint8_t*)r.src + sb.in_lo, sb.in_hi - sb.in_lo, hipMemcpyHostToDevice, c->st_in));
+            HIPCHK(hipEventRecord(e[5], c->st_in));
+            HIPCHK(hipStreamWaitEvent(ks, e[5], 0));
         }
-        if (k > 0) {
-            const tsx_sub& sb = subs[k - 1];
-            HIPCHK(hipEventSynchronize(c->sub_ev[k - 1][4]));          // descriptors of piece k - 1 are on the host
-            memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
-            if (r.host && r.mode != 2 && (rc = copy_back(r, sb, &packed_at, &packed_full))) return rc;
+        if (multi && k > 0 && r.enc) HIPCHK(hipStreamWaitEvent(ks, c->ev_key, 0));
+        return launch_stages(r, sb, e, ks);
+    };
+    auto collect_piece = [&](size_t k) -> int {
+        const tsx_sub& sb = subs[k];
+        HIPCHK(hipEventSynchronize(c->sub_ev[k][4]));                   // descriptors of piece k are on the host
+        memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
+        if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full);
+        return TSX_OK;
+    };
+    if (multi) {
+        for (size_t k = 0; k < ns; k++) if ((rc = enqueue_piece(k))) return rc;
+        for (size_t k = 0; k < ns; k++) if ((rc = collect_piece(k))) return rc;
+        for (size_t k = 1; k < ns; k++) HIPCHK(hipStreamWaitEvent(st, c->sub_ev[k][4], 0));   // the batch's end event covers every piece
+    } else {
+        // software pipeline on the host: copy-in + kernels of piece k are queued before the host waits for piece k - 1's descriptors
+        // (they say how many bytes each chunk produced) and queues its copy-out
+        for (size_t k = 0; k <= ns; k++) {
+            if (k < ns && (rc = enqueue_piece(k))) return rc;
+            if (k > 0 && (rc = collect_piece(k - 1))) return rc;
         }
     }
     if (r.host) HIPCHK(hipEventRecord(c->ev[3], c->st_out));
@@ -680,13 +716,15 @@ static int run_batch_inner(tsx_run& r) {
     if (r.host) { HIPCHK(hipStreamSynchronize(c->st_in)); HIPCHK(hipStreamSynchronize(c->st_out)); }
     HIPCHK(hipGetLastError());
     tsx_timing& t = c->timing;
+    float zmax = 0;
     for (size_t k = 0; k < ns; k++) {
         hipEvent_t* e = c->sub_ev[k];
         const float a = ev_ms(e[0], e[1]), b = ev_ms(e[1], e[2]), d = ev_ms(e[2], e[3]), f = ev_ms(e[3], e[4]);
         if (r.mode == 2) t.crc_ms += a;
-        else if (r.mode == 0) { t.crc_ms += (r.flags & TSX_CRC) ? a : 0; t.zstd_ms += r.comp ? b : 0; t.gcm_ms += d; }
+        else if (r.mode == 0) { t.crc_ms += (r.flags & TSX_CRC) ? a : 0; if (multi) { if (b > zmax) zmax = b; } else t.zstd_ms += r.comp ? b : 0; t.gcm_ms += d; }
         else { t.gcm_ms += r.enc ? b : 0; t.unzstd_ms += d; t.crc_ms += (r.flags & TSX_CRC) ? f : 0; }
     }
+    if (multi) t.zstd_ms = zmax;                                        // co-resident pieces: the longest launch, not their sum
     t.total_ms = ev_ms(c->ev[0], c->ev[1]);
     if (r.host) {
         // with pieces in flight the copies overlap the kernels: h2d_ms / d2h_ms are the spans of the copy streams, not additive
@@ -729,6 +767,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
         hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st);
     }
     hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
+    for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
     if (rc != TSX_OK) (void)hipGetLastError();
     return rc;
 }
