@@ -56,7 +56,7 @@ def run_transform(N, flags, chunks, key=synth.KEY, aad=synth.AAD, mem=None, prof
     return outs, d
 
 
-def run_detransform(N, flags, blobs, out_sizes, key=synth.KEY, aad=synth.AAD):
+def run_detransform(N, flags, blobs, out_sizes, key=synth.KEY, aad=synth.AAD, ctx=None):
     sizes = [len(b) for b in blobs]
     soff, st = [], 0
     for s in sizes:
@@ -70,9 +70,18 @@ def run_detransform(N, flags, blobs, out_sizes, key=synth.KEY, aad=synth.AAD):
     dst = np.zeros(max(dt, 16), np.uint8)
     d = make_descs(sizes, soff, doff, out_sizes)
     p = nat.Native.make_params(flags, key, aad)
-    N.detransform_batch(p, d, src, dst, dst.size)
+    N.detransform_batch(p, d, src, dst, dst.size, ctx=ctx)
     outs = [dst[doff[i]:doff[i] + d["dst_len"][i]].tobytes() for i in range(len(sizes))]
     return outs, d
+
+
+def blockmode_chunks(N, ctx, n):
+    """Test hook of the library: how many of the first n chunks of ctx's last detransform batch the block-parallel decoder form
+    (csrc/zstd_dec_blocks.hip) decoded; -1 when the batch did not use that form."""
+    import ctypes as C
+    f = N.lib.tsx_debug_blockmode_chunks
+    f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_uint32]
+    return f(ctx, n)
 
 
 def oracle_transform(o, flags, chunk, i, segment=0):

@@ -164,6 +164,47 @@ def test_descriptors_beyond_the_source_buffer_are_rejected(emu):
         emu.transform_batch(p, d, src, dst, dst.size, src_size=32)
 
 
+def test_ctxless_compressing_batches_share_launches(emu, oracle):
+    """Context-less compressing batches do not get streams of their own: callers that arrive while the device's lanes are busy join
+    the group the next free lane launches as ONE kernel (segment table: workgroup -> caller's buffers, key, profile).  12 threads, each
+    with its own key, content and memory kind, 5 batches each: every result equals the single-threaded one, every batch was carried by
+    some launch, and the key material of each member is gone afterwards."""
+    import ctypes as C
+    import threading
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    stats = emu.lib.tsx_debug_combiner_stats
+    stats.restype = C.c_int; stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    g0, m0 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g0), C.byref(m0))
+    T, reps = 12, 5
+    sets = []
+    for t in range(T):
+        chunks = [synth.gen_chunk("K" if (t + i) % 3 else "R", 40 + t, t, i, sz) for i, sz in enumerate([30000, 1, 0, 70001, 4096, 12345][: 3 + t % 4])]
+        key = bytes((b + t) & 0xFF for b in synth.KEY)
+        mem = (None, "packed", "device")[t % 3]
+        sets.append((chunks, key, mem, pc.run_transform(emu, flags, chunks, key=key, mem=mem)[0]))
+    g1, m1 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g1), C.byref(m1))
+    assert m1.value - m0.value == T and g1.value - g0.value == T        # one caller at a time: one launch per batch
+    errors = []
+
+    def worker(t):
+        chunks, key, mem, ref = sets[t]
+        try:
+            for _ in range(reps):
+                outs, d = pc.run_transform(emu, flags, chunks, key=key, mem=mem)
+                if outs != ref or (d["status"] != 0).any():
+                    errors.append((t, "differs"))
+        except Exception as e:                                          # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert not errors, errors[:4]
+    g2, m2 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g2), C.byref(m2))
+    assert m2.value - m1.value == T * reps and 1 <= g2.value - g1.value <= T * reps
+    back, d2 = pc.run_detransform(emu, flags, sets[0][3], [int(c.size) for c in sets[0][0]], key=sets[0][1])
+    assert (d2["status"] == 0).all() and back == [c.tobytes() for c in sets[0][0]]
+
+
 def test_crc_only_batches_publish_their_status(emu):
     """A descriptor that comes back from tsx_crc32c_batch says TSX_OK whatever it said before (callers reuse descriptors)."""
     buf = np.zeros(64, np.uint8); buf[:9] = np.frombuffer(b"123456789", np.uint8)
@@ -183,6 +224,8 @@ def test_staged_pipeline_equals_single_shot(emu, flags, monkeypatch):
     refp, dpk = pc.run_transform(emu, flags, chunks, mem="packed")
     monkeypatch.delenv("TSX_NO_PIPELINE")
     monkeypatch.setenv("TSX_SUB_BYTES", "4096")
+    monkeypatch.setenv("TSX_COMP_PIECES", "4")                       # (co-resident pieces are on only with >= 8 hardware queues, or by this switch)
+    monkeypatch.setenv("TSX_NO_COMBINE", "1")                        # ... and belong to the context's own path, not the launch combiner's
     got, dgot = pc.run_transform(emu, flags, chunks)
     gotp, dgp = pc.run_transform(emu, flags, chunks, mem="packed")
     assert got == ref and gotp == refp == ref

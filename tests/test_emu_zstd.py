@@ -144,6 +144,42 @@ def test_decoder_errors(emu, oracle):
         assert _ is not None
 
 
+@pytest.mark.timeout(1200)
+def test_both_decoder_forms_agree(emu, oracle, monkeypatch):
+    """Small batches decode one workgroup per BLOCK (zstd_dec_blocks.hip: index -> decode -> execute with cross-block waits), large
+    ones one workgroup per chunk (zstd_dec.hip); the block form hands anything it does not like back to the chunk form.  Same frames
+    through both: stock libzstd output of levels 1 / 3 / 19 (treeless literals and Repeat-mode tables inherit from earlier blocks,
+    repeat offsets cross block boundaries), frames of many mixed blocks, and 40 damaged frames - identical statuses, identical bytes,
+    and every undamaged frame really went through the block form."""
+    K = synth.gen_chunk("K", 9, 1, 3, 600000); R = synth.gen_chunk("R", 9, 1, 4, 300000)
+    many = np.concatenate([K[:300000], R[:140000], np.zeros(262144, np.uint8), K[300000:420000], np.full(131072, 7, np.uint8), K[420000:600000]])
+    plain = [CASES[n] for n in ("empty", "one", "K1000", "K70000", "K200000", "R50000", "zeros", "period7", "mixKR", "lowent", "skewed")] + [many, K]
+    blobs, sizes = [], []
+    for lvl in (1, 0, 19):
+        for x in plain:
+            blobs.append(oracle.zstd_compress_chunk(x.tobytes(), lvl)); sizes.append(int(x.size))
+    good = len(blobs)
+    fb, fs = _fuzzed_frames(oracle, 40, 23)
+    blobs += fb; sizes += fs
+    ctx = emu.ctx_create(0, 0, 0)
+    try:
+        outs, d = pc.run_detransform(emu, nat.COMPRESS, blobs, sizes, ctx=ctx)
+        taken = pc.blockmode_chunks(emu, ctx, len(blobs))
+        assert pc.blockmode_chunks(emu, ctx, good) == good, "an undamaged frame fell back to the chunk-serial decoder"
+        monkeypatch.setenv("TSX_DEC_BLOCK_CHUNKS", "0")
+        outs0, d0 = pc.run_detransform(emu, nat.COMPRESS, blobs, sizes, ctx=ctx)
+        assert pc.blockmode_chunks(emu, ctx, len(blobs)) == -1
+    finally:
+        emu.ctx_destroy(ctx)
+    assert list(d["status"]) == list(d0["status"]) and (d["status"][:good] == 0).all()
+    for i in range(len(blobs)):
+        if d["status"][i] == 0:
+            assert outs[i] == outs0[i], i
+    for i in range(good):
+        assert outs[i] == plain[i % len(plain)].tobytes(), i
+    assert taken >= good and (d["status"][good:] != 0).sum() >= 10
+
+
 def test_compressed_frames_have_expected_structure(emu):
     outs, _ = pc.run_transform(emu, nat.COMPRESS, [CASES["K200000"], CASES["R50000"]])
     hdr, blocks, data = zi.parse_frame(outs[0])

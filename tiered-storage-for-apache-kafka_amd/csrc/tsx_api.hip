@@ -1,6 +1,9 @@
 // C-ABI front end of libtsxform: device/context management and the batch pipelines.
 // See include/tsxform.h for the contract and the reference call sites each entry point replaces.
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <stdio.h>
@@ -30,6 +33,31 @@ struct tsx_device_scope {
 };
 
 struct tsx_ctx;
+struct tsx_run;
+
+// ---- launch combiner (ctx-less compressing batches) ----------------------------------------------------------------------------
+// The HIP runtime multiplexes a process's streams onto a handful of hardware queues (4 unless GPU_MAX_HW_QUEUES says otherwise),
+// and two streams that share one run their kernels one after the other.  A broker drives the forward chain from >= 10 threads, one
+// 256-chunk segment each (reference README.md:218-222): with a stream per caller, measured on MI355X, 10-24 callers moved 5.5-5.9
+// GiB/s where three 2048-chunk batches move 19 - four kernels at a time, 1024 chunks on a chip that holds 6144 - and the copy
+// streams' event markers sat behind other callers' second-long kernels.  So ctx-less compressing batches do not get streams of
+// their own: per device there are TSX_LANES compute streams and two copy streams, and whoever arrives while all lanes are busy joins
+// the group that the next free lane launches as ONE kernel (zstd_compress_kernel's segment table: workgroup -> caller's buffers).
+// Group commit: the first waiting caller leads - it queues every member's descriptor upload, key schedule, the one compressor
+// launch, every member's status publication and descriptor download on the lane - the others wait for their own completion event.
+#define TSX_LANES_MAX 4
+#define TSX_GROUP_MAX_SEGS 64
+#define TSX_GROUP_MAX_CHUNKS 8192
+struct tsx_zreq { tsx_ctx* c; tsx_run* r; hipEvent_t in_ready; int rc; bool done; };
+struct tsx_lane { hipStream_t st = nullptr; hipEvent_t end = nullptr; bool busy = false; tsx_zseg* h_segs = nullptr; tsx_zseg* d_segs = nullptr; };
+struct tsx_combiner {
+    std::mutex mu; std::condition_variable cv;
+    std::vector<tsx_zreq*> pending; bool leader = false;
+    tsx_lane lane[TSX_LANES_MAX]; uint32_t nlanes = 0;
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    uint64_t groups = 0, members = 0;                      // launches made, batches they carried (tsx_debug_combiner_stats)
+};
+
 struct tsx_device {
     int hip_id = -1;
     tsx_crc_tables* d_crc = nullptr;
@@ -40,6 +68,7 @@ struct tsx_device {
     // pooled contexts of the ctx-less calls: idle ones, how many are out, batches served (all under g_mu)
     std::vector<tsx_ctx*> idle;
     size_t idle_bytes = 0;
+    std::unique_ptr<tsx_combiner> comb;                      // created with the first ctx-less compressing batch
     uint32_t in_use = 0;
     uint64_t batches = 0;
 };
@@ -72,10 +101,12 @@ struct tsx_ctx {
     uint8_t* d_mid = nullptr; size_t mid_cap = 0;  // compressed frames between the Zstd and GCM stages
     size_t mid_stride = 0;
     void* d_zwork = nullptr; size_t zwork_cap = 0; // Zstd per-chunk workspace
+    void* d_bwork = nullptr; size_t bwork_cap = 0; // block-parallel frame decoder (small batches): chunk headers + literal / sequence arenas
     hipEvent_t ev[4] = {nullptr};                  // batch begin / end, first H2D, last D2H
     hipEvent_t sub_ev[TSX_MAX_SUBS][6] = {{nullptr}}; // per sub-batch: stage boundaries 0..4 (st), [5] = staged in (st_in)
     tsx_timing timing{};
     bool pooled = false;
+    bool last_used_blocks = false;                 // the last batch ran the block-parallel frame decoder (test hook)
 };
 
 static std::mutex g_mu;
@@ -112,6 +143,18 @@ extern "C" const char* tsx_strerror(int code) {
 static void device_free_consts(tsx_device& d) {
     if (d.hip_id < 0) return;
     hipSetDevice(d.hip_id);
+    if (d.comb) {
+        for (uint32_t i = 0; i < d.comb->nlanes; i++) {
+            tsx_lane& l = d.comb->lane[i];
+            if (l.st) { hipStreamSynchronize(l.st); hipStreamDestroy(l.st); }
+            if (l.end) hipEventDestroy(l.end);
+            if (l.h_segs) hipHostFree(l.h_segs);
+            if (l.d_segs) hipFree(l.d_segs);
+        }
+        if (d.comb->copy_in) hipStreamDestroy(d.comb->copy_in);
+        if (d.comb->copy_out) hipStreamDestroy(d.comb->copy_out);
+        d.comb.reset();
+    }
     if (d.d_crc) hipFree(d.d_crc);
     if (d.d_aes) hipFree(d.d_aes);
     if (d.d_zc) hipFree(d.d_zc);
@@ -187,7 +230,7 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     // the key schedule and the raw key never outlive the context in readable form
     if (c->d_key) hipMemset(c->d_key, 0, sizeof(tsx_gcm_key));
     if (c->d_keyraw) hipMemset(c->d_keyraw, 0, 128);
-    void* ptrs[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen, c->d_partials, c->d_key, c->d_keyraw, c->d_in, c->d_out, c->d_mid, c->d_zwork};
+    void* ptrs[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen, c->d_partials, c->d_key, c->d_keyraw, c->d_in, c->d_out, c->d_mid, c->d_zwork, c->d_bwork};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_descs) hipHostFree(c->h_descs);
     if (c->h_keyraw) { memset(c->h_keyraw, 0, 128); hipHostFree(c->h_keyraw); }
@@ -222,6 +265,15 @@ static int grow(T** p, size_t* cap, size_t need) {
     *cap = want;
     return TSX_OK;
 }
+
+// Small detransform batches (a fetch: one chunk, a prefetch window) decode one workgroup per BLOCK instead of per chunk: the
+// chunk-serial decoder needs 25-50 ms for a chunk however idle the chip is.  TSX_DEC_BLOCK_CHUNKS: largest batch that takes this
+// form (default 256, 0 = never).
+static uint32_t dec_block_chunks() {
+    if (const char* e = getenv("TSX_DEC_BLOCK_CHUNKS")) { const long v = atol(e); return v < 0 ? 0u : (uint32_t)v; }
+    return 256u;
+}
+static bool dec_use_blocks(uint32_t n, uint32_t max_out) { return n <= dec_block_chunks() && tsx_zstd_blockmode_takes(max_out); }
 
 // max_out: largest output slot of the batch (detransform: the CRC of the restored bytes runs over dst_cap-sized slots)
 static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_out, uint32_t flags, bool host_mem, size_t in_bytes, size_t out_bytes) {
@@ -261,6 +313,12 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
         rc = grow(&zp, &c->zwork_cap, zw);
         c->d_zwork = zp;                                     // also when grow failed: it has freed the old block
         if (rc) return rc;
+        if (max_out && dec_use_blocks(n, max_out)) {         // inverse chain, small batch
+            uint8_t* bp = (uint8_t*)c->d_bwork;
+            rc = grow(&bp, &c->bwork_cap, tsx_zstd_blockmode_bytes(n, max_out));
+            c->d_bwork = bp;
+            if (rc) return rc;
+        }
     }
     return TSX_OK;
 }
@@ -338,7 +396,7 @@ extern "C" int tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use
 }
 
 static size_t ctx_workspace_bytes(const tsx_ctx* c) {
-    return c->descs_cap * (sizeof(tsx_chunk_desc) + sizeof(tsx_gcm_chunk) + 8) + c->partials_cap * 4 + c->in_cap + c->out_cap + c->mid_cap + c->zwork_cap;
+    return c->descs_cap * (sizeof(tsx_chunk_desc) + sizeof(tsx_gcm_chunk) + 8) + c->partials_cap * 4 + c->in_cap + c->out_cap + c->mid_cap + c->zwork_cap + c->bwork_cap;
 }
 
 static tsx_ctx* pool_acquire(int* rc) {
@@ -495,10 +553,11 @@ struct tsx_sub { uint32_t lo, n; size_t in_lo, in_hi; };     // chunks [lo, lo +
 
 struct tsx_run {                                              // what one batch needs everywhere below
     tsx_ctx* c; const tsx_batch_params* params; tsx_chunk_desc* descs; uint32_t n; const void* src; void* dst; size_t src_size, dst_size;
-    int mem_kind, mode; uint32_t flags, max_len, max_out; bool host, packed, enc, comp, fuse_stages;
+    int mem_kind, mode; uint32_t flags, max_len, max_out; bool host, packed, enc, comp, fuse_stages, combined;
     const uint8_t* d_src; uint8_t* d_dst;
 };
 
+static uint32_t zstd_sched_from_env();
 // Enqueues the kernels of chunks [lo, lo + n) on compute stream st; e[0..3] are recorded at the stage boundaries.
 static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st) {
     tsx_ctx* c = r.c;
@@ -533,13 +592,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
             tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr};
             if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
             if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = r.d_dst; }
-            uint32_t sched = 0;                                              // the kernel's default speculation schedule
-            if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1[,p]": explicit schedule (measurements; same bytes)
-                unsigned a = 0, b = 0, pm = 0;                               // optional third field: block priority mode (zs_block_priority)
-                const int got = sscanf(e, "%u,%u,%u", &a, &b, &pm);
-                // third field as the user writes it: absent = the kernel's default, 0 = no priorities, 1..4 = that mode
-                if (got >= 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59 && pm <= 4) sched = a | b << 8 | (got == 3 ? (pm ? pm : 5u) : 0u) << 16;
-            }
+            const uint32_t sched = zstd_sched_from_env();
             t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
                                                        r.params->zstd_profile, sched, fuse);
         }
@@ -569,7 +622,15 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         }
         HIPCHK(hipEventRecord(e[2], st));
         if (r.comp) {
-            t.unzstd_launches += tsx_launch_zstd_decompress(st, c->dev->d_zc, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.d_dst, ds, dzw);
+            const uint32_t* skip = nullptr; uint32_t skip_stride = 0;
+            c->last_used_blocks = false;
+            if (c->d_bwork && dec_use_blocks(r.n, r.max_out) && sb.n == r.n) {
+                c->last_used_blocks = true;
+                // one workgroup per block; what that form does not take (or gives up on) is decoded by the chunk-serial kernel behind it
+                t.unzstd_launches += tsx_launch_zstd_decompress_blocks(st, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.max_out, r.d_dst, ds, c->d_bwork);
+                skip = tsx_zstd_blockmode_skip(c->d_bwork, &skip_stride);
+            }
+            t.unzstd_launches += tsx_launch_zstd_decompress(st, c->dev->d_zc, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.d_dst, ds, dzw, skip, skip_stride);
         } else if (!r.enc) {
             uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
             hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz, (uint64_t)0, 0, r.d_src, r.d_dst, ds, bpc);
@@ -593,7 +654,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
 
 // The bytes chunks [lo, lo + n) produced travel back on st_out (host-memory batches; their descriptors are on the host already).
 // Exactly dst_len bytes per chunk: a slot's slack may hold bytes of an earlier batch on this (possibly pooled) context.
-static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, bool* packed_full) {
+static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, bool* packed_full, hipStream_t out_st) {
     tsx_ctx* c = r.c;
     for (uint32_t i = sb.lo; i < sb.lo + sb.n; i++) {
         tsx_chunk_desc& d = r.descs[i];
@@ -602,12 +663,183 @@ static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, boo
             d.dst_off = *packed_at;
             if (d.status != TSX_OK) { d.dst_len = 0; continue; }
             if (*packed_full || *packed_at + d.dst_len > r.dst_size) { *packed_full = true; d.status = TSX_E_DST_TOO_SMALL; d.dst_len = 0; continue; }
-            if (d.dst_len) HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + *packed_at, c->d_out + slot_off, d.dst_len, hipMemcpyDeviceToHost, c->st_out));
+            if (d.dst_len) HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + *packed_at, c->d_out + slot_off, d.dst_len, hipMemcpyDeviceToHost, out_st));
             *packed_at += d.dst_len;
         } else {
             if (d.status != TSX_OK || d.dst_len == 0) continue;
-            HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + d.dst_off, c->d_out + d.dst_off, d.dst_len, hipMemcpyDeviceToHost, c->st_out));
+            HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + d.dst_off, c->d_out + d.dst_off, d.dst_len, hipMemcpyDeviceToHost, out_st));
         }
+    }
+    return TSX_OK;
+}
+
+static uint32_t zstd_sched_from_env() {
+    uint32_t sched = 0;                                              // the kernel's default speculation schedule
+    if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1[,p]": explicit schedule (measurements; same bytes)
+        unsigned a = 0, b = 0, pm = 0;                               // optional third field: block priority mode (zs_block_priority)
+        const int got = sscanf(e, "%u,%u,%u", &a, &b, &pm);
+        // third field as the user writes it: absent = the kernel's default, 0 = no priorities, 1..4 = that mode
+        if (got >= 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59 && pm <= 4) sched = a | b << 8 | (got == 3 ? (pm ? pm : 5u) : 0u) << 16;
+    }
+    return sched;
+}
+
+static int combiner_get(tsx_device* dev, tsx_combiner** out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!dev->comb) {
+        std::unique_ptr<tsx_combiner> cb(new (std::nothrow) tsx_combiner);
+        if (!cb) return TSX_E_NOMEM;
+        uint32_t nl = 3;
+        if (const char* e = getenv("TSX_LANES")) { const long v = atol(e); if (v >= 1 && v <= TSX_LANES_MAX) nl = (uint32_t)v; }
+        // the copy streams first: whatever the runtime's stream -> hardware-queue assignment, the short copies and their event markers
+        // are not the ones that end up behind a second-long kernel of a lane created later
+        bool ok = hipStreamCreateWithFlags(&cb->copy_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&cb->copy_out, hipStreamNonBlocking) == hipSuccess;
+        for (uint32_t i = 0; ok && i < nl; i++) {
+            tsx_lane& l = cb->lane[i];
+            ok = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&l.end, hipEventDisableTiming) == hipSuccess &&
+                 hipHostMalloc((void**)&l.h_segs, TSX_GROUP_MAX_SEGS * sizeof(tsx_zseg), hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void**)&l.d_segs, TSX_GROUP_MAX_SEGS * sizeof(tsx_zseg)) == hipSuccess;
+            cb->nlanes = i + 1;
+        }
+        dev->comb = std::move(cb);
+        if (!ok) { (void)hipGetLastError(); tsx_device& d = *dev; std::unique_ptr<tsx_combiner> dead = std::move(d.comb);
+                   for (uint32_t i = 0; i < dead->nlanes; i++) { tsx_lane& l = dead->lane[i]; if (l.st) hipStreamDestroy(l.st); if (l.end) hipEventDestroy(l.end); if (l.h_segs) hipHostFree(l.h_segs); if (l.d_segs) hipFree(l.d_segs); }
+                   if (dead->copy_in) hipStreamDestroy(dead->copy_in); if (dead->copy_out) hipStreamDestroy(dead->copy_out);
+                   return TSX_E_DEVICE; }
+    }
+    *out = dev->comb.get();
+    return TSX_OK;
+}
+
+// The leader's part, outside the lock: everything the members of one group need on lane `l`, in stream order.
+static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_zreq*>& grp) {
+    hipStream_t ls = l.st;
+    uint32_t first = 0;
+    for (size_t k = 0; k < grp.size(); k++) {
+        tsx_zreq* q = grp[k]; tsx_ctx* c = q->c; const tsx_run& r = *q->r;
+        const uint32_t n = r.n;
+        if (q->in_ready) HIPCHK(hipStreamWaitEvent(ls, q->in_ready, 0));
+        HIPCHK(hipEventRecord(c->ev[0], ls));
+        memcpy(c->h_descs, r.descs, (size_t)n * sizeof(tsx_chunk_desc));
+        HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, ls));
+        hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_status, n);
+        if (r.enc) {
+            memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
+            HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, ls));
+            tsx_launch_gcm_setup(ls, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
+        }
+        tsx_zseg& sg = l.h_segs[k];
+        memset(&sg, 0, sizeof sg);
+        sg.first = first; sg.n = n; sg.profile = r.params->zstd_profile;
+        sg.src_base = r.d_src; sg.descs = c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
+        sg.work = (uint8_t*)c->d_zwork;
+        sg.fuse.crc = (r.flags & TSX_CRC) ? c->dev->d_crc : nullptr;
+        if (r.enc) { sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->d_key; sg.fuse.out = r.d_dst; }
+        first += n;
+    }
+    HIPCHK(hipMemcpyAsync(l.d_segs, l.h_segs, grp.size() * sizeof(tsx_zseg), hipMemcpyHostToDevice, ls));
+    tsx_launch_zstd_compress_segments(ls, l.d_segs, (uint32_t)grp.size(), first, zstd_sched_from_env());
+    for (tsx_zreq* q : grp) {
+        tsx_ctx* c = q->c; const tsx_run& r = *q->r;
+        const uint32_t n = r.n;
+        if (!r.enc) {                                                    // compression only: the frames go from the staging buffer to the caller's slots
+            const uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
+            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, ls, c->d_descs, (const uint32_t*)c->d_zlen, (uint64_t)c->mid_stride, 1,
+                               (const uint8_t*)c->d_mid, r.d_dst, c->d_status, bpc);
+        }
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_descs, (const int32_t*)c->d_status, n);
+        HIPCHK(hipMemcpyAsync(c->h_descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, ls));
+        if (r.enc) { (void)hipMemsetAsync(c->d_keyraw, 0, 128, ls); (void)hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), ls); }
+        HIPCHK(hipEventRecord(c->ev[1], ls));
+    }
+    HIPCHK(hipEventRecord(l.end, ls));
+    (void)cb;
+    return TSX_OK;
+}
+
+// Hand one batch to the device's combiner and return when its group has been queued (q.done); the caller then waits for its own event.
+static void combiner_submit(tsx_combiner* cb, tsx_zreq& q) {
+    std::unique_lock<std::mutex> lk(cb->mu);
+    cb->pending.push_back(&q);
+    cb->cv.notify_all();
+    while (!q.done) {
+        if (cb->leader) { cb->cv.wait(lk); continue; }
+        cb->leader = true;
+        // ---- lead: wait for a free lane (requests keep arriving meanwhile and join the group), take a group, queue it ----
+        int li = -1;
+        for (;;) {
+            for (uint32_t i = 0; i < cb->nlanes && li < 0; i++) {
+                tsx_lane& l = cb->lane[i];
+                if (l.busy && hipEventQuery(l.end) == hipSuccess) l.busy = false;
+                if (!l.busy) li = (int)i;
+            }
+            if (li >= 0) break;
+            (void)hipGetLastError();                                     // hipErrorNotReady of the queries
+            cb->cv.wait_for(lk, std::chrono::microseconds(200));
+        }
+        std::vector<tsx_zreq*> grp;
+        uint32_t chunks = 0;
+        while (!cb->pending.empty() && grp.size() < TSX_GROUP_MAX_SEGS && (grp.empty() || chunks + cb->pending.front()->r->n <= TSX_GROUP_MAX_CHUNKS)) {
+            grp.push_back(cb->pending.front()); chunks += cb->pending.front()->r->n;
+            cb->pending.erase(cb->pending.begin());
+        }
+        tsx_lane& l = cb->lane[li];
+        l.busy = true;
+        cb->groups++; cb->members += grp.size();
+        lk.unlock();
+        const int rc = combiner_launch(cb, l, grp);
+        if (rc != TSX_OK) { (void)hipGetLastError(); (void)hipStreamSynchronize(l.st); }
+        lk.lock();
+        if (rc != TSX_OK) l.busy = false;
+        for (tsx_zreq* m : grp) { m->rc = rc; m->done = true; }
+        cb->leader = false;
+        cb->cv.notify_all();
+    }
+}
+
+// A ctx-less compressing batch: its buffers live in the pooled context, its work runs on the device's shared streams.
+static int run_combined(tsx_run& r) {
+    tsx_ctx* c = r.c;
+    const uint32_t n = r.n;
+    uint32_t max_len, max_out; size_t in_bytes; bool monotonic;
+    int rc = validate(r.descs, n, r.src_size, r.dst_size, !r.packed, &max_len, &max_out, &in_bytes, &monotonic);
+    if (rc) return rc;
+    size_t out_bytes = r.dst_size;
+    if (r.packed) {
+        const size_t slot = (tsx_transformed_bound(max_len, r.flags) + 63) & ~(size_t)63;
+        if (slot >= ((size_t)1 << 32)) return TSX_E_INVAL;
+        for (uint32_t i = 0; i < n; i++) { r.descs[i].dst_off = (uint64_t)i * slot; r.descs[i].dst_cap = (uint32_t)slot; }
+        out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
+    }
+    r.max_len = max_len; r.max_out = max_out;
+    rc = ctx_reserve(c, n, max_len, 0, r.flags, r.host, in_bytes, out_bytes);
+    if (rc) return rc;
+    tsx_combiner* cb = nullptr;
+    if ((rc = combiner_get(c->dev, &cb))) return rc;
+    r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
+    r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
+    memset(&c->timing, 0, sizeof c->timing);
+    tsx_zreq q{c, &r, nullptr, TSX_OK, false};
+    if (r.host) {
+        HIPCHK(hipEventRecord(c->ev[2], cb->copy_in));
+        if (in_bytes) HIPCHK(hipMemcpyAsync(c->d_in, r.src, in_bytes, hipMemcpyHostToDevice, cb->copy_in));
+        HIPCHK(hipEventRecord(c->sub_ev[0][5], cb->copy_in));
+        q.in_ready = c->sub_ev[0][5];
+    }
+    combiner_submit(cb, q);
+    if (q.rc != TSX_OK) return q.rc;
+    HIPCHK(hipEventSynchronize(c->ev[1]));                              // this batch's descriptors are on the host (its group may still be running for others)
+    memcpy(r.descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc));
+    tsx_timing& t = c->timing;
+    t.zstd_ms = ev_ms(c->ev[0], c->ev[1]); t.zstd_launches = 1; t.total_ms = t.zstd_ms;
+    if (r.host) {
+        size_t packed_at = 0; bool packed_full = false;
+        const tsx_sub sb{0, n, 0, in_bytes};
+        if ((rc = copy_back(r, sb, &packed_at, &packed_full, cb->copy_out))) return rc;
+        HIPCHK(hipEventRecord(c->ev[3], cb->copy_out));
+        HIPCHK(hipEventSynchronize(c->ev[3]));
+        t.h2d_ms = ev_ms(c->ev[2], c->sub_ev[0][5]);
+        t.total_ms = ev_ms(c->ev[2], c->ev[3]);
     }
     return TSX_OK;
 }
@@ -646,11 +878,17 @@ static int run_batch_inner(tsx_run& r) {
     //    piece's output copy.
     std::vector<tsx_sub> subs;
     const bool comp_fwd = r.mode == 0 && r.comp;
-    const bool pipelined = r.host && monotonic && !(comp_fwd && !r.fuse_stages) && !getenv("TSX_NO_PIPELINE");
+    // Co-resident pieces need a hardware queue per compute stream: with the runtime's default of 4 queues for ALL streams of the process
+    // the pieces' kernels and the copy streams' event markers end up behind one another (measured: 945 -> 1300-2400 ms per 2048-chunk
+    // batch).  So only when the process runs with GPU_MAX_HW_QUEUES >= 8, or TSX_COMP_PIECES says so.
+    uint32_t comp_pieces = 1;
+    if (const char* e = getenv("TSX_COMP_PIECES")) { const long v = atol(e); if (v >= 1 && v <= TSX_COMP_PIECES) comp_pieces = (uint32_t)v; }
+    else if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { if (atol(q) >= 8) comp_pieces = TSX_COMP_PIECES; }
+    const bool pipelined = r.host && monotonic && !(comp_fwd && (!r.fuse_stages || comp_pieces < 2)) && !getenv("TSX_NO_PIPELINE");
     if (pipelined) {
         size_t budget = TSX_SUB_BYTES;
         size_t max_subs = TSX_MAX_SUBS;
-        if (comp_fwd) { max_subs = TSX_COMP_PIECES; budget = in_bytes / TSX_COMP_PIECES + 1; if (budget < TSX_SUB_BYTES) budget = TSX_SUB_BYTES; }
+        if (comp_fwd) { max_subs = comp_pieces; budget = in_bytes / comp_pieces + 1; if (budget < TSX_SUB_BYTES) budget = TSX_SUB_BYTES; }
         if (const char* e = getenv("TSX_SUB_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }     // tests / tuning
         if (in_bytes / budget + 1 > max_subs) budget = in_bytes / max_subs + 1;
         const uint32_t min_chunks = (r.comp && !comp_fwd) ? 512u : 1u;
@@ -695,7 +933,7 @@ static int run_batch_inner(tsx_run& r) {
         const tsx_sub& sb = subs[k];
         HIPCHK(hipEventSynchronize(c->sub_ev[k][4]));                   // descriptors of piece k are on the host
         memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
-        if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full);
+        if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, c->st_out);
         return TSX_OK;
     };
     if (multi) {
@@ -737,7 +975,7 @@ static int run_batch_inner(tsx_run& r) {
 }
 
 static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, size_t src_size, void* dst,
-                     size_t dst_size, int mem_kind, int mode /*0 transform, 1 detransform, 2 crc only*/) {
+                     size_t dst_size, int mem_kind, int mode /*0 transform, 1 detransform, 2 crc only*/, bool combined = false) {
     if (!descs || (n && !src) || (mode != 2 && (!params || (n && !dst)))) return TSX_E_INVAL;
     if (mem_kind != TSX_MEM_HOST && mem_kind != TSX_MEM_DEVICE && mem_kind != TSX_MEM_HOST_PACKED) return TSX_E_INVAL;
     const bool packed = mem_kind == TSX_MEM_HOST_PACKED;
@@ -757,7 +995,20 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     r.flags = flags; r.host = mem_kind != TSX_MEM_DEVICE; r.packed = packed;
     r.enc = mode != 2 && (flags & TSX_ENCRYPT); r.comp = mode != 2 && (flags & TSX_COMPRESS);
     r.fuse_stages = r.comp && !getenv("TSX_STAGES_SEPARATE");
-    const int rc = run_batch_inner(r);
+    r.combined = combined && mode == 0 && r.comp && r.fuse_stages && !getenv("TSX_NO_COMBINE");
+    const int rc = r.combined ? run_combined(r) : run_batch_inner(r);
+    if (r.combined) {
+        // the key material on the device was wiped on the lane behind this batch's work; what is left is the pinned mirror - and, when
+        // the call failed half way, whatever of it is still queued on the shared streams
+        if (r.enc) memset(c->h_keyraw, 0, 128);
+        if (rc != TSX_OK) {
+            (void)hipGetLastError();
+            if (c->dev->comb) { (void)hipStreamSynchronize(c->dev->comb->copy_in); (void)hipStreamSynchronize(c->dev->comb->copy_out);
+                                for (uint32_t i = 0; i < c->dev->comb->nlanes; i++) (void)hipStreamSynchronize(c->dev->comb->lane[i].st); }
+            if (r.enc) { hipMemsetAsync(c->d_keyraw, 0, 128, c->st); hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st); hipStreamSynchronize(c->st); }
+        }
+        return rc;
+    }
     // Whatever happened: nothing of this call is still in flight when it returns (the copies reference the caller's buffers), and
     // the data key does not stay behind in a context that may serve another segment next (the native side zeroises its
     // copy; the round keys and H powers are as good as the key).
@@ -778,7 +1029,7 @@ static int with_ctx(tsx_ctx* ctx, const tsx_batch_params* params, tsx_chunk_desc
     int rc = TSX_OK;
     tsx_ctx* c = pool_acquire(&rc);
     if (!c) return rc;
-    rc = run_batch(c, params, descs, n, src, src_size, dst, dst_size, mem_kind, mode);
+    rc = run_batch(c, params, descs, n, src, src_size, dst, dst_size, mem_kind, mode, true);
     pool_release(c);
     return rc;
 }
@@ -809,6 +1060,34 @@ extern "C" int tsx_debug_key_residue(tsx_ctx* c) {
     int acc = 0;
     for (uint8_t b : h) acc |= b;
     return acc;
+}
+
+// Test hook (not part of the ABI): launches the device's combiner has made and the batches they carried.
+extern "C" int tsx_debug_combiner_stats(int device_index, uint64_t* groups, uint64_t* members) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL;
+    tsx_combiner* cb = g_devs[device_index].comb.get();
+    if (groups) *groups = cb ? cb->groups : 0;
+    if (members) *members = cb ? cb->members : 0;
+    return TSX_OK;
+}
+
+// Test hook (not part of the ABI): how many of the first n chunks of the context's LAST detransform batch were decoded by the
+// block-parallel form (the rest went through the chunk-serial kernel); -1 when that batch did not use the form at all.
+extern "C" int tsx_debug_blockmode_chunks(tsx_ctx* c, uint32_t n) {
+    if (!c) return TSX_E_INVAL;
+    if (!c->d_bwork || !c->last_used_blocks) return -1;
+    tsx_device_scope keep;
+    if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
+    uint32_t stride = 0;
+    const uint32_t* skip = tsx_zstd_blockmode_skip(c->d_bwork, &stride);
+    int cnt = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t w = 0;
+        if (hipMemcpy(&w, skip + (size_t)i * stride, 4, hipMemcpyDeviceToHost) != hipSuccess) return TSX_E_DEVICE;
+        cnt += w == 1;
+    }
+    return cnt;
 }
 
 // Pins a caller buffer that will be used for TSX_MEM_HOST / TSX_MEM_HOST_PACKED batches again and again (the JVM side registers its

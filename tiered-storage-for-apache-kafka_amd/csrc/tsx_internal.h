@@ -65,6 +65,13 @@ struct tsx_chain_fuse {          // stages the compressor wave of chunk i runs i
     uint8_t* out;                //             descs[i].dst_len = frame + 28
 };
 
+struct tsx_zseg {                // one caller's batch inside a combined compressor launch (zstd_compress_kernel, tsx_api.hip's combiner)
+    uint32_t first, n;           // workgroups [first, first + n) of the launch work on this batch's chunks 0 .. n - 1
+    uint32_t profile, pad;
+    const uint8_t* src_base; tsx_chunk_desc* descs; uint8_t* mid; uint64_t mid_stride; uint32_t* zlen; int32_t* status; uint8_t* work;
+    tsx_chain_fuse fuse;
+};
+
 struct tsx_gcm_chunk {           // per-chunk work item (device)
     uint64_t in_off;             // plaintext (encrypt) / IV||C||TAG (decrypt) offset within `in`
     uint64_t out_off;            // IV||C||TAG (encrypt) / plaintext (decrypt) offset within `out`

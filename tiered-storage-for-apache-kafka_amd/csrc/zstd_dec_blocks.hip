@@ -1,0 +1,750 @@
+// Zstandard frame decoder, block-parallel form — gfx950.  For SMALL batches (a fetch: one chunk, or the few chunks of a prefetch
+// window - DefaultChunkManager.java:50-70, ChunkCache.java:159-184), where zstd_dec.hip's one-workgroup-per-chunk pipeline is all
+// latency: a 4 MiB chunk is 32 blocks one after the other, 25-50 ms however idle the chip is.  Here the unit of work is the BLOCK:
+//
+//   zb_index_kernel    one wave per chunk.  Frame header; lane 0 walks the block headers (a chain of <= 264 three-byte reads); then
+//                      one lane per block parses the literals-section and sequences-section headers - sizes, table modes, where
+//                      each table description and the bit stream start - and lane 0 assigns every block its place in the literal
+//                      and sequence arenas and notes which earlier block holds the Huffman tree (treeless literals) and the FSE
+//                      tables (Repeat mode) in force.
+//   zb_decode_kernel   one workgroup (two waves) per block, all blocks of all chunks at once.  Wave 1 decodes the literals, wave 0
+//                      the sequences - the same stages as zstd_dec.hip's (11-bit multi-symbol Huffman table, the three FSE state
+//                      machines in lanes 0-2, field extraction on all lanes) - but a block that inherits a tree or a table rebuilds
+//                      it from the earlier block's bytes, and repeat offsets are resolved SYMBOLICALLY: a block does not know the
+//                      history it starts from, so an offset that comes out of the history is recorded as "incoming entry i minus d"
+//                      and the block's outgoing history is a function of the incoming one.
+//   zb_execute_kernel  one wave per block, started in block-major ticket order.  Every wave chains the block summaries up to its
+//                      own block (output position = sum of the regenerated sizes before it, incoming history = composition of the
+//                      outgoing ones: O(1) per block) and executes its sequences 64 at a time as zstd_dec.hip does.  A match whose
+//                      source lies in an EARLIER block waits until that block has produced it: every block publishes its progress
+//                      (agent-scope release + flag, cdna_hip_programming.md Guideline 16), readers poll relaxed and acquire once.
+//                      Log-like content copies mostly from ~100 KB back, i.e. from the previous block at the same relative position,
+//                      so the blocks of a chunk advance side by side.
+//
+// This form is a fast path, not a second authority: anything it does not like (more than 264 blocks, a chunk above 16 MiB, a
+// malformed frame, an offset out of range, a wait that times out) clears the chunk's `mode` word and zstd_decompress_kernel - which
+// is launched behind it with that word as its skip list - decodes the chunk and reports the error code.  Bytes are either final
+// and correct or rewritten by the fallback.
+#include "zstd_dec_dev.h"
+#include "zstd_dec_blocks.h"
+#ifdef ZB_DEBUG
+#include <stdio.h>
+#endif
+
+#define ZB_SYM 0x80000000u                      /* a history-relative offset: ZB_SYM | entry << 28 | decrement */
+#define ZB_SYM_ENTRY(v) (((v) >> 28) & 7u)
+#define ZB_SYM_DEC(v) ((v) & 0x0FFFFFFFu)
+
+#ifdef HIPEMU
+#define ZB_LOAD_AGENT(p) (*(volatile const uint32_t*)(p))
+#define ZB_STORE_AGENT(p, v) do { *(volatile uint32_t*)(p) = (v); } while (0)
+#define ZB_RELEASE() do {} while (0)
+#define ZB_ACQUIRE() do {} while (0)
+#define ZB_SLEEP() do {} while (0)
+#else
+#define ZB_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ZB_STORE_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// producer: this wave's stores have left (vmcnt), the XCD's L2 is written back, and the wait behind the write-back is restated
+// where the compiler cannot drop it (Guideline 16, pitfall 12)
+#define ZB_RELEASE() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define ZB_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define ZB_SLEEP() __builtin_amdgcn_s_sleep(8)
+#endif
+
+__device__ static inline uint32_t zb_sym_dec(uint32_t v) { return (v & ZB_SYM) ? v + 1 : v - 1; }     // "rep0 - 1" on either kind of value
+__device__ static inline uint32_t zb_subst(uint32_t v, uint32_t h0, uint32_t h1, uint32_t h2) {        // a recorded offset given the incoming history
+    if (!(v & ZB_SYM)) return v;
+    const uint32_t e = ZB_SYM_ENTRY(v), r = e == 0 ? h0 : e == 1 ? h1 : h2;
+    return r - ZB_SYM_DEC(v);                                           // 0 or wrapped when the frame is corrupt: caught where it is used
+}
+
+// literals-section header of a compressed block -> section size (0 = malformed)
+struct ZbLit { uint32_t ltype, hl, litSize, csize, streams, section; };
+__device__ static inline ZbLit zb_lit_header(const uint8_t* blk, uint32_t bsize) {
+    ZbLit h; h.section = 0; h.csize = 0; h.streams = 1;
+    const uint32_t b0 = blk[0], sf = (b0 >> 2) & 3;
+    h.ltype = b0 & 3;
+    if (h.ltype < 2) {
+        if (sf == 0 || sf == 2) { h.litSize = b0 >> 3; h.hl = 1; }
+        else if (sf == 1) { if (bsize < 2) return h; h.litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4); h.hl = 2; }
+        else { if (bsize < 3) return h; h.litSize = (b0 >> 4) + ((uint32_t)blk[1] << 4) + ((uint32_t)blk[2] << 12); h.hl = 3; }
+        if (h.litSize > ZS_BLOCK_MAX) return h;
+        const uint32_t sec = h.ltype == 0 ? h.hl + h.litSize : h.hl + 1;
+        if (sec > bsize) return h;
+        h.section = sec;
+    } else {
+        uint32_t bits;
+        if (sf == 0) { h.hl = 3; bits = 10; h.streams = 1; }
+        else if (sf == 1) { h.hl = 3; bits = 10; h.streams = 4; }
+        else if (sf == 2) { h.hl = 4; bits = 14; h.streams = 4; }
+        else { h.hl = 5; bits = 18; h.streams = 4; }
+        if (h.hl > bsize) return h;
+        uint64_t v = 0;
+        for (uint32_t i = 0; i < h.hl; i++) v |= (uint64_t)blk[i] << (8 * i);
+        h.litSize = (uint32_t)(v >> 4) & ((1u << bits) - 1);
+        h.csize = (uint32_t)(v >> (4 + bits)) & ((1u << bits) - 1);
+        if (h.litSize > ZS_BLOCK_MAX || h.hl + h.csize > bsize || h.litSize == 0) return h;
+        h.section = h.hl + h.csize;
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// index: one wave per chunk
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LANES) void zb_index_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                         const tsx_chunk_desc* __restrict__ descs, const int32_t* __restrict__ status,
+                                                         uint8_t* __restrict__ hdrs, uint32_t lit_cap, uint32_t seq_cap) {
+    __shared__ uint32_t sOff[ZB_MAX_BLOCKS], sSize[ZB_MAX_BLOCKS];
+    __shared__ uint8_t sType[ZB_MAX_BLOCKS];
+    __shared__ uint32_t sN, sBad;
+    const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
+    ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
+    if (status[chunk] != TSX_OK) return;                              // mode stays 0 (memset): nothing to decode, nothing to fall back to
+    const tsx_chunk_desc d = descs[chunk];
+    const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
+    const uint32_t srcSize = from_mid ? (d.src_len >= 28 ? d.src_len - 28 : 0) : d.src_len;
+    if (lane == 0) {
+        // every early return below leaves mode = 0: the chunk-serial kernel decodes the chunk (and owns the error codes)
+        uint32_t n = 0, bad = 1;
+        do {
+            if (srcSize < 6 || d.dst_cap > ZB_MAX_CHUNK) break;
+            if (src[0] != 0x28 || src[1] != 0xB5 || src[2] != 0x2F || src[3] != 0xFD) break;
+            const uint32_t fhd = src[4], single = (fhd >> 5) & 1, dictFlag = fhd & 3, fcsFlag = fhd >> 6;
+            const bool hasChecksum = (fhd >> 2) & 1;
+            if (fhd & 8) break;
+            uint32_t p = 5;
+            if (!single) { if (p >= srcSize || (src[p] >> 3) > 21) break; p++; }
+            const uint32_t dl = dictFlag == 0 ? 0 : dictFlag == 1 ? 1 : dictFlag == 2 ? 2 : 4;
+            if (p + dl > srcSize) break;
+            uint32_t dictId = 0; for (uint32_t i = 0; i < dl; i++) dictId |= (uint32_t)src[p + i] << (8 * i);
+            if (dictId) break;
+            p += dl;
+            const uint32_t fl = fcsFlag == 0 ? single : fcsFlag == 1 ? 2 : fcsFlag == 2 ? 4 : 8;
+            if (fl == 0 || p + fl > srcSize) break;
+            uint64_t contentSize = 0;
+            for (uint32_t i = 0; i < fl; i++) contentSize |= (uint64_t)src[p + i] << (8 * i);
+            if (fl == 2) contentSize += 256;
+            p += fl;
+            if (contentSize > d.dst_cap) break;
+            C->contentSize = (uint32_t)contentSize;
+            bool closed = false;
+            while (n < ZB_MAX_BLOCKS) {                                 // the chain of block headers
+                if (p + 3 > srcSize) break;
+                const uint32_t bh = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
+                p += 3;
+                const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+                if (btype == 3) break;
+                if (btype == 2 && (bsize > ZS_BLOCK_MAX || bsize < 2)) break;
+                if (btype != 2 && bsize > ZS_BLOCK_MAX) break;         // a raw / RLE block regenerates Block_Size bytes: <= Block_Maximum_Size
+                const uint32_t body = btype == 1 ? 1 : bsize;
+                if (p + body > srcSize) break;
+                sOff[n] = p; sSize[n] = bsize; sType[n] = (uint8_t)(btype | (last << 2));
+                n++; p += body;
+                if (last) { if (hasChecksum) { if (p + 4 > srcSize) break; p += 4; } closed = p == srcSize; break; }
+            }
+            if (closed) bad = 0;
+        } while (0);
+        sN = n; sBad = bad;
+    }
+    __syncthreads();
+    const uint32_t n = sN;
+    if (sBad) return;
+    // ---- one lane per block: the section headers ----
+    for (uint32_t b = lane; b < n; b += LANES) {
+        ZbBlock B;
+        B.off = sOff[b]; B.bsize = sSize[b]; B.btype = sType[b] & 3; B.last = sType[b] >> 2; B.ltype = 0; B.modes = 0;
+        B.litSize = 0; B.q = 0; B.nbSeq = 0; B.litAt = 0; B.seqAt = 0; B.hufSrc = 0xFFFF; B.tblSrc[0] = B.tblSrc[1] = B.tblSrc[2] = 0xFFFF;
+        B.tOff[0] = B.tOff[1] = B.tOff[2] = 0; B.streamOff = 0; B.regen = B.btype == 2 ? 0 : B.bsize; B.endHist[0] = B.endHist[1] = B.endHist[2] = 0; B.ok = 0;
+        bool bad = false;
+        if (B.btype == 2) {
+            const uint8_t* const blk = src + B.off;
+            const ZbLit h = zb_lit_header(blk, B.bsize);
+            if (!h.section) bad = true;
+            else {
+                B.ltype = (uint8_t)h.ltype; B.litSize = h.litSize; B.q = h.section;
+                uint32_t q = h.section;
+                if (q >= B.bsize) bad = true;
+                else {
+                    uint32_t nbSeq = blk[q];
+                    if (nbSeq < 128) q += 1;
+                    else if (nbSeq < 255) { if (q + 2 > B.bsize) bad = true; else { nbSeq = ((nbSeq - 128) << 8) + blk[q + 1]; q += 2; } }
+                    else { if (q + 3 > B.bsize) bad = true; else { nbSeq = blk[q + 1] + ((uint32_t)blk[q + 2] << 8) + 0x7F00; q += 3; } }
+                    if (!bad && nbSeq > ZS_BLOCK_MAX / 3 + 1) bad = true;
+                    B.nbSeq = nbSeq;
+                    if (!bad && nbSeq == 0 && q != B.bsize) bad = true;
+                    if (!bad && nbSeq) {
+                        if (q >= B.bsize) bad = true;
+                        else {
+                            const uint32_t modes = blk[q];
+                            uint32_t t = q + 1;
+                            if (modes & 3) bad = true;
+                            B.modes = (uint8_t)modes;
+                            for (int k = 0; k < 3 && !bad; k++) {
+                                const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
+                                const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
+                                B.tOff[k] = t;
+                                if (mode == 1) { if (t >= B.bsize) bad = true; t++; }
+                                else if (mode == 2) {
+                                    if (t >= B.bsize) { bad = true; break; }
+                                    short norm[64]; uint32_t ms = maxSymK, tl = 0;
+                                    const uint32_t used = fse_readNCount(norm, &ms, &tl, blk + t, B.bsize - t, maxLogK);
+                                    if (!used) bad = true;
+                                    t += used;
+                                }
+                            }
+                            if (!bad && t >= B.bsize) bad = true;
+                            B.streamOff = t;
+                        }
+                    }
+                }
+            }
+        }
+        if (bad) sBad = 1;                                             // (any lane: same value)
+        C->blk[b] = B;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (sBad) return;
+    // ---- lane 0: arenas, inheritance ----
+    if (lane == 0) {
+        uint32_t litAt = 0, seqAt = 0, huf = 0xFFFF, tb[3] = {0xFFFF, 0xFFFF, 0xFFFF};
+        bool bad = false;
+        for (uint32_t b = 0; b < n && !bad; b++) {
+            ZbBlock* const B = &C->blk[b];
+            if (B->btype != 2) continue;
+            if (B->ltype == 2) huf = b;
+            if (B->ltype == 3) { if (huf == 0xFFFF) bad = true; B->hufSrc = (uint16_t)huf; }
+            if (B->ltype != 0) { B->litAt = litAt; litAt += (B->litSize + 64 + 15) & ~15u; }
+            if (litAt > lit_cap) bad = true;
+            if (B->nbSeq) {
+                for (int k = 0; k < 3; k++) {
+                    const uint32_t mode = (B->modes >> (6 - 2 * k)) & 3;
+                    if (mode != 3) tb[k] = b; else if (tb[k] == 0xFFFF) bad = true;
+                    B->tblSrc[k] = (uint16_t)tb[k];
+                }
+                B->seqAt = seqAt; seqAt += (B->nbSeq + 63) & ~63u;
+                if (seqAt > seq_cap) bad = true;
+            }
+        }
+        if (!bad) { C->nblocks = n; __threadfence(); C->mode = 1; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode: one workgroup (wave 0 sequences, wave 1 literals) per block
+// ---------------------------------------------------------------------------------------------------
+#define ZB_FAIL() do { if (lane == 0) ZB_STORE_AGENT(&C->mode, 0u); return; } while (0)
+
+// The 1 or 4 Huffman streams of a literals section, on lanes 0-3 through per-stream LDS windows (zstd_dec.hip's literal stage):
+// payload = the section's bytes behind the tree description.  Returns false (wave-uniform) on a malformed stream.
+__device__ static bool zb_huf_streams(DecLds& L, const uint8_t* __restrict__ pay, uint32_t payload, uint32_t streams, uint32_t litSize, uint8_t* __restrict__ lit, uint32_t lane) {
+    uint32_t sOff[5], sCnt[4];
+    if (streams == 1) { sOff[0] = 0; sOff[1] = payload; sOff[2] = sOff[3] = sOff[4] = payload; sCnt[0] = litSize; sCnt[1] = sCnt[2] = sCnt[3] = 0; }
+    else {
+        if (payload < 10) return false;
+        const uint32_t s1 = pay[0] | (pay[1] << 8), s2 = pay[2] | (pay[3] << 8), s3 = pay[4] | (pay[5] << 8);
+        if (6 + (uint64_t)s1 + s2 + s3 >= payload) return false;
+        sOff[0] = 6; sOff[1] = 6 + s1; sOff[2] = sOff[1] + s2; sOff[3] = sOff[2] + s3; sOff[4] = payload;
+        const uint32_t seg = (litSize + 3) / 4;
+        if (3 * seg > litSize) return false;
+        sCnt[0] = sCnt[1] = sCnt[2] = seg; sCnt[3] = litSize - 3 * seg;
+    }
+    bool ok = true;
+    const bool mine = lane < streams;
+    uint32_t o = 0; for (uint32_t k = 0; k < lane && k < 4; k++) o += mine ? sCnt[k] : 0;
+    const uint32_t cnt = mine ? sCnt[lane] : 0, sn = mine ? sOff[lane + 1] - sOff[lane] : 0, sbeg = mine ? sOff[lane] : 0;
+    uint8_t* const outp = lit + o;
+    uint32_t hi = 0, Bh = 0; bool hdone = !mine;
+    if (mine) {
+        const uint32_t lastByte = sn ? pay[sbeg + sn - 1] : 0;
+        if (lastByte == 0) { ok = false; hdone = true; }
+        else Bh = 8 * (sn - 1) + dhb32(lastByte);
+    }
+    const uint32_t tableLog = L.hufLog, tmask = (1u << tableLog) - 1;
+    for (;;) {
+        const uint32_t myTop = hdone ? 0 : (Bh >> 3) + 8;
+        const uint32_t myWb = myTop > ZS_HWIN ? (myTop - ZS_HWIN + 15) & ~15u : 0;
+        for (uint32_t s_ = 0; s_ < streams; s_++) {
+            const uint32_t top = (uint32_t)__builtin_amdgcn_readlane(myTop, (int)s_), wb = (uint32_t)__builtin_amdgcn_readlane(myWb, (int)s_), beg = (uint32_t)__builtin_amdgcn_readlane(sbeg, (int)s_), n_ = (uint32_t)__builtin_amdgcn_readlane(sn, (int)s_);
+            const uint32_t k = lane * 16;
+            if (wb + k < top) {
+                uint4 v;
+                if (wb + k + 16 <= n_) __builtin_memcpy(&v, pay + beg + wb + k, 16);
+                else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wb + k + j < n_ ? pay[beg + wb + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
+                *reinterpret_cast<uint4*>(&L.hwin[s_ * (ZS_HWIN + 16) + k]) = v;
+            }
+        }
+        __threadfence_block();
+        WAVE_SYNC();
+        if (!hdone) {
+            const uint8_t* const win = &L.hwin[lane * (ZS_HWIN + 16)];
+            while (hi + 16 <= cnt && Bh >= 56 && ((Bh - 56) >> 3) >= myWb) {
+                const uint32_t lo = Bh - 56;
+                const uint64_t c = wld64(win, myWb, lo >> 3) >> (lo & 7);
+                uint32_t used = 0;
+                #pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t e = L.hufX[(uint32_t)(c >> (45 - used)) & 0x7FF];
+                    const uint32_t sy = e & 0xFFFFFF;
+                    __builtin_memcpy(outp + hi, &sy, 4);
+                    hi += e >> 28; used += (e >> 24) & 15;
+                }
+                Bh -= used;
+            }
+            while (hi < cnt && (hi + 16 > cnt || Bh < 56)) {
+                const uint32_t need = Bh < tableLog ? Bh : tableLog, lo = Bh - need;
+                if ((lo >> 3) < myWb) break;
+                const uint32_t bits = (uint32_t)(wld64(win, myWb, lo >> 3) >> (lo & 7)) & ((1u << need) - 1);
+                const uint32_t e = huf_decode1(L, (bits << (tableLog - need)) & tmask, tableLog);
+                if ((e >> 8) > Bh) { ok = false; hdone = true; break; }
+                outp[hi++] = (uint8_t)e; Bh -= e >> 8;
+            }
+            if (!hdone && hi >= cnt) { if (Bh != 0) ok = false; hdone = true; }
+        }
+        WAVE_SYNC();
+        if (__all(hdone)) break;
+    }
+    return !__any(!ok);
+}
+
+// One of the three sequence tables of a block from its description: mode 0 predefined, 1 RLE, 2 FSE-compressed (never 3 here: the
+// caller has followed a Repeat back to the block that defines the table).  desc / avail: the description's bytes.
+__device__ static bool zb_seq_table(DecLds& L, int k, uint32_t mode, const uint8_t* __restrict__ desc, uint32_t avail, uint32_t lane) {
+    SeqD* const dt = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
+    uint32_t* const logp = k == 0 ? &L.llLog : k == 1 ? &L.ofLog : &L.mlLog;
+    const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
+    if (mode == 0) {
+        const short* const dn = k == 0 ? dLLnorm : k == 1 ? dOFnorm : dMLnorm;
+        const uint32_t dmax = k == 0 ? 35 : k == 1 ? 28 : 52, dlog = k == 1 ? 5 : 6;
+        if (lane <= dmax) L.norm[lane] = dn[lane];
+        if (lane == 0) *logp = dlog;
+        __threadfence_block();
+        WAVE_SYNC();
+        return fse_buildSeqTable_wave(dt, L, dmax, dlog, k, lane);
+    }
+    if (mode == 1) {
+        if (avail < 1) return false;
+        const uint32_t sym = DUNI(desc[0]);
+        if (sym > maxSymK) return false;
+        if (lane == 0) { dt[0] = SEQD(0, 0, seq_ebits(L, sym, k), sym); *logp = 0; }
+        __threadfence_block();
+        WAVE_SYNC();
+        return true;
+    }
+    if (avail < 1) return false;
+    if (lane == 0) {
+        uint32_t ms = maxSymK, tl = 0;
+        const uint32_t used = fse_readNCount(L.norm, &ms, &tl, desc, avail, maxLogK);
+        L.scal[0] = used; L.scal[3] = ms; L.scal[4] = tl;
+        if (used) *logp = tl;
+    }
+    __threadfence_block();
+    WAVE_SYNC();
+    const uint32_t used = DUNI(L.scal[0]), ms = DUNI(L.scal[3]), tl = DUNI(L.scal[4]);
+    WAVE_SYNC();
+    return used && fse_buildSeqTable_wave(dt, L, ms, tl, k, lane);
+}
+
+__global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                              const tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas,
+                                                              uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
+    __shared__ DecLds L;
+    const uint32_t lane = threadIdx.x & (LANES - 1), role = DUNI(threadIdx.x >> 6), b = blockIdx.x, chunk = blockIdx.y;
+    ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
+    if (DUNI(C->mode) != 1 || b >= DUNI(C->nblocks)) return;
+    ZbBlock* const B = &C->blk[b];
+    if (DUNI(B->btype) != 2) return;
+    const tsx_chunk_desc d = descs[chunk];
+    const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
+    uint8_t* const litArena = arenas + (size_t)chunk * astride;
+    uint32_t* const seqArena = (uint32_t*)(litArena + lit_cap);
+    const uint8_t* const blk = src + DUNI(B->off);
+    const uint32_t bsize = DUNI(B->bsize);
+    if (role == 1) {
+        // ---- literals ----
+        const ZbLit h = zb_lit_header(blk, bsize);                      // (validated by the index kernel)
+        if (h.ltype == 0) return;                                       // raw literals are read in place
+        uint8_t* const lit = litArena + DUNI(B->litAt);
+        if (h.ltype == 1) { const uint8_t v = blk[h.hl]; for (uint32_t i = lane; i < h.litSize; i += LANES) lit[i] = v; return; }
+        uint32_t t = h.hl;
+        const uint8_t* tree = blk + h.hl; uint32_t treeAvail = h.csize;
+        if (h.ltype == 3) {                                             // treeless: the tree of the latest block that carried one
+            const ZbBlock* const S = &C->blk[DUNI(B->hufSrc)];
+            const uint8_t* const sblk = src + DUNI(S->off);
+            const ZbLit sh = zb_lit_header(sblk, DUNI(S->bsize));
+            if (sh.ltype != 2 || !sh.section) ZB_FAIL();
+            tree = sblk + sh.hl; treeAvail = sh.csize;
+        }
+        if (lane == 0) { L.hufValid = 0; L.scalH[0] = huf_readTable(L, tree, treeAvail); }
+        __threadfence_block();
+        WAVE_SYNC();
+        const uint32_t used = DUNI(L.scalH[0]);
+        WAVE_SYNC();
+        if (!used) ZB_FAIL();
+        huf_buildX_wave(L, lane);
+        __threadfence_block();
+        WAVE_SYNC();
+        if (h.ltype == 2) t += used;
+        if (t > h.hl + h.csize) ZB_FAIL();
+        if (!zb_huf_streams(L, blk + t, h.hl + h.csize - t, h.streams, h.litSize, lit, lane)) ZB_FAIL();
+        return;
+    }
+    // ---- sequences ----
+    const uint32_t nbSeq = DUNI(B->nbSeq), litSize = DUNI(B->litSize);
+    if (nbSeq == 0) { if (lane == 0) { B->regen = litSize; B->endHist[0] = ZB_SYM; B->endHist[1] = ZB_SYM | (1u << 28); B->endHist[2] = ZB_SYM | (2u << 28); B->ok = 1; } return; }
+    if (lane == 0) L.zeroEntry = 0;
+    if (lane < 36) { L.cLLbase[lane] = dLLbase[lane]; L.cLLbits[lane] = dLLbits[lane]; }
+    if (lane < 53) { L.cMLbase[lane] = dMLbase[lane]; L.cMLbits[lane] = dMLbits[lane]; }
+    __threadfence_block();
+    WAVE_SYNC();
+    for (int k = 0; k < 3; k++) {
+        const ZbBlock* const S = &C->blk[DUNI(B->tblSrc[k])];           // this block itself unless the table is a Repeat
+        const uint32_t mode = (DUNI(S->modes) >> (6 - 2 * k)) & 3, to = DUNI(S->tOff[k]), sb = DUNI(S->bsize);
+        if (mode == 3 || to > sb) ZB_FAIL();
+        if (!zb_seq_table(L, k, mode, src + DUNI(S->off) + to, sb - to, lane)) ZB_FAIL();
+    }
+    uint32_t* const sLL = seqArena + DUNI(B->seqAt); uint32_t* const sML = sLL + seq_cap; uint32_t* const sOF = sML + seq_cap;
+    const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog);
+    const uint8_t* const win = L.swin;
+    const uint32_t t = DUNI(B->streamOff);
+    const uint32_t n = bsize - t;                                       // >= 1 (index kernel)
+    const uint8_t* const stream = blk + t;
+    const uint32_t lastByte = DUNI(stream[n - 1]);
+    if (lastByte == 0) ZB_FAIL();
+    uint32_t Bc = 8 * (n - 1) + dhb32(lastByte), wbase = 0;             // bits of the stream not read yet
+    const SeqD* const tbl = lane == 0 ? L.ll : lane == 1 ? L.ml : lane == 2 ? L.of : &L.zeroEntry;
+    uint16_t* const recp = &L.rec[lane < 3 ? lane : 3];
+    uint32_t st = 0;
+    bool filled = false;
+    uint32_t r0 = ZB_SYM, r1 = ZB_SYM | (1u << 28), r2 = ZB_SYM | (2u << 28);      // the history this block starts from, whatever it is
+    uint32_t sumLL = 0, sumML = 0;
+    for (uint32_t g = 0; g < nbSeq; g += LANES) {
+        const uint32_t cnt = DUNI(nbSeq - g < LANES ? nbSeq - g : LANES);
+        if (!filled || (wbase != 0 && (Bc >> 3) < wbase + 736)) {
+            WAVE_SYNC();
+            const uint32_t top = (Bc >> 3) + 8;
+            wbase = top > ZS_DWIN ? (top - ZS_DWIN) & ~15u : 0;
+            for (uint32_t k = lane * 16; wbase + k < top; k += LANES * 16) {
+                uint4 v;
+                if (wbase + k + 16 <= n) __builtin_memcpy(&v, stream + wbase + k, 16);
+                else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wbase + k + j < n ? stream[wbase + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
+                *reinterpret_cast<uint4*>(&L.swin[k]) = v;
+            }
+            __threadfence_block();
+            WAVE_SYNC();
+            if (!filled) {
+                filled = true;
+                const uint32_t lo = Bc - (llLog + ofLog + mlLog);
+                if ((int32_t)lo < 0) ZB_FAIL();
+                const uint32_t w = DUNI((uint32_t)(wld64(win, wbase, lo >> 3) >> (lo & 7)));
+                const uint32_t sm = w & ((1u << mlLog) - 1), so = (w >> mlLog) & ((1u << ofLog) - 1), sl = (w >> (mlLog + ofLog)) & ((1u << llLog) - 1);
+                st = lane == 0 ? sl : lane == 1 ? sm : lane == 2 ? so : 0;
+                Bc = lo;
+            }
+        }
+        // pass 1: the chain (lanes 0, 1, 2 = the LL, ML, OF state machines; see zstd_dec.hip)
+        uint32_t bad = 0;
+        const uint32_t Bgroup = Bc;
+        const uint32_t upd = g + cnt < nbSeq ? cnt : cnt - 1;
+        for (uint32_t j = 0; j < upd; j++) {
+            const uint32_t p8 = (Bc >> 3) > 7 ? (Bc >> 3) - 7 : 0;
+            uint64_t c8 = wld64(win, wbase, p8);
+            const uint32_t e_ = tbl[st];
+            recp[j * 4] = (uint16_t)st;
+            TSX_SCHED_BARRIER();
+            const uint32_t pc = SEQD_COUNTS(e_);
+            const uint32_t qc = pc + DPP_SHL(pc, 1) + DPP_SHL(pc, 2);
+            const int32_t raw = (int32_t)(Bc - DUNI(qc >> 5));
+            bad |= (uint32_t)raw;
+            const uint32_t lo = (uint32_t)(raw < 0 ? 0 : raw);
+            uint32_t sh = lo - 8 * p8;
+            if (lo < 8 * p8) { c8 = wld64(win, wbase, lo >> 3); sh = lo & 7; }
+            st = SEQD_BASE(e_) + ((uint32_t)(c8 >> (sh + ((qc - pc) & 31))) & ((1u << (pc & 31)) - 1));
+            Bc = lo;
+        }
+        if (upd < cnt) {
+            const uint32_t e_ = tbl[st];
+            recp[upd * 4] = (uint16_t)st;
+            const uint32_t eb = SEQD_EBITS(e_);
+            const int32_t raw = (int32_t)(Bc - DUNI(eb + DPP_SHL(eb, 1) + DPP_SHL(eb, 2)));
+            bad |= (uint32_t)raw;
+            Bc = (uint32_t)(raw < 0 ? 0 : raw);
+        }
+        if (bad >> 31) ZB_FAIL();
+        __threadfence_block();
+        WAVE_SYNC();
+        // pass 2: every lane decodes the fields of its own sequence
+        const bool valid = lane < cnt;
+        uint32_t ll = 0, ml = 0, offBase = 4;
+        {
+            uint32_t el = 0, eo = 0, em = 0, mine = 0;
+            if (valid) {
+                uint64_t r; __builtin_memcpy(&r, &L.rec[lane * 4], 8);
+                el = L.ll[(uint32_t)r & 0xFFFF]; em = L.ml[(uint32_t)(r >> 16) & 0xFFFF]; eo = L.of[(uint32_t)(r >> 32) & 0xFFFF];
+                mine = SEQD_TOT(el) + SEQD_TOT(eo) + SEQD_TOT(em);
+                if (g + lane + 1 == nbSeq) mine = SEQD_EBITS(el) + SEQD_EBITS(eo) + SEQD_EBITS(em);
+            }
+            uint32_t incl = mine;
+            for (uint32_t o = 1; o < LANES; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (valid) {
+                const uint32_t oc = SEQD_EBITS(eo), mbits = SEQD_EBITS(em), lbits = SEQD_EBITS(el);
+                const uint32_t lbase = L.cLLbase[SEQD_SYM(el)], mbase = L.cMLbase[SEQD_SYM(em)];
+                const uint32_t lo1 = Bgroup - (incl - mine) - oc;
+                offBase = (1u << oc) + ((uint32_t)(wld64(win, wbase, lo1 >> 3) >> (lo1 & 7)) & ((1u << oc) - 1));
+                const uint32_t lo2 = lo1 - mbits - lbits;
+                const uint32_t w2 = (uint32_t)(wld64(win, wbase, lo2 >> 3) >> (lo2 & 7));
+                ll = lbase + (w2 & ((1u << lbits) - 1));
+                ml = mbase + ((w2 >> lbits) & ((1u << mbits) - 1));
+            }
+        }
+        if (__any(valid && offBase > 3 && offBase - 3 >= ZB_SYM)) ZB_FAIL();     // an offset of 2 GiB or more: not in a frame this form takes
+        // pass 3: repeat offsets, on values that are either offsets or references into the incoming history
+        uint32_t off = offBase - 3;
+        {
+            const unsigned long long ll0 = __ballot(valid && ll == 0);
+            unsigned long long users = __ballot(valid && offBase <= 3);
+            uint32_t prev = 0;
+            for (;;) {
+                const uint32_t j = users ? (uint32_t)__ffsll((long long)users) - 1 : cnt;
+                const uint32_t gap = j - prev;
+                const uint32_t a1 = __builtin_amdgcn_readlane(offBase, (int)(j >= 1 ? j - 1 : 0)) - 3;
+                const uint32_t a2 = __builtin_amdgcn_readlane(offBase, (int)(j >= 2 ? j - 2 : 0)) - 3;
+                const uint32_t a3 = __builtin_amdgcn_readlane(offBase, (int)(j >= 3 ? j - 3 : 0)) - 3;
+                const uint32_t n2 = gap >= 3 ? a3 : gap == 2 ? r0 : gap == 1 ? r1 : r2;
+                const uint32_t n1 = gap >= 2 ? a2 : gap == 1 ? r0 : r1;
+                const uint32_t n0 = gap >= 1 ? a1 : r0;
+                r0 = n0; r1 = n1; r2 = n2;
+                if (!users) break;
+                users &= users - 1;
+                const uint32_t ob = __builtin_amdgcn_readlane(offBase, (int)j);
+                const uint32_t idx = ob - 1 + (uint32_t)((ll0 >> j) & 1);
+                const uint32_t c01 = idx == 0 ? r0 : r1, c23 = idx == 2 ? r2 : zb_sym_dec(r0);
+                const uint32_t o_ = idx < 2 ? c01 : c23;
+                r2 = idx >= 2 ? r1 : r2;
+                r1 = idx >= 1 ? r0 : r1;
+                r0 = o_;
+                off = tsx_writelane(o_, j, off);
+                prev = j + 1;
+            }
+        }
+        if (valid) { sLL[g + lane] = ll; sML[g + lane] = ml; sOF[g + lane] = off; }
+        uint32_t a = ll, m = ml;
+        for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); m += __shfl_xor(m, o); }
+        sumLL += DUNI(a); sumML += DUNI(m);
+        if (sumLL > litSize || litSize + sumML > ZS_BLOCK_MAX) ZB_FAIL();   // a block regenerates at most Block_Maximum_Size bytes
+    }
+    if (Bc != 0) ZB_FAIL();                                             // every bit of the stream was used
+    if (lane == 0) { B->regen = litSize + sumML; B->endHist[0] = r0; B->endHist[1] = r1; B->endHist[2] = r2; B->ok = 1; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// execute: one wave per block, block-major ticket order
+// ---------------------------------------------------------------------------------------------------
+#define ZB_SPIN_LIMIT (1u << 22)
+
+__global__ __launch_bounds__(LANES) void zb_execute_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                           tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
+                                                           uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap,
+                                                           uint32_t seq_cap, uint32_t nchunks, uint32_t* __restrict__ ticket) {
+    __shared__ uint32_t sStart[ZB_MAX_BLOCKS + 1];                      // output position of every block (exclusive prefix of the regenerated sizes)
+    __shared__ uint32_t sSeen[ZB_MAX_BLOCKS];                           // progress of the earlier blocks as last observed (and acquired)
+    __shared__ uint32_t sHist[3][ZB_MAX_BLOCKS];                        // outgoing history of every block (symbolic in its incoming one)
+    __shared__ uint8_t sFlag[ZB_MAX_BLOCKS];                            // 1 compressed, 2 decoded fine, 4 has sequences
+    __shared__ uint32_t sTicket;
+    const uint32_t lane = threadIdx.x;
+    // Work comes in block-major ticket order: whoever holds ticket t started after the holders of all tickets < t, so the blocks a
+    // wave may wait for are running or done whatever order the hardware dispatches workgroups in.
+    if (lane == 0) sTicket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tk = DUNI(sTicket), b = tk / nchunks, chunk = tk % nchunks;
+    ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
+    if (ZB_LOAD_AGENT(&C->mode) != 1) return;
+    const uint32_t nb = DUNI(C->nblocks);
+    if (b >= nb) return;
+    const tsx_chunk_desc d = descs[chunk];
+    const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
+    uint8_t* __restrict__ out = dst_base + d.dst_off;
+    const uint8_t* const litArena = arenas + (size_t)chunk * astride;
+    const uint32_t* const seqArena = (const uint32_t*)(litArena + lit_cap);
+    // ---- the chain: positions of all blocks, history of this one ----
+    for (uint32_t i = lane; i < nb; i += LANES) {
+        const ZbBlock* const S = &C->blk[i];
+        sStart[i] = S->regen; sSeen[i] = 0;
+        sHist[0][i] = S->endHist[0]; sHist[1][i] = S->endHist[1]; sHist[2][i] = S->endHist[2];
+        sFlag[i] = (uint8_t)((S->btype == 2 ? 1 : 0) | (S->ok ? 2 : 0) | (S->nbSeq ? 4 : 0));
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t h0 = 1, h1 = 4, h2 = 8;
+    {
+        uint32_t pos = 0; bool okAll = true;
+        for (uint32_t i = 0; i < nb; i++) {                             // wave-uniform; O(1) per block
+            const uint32_t rg = sStart[i];
+            WAVE_SYNC();
+            if (lane == 0) sStart[i] = pos;
+            const uint32_t fl = DUNI(sFlag[i]);
+            if (fl & 1) {
+                if (!(fl & 2)) okAll = false;
+                if (i < b && (fl & 4)) {
+                    const uint32_t e0 = DUNI(sHist[0][i]), e1 = DUNI(sHist[1][i]), e2 = DUNI(sHist[2][i]);
+                    const uint32_t n0 = zb_subst(e0, h0, h1, h2), n1 = zb_subst(e1, h0, h1, h2), n2 = zb_subst(e2, h0, h1, h2);
+                    h0 = n0; h1 = n1; h2 = n2;
+                }
+            }
+            pos += rg;
+            if (pos > ZB_MAX_CHUNK) { okAll = false; break; }
+        }
+        if (lane == 0) sStart[nb] = pos;
+        __threadfence_block();
+        __syncthreads();
+        if (!okAll || pos != DUNI(C->contentSize)) { if (lane == 0) ZB_STORE_AGENT(&C->mode, 0u); return; }      // every wave of the chunk sees the same sums
+    }
+    const ZbBlock* const B = &C->blk[b];
+    const uint32_t myStart = DUNI(sStart[b]), regen = DUNI(sStart[b + 1]) - myStart, btype = DUNI(B->btype), boff = DUNI(B->off);
+    uint32_t* const prog = &C->prog[b];
+    const uint32_t contentSize = DUNI(C->contentSize);
+    if (b == 0 && lane == 0) descs[chunk].dst_len = contentSize;
+    if (btype == 0) { for (uint32_t i = lane; i < regen; i += LANES) out[myStart + i] = src[boff + i]; ZB_RELEASE(); if (lane == 0) ZB_STORE_AGENT(prog, regen | 0x80000000u); return; }
+    if (btype == 1) { const uint8_t v = src[boff]; for (uint32_t i = lane; i < regen; i += LANES) out[myStart + i] = v; ZB_RELEASE(); if (lane == 0) ZB_STORE_AGENT(prog, regen | 0x80000000u); return; }
+    const uint32_t litSize = DUNI(B->litSize), nbSeq = DUNI(B->nbSeq);
+    const uint8_t* litPtr = litArena + DUNI(B->litAt);
+    if (DUNI(B->ltype) == 0) { const ZbLit h = zb_lit_header(src + boff, DUNI(B->bsize)); litPtr = src + boff + h.hl; }
+    const uint32_t* const sLL = seqArena + DUNI(B->seqAt); const uint32_t* const sML = sLL + seq_cap; const uint32_t* const sOF = sML + seq_cap;
+    uint32_t lp = 0, opos = myStart;
+    bool fail = false;
+    for (uint32_t g = 0; g < nbSeq && !fail; g += LANES) {
+        const uint32_t cnt = nbSeq - g < LANES ? nbSeq - g : LANES;
+        const bool valid = lane < cnt;
+        const uint32_t ll = valid ? sLL[g + lane] : 0, ml = valid ? sML[g + lane] : 0;
+        uint32_t off = valid ? sOF[g + lane] : 0;
+        if (off & ZB_SYM) off = zb_subst(off, h0, h1, h2);
+#ifdef ZB_DEBUG
+        if (g == 0 && lane < 6) fprintf(stderr, "blk %u lane %u ll %u ml %u off %u (raw %08x) litSize %u nbSeq %u h %u %u %u\n", b, lane, ll, ml, off, valid ? sOF[g + lane] : 0, litSize, nbSeq, h0, h1, h2);
+#endif
+        uint32_t litIncl = ll, totIncl = ll + ml;
+        for (int o = 1; o < LANES; o <<= 1) {
+            const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
+            if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
+        }
+        const uint32_t groupLit = (uint32_t)__builtin_amdgcn_readlane(litIncl, LANES - 1), groupTot = (uint32_t)__builtin_amdgcn_readlane(totIncl, LANES - 1);
+        if (lp + groupLit > litSize || opos + groupTot > myStart + regen) { fail = true; break; }
+        const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
+        if (__any(valid && ml && (off == 0 || off > mOut))) { fail = true; break; }
+        const uint32_t s0 = mOut - off;
+        // ---- sources in earlier blocks: wait until they exist ----
+        const bool cross = valid && ml && s0 < myStart;
+        if (__any(cross)) {
+            const uint32_t eHi = s0 + ml < myStart ? s0 + ml : myStart;    // the part of the source that lies before this block
+            uint32_t js = 0, je = 0;
+            if (cross) {                                                  // blocks holding bytes s0 and eHi - 1: the last i with sStart[i] <= x
+                uint32_t lo_ = 0, hi_ = b;
+                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (sStart[mid] <= s0) lo_ = mid; else hi_ = mid; }
+                js = lo_; lo_ = js; hi_ = b;
+                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (sStart[mid] <= eHi - 1) lo_ = mid; else hi_ = mid; }
+                je = lo_;
+            }
+            uint32_t vmin = cross ? js : 0xFFFFFFFFu, vmax = cross ? je : 0u;
+            for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(vmin, o), y = __shfl_xor(vmax, o); vmin = x < vmin ? x : vmin; vmax = y > vmax ? y : vmax; }
+            const uint32_t bLo = DUNI(vmin), bHi = DUNI(vmax);
+            bool polled = false;
+            for (uint32_t bb = bLo; bb <= bHi && !fail; bb++) {
+                uint32_t need = 0;
+                if (cross && bb >= js && bb <= je) need = bb < je ? sStart[bb + 1] - sStart[bb] : eHi - sStart[bb];
+                for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(need, o); need = x > need ? x : need; }
+                need = DUNI(need);
+                if (need == 0 || (DUNI(sSeen[bb]) & 0x7FFFFFFFu) >= need) continue;
+                uint32_t seen = 0, spins = 0;
+                for (;;) {                                                // ONE word, relaxed; the acquire comes once, behind the loop
+                    seen = DUNI(ZB_LOAD_AGENT(&C->prog[bb]));
+                    if ((seen & 0x7FFFFFFFu) >= need) break;
+                    if (ZB_LOAD_AGENT(&C->mode) != 1 || ++spins > ZB_SPIN_LIMIT) { fail = true; break; }
+                    ZB_SLEEP();
+                }
+                WAVE_SYNC();
+                if (lane == 0) sSeen[bb] = seen;
+                polled = true;
+            }
+            if (fail) break;
+            if (polled) { ZB_ACQUIRE(); __threadfence_block(); WAVE_SYNC(); }
+        }
+        // ---- copies (zstd_dec.hip's execution stage; sources before this block are final now) ----
+        exec_copies(out + myOut, litPtr + myLit, ll, valid && ll, lane);
+        unsigned long long pend = __ballot(valid && ml);
+        bool first = true;
+        do {
+            const bool mineP = (pend >> lane) & 1;
+            bool blocked = mineP && off < ml;
+            if (first) blocked = mineP && s0 + ml > opos;
+            else
+                for (unsigned long long m = pend; m; m &= m - 1) {
+                    const int j = __ffsll((long long)m) - 1;
+                    const uint32_t dj = __builtin_amdgcn_readlane(mOut, j), ej = dj + __builtin_amdgcn_readlane(ml, j);
+                    if ((uint32_t)j < lane && s0 < ej && s0 + ml > dj) blocked = true;
+                }
+            const unsigned long long ready = __ballot(mineP && !blocked);
+            if (ready || first) {
+                exec_copies(out + mOut, out + s0, ml, (ready >> lane) & 1, lane);
+                pend &= ~ready;
+                first = false;
+            } else {
+                const int i = __ffsll((long long)pend) - 1;
+                pend &= pend - 1;
+                const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
+                const uint32_t from = dpos - o_;
+                if (o_ >= LANES) {
+                    for (uint32_t k = 0; k < m_; k += LANES) {
+                        if (k) __threadfence_block();
+                        if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
+                    }
+                } else {
+                    for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];
+                }
+            }
+            __threadfence_block();
+        } while (pend);
+        lp += groupLit; opos += groupTot;
+        // ---- publish: everything up to opos is final ----
+        if (b + 1 < nb) { ZB_RELEASE(); if (lane == 0) ZB_STORE_AGENT(prog, opos - myStart); }
+    }
+    if (!fail) {
+        const uint32_t tail = litSize - lp;
+        if (opos + tail != myStart + regen) fail = true;
+        else {
+            for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
+            ZB_RELEASE();
+            if (lane == 0) ZB_STORE_AGENT(prog, regen | 0x80000000u);
+        }
+    }
+    if (fail && lane == 0) ZB_STORE_AGENT(&C->mode, 0u);                // the chunk-serial kernel behind this launch redoes the chunk
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+static inline uint32_t zb_lit_cap(uint32_t max_out) { return ((max_out + 80u * ZB_MAX_BLOCKS) + 255u) & ~255u; }
+static inline uint32_t zb_seq_cap(uint32_t max_out) { return ((max_out / 3u + 64u * ZB_MAX_BLOCKS + 64u) + 63u) & ~63u; }
+static inline size_t zb_arena_stride(uint32_t max_out) { return ((size_t)zb_lit_cap(max_out) + 12u * (size_t)zb_seq_cap(max_out) + 255u) & ~(size_t)255u; }
+// workspace of a batch: [256 bytes: ticket counter][n chunk headers][n arenas: literals | literal lengths | match lengths | offsets]
+size_t tsx_zstd_blockmode_bytes(uint32_t n, uint32_t max_out) { return 256 + (size_t)n * (ZB_CHUNK_HDR_BYTES + zb_arena_stride(max_out)); }
+bool tsx_zstd_blockmode_takes(uint32_t max_out) { return max_out <= ZB_MAX_CHUNK; }
+// the list zstd_decompress_kernel skips by: word i * stride == 1 <=> chunk i was decoded here
+const uint32_t* tsx_zstd_blockmode_skip(const void* bwork, uint32_t* stride_words) {
+    *stride_words = (uint32_t)(ZB_CHUNK_HDR_BYTES / 4);
+    return (const uint32_t*)((const uint8_t*)bwork + 256 + offsetof(ZbChunk, mode));
+}
+
+// Headers and the ticket are zeroed on the stream ahead of the launches (polled words are re-initialised every call).
+uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames, int from_mid, uint64_t mid_stride, tsx_chunk_desc* d_descs, uint32_t n,
+                                           uint32_t max_out, uint8_t* dst, int32_t* d_status, void* bwork) {
+    if (!n) return 0;
+    uint8_t* const hdrs = (uint8_t*)bwork + 256;
+    uint8_t* const arenas = hdrs + (size_t)n * ZB_CHUNK_HDR_BYTES;
+    const size_t astride = zb_arena_stride(max_out);
+    (void)hipMemsetAsync(bwork, 0, 256 + (size_t)n * ZB_CHUNK_HDR_BYTES, st);
+    const uint32_t lit_cap = zb_lit_cap(max_out), seq_cap = zb_seq_cap(max_out);
+    hipLaunchKernelGGL(zb_index_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, (const int32_t*)d_status, hdrs, lit_cap, seq_cap);
+    hipLaunchKernelGGL(zb_decode_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(2 * LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
+    hipLaunchKernelGGL(zb_execute_kernel, dim3(ZB_MAX_BLOCKS * n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap, n, (uint32_t*)bwork);
+    return 3;
+}

@@ -1528,16 +1528,30 @@ __device__ static __forceinline__ void zs_block_priority(uint32_t mode, uint32_t
 #endif
 }
 static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
-__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
-                                                              uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
-                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
-                                                              const tsx_chain_fuse fuse
+__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base_, tsx_chunk_desc* __restrict__ descs_,
+                                                              uint8_t* __restrict__ mid_, uint64_t mid_stride_, uint32_t* __restrict__ zlen_,
+                                                              int32_t* __restrict__ status_, uint8_t* __restrict__ work_, uint32_t profile_, uint32_t sched,
+                                                              const tsx_chain_fuse fuse_, const tsx_zseg* __restrict__ segs, uint32_t nsegs
 #ifdef TSX_PROF
                                                               , unsigned long long* __restrict__ prof_out
 #endif
                                                               ) {
     __shared__ EncLds L;
-    const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    // One launch may carry the batches of several callers (tsx_api.hip, the launch combiner): workgroup b belongs to the segment
+    // whose range holds b and works on that caller's buffers.  nsegs == 0: one batch, the kernel arguments themselves.
+    uint32_t chunk = blockIdx.x, nChunks = gridDim.x;
+    const uint8_t* __restrict__ src_base = src_base_; tsx_chunk_desc* __restrict__ descs = descs_; uint8_t* __restrict__ mid = mid_;
+    uint64_t mid_stride = mid_stride_; uint32_t* __restrict__ zlen = zlen_; int32_t* __restrict__ status = status_; uint8_t* __restrict__ work = work_;
+    uint32_t profile = profile_; tsx_chain_fuse fuse = fuse_;
+    if (nsegs) {
+        uint32_t k = 0;
+        while (k + 1 < nsegs && segs[k + 1].first <= blockIdx.x) k++;
+        const tsx_zseg sg = segs[k];
+        chunk = blockIdx.x - sg.first; nChunks = sg.n;
+        src_base = sg.src_base; descs = sg.descs; mid = sg.mid; mid_stride = sg.mid_stride; zlen = sg.zlen; status = sg.status; work = sg.work;
+        profile = sg.profile; fuse = sg.fuse;
+    }
 #ifdef TSX_PROF
     if (lane == 0) { for (int i = 0; i < 24; i++) g_prof[i] = 0; g_prof[22] = g_prof[23] = (unsigned long long)clock64(); }
     __syncthreads();
@@ -1604,7 +1618,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
     const uint32_t prioMode = (UNI(sched) >> 16) & 0xF;
     uint32_t blk = 0;
     while (remaining) {
-        zs_block_priority(prioMode, chunk, gridDim.x, blk++);
+        zs_block_priority(prioMode, chunk, nChunks, blk++);
         // ---- block size (ZSTD_optimalBlockSize) ----
         uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
         if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
@@ -1684,12 +1698,25 @@ size_t tsx_zstd_consts_bytes(void) { return sizeof(tsx_zstd_consts); }
 void tsx_zstd_build_consts(tsx_zstd_consts* h) { h->abi = 1; h->pad[0] = h->pad[1] = h->pad[2] = 0; }
 size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size_t)n * ZS_WS_BYTES; }
 
+// Several callers' batches in one launch: d_segs[0 .. nsegs) (device memory, ascending .first, segment k = workgroups [first, first + n)).
+uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched) {
+    if (!total_chunks || !nsegs) return 0;
+    tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(zstd_compress_kernel, dim3(total_chunks), dim3(LANES), 0, st, (const uint8_t*)nullptr, (tsx_chunk_desc*)nullptr, (uint8_t*)nullptr, (uint64_t)0,
+                       (uint32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, 0u, sched, none, d_segs, nsegs
+#ifdef TSX_PROF
+                       , g_prof_out
+#endif
+                       );
+    return 1;
+}
+
 uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* src, tsx_chunk_desc* d_descs, uint32_t n,
                                   uint32_t /*max_len*/, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status, void* d_work,
                                   uint32_t profile, uint32_t sched, tsx_chain_fuse fuse) {
     if (!n) return 0;
     hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
-                       (uint8_t*)d_work, profile, sched, fuse
+                       (uint8_t*)d_work, profile, sched, fuse, (const tsx_zseg*)nullptr, 0u
 #ifdef TSX_PROF
                        , g_prof_out
 #endif

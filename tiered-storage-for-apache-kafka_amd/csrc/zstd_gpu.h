@@ -15,8 +15,21 @@ size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t max_len);
 uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* src, tsx_chunk_desc* d_descs,
                                   uint32_t n, uint32_t max_len, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status,
                                   void* d_work, uint32_t profile, uint32_t sched /* 0 lean, 1 wide speculation: zstd_enc.hip */, tsx_chain_fuse fuse);
+// Several callers' batches in ONE launch (the front end's launch combiner): segment k of d_segs (device memory) covers workgroups
+// [first, first + n) and names that caller's buffers, key and profile.
+uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched);
 // Inverse (DecompressionChunkEnumeration.java:39-46): frame i at (from_mid ? frames + i*mid_stride :
 // frames + descs[i].src_off), length descs[i].src_len - (from_mid ? 28 : 0); output to dst + descs[i].dst_off,
 // descs[i].dst_len set; status TSX_E_BAD_SIZE / TSX_E_BAD_FRAME / TSX_E_DST_TOO_SMALL on failure.
+// skip (may be NULL): chunk i is left alone when skip[i * skip_stride] == 1 - it was decoded by the block-parallel form below.
 uint32_t tsx_launch_zstd_decompress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* frames, int from_mid, uint64_t mid_stride,
-                                    tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work);
+                                    tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work,
+                                    const uint32_t* skip, uint32_t skip_stride);
+// The same, one workgroup per BLOCK (zstd_dec_blocks.hip): for small batches, where a chunk's 32 blocks one after the other are all
+// latency.  A fast path with a fallback: chunks it does not take (or gives up on) keep their skip word at 0 and must be decoded by
+// tsx_launch_zstd_decompress behind it, with tsx_zstd_blockmode_skip() as the skip list.  bwork: tsx_zstd_blockmode_bytes(n, max_out).
+size_t tsx_zstd_blockmode_bytes(uint32_t n, uint32_t max_out);
+bool tsx_zstd_blockmode_takes(uint32_t max_out);
+const uint32_t* tsx_zstd_blockmode_skip(const void* bwork, uint32_t* stride_words);
+uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames, int from_mid, uint64_t mid_stride, tsx_chunk_desc* d_descs, uint32_t n,
+                                           uint32_t max_out, uint8_t* dst, int32_t* d_status, void* bwork);
