@@ -20,6 +20,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes every stream of the process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share
+# one run their kernels one after the other.  The library's shared lanes + copy streams (ctx-less calls) and the caller contexts of
+# the legs below are more than 4: the process asks for 16, as INTEGRATION.md tells a broker's launcher to (must be set before the
+# runtime initialises, i.e. before torch is imported; an explicit setting wins).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 GiB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 
@@ -392,6 +397,28 @@ def main():
         rec, fresh = pmc_record("detransform/%s/%d" % (args.dist, n))
         inv_traffic = rec["hbm_bytes_per_launch"] if rec and fresh else None
         ach = alg_inv / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # fetch latency: a single chunk and a 4-chunk prefetch window (16 MiB, ChunkCache's default window is a few chunks), host buffers
+        # in -> host buffers out, registered; small batches take the block-parallel decoder form (csrc/zstd_dec_blocks.hip)
+        if rank == 0 and world == 1 and not rehearse and n >= 4:
+            try:
+                hfr = dst[:4 * slot].cpu().numpy(); hbk = np.zeros(4 * CH, np.uint8)
+                N.host_register(hfr); N.host_register(hbk)
+                lat = {}
+                for k_ in (1, 4):
+                    ee = e[:k_].copy(); ee["dst_off"] = np.arange(k_, dtype=np.uint64) * CH
+                    tt = []
+                    for _ in range(7):
+                        t1 = time.perf_counter()
+                        N.detransform_batch(params, ee, hfr, hbk, hbk.size, nat.MEM_HOST, ctx=ctx)
+                        tt.append(time.perf_counter() - t1)
+                    okk = bool((ee["status"] == 0).all() and np.array_equal(hbk[:k_ * CH], src[:k_ * CH].cpu().numpy()))
+                    lat[k_] = (round(float(np.median(tt[2:])) * 1e3, 3), okk)
+                N.host_unregister(hfr); N.host_unregister(hbk)
+                inverse["single_chunk_ms"] = lat[1][0]; inverse["window4_ms"] = lat[4][0]
+                inverse["small_batches_exact"] = bool(lat[1][1] and lat[4][1])
+                inverse["small_batch_note"] = "host -> host, registered buffers, median of 5; batches of <= 256 chunks decode one workgroup per block"
+            except nat.TsxError as ex:
+                inverse["small_batch_error"] = str(ex)
         inverse["roofline"] = {"bound": "hbm", "kernel": dom_k, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": inv_traffic,
                                "traffic_source": None if not rec else (rec.get("source") if fresh else "STALE: %s was measured on another build of the kernel" % rec.get("source")),
@@ -669,6 +696,7 @@ def main():
                        "object_gathered_on_rank0_sha": None if not objects else __import__("hashlib").sha256(
                            b"".join((objects[k].cpu().numpy() if hasattr(objects[k], "cpu") else np.asarray(objects[k])).tobytes() for k in sorted(objects))).hexdigest()[:16],
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
+                       "hip_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "verified_chunks_vs_oracle": verified},
             "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "end_to_end": e2e, "detransform": inverse,
         }

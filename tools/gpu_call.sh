@@ -7,7 +7,7 @@
 #   broker         tools/broker_probe.py (10/20/24 callers x 256-chunk batches), device + host memory, GPU_MAX_HW_QUEUES variants
 #   pmc            PMC passes over the compressor + decoder (tools/pmc_zstd.sh, tools/pmc_dec.sh)
 #   trace          rocprofv3 --kernel-trace --stats of the bench's timed region
-#   dec            decoder small-batch latencies (tools/detransform_bench.py windows)
+#   dec[:nmax]     fetch-side latency of 1 .. nmax chunks, block-parallel vs chunk-serial decoder form (tools/dec_latency.py)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
 O=$R/gpurun_out/$TAG
@@ -35,9 +35,9 @@ except Exception as e: print("regime $cfg failed", e)
 PY
       done ;;
     broker)
-      for q in "" 16 32; do
-        for mem in device host; do
-          extra=""; [ "$mem" == host ] && extra="--ctxless"
+      for q in "" 16; do
+        for mem in host; do
+          extra="--ctxless"
           ( [ -n "$q" ] && export GPU_MAX_HW_QUEUES=$q; timeout 400 python tools/broker_probe.py --mem $mem $extra --configs ${arg:-10x256,20x256,40x128} --pool-chunks 512 --seconds 5 --tag "q=$q" >> $O/broker.jsonl 2>> $O/broker.err )
         done
       done
@@ -50,7 +50,7 @@ PY
       f=$(find $O/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_rocprofv3_kernel_stats.csv && head -8 $f
       find $O/trace -name "*kernel_trace.csv" -delete ;;
     dec)
-      timeout 600 python tools/detransform_bench.py --windows > $O/dec_windows.txt 2>&1; cat $O/dec_windows.txt ;;
+      timeout 600 python tools/dec_latency.py ${arg:-256} > $O/dec_latency.jsonl 2> $O/dec_latency.err; cat $O/dec_latency.jsonl; tail -3 $O/dec_latency.err ;;
     *) echo "unknown section $name" ;;
   esac
 done
