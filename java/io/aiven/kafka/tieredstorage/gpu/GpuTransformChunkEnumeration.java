@@ -202,6 +202,7 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
             if (key != null) {
                 Arrays.fill(key, (byte) 0);            // the copy does not wait for the garbage collector
             }
+            TsxNative.setThreadDevice(-1);             // the hint is this batch's: later ctx-less calls of the thread (a fetch) choose freely again
         }
         if (rc != TsxNative.OK) {
             throw new RuntimeException(TsxNative.strerror(rc));

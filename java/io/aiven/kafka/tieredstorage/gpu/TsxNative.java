@@ -85,7 +85,8 @@ public final class TsxNative {
             if (old != null && pin) {
                 hostUnregister(old);
             }
-            final ByteBuffer fresh = ByteBuffer.allocateDirect((int) (need + need / 8 + 64)).order(java.nio.ByteOrder.LITTLE_ENDIAN);
+            final ByteBuffer fresh = ByteBuffer.allocateDirect((int) Math.min(need + need / 8 + 64, (long) Integer.MAX_VALUE - 64))
+                .order(java.nio.ByteOrder.LITTLE_ENDIAN);          // headroom for the next, slightly larger batch - never beyond what one buffer holds
             if (pin) {
                 hostRegister(fresh);          // best effort: an unpinned buffer still works (runtime-staged copies)
             }

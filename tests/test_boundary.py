@@ -129,3 +129,34 @@ def test_java_binding_agrees_with_the_header_and_the_shim():
     for f in os.listdir(jdir):
         for ref in re.findall(r"TsxNative\.(\w+)", open(os.path.join(jdir, f)).read()):
             assert ref in natives or ref in consts or ref == "Buffers", (f, ref)
+
+
+def test_gpu_chunk_cache_meets_the_references_cache_selection_contract():
+    """`fetch.chunk.cache.class` selects a cache by reflection (reference ChunkManagerFactory.java:39-46):
+    cacheClass.getDeclaredConstructor(ChunkManager.class).newInstance(defaultChunkManager) assigned to a ChunkCache<?>, then
+    configure(prefix-stripped map).  No JDK here, so the source is checked for exactly that shape: subclass of ChunkCache, the
+    one-argument constructor, configure(Map) reading the reference's keys through ChunkCacheConfig, ChunkCache's four abstract hooks,
+    and - ADVICE r2 - no ForkJoinPool (its workers time out and would leave pinned buffers registered with the device runtime)."""
+    jdir = os.path.join(ROOT, "java", "io", "aiven", "kafka", "tieredstorage", "gpu")
+    src = open(os.path.join(jdir, "GpuChunkCache.java")).read()
+    code = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    code = re.sub(r"//[^\n]*", "", code)
+    assert re.search(r"public class GpuChunkCache extends ChunkCache<byte\[\]>", code)
+    assert re.search(r"public GpuChunkCache\(final ChunkManager \w+\)\s*\{\s*super\(\w+\);", code)
+    assert re.search(r"public void configure\(final Map<String, \?> configs\)", code) and "new ChunkCacheConfig(configs)" in code
+    for accessor in ("cachePrefetchingSize()", "cacheSize()", "getTimeout()", "threadPoolSize()"):
+        assert accessor in code, accessor
+    assert '"gpu.coalesce.wait.us"' in code
+    for hook in ("cachedChunkToInputStream", "cacheChunk", "removalListener", "weigher"):
+        assert re.search(r"@Override\s+public [\w<>\[\], ]+ %s\(" % hook, code), hook
+    assert "ForkJoinPool" not in code and "newFixedThreadPool" in code and "TsxNative.Buffers.release()" in code
+    # the reference's abstract class really has these hooks and this constructor shape (if the reference tree is at hand)
+    ref = "/root/reference/core/src/main/java/io/aiven/kafka/tieredstorage/fetch/cache/ChunkCache.java"
+    if os.path.exists(ref):
+        r = open(ref).read()
+        for hook in ("cachedChunkToInputStream", "cacheChunk", "removalListener", "weigher"):
+            assert re.search(r"public abstract [\w<>\[\], ]+ %s\(" % hook, r), hook
+        assert "protected ChunkCache(final ChunkManager chunkManager)" in r
+    # the upload side gives its device hint back
+    t = open(os.path.join(jdir, "GpuTransformChunkEnumeration.java")).read()
+    assert "TsxNative.setThreadDevice(-1)" in t
