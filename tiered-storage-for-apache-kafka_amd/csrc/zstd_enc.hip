@@ -1528,7 +1528,12 @@ __device__ static __forceinline__ void zs_block_priority(uint32_t mode, uint32_t
 #endif
 }
 static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
-__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base_, tsx_chunk_desc* __restrict__ descs_,
+// SEG = false: one batch, the kernel arguments themselves (the body is exactly the single-batch kernel: the segment lookup folds away
+// and the arguments stay reloadable kernel arguments instead of live registers).  SEG = true: one launch carries the batches of
+// several callers (tsx_api.hip, the launch combiner): workgroup b belongs to the segment whose range holds b and works on that
+// caller's buffers, key and profile.
+template <bool SEG>
+__device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restrict__ src_base_, tsx_chunk_desc* __restrict__ descs_,
                                                               uint8_t* __restrict__ mid_, uint64_t mid_stride_, uint32_t* __restrict__ zlen_,
                                                               int32_t* __restrict__ status_, uint8_t* __restrict__ work_, uint32_t profile_, uint32_t sched,
                                                               const tsx_chain_fuse fuse_, const tsx_zseg* __restrict__ segs, uint32_t nsegs
@@ -1538,13 +1543,11 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
                                                               ) {
     __shared__ EncLds L;
     const uint32_t lane = threadIdx.x;
-    // One launch may carry the batches of several callers (tsx_api.hip, the launch combiner): workgroup b belongs to the segment
-    // whose range holds b and works on that caller's buffers.  nsegs == 0: one batch, the kernel arguments themselves.
     uint32_t chunk = blockIdx.x, nChunks = gridDim.x;
     const uint8_t* __restrict__ src_base = src_base_; tsx_chunk_desc* __restrict__ descs = descs_; uint8_t* __restrict__ mid = mid_;
     uint64_t mid_stride = mid_stride_; uint32_t* __restrict__ zlen = zlen_; int32_t* __restrict__ status = status_; uint8_t* __restrict__ work = work_;
     uint32_t profile = profile_; tsx_chain_fuse fuse = fuse_;
-    if (nsegs) {
+    if (SEG) {
         uint32_t k = 0;
         while (k + 1 < nsegs && segs[k + 1].first <= blockIdx.x) k++;
         const tsx_zseg sg = segs[k];
@@ -1691,6 +1694,24 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
 #endif
 }
 
+#ifdef TSX_PROF
+#define ZS_PROF_PARAM , unsigned long long* __restrict__ prof_out
+#define ZS_PROF_ARG , prof_out
+#else
+#define ZS_PROF_PARAM
+#define ZS_PROF_ARG
+#endif
+__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
+                                                              uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
+                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
+                                                              const tsx_chain_fuse fuse ZS_PROF_PARAM) {
+    zstd_compress_body<false>(src_base, descs, mid, mid_stride, zlen, status, work, profile, sched, fuse, nullptr, 0u ZS_PROF_ARG);
+}
+__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segments_kernel(const tsx_zseg* __restrict__ segs, uint32_t nsegs, uint32_t sched ZS_PROF_PARAM) {
+    const tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr};
+    zstd_compress_body<true>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0u, sched, none, segs, nsegs ZS_PROF_ARG);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
@@ -1701,9 +1722,7 @@ size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size
 // Several callers' batches in one launch: d_segs[0 .. nsegs) (device memory, ascending .first, segment k = workgroups [first, first + n)).
 uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched) {
     if (!total_chunks || !nsegs) return 0;
-    tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(zstd_compress_kernel, dim3(total_chunks), dim3(LANES), 0, st, (const uint8_t*)nullptr, (tsx_chunk_desc*)nullptr, (uint8_t*)nullptr, (uint64_t)0,
-                       (uint32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, 0u, sched, none, d_segs, nsegs
+    hipLaunchKernelGGL(zstd_compress_segments_kernel, dim3(total_chunks), dim3(LANES), 0, st, d_segs, nsegs, sched
 #ifdef TSX_PROF
                        , g_prof_out
 #endif
@@ -1716,7 +1735,7 @@ uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*
                                   uint32_t profile, uint32_t sched, tsx_chain_fuse fuse) {
     if (!n) return 0;
     hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
-                       (uint8_t*)d_work, profile, sched, fuse, (const tsx_zseg*)nullptr, 0u
+                       (uint8_t*)d_work, profile, sched, fuse
 #ifdef TSX_PROF
                        , g_prof_out
 #endif
