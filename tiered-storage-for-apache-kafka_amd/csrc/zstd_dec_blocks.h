@@ -21,7 +21,6 @@ struct ZbBlock {
 struct ZbChunk {
     uint32_t mode;                               // 1: the block form is decoding this chunk; 0: left to (or handed back to) zstd_decompress_kernel
     uint32_t nblocks, contentSize, pad;
-    uint32_t prog[ZB_MAX_BLOCKS];                // bytes of each block's output that are final (bit 31: the block is complete)
     ZbBlock blk[ZB_MAX_BLOCKS];
 };
 #define ZB_CHUNK_HDR_BYTES ((sizeof(ZbChunk) + 255u) & ~(size_t)255u)

@@ -13,16 +13,16 @@
 //                      it from the earlier block's bytes, and repeat offsets are resolved SYMBOLICALLY: a block does not know the
 //                      history it starts from, so an offset that comes out of the history is recorded as "incoming entry i minus d"
 //                      and the block's outgoing history is a function of the incoming one.
-//   zb_execute_kernel  one wave per block, started in block-major ticket order.  Every wave chains the block summaries up to its
-//                      own block (output position = sum of the regenerated sizes before it, incoming history = composition of the
-//                      outgoing ones: O(1) per block) and executes its sequences 64 at a time as zstd_dec.hip does.  A match whose
-//                      source lies in an EARLIER block waits until that block has produced it: every block publishes its progress
-//                      (agent-scope release + flag, cdna_hip_programming.md Guideline 16), readers poll relaxed and acquire once.
-//                      Log-like content copies mostly from ~100 KB back, i.e. from the previous block at the same relative position,
-//                      so the blocks of a chunk advance side by side.
+//   zb_scatter_kernel  one wave per block.  Chains the block summaries up to its own block (output position = sum of the regenerated
+//                      sizes before it, incoming history = composition of the outgoing ones: O(1) per block) and writes ONE WORD PER
+//                      OUTPUT BYTE: the byte itself for a literal, the position it copies from for a match byte.
+//   zb_jump_kernel     log2(size) rounds of pointer doubling over those words: "where I copy from" becomes "where that copies from"
+//                      until every word is a literal - the execution stage without any order between sequences, blocks or
+//                      workgroups (in-order execution is ONE dependency chain through the whole chunk: see the comment there).
+//   zb_emit_kernel     words -> bytes.
 //
 // This form is a fast path, not a second authority: anything it does not like (more than 264 blocks, a chunk above 16 MiB, a
-// malformed frame, an offset out of range, a wait that times out) clears the chunk's `mode` word and zstd_decompress_kernel - which
+// malformed frame, an offset out of range, a copy chain that does not end in a literal) clears the chunk's `mode` word and zstd_decompress_kernel - which
 // is launched behind it with that word as its skip list - decodes the chunk and reports the error code.  Bytes are either final
 // and correct or rewritten by the fallback.
 #include "zstd_dec_dev.h"
@@ -38,17 +38,9 @@
 #ifdef HIPEMU
 #define ZB_LOAD_AGENT(p) (*(volatile const uint32_t*)(p))
 #define ZB_STORE_AGENT(p, v) do { *(volatile uint32_t*)(p) = (v); } while (0)
-#define ZB_RELEASE() do {} while (0)
-#define ZB_ACQUIRE() do {} while (0)
-#define ZB_SLEEP() do {} while (0)
 #else
 #define ZB_LOAD_AGENT(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define ZB_STORE_AGENT(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-// producer: this wave's stores have left (vmcnt), the XCD's L2 is written back, and the wait behind the write-back is restated
-// where the compiler cannot drop it (Guideline 16, pitfall 12)
-#define ZB_RELEASE() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-#define ZB_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
-#define ZB_SLEEP() __builtin_amdgcn_s_sleep(8)
 #endif
 
 __device__ static inline uint32_t zb_sym_dec(uint32_t v) { return (v & ZB_SYM) ? v + 1 : v - 1; }     // "rep0 - 1" on either kind of value
@@ -539,38 +531,40 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
-// execute: one wave per block, block-major ticket order
+// execution by pointer jumping: scatter -> log2(size) jump rounds -> emit
+//
+// Executing sequences in order is a dependency chain through the whole chunk: in log-like content every record copies its field
+// names from the record before it (offset ~ one record), so byte p of record r is a copy of a copy ... of record 0 - the first
+// sequences of a block read the last bytes of the block before it, and 32 blocks "side by side" still run one after the other
+// (measured: 24 ms per chunk with cross-block waits against 33 ms for the chunk-serial kernel).  What breaks the chain is not
+// order but TRANSITIVITY: give every output byte a word - the byte itself when it is a literal, else the position it copies
+// from (p - offset, always < p) - and replace "where I copy from" by "where THAT copies from" until every word is a literal:
+// pointer doubling, log2(chain depth) <= log2(size) rounds, all bytes of all blocks at once, no ordering between workgroups at
+// all (a word read while another thread replaces it holds either ancestor - both are valid - so the update is done in place).
 // ---------------------------------------------------------------------------------------------------
-#define ZB_SPIN_LIMIT (1u << 22)
+#define ZB_LIT 0x80000000u                      /* src word: ZB_LIT | byte (resolved), else the chunk position this byte copies from */
 
-__global__ __launch_bounds__(LANES) void zb_execute_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
-                                                           tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
-                                                           uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap,
-                                                           uint32_t seq_cap, uint32_t nchunks, uint32_t* __restrict__ ticket) {
+// one wave per block: the chain over the block summaries (positions, incoming repeat-offset history), then one word per output byte
+__global__ __launch_bounds__(LANES) void zb_scatter_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                           tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas,
+                                                           uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
     __shared__ uint32_t sStart[ZB_MAX_BLOCKS + 1];                      // output position of every block (exclusive prefix of the regenerated sizes)
-    __shared__ uint32_t sSeen[ZB_MAX_BLOCKS];                           // progress of the earlier blocks as last observed (and acquired)
     __shared__ uint32_t sHist[3][ZB_MAX_BLOCKS];                        // outgoing history of every block (symbolic in its incoming one)
     __shared__ uint8_t sFlag[ZB_MAX_BLOCKS];                            // 1 compressed, 2 decoded fine, 4 has sequences
-    __shared__ uint32_t sTicket;
-    const uint32_t lane = threadIdx.x;
-    // Work comes in block-major ticket order: whoever holds ticket t started after the holders of all tickets < t, so the blocks a
-    // wave may wait for are running or done whatever order the hardware dispatches workgroups in.
-    if (lane == 0) sTicket = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t tk = DUNI(sTicket), b = tk / nchunks, chunk = tk % nchunks;
+    __shared__ uint32_t gStart[LANES + 1], gLL[LANES], gLit[LANES], gSrc[LANES];   // the group of 64 sequences being scattered
+    const uint32_t lane = threadIdx.x, b = blockIdx.x, chunk = blockIdx.y;
     ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
-    if (ZB_LOAD_AGENT(&C->mode) != 1) return;
+    if (DUNI(ZB_LOAD_AGENT(&C->mode)) != 1) return;
     const uint32_t nb = DUNI(C->nblocks);
     if (b >= nb) return;
     const tsx_chunk_desc d = descs[chunk];
     const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
-    uint8_t* __restrict__ out = dst_base + d.dst_off;
     const uint8_t* const litArena = arenas + (size_t)chunk * astride;
     const uint32_t* const seqArena = (const uint32_t*)(litArena + lit_cap);
-    // ---- the chain: positions of all blocks, history of this one ----
+    uint32_t* const words = (uint32_t*)(litArena + lit_cap + 12u * (size_t)seq_cap);      // one per output byte
     for (uint32_t i = lane; i < nb; i += LANES) {
         const ZbBlock* const S = &C->blk[i];
-        sStart[i] = S->regen; sSeen[i] = 0;
+        sStart[i] = S->regen;
         sHist[0][i] = S->endHist[0]; sHist[1][i] = S->endHist[1]; sHist[2][i] = S->endHist[2];
         sFlag[i] = (uint8_t)((S->btype == 2 ? 1 : 0) | (S->ok ? 2 : 0) | (S->nbSeq ? 4 : 0));
     }
@@ -602,26 +596,22 @@ __global__ __launch_bounds__(LANES) void zb_execute_kernel(const uint8_t* __rest
     }
     const ZbBlock* const B = &C->blk[b];
     const uint32_t myStart = DUNI(sStart[b]), regen = DUNI(sStart[b + 1]) - myStart, btype = DUNI(B->btype), boff = DUNI(B->off);
-    uint32_t* const prog = &C->prog[b];
     const uint32_t contentSize = DUNI(C->contentSize);
     if (b == 0 && lane == 0) descs[chunk].dst_len = contentSize;
-    if (btype == 0) { for (uint32_t i = lane; i < regen; i += LANES) out[myStart + i] = src[boff + i]; ZB_RELEASE(); if (lane == 0) ZB_STORE_AGENT(prog, regen | 0x80000000u); return; }
-    if (btype == 1) { const uint8_t v = src[boff]; for (uint32_t i = lane; i < regen; i += LANES) out[myStart + i] = v; ZB_RELEASE(); if (lane == 0) ZB_STORE_AGENT(prog, regen | 0x80000000u); return; }
+    if (btype == 0) { for (uint32_t i = lane; i < regen; i += LANES) words[myStart + i] = ZB_LIT | src[boff + i]; return; }
+    if (btype == 1) { const uint32_t v = ZB_LIT | src[boff]; for (uint32_t i = lane; i < regen; i += LANES) words[myStart + i] = v; return; }
     const uint32_t litSize = DUNI(B->litSize), nbSeq = DUNI(B->nbSeq);
     const uint8_t* litPtr = litArena + DUNI(B->litAt);
     if (DUNI(B->ltype) == 0) { const ZbLit h = zb_lit_header(src + boff, DUNI(B->bsize)); litPtr = src + boff + h.hl; }
     const uint32_t* const sLL = seqArena + DUNI(B->seqAt); const uint32_t* const sML = sLL + seq_cap; const uint32_t* const sOF = sML + seq_cap;
     uint32_t lp = 0, opos = myStart;
     bool fail = false;
-    for (uint32_t g = 0; g < nbSeq && !fail; g += LANES) {
+    for (uint32_t g = 0; g < nbSeq; g += LANES) {
         const uint32_t cnt = nbSeq - g < LANES ? nbSeq - g : LANES;
         const bool valid = lane < cnt;
         const uint32_t ll = valid ? sLL[g + lane] : 0, ml = valid ? sML[g + lane] : 0;
         uint32_t off = valid ? sOF[g + lane] : 0;
         if (off & ZB_SYM) off = zb_subst(off, h0, h1, h2);
-#ifdef ZB_DEBUG
-        if (g == 0 && lane < 6) fprintf(stderr, "blk %u lane %u ll %u ml %u off %u (raw %08x) litSize %u nbSeq %u h %u %u %u\n", b, lane, ll, ml, off, valid ? sOF[g + lane] : 0, litSize, nbSeq, h0, h1, h2);
-#endif
         uint32_t litIncl = ll, totIncl = ll + ml;
         for (int o = 1; o < LANES; o <<= 1) {
             const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
@@ -631,92 +621,71 @@ __global__ __launch_bounds__(LANES) void zb_execute_kernel(const uint8_t* __rest
         if (lp + groupLit > litSize || opos + groupTot > myStart + regen) { fail = true; break; }
         const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
         if (__any(valid && ml && (off == 0 || off > mOut))) { fail = true; break; }
-        const uint32_t s0 = mOut - off;
-        // ---- sources in earlier blocks: wait until they exist ----
-        const bool cross = valid && ml && s0 < myStart;
-        if (__any(cross)) {
-            const uint32_t eHi = s0 + ml < myStart ? s0 + ml : myStart;    // the part of the source that lies before this block
-            uint32_t js = 0, je = 0;
-            if (cross) {                                                  // blocks holding bytes s0 and eHi - 1: the last i with sStart[i] <= x
-                uint32_t lo_ = 0, hi_ = b;
-                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (sStart[mid] <= s0) lo_ = mid; else hi_ = mid; }
-                js = lo_; lo_ = js; hi_ = b;
-                while (hi_ - lo_ > 1) { const uint32_t mid = (lo_ + hi_) >> 1; if (sStart[mid] <= eHi - 1) lo_ = mid; else hi_ = mid; }
-                je = lo_;
-            }
-            uint32_t vmin = cross ? js : 0xFFFFFFFFu, vmax = cross ? je : 0u;
-            for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(vmin, o), y = __shfl_xor(vmax, o); vmin = x < vmin ? x : vmin; vmax = y > vmax ? y : vmax; }
-            const uint32_t bLo = DUNI(vmin), bHi = DUNI(vmax);
-            bool polled = false;
-            for (uint32_t bb = bLo; bb <= bHi && !fail; bb++) {
-                uint32_t need = 0;
-                if (cross && bb >= js && bb <= je) need = bb < je ? sStart[bb + 1] - sStart[bb] : eHi - sStart[bb];
-                for (int o = 32; o; o >>= 1) { const uint32_t x = __shfl_xor(need, o); need = x > need ? x : need; }
-                need = DUNI(need);
-                if (need == 0 || (DUNI(sSeen[bb]) & 0x7FFFFFFFu) >= need) continue;
-                uint32_t seen = 0, spins = 0;
-                for (;;) {                                                // ONE word, relaxed; the acquire comes once, behind the loop
-                    seen = DUNI(ZB_LOAD_AGENT(&C->prog[bb]));
-                    if ((seen & 0x7FFFFFFFu) >= need) break;
-                    if (ZB_LOAD_AGENT(&C->mode) != 1 || ++spins > ZB_SPIN_LIMIT) { fail = true; break; }
-                    ZB_SLEEP();
-                }
-                WAVE_SYNC();
-                if (lane == 0) sSeen[bb] = seen;
-                polled = true;
-            }
-            if (fail) break;
-            if (polled) { ZB_ACQUIRE(); __threadfence_block(); WAVE_SYNC(); }
+        // the group's ~1.5 KB of output, one word per byte, written by all lanes side by side: position -> its sequence by a
+        // binary search over the 64 start positions (a lane walking its own run would serialise a 100 KB match on one lane)
+        WAVE_SYNC();
+        gStart[lane] = valid ? myOut : opos + groupTot; gLL[lane] = ll; gLit[lane] = myLit; gSrc[lane] = mOut - off;
+        if (lane == 0) gStart[LANES] = opos + groupTot;
+        __threadfence_block();
+        WAVE_SYNC();
+        for (uint32_t p = opos + lane; p < opos + groupTot; p += LANES) {
+            uint32_t i = 0;
+            for (uint32_t s_ = 32; s_; s_ >>= 1) if (gStart[i + s_] <= p) i += s_;      // the last sequence that starts at or before p
+            const uint32_t rel = p - gStart[i], l_ = gLL[i];
+            words[p] = rel < l_ ? (ZB_LIT | litPtr[gLit[i] + rel]) : gSrc[i] + (rel - l_);
         }
-        // ---- copies (zstd_dec.hip's execution stage; sources before this block are final now) ----
-        exec_copies(out + myOut, litPtr + myLit, ll, valid && ll, lane);
-        unsigned long long pend = __ballot(valid && ml);
-        bool first = true;
-        do {
-            const bool mineP = (pend >> lane) & 1;
-            bool blocked = mineP && off < ml;
-            if (first) blocked = mineP && s0 + ml > opos;
-            else
-                for (unsigned long long m = pend; m; m &= m - 1) {
-                    const int j = __ffsll((long long)m) - 1;
-                    const uint32_t dj = __builtin_amdgcn_readlane(mOut, j), ej = dj + __builtin_amdgcn_readlane(ml, j);
-                    if ((uint32_t)j < lane && s0 < ej && s0 + ml > dj) blocked = true;
-                }
-            const unsigned long long ready = __ballot(mineP && !blocked);
-            if (ready || first) {
-                exec_copies(out + mOut, out + s0, ml, (ready >> lane) & 1, lane);
-                pend &= ~ready;
-                first = false;
-            } else {
-                const int i = __ffsll((long long)pend) - 1;
-                pend &= pend - 1;
-                const uint32_t dpos = __builtin_amdgcn_readlane(mOut, i), o_ = __builtin_amdgcn_readlane(off, i), m_ = __builtin_amdgcn_readlane(ml, i);
-                const uint32_t from = dpos - o_;
-                if (o_ >= LANES) {
-                    for (uint32_t k = 0; k < m_; k += LANES) {
-                        if (k) __threadfence_block();
-                        if (k + lane < m_) out[dpos + k + lane] = out[from + k + lane];
-                    }
-                } else {
-                    for (uint32_t k = lane; k < m_; k += LANES) out[dpos + k] = out[from + (k % o_)];
-                }
-            }
-            __threadfence_block();
-        } while (pend);
         lp += groupLit; opos += groupTot;
-        // ---- publish: everything up to opos is final ----
-        if (b + 1 < nb) { ZB_RELEASE(); if (lane == 0) ZB_STORE_AGENT(prog, opos - myStart); }
     }
     if (!fail) {
         const uint32_t tail = litSize - lp;
         if (opos + tail != myStart + regen) fail = true;
-        else {
-            for (uint32_t k = lane; k < tail; k += LANES) out[opos + k] = litPtr[lp + k];
-            ZB_RELEASE();
-            if (lane == 0) ZB_STORE_AGENT(prog, regen | 0x80000000u);
-        }
+        else for (uint32_t k = lane; k < tail; k += LANES) words[opos + k] = ZB_LIT | litPtr[lp + k];
     }
     if (fail && lane == 0) ZB_STORE_AGENT(&C->mode, 0u);                // the chunk-serial kernel behind this launch redoes the chunk
+}
+
+// one jump round: every unresolved word takes its source's word (four words per thread)
+__global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
+    const uint32_t chunk = blockIdx.y;
+    const ZbChunk* const C = (const ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
+    if (C->mode != 1) return;
+    const uint32_t n = C->contentSize, p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= n) return;
+    uint32_t* const words = (uint32_t*)(arenas + (size_t)chunk * astride + lit_cap + 12u * (size_t)seq_cap);
+    if (p + 4 <= n) {
+        uint4 v = *reinterpret_cast<const uint4*>(words + p);
+        if ((v.x & v.y & v.z & v.w) & ZB_LIT) return;                   // all four resolved already
+        const uint32_t a = (v.x & ZB_LIT) ? v.x : words[v.x], b_ = (v.y & ZB_LIT) ? v.y : words[v.y], c = (v.z & ZB_LIT) ? v.z : words[v.z], d_ = (v.w & ZB_LIT) ? v.w : words[v.w];
+        v.x = a; v.y = b_; v.z = c; v.w = d_;
+        *reinterpret_cast<uint4*>(words + p) = v;
+    } else {
+        for (uint32_t q = p; q < n; q++) { const uint32_t v = words[q]; if (!(v & ZB_LIT)) words[q] = words[v]; }
+    }
+}
+
+// words -> bytes; a word that is still a position after the last round means a corrupt chain: the chunk goes back to the fallback
+__global__ __launch_bounds__(256) void zb_emit_kernel(const tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base, uint8_t* __restrict__ hdrs,
+                                                      uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
+    const uint32_t chunk = blockIdx.y;
+    ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
+    if (C->mode != 1) return;
+    const uint32_t n = C->contentSize, p = (blockIdx.x * 256 + threadIdx.x) * 16;
+    if (p >= n) return;
+    const uint32_t* const words = (const uint32_t*)(arenas + (size_t)chunk * astride + lit_cap + 12u * (size_t)seq_cap);
+    uint8_t* const out = dst_base + descs[chunk].dst_off;                // slots are 16-byte aligned
+    uint32_t all = ZB_LIT;
+    if (p + 16 <= n) {
+        uint32_t w[4];
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(words + p + 4 * k);
+            all &= v.x & v.y & v.z & v.w;
+            w[k] = (v.x & 0xFF) | (v.y & 0xFF) << 8 | (v.z & 0xFF) << 16 | (v.w & 0xFF) << 24;
+        }
+        *reinterpret_cast<uint4*>(out + p) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (uint32_t q = p; q < n; q++) { const uint32_t v = words[q]; all &= v; out[q] = (uint8_t)v; }
+    }
+    if (!(all & ZB_LIT)) ZB_STORE_AGENT(&C->mode, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -724,27 +693,35 @@ __global__ __launch_bounds__(LANES) void zb_execute_kernel(const uint8_t* __rest
 // ---------------------------------------------------------------------------------------------------
 static inline uint32_t zb_lit_cap(uint32_t max_out) { return ((max_out + 80u * ZB_MAX_BLOCKS) + 255u) & ~255u; }
 static inline uint32_t zb_seq_cap(uint32_t max_out) { return ((max_out / 3u + 64u * ZB_MAX_BLOCKS + 64u) + 63u) & ~63u; }
-static inline size_t zb_arena_stride(uint32_t max_out) { return ((size_t)zb_lit_cap(max_out) + 12u * (size_t)zb_seq_cap(max_out) + 255u) & ~(size_t)255u; }
-// workspace of a batch: [256 bytes: ticket counter][n chunk headers][n arenas: literals | literal lengths | match lengths | offsets]
-size_t tsx_zstd_blockmode_bytes(uint32_t n, uint32_t max_out) { return 256 + (size_t)n * (ZB_CHUNK_HDR_BYTES + zb_arena_stride(max_out)); }
+static inline size_t zb_arena_stride(uint32_t max_out) {
+    return ((size_t)zb_lit_cap(max_out) + 12u * (size_t)zb_seq_cap(max_out) + 4u * ((size_t)max_out + 64u) + 255u) & ~(size_t)255u;
+}
+// workspace of a batch: [n chunk headers][n arenas: literals | literal lengths | match lengths | offsets | one word per output byte]
+size_t tsx_zstd_blockmode_bytes(uint32_t n, uint32_t max_out) { return (size_t)n * (ZB_CHUNK_HDR_BYTES + zb_arena_stride(max_out)); }
 bool tsx_zstd_blockmode_takes(uint32_t max_out) { return max_out <= ZB_MAX_CHUNK; }
 // the list zstd_decompress_kernel skips by: word i * stride == 1 <=> chunk i was decoded here
 const uint32_t* tsx_zstd_blockmode_skip(const void* bwork, uint32_t* stride_words) {
     *stride_words = (uint32_t)(ZB_CHUNK_HDR_BYTES / 4);
-    return (const uint32_t*)((const uint8_t*)bwork + 256 + offsetof(ZbChunk, mode));
+    return (const uint32_t*)((const uint8_t*)bwork + offsetof(ZbChunk, mode));
 }
 
-// Headers and the ticket are zeroed on the stream ahead of the launches (polled words are re-initialised every call).
+// The headers are zeroed on the stream ahead of the launches (every `mode` word starts at 0 = "not taken").
 uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames, int from_mid, uint64_t mid_stride, tsx_chunk_desc* d_descs, uint32_t n,
                                            uint32_t max_out, uint8_t* dst, int32_t* d_status, void* bwork) {
     if (!n) return 0;
-    uint8_t* const hdrs = (uint8_t*)bwork + 256;
+    uint8_t* const hdrs = (uint8_t*)bwork;
     uint8_t* const arenas = hdrs + (size_t)n * ZB_CHUNK_HDR_BYTES;
     const size_t astride = zb_arena_stride(max_out);
-    (void)hipMemsetAsync(bwork, 0, 256 + (size_t)n * ZB_CHUNK_HDR_BYTES, st);
+    (void)hipMemsetAsync(bwork, 0, (size_t)n * ZB_CHUNK_HDR_BYTES, st);
     const uint32_t lit_cap = zb_lit_cap(max_out), seq_cap = zb_seq_cap(max_out);
     hipLaunchKernelGGL(zb_index_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, (const int32_t*)d_status, hdrs, lit_cap, seq_cap);
     hipLaunchKernelGGL(zb_decode_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(2 * LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
-    hipLaunchKernelGGL(zb_execute_kernel, dim3(ZB_MAX_BLOCKS * n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap, n, (uint32_t*)bwork);
-    return 3;
+    hipLaunchKernelGGL(zb_scatter_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
+    // a copy chain is at most as long as the chunk: ceil(log2(max_out)) doublings resolve every word (a round over resolved words is a read)
+    uint32_t rounds = 1; while ((1ull << rounds) < (uint64_t)max_out + 1) rounds++;
+    const uint32_t tiles = (max_out + 1023) / 1024;                     // 256 threads x 4 words
+    for (uint32_t r = 0; r < rounds; r++)
+        hipLaunchKernelGGL(zb_jump_kernel, dim3(tiles, n), dim3(256), 0, st, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
+    hipLaunchKernelGGL(zb_emit_kernel, dim3((max_out + 4095) / 4096, n), dim3(256), 0, st, (const tsx_chunk_desc*)d_descs, dst, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
+    return 4 + rounds;
 }
