@@ -187,6 +187,8 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void* p);
 hipError_t hipHostRegister(void* p, size_t n, unsigned flags);
 hipError_t hipHostUnregister(void* p);
+struct hipPointerAttribute_t { int type; };
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);

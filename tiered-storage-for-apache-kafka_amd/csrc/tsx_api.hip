@@ -45,7 +45,7 @@ struct tsx_run;
 // the group that the next free lane launches as ONE kernel (zstd_compress_kernel's segment table: workgroup -> caller's buffers).
 // Group commit: the first waiting caller leads - it queues every member's descriptor upload, key schedule, the one compressor
 // launch, every member's status publication and descriptor download on the lane - the others wait for their own completion event.
-#define TSX_LANES_MAX 4
+#define TSX_LANES_MAX 8
 #define TSX_GROUP_MAX_SEGS 64
 #define TSX_GROUP_MAX_CHUNKS 8192
 struct tsx_zreq { tsx_ctx* c; tsx_run* r; hipEvent_t in_ready; int rc; bool done; };
@@ -689,7 +689,11 @@ static int combiner_get(tsx_device* dev, tsx_combiner** out) {
     if (!dev->comb) {
         std::unique_ptr<tsx_combiner> cb(new (std::nothrow) tsx_combiner);
         if (!cb) return TSX_E_NOMEM;
+        // lanes: 3 with the runtime's default of 4 hardware queues (lanes + the two copy streams must not pile up on them); a process that
+        // runs with GPU_MAX_HW_QUEUES = q >= 8 gets q / 2 lanes, at most 8 - a caller waits for a free lane 1 / lanes of a kernel's duration
+        // on average, and what waits is not in flight.  TSX_LANES overrides.
         uint32_t nl = 3;
+        if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { const long v = atol(q); if (v >= 8) nl = (uint32_t)(v / 2 > TSX_LANES_MAX ? TSX_LANES_MAX : v / 2); }
         if (const char* e = getenv("TSX_LANES")) { const long v = atol(e); if (v >= 1 && v <= TSX_LANES_MAX) nl = (uint32_t)v; }
         // the copy streams first: whatever the runtime's stream -> hardware-queue assignment, the short copies and their event markers
         // are not the ones that end up behind a second-long kernel of a lane created later
@@ -884,6 +888,14 @@ static int run_batch_inner(tsx_run& r) {
     uint32_t comp_pieces = 1;
     if (const char* e = getenv("TSX_COMP_PIECES")) { const long v = atol(e); if (v >= 1 && v <= TSX_COMP_PIECES) comp_pieces = (uint32_t)v; }
     else if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { if (atol(q) >= 8) comp_pieces = TSX_COMP_PIECES; }
+    if (comp_fwd && comp_pieces > 1 && r.host && !getenv("TSX_COMP_PIECES")) {
+        // ... and only from / to pinned memory: a pageable copy is staged by the runtime with a copy kernel, and a copy kernel queued while
+        // the chip is full of second-long compressor waves waits for them (measured: 2.4 s per 2048-chunk batch instead of 0.95)
+        hipPointerAttribute_t a;
+        const bool src_pinned = hipPointerGetAttributes(&a, r.src) == hipSuccess, dst_pinned = hipPointerGetAttributes(&a, r.dst) == hipSuccess;
+        (void)hipGetLastError();
+        if (!src_pinned || !dst_pinned) comp_pieces = 1;
+    }
     const bool pipelined = r.host && monotonic && !(comp_fwd && (!r.fuse_stages || comp_pieces < 2)) && !getenv("TSX_NO_PIPELINE");
     if (pipelined) {
         size_t budget = TSX_SUB_BYTES;

@@ -7,6 +7,7 @@
 #   broker         tools/broker_probe.py (10/20/24 callers x 256-chunk batches), device + host memory, GPU_MAX_HW_QUEUES variants
 #   pmc            PMC passes over the compressor + decoder (tools/pmc_zstd.sh, tools/pmc_dec.sh)
 #   trace          rocprofv3 --kernel-trace --stats of the bench's timed region
+#   prio           per-block wave priority modes in the sustained regime (tools/steady_state_probe.py)
 #   dec[:nmax]     fetch-side latency of 1 .. nmax chunks, block-parallel vs chunk-serial decoder form (tools/dec_latency.py)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
@@ -51,6 +52,11 @@ PY
       find $O/trace -name "*kernel_trace.csv" -delete ;;
     dec)
       timeout 600 python tools/dec_latency.py ${arg:-256} > $O/dec_latency.jsonl 2> $O/dec_latency.err; cat $O/dec_latency.jsonl; tail -3 $O/dec_latency.err ;;
+    prio)
+      # per-block wave priorities (zs_block_priority) in the continuously fed regime, alternating processes
+      for m in "4,32,0" "4,32,2" "4,32,3" "4,32,0" "4,32,2"; do
+        echo -n "TSX_ZSTD_SCHED=$m: "; TSX_ZSTD_SCHED=$m timeout 150 python tools/steady_state_probe.py 5 10 250 2>&1 | tail -1
+      done | tee $O/prio_sustained.txt ;;
     *) echo "unknown section $name" ;;
   esac
 done
