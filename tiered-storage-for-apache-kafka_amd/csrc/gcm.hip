@@ -22,6 +22,7 @@
 // H^(distance to the end) to every sub-block, adds the AAD and length blocks, encrypts J0 and writes /
 // verifies the tag.  GF(2^128) has no carry-less multiply on CDNA4: everything is shifts, XORs and
 // table lookups.  Algorithmic traffic: n bytes read + n + 28 bytes written per chunk.
+#include <string.h>
 #include "tsx_internal.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -44,6 +45,97 @@ void tsx_aes_build_tables(tsx_aes_tables* t) {
         uint8_t s2 = (uint8_t)((s << 1) ^ ((s & 0x80) ? 0x1B : 0));
         uint8_t s3 = (uint8_t)(s2 ^ s);
         t->te0[x] = (uint32_t)s2 | ((uint32_t)s << 8) | ((uint32_t)s << 16) | ((uint32_t)s3 << 24);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-key setup on the HOST: the arithmetic of gcm_setup_kernel below, word for word, in plain C++ (round keys, H = E_K(0),
+// powers of H, the 4-bit tables of H^256 and the 2-bit tables of H^64).  ~0.1 ms of one core per batch key.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct HostAes { uint32_t te0[256]; bool ready = false; };
+HostAes g_host_aes;
+inline uint32_t h_rotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
+inline uint32_t h_sbx(uint32_t x) { return (g_host_aes.te0[x & 0xFF] >> 8) & 0xFFu; }
+inline uint32_t h_bswap(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
+inline void h_mulx(tsx_gf128& v) {                                   // v * x in GF(2^128), bit 63 of hi = x^0
+    const uint64_t carry = v.lo & 1;
+    v.lo = (v.lo >> 1) | (v.hi << 63);
+    v.hi >>= 1;
+    if (carry) v.hi ^= 0xE100000000000000ull;
+}
+inline tsx_gf128 h_mul(const tsx_gf128& x, tsx_gf128 v) {
+    tsx_gf128 z; z.hi = 0; z.lo = 0;
+    for (int i = 0; i < 64; i++) { if ((x.hi >> (63 - i)) & 1) { z.hi ^= v.hi; z.lo ^= v.lo; } h_mulx(v); }
+    for (int i = 0; i < 64; i++) { if ((x.lo >> (63 - i)) & 1) { z.hi ^= v.hi; z.lo ^= v.lo; } h_mulx(v); }
+    return z;
+}
+// one AES-256 block through the Te0 table (little-endian state words, as aes256_encrypt in gcm_dev.h)
+inline void h_aes256(const uint32_t* rk, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+    const uint32_t* T = g_host_aes.te0;
+    uint32_t s0 = w0 ^ rk[0], s1 = w1 ^ rk[1], s2 = w2 ^ rk[2], s3 = w3 ^ rk[3];
+    auto col = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        return T[a & 0xFF] ^ h_rotl(T[(b >> 8) & 0xFF], 8) ^ h_rotl(T[(c >> 16) & 0xFF], 16) ^ h_rotl(T[(d >> 24) & 0xFF], 24);
+    };
+    for (int r = 1; r < 14; r++) {
+        const uint32_t t0 = col(s0, s1, s2, s3) ^ rk[4 * r], t1 = col(s1, s2, s3, s0) ^ rk[4 * r + 1], t2 = col(s2, s3, s0, s1) ^ rk[4 * r + 2],
+                       t3 = col(s3, s0, s1, s2) ^ rk[4 * r + 3];
+        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+    }
+    auto last = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        return h_sbx(a) | (h_sbx(b >> 8) << 8) | (h_sbx(c >> 16) << 16) | (h_sbx(d >> 24) << 24);
+    };
+    w0 = last(s0, s1, s2, s3) ^ rk[56]; w1 = last(s1, s2, s3, s0) ^ rk[57]; w2 = last(s2, s3, s0, s1) ^ rk[58]; w3 = last(s3, s0, s1, s2) ^ rk[59];
+}
+}  // namespace
+
+void tsx_gcm_key_build_host(const uint8_t key32[32], const uint8_t* aad, uint32_t aad_len, tsx_gcm_key* out) {
+    if (!g_host_aes.ready) { tsx_aes_tables t; tsx_aes_build_tables(&t); memcpy(g_host_aes.te0, t.te0, sizeof g_host_aes.te0); g_host_aes.ready = true; }
+    memset(out, 0, sizeof *out);
+    uint32_t* rk = out->rk;
+    for (int i = 0; i < 8; i++) rk[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);
+    uint32_t rcon = 1;
+    for (int i = 8; i < 60; i++) {
+        uint32_t tmp = rk[i - 1];
+        if ((i & 7) == 0) {
+            tmp = (tmp >> 8) | (tmp << 24);
+            tmp = h_sbx(tmp) | (h_sbx(tmp >> 8) << 8) | (h_sbx(tmp >> 16) << 16) | (h_sbx(tmp >> 24) << 24);
+            tmp ^= rcon;
+            rcon = ((rcon << 1) ^ ((rcon & 0x80) ? 0x1B : 0)) & 0xFF;
+        } else if ((i & 7) == 4) {
+            tmp = h_sbx(tmp) | (h_sbx(tmp >> 8) << 8) | (h_sbx(tmp >> 16) << 16) | (h_sbx(tmp >> 24) << 24);
+        }
+        rk[i] = rk[i - 8] ^ tmp;
+    }
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    h_aes256(rk, w0, w1, w2, w3);
+    tsx_gf128 h; h.hi = ((uint64_t)h_bswap(w0) << 32) | h_bswap(w1); h.lo = ((uint64_t)h_bswap(w2) << 32) | h_bswap(w3);
+    out->h = h; out->aad_len = aad_len;
+    for (uint32_t t = 0; t < 64; t++) out->aad[t] = t < aad_len ? aad[t] : 0;
+    out->hpow2[0] = h;
+    for (int k = 1; k < 32; k++) out->hpow2[k] = h_mul(out->hpow2[k - 1], out->hpow2[k - 1]);
+    tsx_gf128 one; one.hi = 0x8000000000000000ull; one.lo = 0;
+    out->hpow[0] = one; out->hpow[1] = h;
+    for (int k = 1; k < 9; k++) { const uint32_t half = 1u << k; for (uint32_t d = 0; d < half; d++) out->hpow[half + d] = h_mul(out->hpow[d], out->hpow2[k]); }
+    tsx_gf128 sv[128];
+    { tsx_gf128 v = out->hpow2[8]; for (int i = 0; i < 128; i++) { sv[i] = v; h_mulx(v); } }
+    for (uint32_t e = 0; e < 512; e++) {                               // 4-bit (Shoup) tables of H^256
+        const uint32_t p = e >> 4, val = e & 15;
+        tsx_gf128 r; r.hi = 0; r.lo = 0;
+        for (int b = 0; b < 4; b++) if ((val >> (3 - b)) & 1u) { r.hi ^= sv[4 * p + b].hi; r.lo ^= sv[4 * p + b].lo; }
+        out->hstride_tab[p][val] = r;
+    }
+    {   // 2-bit tables of H^64: entry (p, val) = val.bit1 * H^64 x^(2p)  xor  val.bit0 * H^64 x^(2p+1)
+        tsx_gf128 v = out->hpow[64];
+        for (uint32_t p = 0; p < 64; p++) {
+            tsx_gf128 a = v; h_mulx(v); tsx_gf128 b = v; h_mulx(v);
+            for (uint32_t val = 0; val < 4; val++) {
+                tsx_gf128 r; r.hi = 0; r.lo = 0;
+                if (val & 2u) { r.hi ^= a.hi; r.lo ^= a.lo; }
+                if (val & 1u) { r.hi ^= b.hi; r.lo ^= b.lo; }
+                out->h64_tab[p][val] = r;
+            }
+        }
     }
 }
 

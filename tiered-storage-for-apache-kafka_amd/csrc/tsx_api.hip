@@ -90,6 +90,7 @@ struct tsx_ctx {
     tsx_chunk_desc* d_descs = nullptr; size_t descs_cap = 0;
     tsx_chunk_desc* h_descs = nullptr;             // pinned mirror of the descriptors: no pageable copy ever sits in a stream
     uint8_t* h_keyraw = nullptr;                   // pinned 128 bytes: key + aad on their way in (wiped after the batch)
+    tsx_gcm_key* h_key = nullptr;                  // pinned: the key schedule built on the host (compressing batches; wiped after the batch)
     tsx_gcm_chunk* d_gchunks = nullptr;
     int32_t* d_status = nullptr;
     uint32_t* d_zlen = nullptr;
@@ -234,6 +235,7 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->h_descs) hipHostFree(c->h_descs);
     if (c->h_keyraw) { memset(c->h_keyraw, 0, 128); hipHostFree(c->h_keyraw); }
+    if (c->h_key) { memset(c->h_key, 0, sizeof(tsx_gcm_key)); hipHostFree(c->h_key); }
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     for (auto& row : c->sub_ev) for (auto& e : row) if (e) hipEventDestroy(e);
     if (c->st) hipStreamDestroy(c->st);
@@ -334,6 +336,7 @@ static int ctx_init_device_objects(tsx_ctx* c) {
     HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
     HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
     HIPCHK(hipHostMalloc((void**)&c->h_keyraw, 128, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_key, sizeof(tsx_gcm_key), hipHostMallocDefault));
     return TSX_OK;
 }
 
@@ -572,7 +575,8 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     tsx_timing& t = c->timing;
     memcpy(c->h_descs + lo, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc));
     HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
+    const bool lean = r.mode == 0 && r.comp && r.enc && r.fuse_stages;   // the compressor waves own and publish their chunks' statuses
+    if (!lean) hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
     HIPCHK(hipEventRecord(e[0], st));
     if (r.mode == 2) {
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, c->d_partials, 0);
@@ -589,9 +593,9 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         bool fused = false;
         if (r.comp) {
             fused = r.enc && r.fuse_stages;
-            tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr};
+            tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
             if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
-            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = r.d_dst; }
+            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = r.d_dst; fuse.self_status = 1; }
             const uint32_t sched = zstd_sched_from_env();
             t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
                                                        r.params->zstd_profile, sched, fuse);
@@ -609,7 +613,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
             hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz,
                                (uint64_t)c->mid_stride, r.comp ? 1 : 0, r.comp ? (const uint8_t*)dmid : r.d_src, r.d_dst, ds, bpc);
         }
-        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
+        if (!lean) hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
     } else {
         HIPCHK(hipEventRecord(e[1], st));
         const uint8_t* zsrc = r.d_src;    // where the Zstd frames live when there is no encryption
@@ -675,11 +679,9 @@ static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, boo
 
 static uint32_t zstd_sched_from_env() {
     uint32_t sched = 0;                                              // the kernel's default speculation schedule
-    if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1[,p]": explicit schedule (measurements; same bytes)
-        unsigned a = 0, b = 0, pm = 0;                               // optional third field: block priority mode (zs_block_priority)
-        const int got = sscanf(e, "%u,%u,%u", &a, &b, &pm);
-        // third field as the user writes it: absent = the kernel's default, 0 = no priorities, 1..4 = that mode
-        if (got >= 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59 && pm <= 4) sched = a | b << 8 | (got == 3 ? (pm ? pm : 5u) : 0u) << 16;
+    if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1": explicit schedule (measurements; same bytes)
+        unsigned a = 0, b = 0;
+        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) sched = a | b << 8;
     }
     return sched;
 }
@@ -726,11 +728,11 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
         HIPCHK(hipEventRecord(c->ev[0], ls));
         memcpy(c->h_descs, r.descs, (size_t)n * sizeof(tsx_chunk_desc));
         HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, ls));
-        hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_status, n);
+        // with encryption the launch is the group's ONLY kernel: key schedules built here on the host, statuses owned by the waves
+        if (!r.enc) hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_status, n);
         if (r.enc) {
-            memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
-            HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, ls));
-            tsx_launch_gcm_setup(ls, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
+            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
+            HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, ls));
         }
         tsx_zseg& sg = l.h_segs[k];
         memset(&sg, 0, sizeof sg);
@@ -738,7 +740,7 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
         sg.src_base = r.d_src; sg.descs = c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
         sg.work = (uint8_t*)c->d_zwork;
         sg.fuse.crc = (r.flags & TSX_CRC) ? c->dev->d_crc : nullptr;
-        if (r.enc) { sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->d_key; sg.fuse.out = r.d_dst; }
+        if (r.enc) { sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->d_key; sg.fuse.out = r.d_dst; sg.fuse.self_status = 1; }
         first += n;
     }
     HIPCHK(hipMemcpyAsync(l.d_segs, l.h_segs, grp.size() * sizeof(tsx_zseg), hipMemcpyHostToDevice, ls));
@@ -750,10 +752,10 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
             const uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
             hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, ls, c->d_descs, (const uint32_t*)c->d_zlen, (uint64_t)c->mid_stride, 1,
                                (const uint8_t*)c->d_mid, r.d_dst, c->d_status, bpc);
+            hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_descs, (const int32_t*)c->d_status, n);
         }
-        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_descs, (const int32_t*)c->d_status, n);
         HIPCHK(hipMemcpyAsync(c->h_descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, ls));
-        if (r.enc) { (void)hipMemsetAsync(c->d_keyraw, 0, 128, ls); (void)hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), ls); }
+        if (r.enc) (void)hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), ls);
         HIPCHK(hipEventRecord(c->ev[1], ls));
     }
     HIPCHK(hipEventRecord(l.end, ls));
@@ -919,10 +921,19 @@ static int run_batch_inner(tsx_run& r) {
     if (multi) for (size_t k = 1; k < ns; k++) if (!c->st_pc[k - 1]) HIPCHK(hipStreamCreateWithFlags(&c->st_pc[k - 1], hipStreamNonBlocking));
     auto stream_of = [&](size_t k) { return (multi && k > 0) ? c->st_pc[k - 1] : st; };
     HIPCHK(hipEventRecord(c->ev[0], st));
+    // A compressing batch whose waves run the whole chain needs no kernel besides the compressor's: the key schedule is built on the
+    // host, every wave owns its chunk's status.  (Small kernels around a launch wait for a slot on a chip that is full of second-long
+    // compressor waves: gcm_setup's workgroup wants 11 KiB of LDS where 3 KiB per CU are free.)
+    const bool lean = comp_fwd && r.enc && r.fuse_stages;
     if (r.enc) {
-        memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
-        HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, st));
-        tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
+        if (lean) {
+            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
+            HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, st));
+        } else {
+            memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
+            HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, st));
+            tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
+        }
         if (multi) HIPCHK(hipEventRecord(c->ev_key, st));
     }
     if (r.host) HIPCHK(hipEventRecord(c->ev[2], c->st_in));
@@ -1012,7 +1023,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     if (r.combined) {
         // the key material on the device was wiped on the lane behind this batch's work; what is left is the pinned mirror - and, when
         // the call failed half way, whatever of it is still queued on the shared streams
-        if (r.enc) memset(c->h_keyraw, 0, 128);
+        if (r.enc) { memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key)); }
         if (rc != TSX_OK) {
             (void)hipGetLastError();
             if (c->dev->comb) { (void)hipStreamSynchronize(c->dev->comb->copy_in); (void)hipStreamSynchronize(c->dev->comb->copy_out);
@@ -1025,7 +1036,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     // the data key does not stay behind in a context that may serve another segment next (the native side zeroises its
     // copy; the round keys and H powers are as good as the key).
     if (r.enc) {
-        memset(c->h_keyraw, 0, 128);
+        memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key));
         hipMemsetAsync(c->d_keyraw, 0, 128, c->st);
         hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st);
     }

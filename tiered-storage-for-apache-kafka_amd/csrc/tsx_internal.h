@@ -63,6 +63,8 @@ struct tsx_chain_fuse {          // stages the compressor wave of chunk i runs i
     const tsx_aes_tables* aes;
     const tsx_gcm_key* key;      // != nullptr: GCM over the finished frame: IV||C||TAG -> out + descs[i].dst_off,
     uint8_t* out;                //             descs[i].dst_len = frame + 28
+    uint32_t self_status;        // != 0: the wave owns its chunk's status - it starts from TSX_OK without reading status[] and publishes it in
+    uint32_t pad_;               //       descs[i].status itself, so that the batch needs no init / publish kernels around the launch
 };
 
 struct tsx_zseg {                // one caller's batch inside a combined compressor launch (zstd_compress_kernel, tsx_api.hip's combiner)
@@ -80,6 +82,9 @@ struct tsx_gcm_chunk {           // per-chunk work item (device)
     uint8_t  iv[12];
 };
 
+// The same key material computed on the host (no kernel: a 256-thread workgroup that wants 11 KiB of LDS can wait hundreds of
+// milliseconds for a slot on a chip full of compressor waves); the caller uploads *out with a plain copy and wipes it afterwards.
+void tsx_gcm_key_build_host(const uint8_t key32[32], const uint8_t* aad, uint32_t aad_len, tsx_gcm_key* out);
 void tsx_launch_gcm_setup(hipStream_t st, const tsx_aes_tables* d_aes, const uint8_t* d_key32, const uint8_t* d_aad, uint32_t aad_len, tsx_gcm_key* d_key);
 // encrypt: writes IV||C||TAG.  decrypt: verifies TAG (status[i] = TSX_E_TAG_MISMATCH on failure) and
 // writes the plaintext.  d_partials: n * max_sub * 4 u32.

@@ -1491,42 +1491,13 @@ __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ des
     __syncthreads();
     const uint64_t dstOff = descs[chunk].dst_off;
     if ((uint64_t)flen + 28 > descs[chunk].dst_cap) {
-        if (lane == 0) { status[chunk] = TSX_E_DST_TOO_SMALL; descs[chunk].dst_len = 0; }
+        if (lane == 0) { status[chunk] = TSX_E_DST_TOO_SMALL; descs[chunk].dst_len = 0; if (fuse.self_status) descs[chunk].status = TSX_E_DST_TOO_SMALL; }
         return;
     }
     gcm_encrypt_wave(fuse.aes, fuse.key, descs[chunk].iv, frame, flen, fuse.out + dstOff, L.g.t0, L.g.tab, lane);
-    if (lane == 0) descs[chunk].dst_len = flen + 28;
+    if (lane == 0) { descs[chunk].dst_len = flen + 28; if (fuse.self_status) descs[chunk].status = TSX_OK; }
 }
 
-// Issue priority of this chunk's wave for the coming block (sched bits 16-19; scheduling only, never the output).  Measured
-// (tools/chunk_time_spread.py, profiles/r02_chunk_time_spread.txt): the workgroups of the later half of a grid - the younger wave
-// on every SIMD - run 5-8 % slower than the first half, because the SIMD's arbiter serves its oldest wave first; a batch is over
-// when its slowest chunk is, so with three batches in flight 11-17 % of the slot-time goes to chunks that have already finished.
-//   1 later half of the grid above the first (over-compensates: the order flips)   2 the halves alternate block by block
-//   (quarters of the grid within 2 %, slowest chunk 12 % earlier, a lone batch 3 % faster)   3 pseudo-random per (chunk, block)
-//   4 graded by position in the grid (worse)   5 none   0 = the default.
-// The default stays NONE: with priorities the three-batches-in-flight rate came out at 17.2-17.7 GiB/s in five processes out of five,
-// without them 17.4-17.5 in two and 19.3 in one (same boxes, same hour) - the callers never fell in step - and in flight is the headline.
-#define ZS_PRIO_DEFAULT 5u
-__device__ static __forceinline__ void zs_block_priority(uint32_t mode, uint32_t chunk, uint32_t nChunks, uint32_t blk) {
-#ifndef HIPEMU
-    uint32_t p = 0;
-    const uint32_t later = (2 * chunk >= nChunks) ? 1u : 0u;
-    if (mode == 0) mode = ZS_PRIO_DEFAULT;
-    if (mode == 1) p = later;
-    else if (mode == 2) p = later ^ (blk & 1);
-    else if (mode == 3) p = ((chunk * 0x9E3779B1u + blk * 0x85EBCA77u) >> 30);
-    else if (mode == 4) p = (uint32_t)(((uint64_t)chunk * 4) / (nChunks ? nChunks : 1));
-    else return;
-    p = UNI(p);
-    if (p == 0) __builtin_amdgcn_s_setprio(0);
-    else if (p == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
-#else
-    (void)mode; (void)chunk; (void)nChunks; (void)blk;
-#endif
-}
 static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
 // SEG = false: one batch, the kernel arguments themselves (the body is exactly the single-batch kernel: the segment lookup folds away
 // and the arguments stay reloadable kernel arguments instead of live registers).  SEG = true: one launch carries the batches of
@@ -1543,7 +1514,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
                                                               ) {
     __shared__ EncLds L;
     const uint32_t lane = threadIdx.x;
-    uint32_t chunk = blockIdx.x, nChunks = gridDim.x;
+    uint32_t chunk = blockIdx.x;
     const uint8_t* __restrict__ src_base = src_base_; tsx_chunk_desc* __restrict__ descs = descs_; uint8_t* __restrict__ mid = mid_;
     uint64_t mid_stride = mid_stride_; uint32_t* __restrict__ zlen = zlen_; int32_t* __restrict__ status = status_; uint8_t* __restrict__ work = work_;
     uint32_t profile = profile_; tsx_chain_fuse fuse = fuse_;
@@ -1551,7 +1522,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
         uint32_t k = 0;
         while (k + 1 < nsegs && segs[k + 1].first <= blockIdx.x) k++;
         const tsx_zseg sg = segs[k];
-        chunk = blockIdx.x - sg.first; nChunks = sg.n;
+        chunk = blockIdx.x - sg.first;
         src_base = sg.src_base; descs = sg.descs; mid = sg.mid; mid_stride = sg.mid_stride; zlen = sg.zlen; status = sg.status; work = sg.work;
         profile = sg.profile; fuse = sg.fuse;
     }
@@ -1574,7 +1545,8 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
         const uint32_t crc = crc32c_wave(fuse.crc, src, srcSize, L.crcTab, lane);
         if (lane == 0) descs[chunk].crc32c = crc;
     }
-    if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } return; }
+    if (fuse.self_status) { if (lane == 0) status[chunk] = TSX_OK; }    // (only with fuse.key: finish_frame publishes)
+    else if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } return; }
 
     const zs_cparams cp = zs_level3_cparams(srcSize);
     {   // fresh tables (ZSTD_reset_matchState): zero hashLong[1 << hashLog] and hashSmall[1 << chainLog]
@@ -1618,10 +1590,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
     int64_t savings = 0;
     int cur = 0;                 // index of the confirmed Huffman table (L.huf[cur]); a candidate is built in L.huf[cur ^ 1]
     bool first = true;
-    const uint32_t prioMode = (UNI(sched) >> 16) & 0xF;
-    uint32_t blk = 0;
     while (remaining) {
-        zs_block_priority(prioMode, chunk, nChunks, blk++);
         // ---- block size (ZSTD_optimalBlockSize) ----
         uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
         if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
@@ -1708,7 +1677,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
     zstd_compress_body<false>(src_base, descs, mid, mid_stride, zlen, status, work, profile, sched, fuse, nullptr, 0u ZS_PROF_ARG);
 }
 __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segments_kernel(const tsx_zseg* __restrict__ segs, uint32_t nsegs, uint32_t sched ZS_PROF_PARAM) {
-    const tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr};
+    const tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr, 0, 0};
     zstd_compress_body<true>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0u, sched, none, segs, nsegs ZS_PROF_ARG);
 }
 
