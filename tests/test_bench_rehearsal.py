@@ -99,7 +99,7 @@ def test_single_rank_line_has_every_leg(emu, oracle):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["config"]["batches_in_flight"] == 3 and j["config"]["verified_chunks_vs_oracle"] == 6
+    assert j["n_gpus"] == 1 and j["steps"] == 4 and j["config"]["batches_in_flight"] == 4 and j["config"]["verified_chunks_vs_oracle"] == 6
     s = j["sustained"]
     assert s["callers"] == 5 and s["batches"] == 15 and s["value"] >= 0 and "slope" in s["method"]
     assert j["detransform"]["round_trip_exact"] is True and j["roofline"]["bound"] == "hbm"
