@@ -63,6 +63,9 @@ struct tsx_device {
     tsx_crc_tables* d_crc = nullptr;
     tsx_aes_tables* d_aes = nullptr;
     tsx_zstd_consts* d_zc = nullptr;
+    uint8_t* h_zeros = nullptr;                    // pinned sizeof(tsx_gcm_key) zero bytes: key material is wiped by COPYING zeros - a memset is a
+                                                   // kernel, and a kernel waits for a slot on a chip full of compressor waves (measured: 52 ms on
+                                                   // average, up to 489 ms, per wipe: profiles/r03_bench_rocprofv3_kernel_stats_before_zero_copy_wipes.csv)
     char name[256] = {0};
     char arch[256] = {0};
     // pooled contexts of the ctx-less calls: idle ones, how many are out, batches served (all under g_mu)
@@ -159,7 +162,8 @@ static void device_free_consts(tsx_device& d) {
     if (d.d_crc) hipFree(d.d_crc);
     if (d.d_aes) hipFree(d.d_aes);
     if (d.d_zc) hipFree(d.d_zc);
-    d.d_crc = nullptr; d.d_aes = nullptr; d.d_zc = nullptr;
+    if (d.h_zeros) hipHostFree(d.h_zeros);
+    d.d_crc = nullptr; d.d_aes = nullptr; d.d_zc = nullptr; d.h_zeros = nullptr;
 }
 
 static int init_devices(std::vector<tsx_device>& devs, int want, const int* device_ids, const tsx_crc_tables* hc, const tsx_aes_tables* ha,
@@ -180,6 +184,8 @@ static int init_devices(std::vector<tsx_device>& devs, int want, const int* devi
         HIPCHK(hipMalloc((void**)&d.d_crc, sizeof(tsx_crc_tables)));
         HIPCHK(hipMalloc((void**)&d.d_aes, sizeof(tsx_aes_tables)));
         HIPCHK(hipMalloc((void**)&d.d_zc, tsx_zstd_consts_bytes()));
+        HIPCHK(hipHostMalloc((void**)&d.h_zeros, sizeof(tsx_gcm_key), hipHostMallocDefault));
+        memset(d.h_zeros, 0, sizeof(tsx_gcm_key));
         HIPCHK(hipMemcpy(d.d_crc, hc, sizeof(tsx_crc_tables), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.d_aes, ha, sizeof(tsx_aes_tables), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.d_zc, hz, tsx_zstd_consts_bytes(), hipMemcpyHostToDevice));
@@ -270,10 +276,10 @@ static int grow(T** p, size_t* cap, size_t need) {
 
 // Small detransform batches (a fetch: one chunk, a prefetch window) decode one workgroup per BLOCK instead of per chunk: the
 // chunk-serial decoder needs 25-50 ms for a chunk however idle the chip is.  TSX_DEC_BLOCK_CHUNKS: largest batch that takes this
-// form (default 256, 0 = never).
+// form (default 192, 0 = never).
 static uint32_t dec_block_chunks() {
     if (const char* e = getenv("TSX_DEC_BLOCK_CHUNKS")) { const long v = atol(e); return v < 0 ? 0u : (uint32_t)v; }
-    return 256u;
+    return 192u;                                            // measured: the two forms meet at ~240 chunks (34 ms), profiles/r03_dec_latency_block_form.jsonl
 }
 static bool dec_use_blocks(uint32_t n, uint32_t max_out) { return n <= dec_block_chunks() && tsx_zstd_blockmode_takes(max_out); }
 
@@ -755,7 +761,7 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
             hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_descs, (const int32_t*)c->d_status, n);
         }
         HIPCHK(hipMemcpyAsync(c->h_descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, ls));
-        if (r.enc) (void)hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), ls);
+        if (r.enc) (void)hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, ls);     // wiped by a copy, not a kernel
         HIPCHK(hipEventRecord(c->ev[1], ls));
     }
     HIPCHK(hipEventRecord(l.end, ls));
@@ -1028,7 +1034,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
             (void)hipGetLastError();
             if (c->dev->comb) { (void)hipStreamSynchronize(c->dev->comb->copy_in); (void)hipStreamSynchronize(c->dev->comb->copy_out);
                                 for (uint32_t i = 0; i < c->dev->comb->nlanes; i++) (void)hipStreamSynchronize(c->dev->comb->lane[i].st); }
-            if (r.enc) { hipMemsetAsync(c->d_keyraw, 0, 128, c->st); hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st); hipStreamSynchronize(c->st); }
+            if (r.enc) { hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st); hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st); hipStreamSynchronize(c->st); }
         }
         return rc;
     }
@@ -1037,8 +1043,8 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     // copy; the round keys and H powers are as good as the key).
     if (r.enc) {
         memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key));
-        hipMemsetAsync(c->d_keyraw, 0, 128, c->st);
-        hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st);
+        hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);                 // wiped by copies, not kernels
+        hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st);
     }
     hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
     for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);

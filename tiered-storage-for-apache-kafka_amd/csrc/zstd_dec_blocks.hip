@@ -92,7 +92,9 @@ __global__ __launch_bounds__(LANES) void zb_index_kernel(const uint8_t* __restri
     __shared__ uint32_t sN, sBad;
     const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
     ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
-    if (status[chunk] != TSX_OK) return;                              // mode stays 0 (memset): nothing to decode, nothing to fall back to
+    if (lane == 0) C->mode = 0;                                       // "not taken" until the last line of this kernel says otherwise (no memset launch: nothing
+                                                                      // else of the header is read before this kernel has written it)
+    if (status[chunk] != TSX_OK) return;                              // nothing to decode, nothing to fall back to
     const tsx_chunk_desc d = descs[chunk];
     const uint8_t* __restrict__ src = from_mid ? frames + (uint64_t)chunk * mid_stride : frames + d.src_off;
     const uint32_t srcSize = from_mid ? (d.src_len >= 28 ? d.src_len - 28 : 0) : d.src_len;
@@ -705,14 +707,12 @@ const uint32_t* tsx_zstd_blockmode_skip(const void* bwork, uint32_t* stride_word
     return (const uint32_t*)((const uint8_t*)bwork + offsetof(ZbChunk, mode));
 }
 
-// The headers are zeroed on the stream ahead of the launches (every `mode` word starts at 0 = "not taken").
 uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames, int from_mid, uint64_t mid_stride, tsx_chunk_desc* d_descs, uint32_t n,
                                            uint32_t max_out, uint8_t* dst, int32_t* d_status, void* bwork) {
     if (!n) return 0;
     uint8_t* const hdrs = (uint8_t*)bwork;
     uint8_t* const arenas = hdrs + (size_t)n * ZB_CHUNK_HDR_BYTES;
     const size_t astride = zb_arena_stride(max_out);
-    (void)hipMemsetAsync(bwork, 0, (size_t)n * ZB_CHUNK_HDR_BYTES, st);
     const uint32_t lit_cap = zb_lit_cap(max_out), seq_cap = zb_seq_cap(max_out);
     hipLaunchKernelGGL(zb_index_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, (const int32_t*)d_status, hdrs, lit_cap, seq_cap);
     hipLaunchKernelGGL(zb_decode_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(2 * LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);

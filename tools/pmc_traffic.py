@@ -23,7 +23,7 @@ def source_sha(names):
 
 
 ENC_SOURCES = ["zstd_enc.hip", "zstd_common.h", "gcm_dev.h", "crc_dev.h"]
-DEC_SOURCES = ["zstd_dec.hip", "zstd_common.h"]
+DEC_SOURCES = ["zstd_dec.hip", "zstd_dec_dev.h", "zstd_common.h"]
 
 
 def counters(d):
