@@ -185,8 +185,11 @@ hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void* p);
+enum { hipHostMallocMapped = 2, hipHostMallocPortable = 1 };
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned flags);
 hipError_t hipHostRegister(void* p, size_t n, unsigned flags);
 hipError_t hipHostUnregister(void* p);
+enum { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1 };
 struct hipPointerAttribute_t { int type; };
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);

@@ -193,7 +193,8 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n);
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 hipError_t hipHostUnregister(void*) { return hipSuccess; }
-hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = 0; return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = hipMemoryTypeHost; return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }

@@ -49,7 +49,7 @@ struct tsx_run;
 #define TSX_GROUP_MAX_SEGS 64
 #define TSX_GROUP_MAX_CHUNKS 8192
 struct tsx_zreq { tsx_ctx* c; tsx_run* r; hipEvent_t in_ready; int rc; bool done; };
-struct tsx_lane { hipStream_t st = nullptr; hipEvent_t end = nullptr; bool busy = false; tsx_zseg* h_segs = nullptr; tsx_zseg* d_segs = nullptr; };
+struct tsx_lane { hipStream_t st = nullptr; hipEvent_t end = nullptr; bool busy = false; tsx_zseg* h_segs = nullptr; tsx_zseg* d_segs = nullptr; /* pinned segment table: host view, device alias */ };
 struct tsx_combiner {
     std::mutex mu; std::condition_variable cv;
     std::vector<tsx_zreq*> pending; bool leader = false;
@@ -92,8 +92,10 @@ struct tsx_ctx {
     // device workspace (grown on demand)
     tsx_chunk_desc* d_descs = nullptr; size_t descs_cap = 0;
     tsx_chunk_desc* h_descs = nullptr;             // pinned mirror of the descriptors: no pageable copy ever sits in a stream
+    tsx_chunk_desc* hd_descs = nullptr;            // ... as the device addresses it: lean compressing batches read and write it in place
     uint8_t* h_keyraw = nullptr;                   // pinned 128 bytes: key + aad on their way in (wiped after the batch)
     tsx_gcm_key* h_key = nullptr;                  // pinned: the key schedule built on the host (compressing batches; wiped after the batch)
+    tsx_gcm_key* hd_key = nullptr;                 // ... as the device addresses it (every compressor wave takes its own copy, tsx_chain_fuse.key_on_host)
     tsx_gcm_chunk* d_gchunks = nullptr;
     int32_t* d_status = nullptr;
     uint32_t* d_zlen = nullptr;
@@ -153,7 +155,6 @@ static void device_free_consts(tsx_device& d) {
             if (l.st) { hipStreamSynchronize(l.st); hipStreamDestroy(l.st); }
             if (l.end) hipEventDestroy(l.end);
             if (l.h_segs) hipHostFree(l.h_segs);
-            if (l.d_segs) hipFree(l.d_segs);
         }
         if (d.comb->copy_in) hipStreamDestroy(d.comb->copy_in);
         if (d.comb->copy_out) hipStreamDestroy(d.comb->copy_out);
@@ -290,11 +291,12 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
         void* olds[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen};
         for (void* p : olds) if (p) hipFree(p);
         if (c->h_descs) hipHostFree(c->h_descs);
-        c->d_descs = nullptr; c->d_gchunks = nullptr; c->d_status = nullptr; c->d_zlen = nullptr; c->h_descs = nullptr;
+        c->d_descs = nullptr; c->d_gchunks = nullptr; c->d_status = nullptr; c->d_zlen = nullptr; c->h_descs = nullptr; c->hd_descs = nullptr;
         c->descs_cap = 0;                                    // a failure below leaves a context that reallocates, not one with holes
         size_t cap = (size_t)n + n / 4 + 16;
         HIPCHK(hipMalloc((void**)&c->d_descs, cap * sizeof(tsx_chunk_desc)));
-        HIPCHK(hipHostMalloc((void**)&c->h_descs, cap * sizeof(tsx_chunk_desc), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&c->h_descs, cap * sizeof(tsx_chunk_desc), hipHostMallocMapped | hipHostMallocPortable));
+        HIPCHK(hipHostGetDevicePointer((void**)&c->hd_descs, c->h_descs, 0));
         HIPCHK(hipMalloc((void**)&c->d_gchunks, cap * sizeof(tsx_gcm_chunk)));
         HIPCHK(hipMalloc((void**)&c->d_status, cap * sizeof(int32_t)));
         HIPCHK(hipMalloc((void**)&c->d_zlen, cap * sizeof(uint32_t)));
@@ -342,7 +344,8 @@ static int ctx_init_device_objects(tsx_ctx* c) {
     HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
     HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
     HIPCHK(hipHostMalloc((void**)&c->h_keyraw, 128, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&c->h_key, sizeof(tsx_gcm_key), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_key, sizeof(tsx_gcm_key), hipHostMallocMapped | hipHostMallocPortable));
+    HIPCHK(hipHostGetDevicePointer((void**)&c->hd_key, c->h_key, 0));
     return TSX_OK;
 }
 
@@ -571,7 +574,7 @@ static uint32_t zstd_sched_from_env();
 static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st) {
     tsx_ctx* c = r.c;
     const uint32_t n = sb.n, lo = sb.lo, flags = r.flags;
-    tsx_chunk_desc* dd = c->d_descs + lo;
+    tsx_chunk_desc* dd = c->d_descs + lo;                              // (lean batches: the pinned host mirror instead, below)
     int32_t* ds = c->d_status + lo;
     uint32_t* dz = c->d_zlen + lo;
     tsx_gcm_chunk* dg = c->d_gchunks + lo;
@@ -580,9 +583,16 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     void* dzw = c->d_zwork ? (uint8_t*)c->d_zwork + (size_t)lo * tsx_zstd_workspace_bytes(1, 0) : nullptr;
     tsx_timing& t = c->timing;
     memcpy(c->h_descs + lo, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc));
-    HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
-    const bool lean = r.mode == 0 && r.comp && r.enc && r.fuse_stages;   // the compressor waves own and publish their chunks' statuses
-    if (!lean) hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
+    // lean: the compressor waves own and publish their chunks' statuses and work on the descriptors and the key schedule where they
+    // are - in the context's pinned host memory.  Nothing but the launch goes into the stream: a small copy queued while the copy
+    // engines move other callers' gigabytes waits for them (measured: +550 ms per 256-chunk call with 10 callers), a small kernel
+    // waits for a slot on a chip full of compressor waves.
+    const bool lean = r.mode == 0 && r.comp && r.enc && r.fuse_stages;
+    if (lean) dd = c->hd_descs + lo;
+    else {
+        HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
+    }
     HIPCHK(hipEventRecord(e[0], st));
     if (r.mode == 2) {
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, c->d_partials, 0);
@@ -601,7 +611,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
             fused = r.enc && r.fuse_stages;
             tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
             if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
-            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->d_key; fuse.out = r.d_dst; fuse.self_status = 1; }
+            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->hd_key; fuse.out = r.d_dst; fuse.self_status = 1; fuse.key_on_host = 1; }
             const uint32_t sched = zstd_sched_from_env();
             t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
                                                        r.params->zstd_profile, sched, fuse);
@@ -657,7 +667,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, c->d_partials, 1);
         t.crc_launches += 2;
     }
-    HIPCHK(hipMemcpyAsync(c->h_descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
+    if (!lean) HIPCHK(hipMemcpyAsync(c->h_descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(e[4], st));                                   // the caller's descriptors are filled in when this event has passed
     return TSX_OK;
 }
@@ -709,13 +719,13 @@ static int combiner_get(tsx_device* dev, tsx_combiner** out) {
         for (uint32_t i = 0; ok && i < nl; i++) {
             tsx_lane& l = cb->lane[i];
             ok = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&l.end, hipEventDisableTiming) == hipSuccess &&
-                 hipHostMalloc((void**)&l.h_segs, TSX_GROUP_MAX_SEGS * sizeof(tsx_zseg), hipHostMallocDefault) == hipSuccess &&
-                 hipMalloc((void**)&l.d_segs, TSX_GROUP_MAX_SEGS * sizeof(tsx_zseg)) == hipSuccess;
+                 hipHostMalloc((void**)&l.h_segs, TSX_GROUP_MAX_SEGS * sizeof(tsx_zseg), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
+                 hipHostGetDevicePointer((void**)&l.d_segs, l.h_segs, 0) == hipSuccess;
             cb->nlanes = i + 1;
         }
         dev->comb = std::move(cb);
         if (!ok) { (void)hipGetLastError(); tsx_device& d = *dev; std::unique_ptr<tsx_combiner> dead = std::move(d.comb);
-                   for (uint32_t i = 0; i < dead->nlanes; i++) { tsx_lane& l = dead->lane[i]; if (l.st) hipStreamDestroy(l.st); if (l.end) hipEventDestroy(l.end); if (l.h_segs) hipHostFree(l.h_segs); if (l.d_segs) hipFree(l.d_segs); }
+                   for (uint32_t i = 0; i < dead->nlanes; i++) { tsx_lane& l = dead->lane[i]; if (l.st) hipStreamDestroy(l.st); if (l.end) hipEventDestroy(l.end); if (l.h_segs) hipHostFree(l.h_segs); }
                    if (dead->copy_in) hipStreamDestroy(dead->copy_in); if (dead->copy_out) hipStreamDestroy(dead->copy_out);
                    return TSX_E_DEVICE; }
     }
@@ -733,24 +743,23 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
         if (q->in_ready) HIPCHK(hipStreamWaitEvent(ls, q->in_ready, 0));
         HIPCHK(hipEventRecord(c->ev[0], ls));
         memcpy(c->h_descs, r.descs, (size_t)n * sizeof(tsx_chunk_desc));
-        HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, ls));
-        // with encryption the launch is the group's ONLY kernel: key schedules built here on the host, statuses owned by the waves
-        if (!r.enc) hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_status, n);
-        if (r.enc) {
-            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
-            HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, ls));
+        // with encryption the launch is the group's ONLY operation on the lane: descriptors and key schedules stay in the members' pinned
+        // memory (the waves read and write them in place), statuses are owned by the waves
+        if (r.enc) tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
+        else {
+            HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, ls));
+            hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_status, n);
         }
         tsx_zseg& sg = l.h_segs[k];
         memset(&sg, 0, sizeof sg);
         sg.first = first; sg.n = n; sg.profile = r.params->zstd_profile;
-        sg.src_base = r.d_src; sg.descs = c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
+        sg.src_base = r.d_src; sg.descs = r.enc ? c->hd_descs : c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
         sg.work = (uint8_t*)c->d_zwork;
         sg.fuse.crc = (r.flags & TSX_CRC) ? c->dev->d_crc : nullptr;
-        if (r.enc) { sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->d_key; sg.fuse.out = r.d_dst; sg.fuse.self_status = 1; }
+        if (r.enc) { sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->hd_key; sg.fuse.out = r.d_dst; sg.fuse.self_status = 1; sg.fuse.key_on_host = 1; }
         first += n;
     }
-    HIPCHK(hipMemcpyAsync(l.d_segs, l.h_segs, grp.size() * sizeof(tsx_zseg), hipMemcpyHostToDevice, ls));
-    tsx_launch_zstd_compress_segments(ls, l.d_segs, (uint32_t)grp.size(), first, zstd_sched_from_env());
+    tsx_launch_zstd_compress_segments(ls, l.d_segs, l.h_segs, (uint32_t)grp.size(), first, zstd_sched_from_env());
     for (tsx_zreq* q : grp) {
         tsx_ctx* c = q->c; const tsx_run& r = *q->r;
         const uint32_t n = r.n;
@@ -759,9 +768,8 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
             hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, ls, c->d_descs, (const uint32_t*)c->d_zlen, (uint64_t)c->mid_stride, 1,
                                (const uint8_t*)c->d_mid, r.d_dst, c->d_status, bpc);
             hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_descs, (const int32_t*)c->d_status, n);
+            HIPCHK(hipMemcpyAsync(c->h_descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, ls));
         }
-        HIPCHK(hipMemcpyAsync(c->h_descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, ls));
-        if (r.enc) (void)hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, ls);     // wiped by a copy, not a kernel
         HIPCHK(hipEventRecord(c->ev[1], ls));
     }
     HIPCHK(hipEventRecord(l.end, ls));
@@ -900,7 +908,9 @@ static int run_batch_inner(tsx_run& r) {
         // ... and only from / to pinned memory: a pageable copy is staged by the runtime with a copy kernel, and a copy kernel queued while
         // the chip is full of second-long compressor waves waits for them (measured: 2.4 s per 2048-chunk batch instead of 0.95)
         hipPointerAttribute_t a;
-        const bool src_pinned = hipPointerGetAttributes(&a, r.src) == hipSuccess, dst_pinned = hipPointerGetAttributes(&a, r.dst) == hipSuccess;
+        // (the runtime answers for pageable memory too - hipMemoryTypeUnregistered - instead of failing)
+        const bool src_pinned = hipPointerGetAttributes(&a, r.src) == hipSuccess && a.type == hipMemoryTypeHost;
+        const bool dst_pinned = hipPointerGetAttributes(&a, r.dst) == hipSuccess && a.type == hipMemoryTypeHost;
         (void)hipGetLastError();
         if (!src_pinned || !dst_pinned) comp_pieces = 1;
     }
@@ -932,10 +942,8 @@ static int run_batch_inner(tsx_run& r) {
     // compressor waves: gcm_setup's workgroup wants 11 KiB of LDS where 3 KiB per CU are free.)
     const bool lean = comp_fwd && r.enc && r.fuse_stages;
     if (r.enc) {
-        if (lean) {
-            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
-            HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, st));
-        } else {
+        if (lean) tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);      // stays in pinned memory: the waves fetch it
+        else {
             memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
             HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, st));
             tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
@@ -1027,24 +1035,27 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     r.combined = combined && mode == 0 && r.comp && r.fuse_stages && !getenv("TSX_NO_COMBINE");
     const int rc = r.combined ? run_combined(r) : run_batch_inner(r);
     if (r.combined) {
-        // the key material on the device was wiped on the lane behind this batch's work; what is left is the pinned mirror - and, when
-        // the call failed half way, whatever of it is still queued on the shared streams
-        if (r.enc) { memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key)); }
+        // nothing of the key was uploaded (every wave took and wiped its own copy of the schedule); what is left is the pinned original -
+        // wiped once nothing of this call can still be running
         if (rc != TSX_OK) {
             (void)hipGetLastError();
             if (c->dev->comb) { (void)hipStreamSynchronize(c->dev->comb->copy_in); (void)hipStreamSynchronize(c->dev->comb->copy_out);
                                 for (uint32_t i = 0; i < c->dev->comb->nlanes; i++) (void)hipStreamSynchronize(c->dev->comb->lane[i].st); }
-            if (r.enc) { hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st); hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st); hipStreamSynchronize(c->st); }
         }
+        if (r.enc) { memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key)); }
         return rc;
     }
     // Whatever happened: nothing of this call is still in flight when it returns (the copies reference the caller's buffers), and
     // the data key does not stay behind in a context that may serve another segment next (the native side zeroises its
     // copy; the round keys and H powers are as good as the key).
     if (r.enc) {
+        hipStreamSynchronize(c->st);                                      // (a wave may still be reading the pinned key schedule on an error path)
+        for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
         memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key));
-        hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);                 // wiped by copies, not kernels
-        hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st);
+        if (!(mode == 0 && r.comp && r.fuse_stages)) {                    // lean batches uploaded nothing: every wave wiped its own copy of the schedule
+            hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);             // wiped by copies, not kernels
+            hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st);
+        }
     }
     hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
     for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);

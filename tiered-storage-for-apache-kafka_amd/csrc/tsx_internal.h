@@ -64,7 +64,9 @@ struct tsx_chain_fuse {          // stages the compressor wave of chunk i runs i
     const tsx_gcm_key* key;      // != nullptr: GCM over the finished frame: IV||C||TAG -> out + descs[i].dst_off,
     uint8_t* out;                //             descs[i].dst_len = frame + 28
     uint32_t self_status;        // != 0: the wave owns its chunk's status - it starts from TSX_OK without reading status[] and publishes it in
-    uint32_t pad_;               //       descs[i].status itself, so that the batch needs no init / publish kernels around the launch
+    uint32_t key_on_host;        //       descs[i].status itself, so that the batch needs no init / publish kernels around the launch
+                                 // key_on_host != 0: `key` points into pinned HOST memory - the wave copies it into its chunk's workspace
+                                 // before the GCM tail and wipes that copy afterwards (no upload, no device-side wipe: nothing but the launch)
 };
 
 struct tsx_zseg {                // one caller's batch inside a combined compressor launch (zstd_compress_kernel, tsx_api.hip's combiner)
@@ -73,6 +75,7 @@ struct tsx_zseg {                // one caller's batch inside a combined compres
     const uint8_t* src_base; tsx_chunk_desc* descs; uint8_t* mid; uint64_t mid_stride; uint32_t* zlen; int32_t* status; uint8_t* work;
     tsx_chain_fuse fuse;
 };
+struct tsx_zfirsts { uint32_t first[64]; };   // .first of every segment, passed by value: a wave finds its segment without a memory access
 
 struct tsx_gcm_chunk {           // per-chunk work item (device)
     uint64_t in_off;             // plaintext (encrypt) / IV||C||TAG (decrypt) offset within `in`

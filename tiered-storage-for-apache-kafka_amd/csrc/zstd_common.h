@@ -31,7 +31,9 @@ struct zs_seq { uint32_t offBase, litLength, mlBase, litPos; };   /* litPos: chu
 #define ZS_WS_BLOCKOUT (ZS_WS_STBITS + 6u * ZS_WS_CODE_STRIDE)        /* compressed block being built       */
 #define ZS_BLOCKOUT_CAP (384u << 10)
 #define ZS_WS_HUFSAVE (ZS_WS_BLOCKOUT + ZS_BLOCKOUT_CAP + 256)        /* the two Huffman tables of the literal stage, between blocks */
-#define ZS_WS_BYTES ((size_t)(ZS_WS_HUFSAVE + 2048))
+#define ZS_WS_KEYCOPY (ZS_WS_HUFSAVE + 2048)                           /* the wave's own copy of the batch key schedule (tsx_gcm_key), wiped by the wave */
+#define ZS_WS_KEYCOPY_BYTES 21504u
+#define ZS_WS_BYTES ((size_t)(ZS_WS_KEYCOPY + ZS_WS_KEYCOPY_BYTES))
 #define ZS_WS_HASH_BYTES (ZS_WS_SEQS)                                 /* prefix that must be zero at start  */
 
 struct zs_cparams { uint32_t windowLog, chainLog, hashLog, minMatch; };

@@ -1484,7 +1484,7 @@ __device__ static bool wave_is_rle(const uint8_t* __restrict__ p, uint32_t n, ui
 // GCM launch would need 40 KiB of LDS per workgroup on CUs whose LDS and VGPRs are held by compressor waves of the batches in
 // flight, and sat hundreds of ms in the queue for 20 ms of work; here it costs the wave a few ms of its second-long life.
 __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ descs, uint32_t chunk, const uint8_t* frame, uint32_t flen,
-                                    uint32_t* __restrict__ zlen, int32_t* __restrict__ status, const tsx_chain_fuse fuse, EncLds& L, uint32_t lane) {
+                                    uint32_t* __restrict__ zlen, int32_t* __restrict__ status, const tsx_chain_fuse fuse, uint8_t* keyLocal, EncLds& L, uint32_t lane) {
     if (lane == 0) zlen[chunk] = flen;
     if (!fuse.key) return;
     __threadfence_block();
@@ -1494,7 +1494,26 @@ __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ des
         if (lane == 0) { status[chunk] = TSX_E_DST_TOO_SMALL; descs[chunk].dst_len = 0; if (fuse.self_status) descs[chunk].status = TSX_E_DST_TOO_SMALL; }
         return;
     }
-    gcm_encrypt_wave(fuse.aes, fuse.key, descs[chunk].iv, frame, flen, fuse.out + dstOff, L.g.t0, L.g.tab, lane);
+    const tsx_gcm_key* key = fuse.key;
+    if (fuse.key_on_host) {
+        // the key schedule waits in the caller's pinned memory: 21 KB over PCIe once per chunk, into this chunk's workspace
+        static_assert(sizeof(tsx_gcm_key) <= ZS_WS_KEYCOPY_BYTES && sizeof(tsx_gcm_key) % 16 == 0, "key copy fits its workspace region");
+        const uint4* s_ = reinterpret_cast<const uint4*>(fuse.key); uint4* d_ = reinterpret_cast<uint4*>(keyLocal);
+        for (uint32_t i = lane; i < sizeof(tsx_gcm_key) / 16; i += LANES) d_[i] = s_[i];
+        __threadfence_block();
+        __syncthreads();
+        key = reinterpret_cast<const tsx_gcm_key*>(keyLocal);
+    }
+    uint8_t iv[12];
+    { const uint8_t* p_ = descs[chunk].iv; for (int i = 0; i < 12; i++) iv[i] = p_[i]; }
+    gcm_encrypt_wave(fuse.aes, key, iv, frame, flen, fuse.out + dstOff, L.g.t0, L.g.tab, lane);
+    if (fuse.key_on_host) {
+        __threadfence_block();
+        __syncthreads();
+        uint4 z; z.x = z.y = z.z = z.w = 0;
+        uint4* d_ = reinterpret_cast<uint4*>(keyLocal);
+        for (uint32_t i = lane; i < sizeof(tsx_gcm_key) / 16; i += LANES) d_[i] = z;      // the copy does not outlive the chunk
+    }
     if (lane == 0) { descs[chunk].dst_len = flen + 28; if (fuse.self_status) descs[chunk].status = TSX_OK; }
 }
 
@@ -1507,7 +1526,7 @@ template <bool SEG>
 __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restrict__ src_base_, tsx_chunk_desc* __restrict__ descs_,
                                                               uint8_t* __restrict__ mid_, uint64_t mid_stride_, uint32_t* __restrict__ zlen_,
                                                               int32_t* __restrict__ status_, uint8_t* __restrict__ work_, uint32_t profile_, uint32_t sched,
-                                                              const tsx_chain_fuse fuse_, const tsx_zseg* __restrict__ segs, uint32_t nsegs
+                                                              const tsx_chain_fuse fuse_, const tsx_zseg* __restrict__ segs, const tsx_zfirsts& firsts, uint32_t nsegs
 #ifdef TSX_PROF
                                                               , unsigned long long* __restrict__ prof_out
 #endif
@@ -1519,9 +1538,10 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
     uint64_t mid_stride = mid_stride_; uint32_t* __restrict__ zlen = zlen_; int32_t* __restrict__ status = status_; uint8_t* __restrict__ work = work_;
     uint32_t profile = profile_; tsx_chain_fuse fuse = fuse_;
     if (SEG) {
-        uint32_t k = 0;
-        while (k + 1 < nsegs && segs[k + 1].first <= blockIdx.x) k++;
-        const tsx_zseg sg = segs[k];
+        uint32_t k = 0;                                                  // .first values come with the kernel arguments: no memory access to find the segment
+#pragma unroll
+        for (uint32_t i = 1; i < 64; i++) if (i < nsegs && firsts.first[i] <= blockIdx.x) k = i;
+        const tsx_zseg sg = segs[k];                                     // (the table itself may sit in pinned host memory: ONE entry is read)
         chunk = blockIdx.x - sg.first;
         src_base = sg.src_base; descs = sg.descs; mid = sg.mid; mid_stride = sg.mid_stride; zlen = sg.zlen; status = sg.status; work = sg.work;
         profile = sg.profile; fuse = sg.fuse;
@@ -1573,7 +1593,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
     uint8_t* op = frame + hdr;
     if (srcSize == 0) {
         if (lane == 0) { op[0] = 1; op[1] = 0; op[2] = 0; }
-        finish_frame(descs, chunk, frame, hdr + 3, zlen, status, fuse, L, lane);
+        finish_frame(descs, chunk, frame, hdr + 3, zlen, status, fuse, ws + ZS_WS_KEYCOPY, L, lane);
         return;
     }
     uint32_t* const hufSave = (uint32_t*)(ws + ZS_WS_HUFSAVE);
@@ -1657,7 +1677,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
         ipos += blockSize; remaining -= blockSize; op += cSize; first = false;
         __syncthreads();
     }
-    finish_frame(descs, chunk, frame, (uint32_t)(op - frame), zlen, status, fuse, L, lane);
+    finish_frame(descs, chunk, frame, (uint32_t)(op - frame), zlen, status, fuse, ws + ZS_WS_KEYCOPY, L, lane);
 #ifdef TSX_PROF
     if (lane == 0 && prof_out) { g_prof[14] = (unsigned long long)clock64() - g_prof[22]; for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i]; }
 #endif
@@ -1674,11 +1694,13 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel
                                                               uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
                                                               int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
                                                               const tsx_chain_fuse fuse ZS_PROF_PARAM) {
-    zstd_compress_body<false>(src_base, descs, mid, mid_stride, zlen, status, work, profile, sched, fuse, nullptr, 0u ZS_PROF_ARG);
+    const tsx_zfirsts nofirsts{};
+    zstd_compress_body<false>(src_base, descs, mid, mid_stride, zlen, status, work, profile, sched, fuse, nullptr, nofirsts, 0u ZS_PROF_ARG);
 }
-__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segments_kernel(const tsx_zseg* __restrict__ segs, uint32_t nsegs, uint32_t sched ZS_PROF_PARAM) {
+__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segments_kernel(const tsx_zseg* __restrict__ segs, const tsx_zfirsts firsts, uint32_t nsegs,
+                                                                                          uint32_t sched ZS_PROF_PARAM) {
     const tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr, 0, 0};
-    zstd_compress_body<true>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0u, sched, none, segs, nsegs ZS_PROF_ARG);
+    zstd_compress_body<true>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0u, sched, none, segs, firsts, nsegs ZS_PROF_ARG);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1689,9 +1711,11 @@ void tsx_zstd_build_consts(tsx_zstd_consts* h) { h->abi = 1; h->pad[0] = h->pad[
 size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size_t)n * ZS_WS_BYTES; }
 
 // Several callers' batches in one launch: d_segs[0 .. nsegs) (device memory, ascending .first, segment k = workgroups [first, first + n)).
-uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched) {
-    if (!total_chunks || !nsegs) return 0;
-    hipLaunchKernelGGL(zstd_compress_segments_kernel, dim3(total_chunks), dim3(LANES), 0, st, d_segs, nsegs, sched
+uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, const tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched) {
+    if (!total_chunks || !nsegs || nsegs > 64) return 0;
+    tsx_zfirsts f{};
+    for (uint32_t k = 0; k < nsegs; k++) f.first[k] = h_segs[k].first;
+    hipLaunchKernelGGL(zstd_compress_segments_kernel, dim3(total_chunks), dim3(LANES), 0, st, d_segs, f, nsegs, sched
 #ifdef TSX_PROF
                        , g_prof_out
 #endif

@@ -15,9 +15,10 @@ size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t max_len);
 uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* src, tsx_chunk_desc* d_descs,
                                   uint32_t n, uint32_t max_len, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status,
                                   void* d_work, uint32_t profile, uint32_t sched /* 0 lean, 1 wide speculation: zstd_enc.hip */, tsx_chain_fuse fuse);
-// Several callers' batches in ONE launch (the front end's launch combiner): segment k of d_segs (device memory) covers workgroups
-// [first, first + n) and names that caller's buffers, key and profile.
-uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched);
+// Several callers' batches in ONE launch (the front end's launch combiner): segment k of the table covers workgroups [first, first + n)
+// and names that caller's buffers, key and profile.  d_segs: the table as the DEVICE reads it (device memory, or the device alias of
+// pinned host memory - a wave reads one entry); h_segs: the same table as the host reads it (its .first values travel as kernel arguments).
+uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, const tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched);
 // Inverse (DecompressionChunkEnumeration.java:39-46): frame i at (from_mid ? frames + i*mid_stride :
 // frames + descs[i].src_off), length descs[i].src_len - (from_mid ? 28 : 0); output to dst + descs[i].dst_off,
 // descs[i].dst_len set; status TSX_E_BAD_SIZE / TSX_E_BAD_FRAME / TSX_E_DST_TOO_SMALL on failure.
