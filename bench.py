@@ -631,7 +631,8 @@ def main():
         # ... and in the broker's real shape (reference README.md:218-222, RemoteStorageManager.java:400-432: >= 10 RLM upload threads, one
         # segment each): `callers` threads, every call ONE 256-chunk segment, context-less (pooled contexts, as the JNI shim calls),
         # TSX_MEM_HOST_PACKED from a registered source into a registered per-thread output buffer - what GpuTransformChunkEnumeration
-        # issues (20 callers = 10 threads with one batch of read-ahead each).
+        # issues (20 callers = 10 threads with one batch of read-ahead each; 32 = 16 such threads).  The loop is closed - a caller's next
+        # call follows its last - so the row is bounded by the chunks the callers OFFER: 2560 / 5120 / 8192 against the 6144 the chip holds.
         broker = None
         if T > 1 and n >= 256 and not args.no_broker:
             broker = []
@@ -640,7 +641,7 @@ def main():
             N.host_register(hsrc)
             bufs = []
             try:
-                for callers in (10, 20):
+                for callers in (10, 20, 32):
                     while len(bufs) < callers:
                         hb = np.zeros(cap, np.uint8); N.host_register(hb); bufs.append(hb)
                     segs = [hsrc[(t % (n // B)) * B * CH:((t % (n // B)) + 1) * B * CH] for t in range(callers)]
@@ -650,28 +651,39 @@ def main():
                         dd["src_off"] = np.arange(B, dtype=np.uint64) * CH; dd["src_len"] = CH
                         dd["iv"] = d["iv"][(t % (n // B)) * B:((t % (n // B)) + 1) * B]
                         des.append(dd)
-                    reps = 4
+                    window = 5.0                                          # seconds of continuous calling per row (closed loop: a caller's next call follows its last)
                     lat = [[] for _ in range(callers)]
+                    stamps = []
+                    stop_at = [0.0]
 
-                    def bworker(t, k):
-                        for _ in range(k):
+                    def bworker(t, warm):
+                        while True:
                             a = time.perf_counter()
                             N.transform_batch(params, des[t], segs[t], bufs[t], cap, nat.MEM_HOST_PACKED, ctx=None)
-                            lat[t].append(time.perf_counter() - a)
+                            b_ = time.perf_counter()
+                            if warm:
+                                return
+                            lat[t].append(b_ - a)
+                            with lock:
+                                stamps.append(b_)
+                            if b_ >= stop_at[0]:
+                                return
 
-                    th = [threading.Thread(target=bworker, args=(t, 1)) for t in range(callers)]     # pooled contexts and their workspaces exist
+                    th = [threading.Thread(target=bworker, args=(t, True)) for t in range(callers)]     # pooled contexts and their workspaces exist
                     [x.start() for x in th]; [x.join() for x in th]
-                    lat = [[] for _ in range(callers)]
                     t1 = time.perf_counter()
-                    th = [threading.Thread(target=bworker, args=(t, reps)) for t in range(callers)]
+                    stop_at[0] = t1 + window
+                    th = [threading.Thread(target=bworker, args=(t, False)) for t in range(callers)]
                     [x.start() for x in th]; [x.join() for x in th]
-                    el = time.perf_counter() - t1
                     ok = all(bool((dd["status"] == 0).all()) and bool((dd["dst_len"] == d["dst_len"][(t % (n // B)) * B:((t % (n // B)) + 1) * B]).all())
                              for t, dd in enumerate(des))
-                    gibs = float(callers * reps * B) * CH / GiB / el
-                    broker.append({"callers": callers, "batch_chunks": B, "calls": callers * reps, "context": "pooled (ctx = NULL)", "dst_layout": "packed",
+                    # rate = calls completed inside the window / window (the calls still running at its end are not counted, the ramp at its start is)
+                    done = sum(1 for x in stamps if x <= stop_at[0])
+                    gibs = float(done * B) * CH / GiB / window
+                    broker.append({"callers": callers, "batch_chunks": B, "chunks_offered": callers * B, "calls": done, "seconds": window,
+                                   "context": "pooled (ctx = NULL), launch combiner", "dst_layout": "packed",
                                    "host_memory": "source and outputs registered", "gibs": round(gibs, 4), "frac_of_device_resident_value": round(gibs / value, 3),
-                                   "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat]))) * 1e3, 1),
+                                   "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat if x]))) * 1e3, 1),
                                    "same_sizes_as_device_run": ok})
             finally:
                 for hb in bufs:

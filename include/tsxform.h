@@ -135,7 +135,7 @@ int  tsx_ctx_device(const tsx_ctx* ctx);                /* device index (0 .. ts
 /* Device of the calling thread's ctx-less calls: 0 .. tsx_device_count()-1, or -1 = automatic (least loaded).  The JVM side
  * passes  segment hash % devices  so that the chunks of one segment stay on one GPU (segment s -> GPU s mod N). */
 int  tsx_set_thread_device(int device_index);
-/* Pool of the ctx-less calls on one device: idle contexts kept (at most 32, and at most 96 GiB of device workspace between them),
+/* Pool of the ctx-less calls on one device: idle contexts kept (at most 32, and at most 128 GiB of device workspace between them),
  * contexts out right now, batches served so far. */
 int  tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use, uint64_t* batches);
 

@@ -79,7 +79,7 @@ struct tsx_device {
 #define TSX_MAX_SUBS 64                 /* sub-batches of one host-memory batch (staging pipeline) */
 #define TSX_SUB_BYTES ((size_t)64 << 20) /* input bytes per sub-batch: >= 1000 workgroups of the GCM / CRC kernels */
 #define TSX_POOL_MAX_IDLE 32            /* idle pooled contexts kept per device (a broker: >= 10 RLM threads + read-ahead helpers + the fetch pool) ... */
-#define TSX_POOL_MAX_IDLE_BYTES ((size_t)96 << 30) /* ... as long as their workspaces together stay under a third of the 288 GB; the rest are destroyed on release */
+#define TSX_POOL_MAX_IDLE_BYTES ((size_t)128 << 30) /* ... as long as their workspaces together stay under 128 of the 288 GB; the rest are destroyed on release */
 #define TSX_COMP_PIECES 4               /* pieces of a host-memory batch on the compress path: one compute stream each (they must co-reside) */
 
 struct tsx_ctx {
