@@ -152,6 +152,20 @@ int main(int argc, char** argv) {
         {"cache 512+512 ev-only (16,48)", {16, 48, 512, 512, 0, 1}},
         {"cache 512+512 ev-only (32,59)", {32, 59, 512, 512, 0, 1}},
         {"cache 512+512 ev-only nocut (4,32)", {4, 32, 512, 512, 0, 0}},
+        {"gram 256 d4 m3 (3,59)", {3, 59, 0,0,0,0, 0,0,0, 256, 4, 3}},
+        {"gram 512 d4 m3 (3,59)", {3, 59, 0,0,0,0, 0,0,0, 512, 4, 3}},
+        {"gram 1K d4 m3 (3,59)", {3, 59, 0,0,0,0, 0,0,0, 1024, 4, 3}},
+        {"gram 256 d4 m3 (4,32)", {4, 32, 0,0,0,0, 0,0,0, 256, 4, 3}},
+        {"gram 512 d4 m3 (4,32)", {4, 32, 0,0,0,0, 0,0,0, 512, 4, 3}},
+        {"gram 1K d4 m3 (4,32)", {4, 32, 0,0,0,0, 0,0,0, 1024, 4, 3}},
+        {"gram 2K d4 m3 (2,59)", {2, 59, 0,0,0,0, 0,0,0, 2048, 4, 3}},
+        {"gram 2K d4 m3 (3,59)", {3, 59, 0,0,0,0, 0,0,0, 2048, 4, 3}},
+        {"gram 2K d4 m3 (4,59)", {4, 59, 0,0,0,0, 0,0,0, 2048, 4, 3}},
+        {"gram 2K d4 m3 (4,32)", {4, 32, 0,0,0,0, 0,0,0, 2048, 4, 3}},
+        {"gram 2K d4 m2 (4,59)", {4, 59, 0,0,0,0, 0,0,0, 2048, 4, 2}},
+        {"gram 2K d4 m2 (3,59)", {3, 59, 0,0,0,0, 0,0,0, 2048, 4, 2}},
+        {"gram 2K d4 m1 (4,59)", {4, 59, 0,0,0,0, 0,0,0, 2048, 4, 1}},
+        {"gram 2K d4 m3 (6,59)", {6, 59, 0,0,0,0, 0,0,0, 2048, 4, 3}},
         {"gram 2K d4 m3 (8,59)", {8, 59, 0,0,0,0, 0,0,0, 2048, 4, 3}},
         {"gram 2K d4 m2 (8,59)", {8, 59, 0,0,0,0, 0,0,0, 2048, 4, 2}},
         {"gram 2K d3 m2 (8,59)", {8, 59, 0,0,0,0, 0,0,0, 2048, 3, 2}},
