@@ -59,8 +59,8 @@ PY
       done | tee $O/prio_sustained.txt ;;
     sched)
       # speculation predictor / schedule A/B: alternating processes, timed region only (5 callers x 40 steps)
-      for round in 1 2; do
-        for m in ${arg:-"0,0,0 0,0,1 4,32,1"}; do
+      for round in 1 2 3; do
+        for m in ${arg:-0,0,0 0,0,1 4,32,1}; do
           echo -n "round $round TSX_ZSTD_SCHED=$m: "
           TSX_ZSTD_SCHED=$m timeout 400 python bench.py --steps 40 --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained --no-verify 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['gibs_one_batch_at_a_time'])"
         done
