@@ -22,6 +22,7 @@
 // H^(distance to the end) to every sub-block, adds the AAD and length blocks, encrypts J0 and writes /
 // verifies the tag.  GF(2^128) has no carry-less multiply on CDNA4: everything is shifts, XORs and
 // table lookups.  Algorithmic traffic: n bytes read + n + 28 bytes written per chunk.
+#include <mutex>
 #include <string.h>
 #include "tsx_internal.h"
 
@@ -53,7 +54,7 @@ void tsx_aes_build_tables(tsx_aes_tables* t) {
 // powers of H, the 4-bit tables of H^256 and the 2-bit tables of H^64).  ~0.1 ms of one core per batch key.
 // ---------------------------------------------------------------------------------------------------
 namespace {
-struct HostAes { uint32_t te0[256]; bool ready = false; };
+struct HostAes { uint32_t te0[256]; std::once_flag once; };
 HostAes g_host_aes;
 inline uint32_t h_rotl(uint32_t v, int r) { return (v << r) | (v >> (32 - r)); }
 inline uint32_t h_sbx(uint32_t x) { return (g_host_aes.te0[x & 0xFF] >> 8) & 0xFFu; }
@@ -90,7 +91,7 @@ inline void h_aes256(const uint32_t* rk, uint32_t& w0, uint32_t& w1, uint32_t& w
 }  // namespace
 
 void tsx_gcm_key_build_host(const uint8_t key32[32], const uint8_t* aad, uint32_t aad_len, tsx_gcm_key* out) {
-    if (!g_host_aes.ready) { tsx_aes_tables t; tsx_aes_build_tables(&t); memcpy(g_host_aes.te0, t.te0, sizeof g_host_aes.te0); g_host_aes.ready = true; }
+    std::call_once(g_host_aes.once, [] { tsx_aes_tables t; tsx_aes_build_tables(&t); memcpy(g_host_aes.te0, t.te0, sizeof g_host_aes.te0); });
     memset(out, 0, sizeof *out);
     uint32_t* rk = out->rk;
     for (int i = 0; i < 8; i++) rk[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) | ((uint32_t)key32[4 * i + 3] << 24);

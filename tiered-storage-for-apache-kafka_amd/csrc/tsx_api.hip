@@ -695,10 +695,9 @@ static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, boo
 
 static uint32_t zstd_sched_from_env() {
     uint32_t sched = 0;                                              // the kernel's default speculation schedule
-    if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1[,p]": explicit schedule (measurements; same bytes); p = 0 switches
-        unsigned a = 0, b = 0, pr = 1;                               // the speculation predictor off; k0 = k1 = 0 keeps the defaults
-        const int got = sscanf(e, "%u,%u,%u", &a, &b, &pr);
-        if (got >= 2 && a <= 59 && b <= 59) sched = a | b << 8 | (got == 3 && pr == 0 ? 1u << 16 : 0u);
+    if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1": explicit schedule (measurements; same bytes)
+        unsigned a = 0, b = 0;
+        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) sched = a | b << 8;
     }
     return sched;
 }

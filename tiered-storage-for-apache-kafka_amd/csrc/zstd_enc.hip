@@ -80,7 +80,6 @@ template <class T> __device__ static inline T* uni_ptr(T* p) {
 #define ZS_WAVES_PER_SIMD 6   /* occupancy target: 80 VGPRs, <= 6826 B of LDS -> 24 chunks per CU */
 #endif
 #define ZS_SCR 1024u          /* slots of the intra-step hash-collision detector (per table) */
-#define ZS_GRAM 256u          /* entries (bytes) of the 4-gram recency filter that bounds a step's speculation */
 // cold, register-hungry scalar stages are kept out of line so the speculative match loop keeps its occupancy
 #define ZS_NOINLINE __attribute__((noinline))
 
@@ -187,7 +186,6 @@ struct EncLds {
         struct {                // parse stage of a block (re-primed per block): source window + collision scoreboard
             uint32_t ring[ZS_RING / 4 + 4];     // + 16-byte mirror of the first bytes
             uint8_t scr[2 * ZS_SCR];
-            uint8_t gram[ZS_GRAM];              // 4-gram recency filter of the speculation predictor (fits the slack under the entropy stage's size)
         } p;
         struct {                // GCM tail over the finished frame (gcm_encrypt_wave)
             tsx_gf128 tab[256];
@@ -342,12 +340,6 @@ struct MfState { uint32_t nbSeq, litSize, lastLL, anchor; };
 #ifndef ZS_K1
 #define ZS_K1 32u             /* ... of the second step; doubling from there */
 #endif
-#ifndef ZS_K0P
-#define ZS_K0P 3u             /* the same with the predictor on: narrower first step, widest second step (the predictor bounds it) */
-#endif
-#ifndef ZS_K1P
-#define ZS_K1P 59u
-#endif
 #define ZS_KMAX 59u           /* lanes 3..61 search, 62 looks ahead, 63 serves the immediate repcode */
 // the rare continuations (matches longer than the 64 bytes the first comparison covers) stay out of line
 __device__ ZS_NOINLINE static uint32_t count_more(const uint8_t* __restrict__ src, const uint32_t* ring, const Win w, uint32_t a, uint32_t b, uint32_t iend, uint32_t lane) {
@@ -376,25 +368,20 @@ __device__ static inline uint32_t cto64(unsigned long long m) { return m == ~0ul
 __device__ ZS_NOINLINE static void match_block(const uint8_t* __restrict__ src, const uint32_t srcSize_, const uint32_t blockStart,
                                                     const uint32_t blockSize_, uint32_t* __restrict__ hashLong, uint32_t* __restrict__ hashSmall,
                                                     const zs_cparams cp, const uint32_t dictLimitIn, uint32_t* rep, zs_seq* __restrict__ seqs,
-                                                    MfState& ms, uint32_t* ring, uint8_t* scr, uint8_t* gram, const uint32_t lane, const uint32_t sched) {
+                                                    MfState& ms, uint32_t* ring, uint8_t* scr, const uint32_t lane, const uint32_t sched) {
     // Speculation schedule (never changes the output, only what a search run costs): positions of the first step after a match, of the
     // second step; doubling from there.  sched = K0 | K1 << 8, 0 in a field = the compile-time default (4, 32).  Measured with 18-step
     // runs, three batches in flight / one at a time (profiles/r02_sweep_k_schedule.txt): (2,16) 17.6-17.9 GiB/s / 762 ms, (3,24) 18.5-18.6 /
     // 729-735, (4,32) 18.8 / 719, (4,48) 18.8 / 725, (6,32) 18.75 / 723: the dependent round trips a wider step saves are worth more than
     // the table lines it wastes, on a full chip too.  (Sweeps of 6 steps had said the opposite - their start-up transient dominates.)
-    // Round 3: a step's width is also bounded by a PREDICTOR (never the output, only what a run costs).  On log-like content the first
-    // event of a run sits where the 8-byte window turns from novel bytes (ids, payload) into recurring ones (field names): a 256-byte
-    // recency filter over the 4-grams of the bytes already parsed says for every search lane whether the TAIL of its window (bytes
-    // pos + 4 .. pos + 8) has been seen lately; the first lane that says yes ends the step three lanes later.  Model on the exact parse
-    // (tools/stats/step_sim.c, profiles/r03_step_sim_K.txt): 15.8 -> 5.3 speculative reads and 1.26 -> 1.24 steps per sequence at
-    // schedule (3, 59); the filter costs no LDS (it lives in the slack under the entropy stage's size) and ~16 instructions per step.
-    // sched bit 16: predictor off (A/B measurements).
-    const bool usePred = !((UNI(sched) >> 16) & 1u);
-    const uint32_t kFirst = (UNI(sched) & 0xFF) ? (UNI(sched) & 0xFF) : (usePred ? ZS_K0P : ZS_K0),
-                   kSecond = ((UNI(sched) >> 8) & 0xFF) ? ((UNI(sched) >> 8) & 0xFF) : (usePred ? ZS_K1P : ZS_K1);
-    for (uint32_t i = lane; i < ZS_GRAM / 4; i += LANES) reinterpret_cast<uint32_t*>(gram)[i] = 0;    // (the parse stage's LDS is re-primed per block)
-    uint32_t gmark = UNI(blockStart);                                  // bytes before gmark have been offered to the filter
-    WAVE_MEM_SYNC();
+    // Round 3 tried to bound a step by a PREDICTOR as well: a 256-byte recency filter over the 4-grams of the bytes already parsed says
+    // for every search lane whether the tail of its 8-byte window has been seen lately (on log-like content the first event of a run sits
+    // where the window turns from novel bytes into recurring ones).  On the exact parse it cuts the speculative reads from 15.8 to 5.3
+    // per sequence at fewer steps (tools/stats/step_sim.c, profiles/r03_step_sim_K.txt) - and on the device it LOSES: 18.6-18.8 GiB/s
+    // against 19.2-19.4 in flight, 9.6 against 10.3 one batch at a time (three alternating rounds, profiles/r03_gram_predictor_ab.txt),
+    // like round 2's event-position predictor: ~16 instructions and two LDS round trips per step on the serial path cost more than the
+    // table lines they save.  The code is in the history (commit "Parser: 4-gram recency predictor"), not in the kernel.
+    const uint32_t kFirst = (UNI(sched) & 0xFF) ? (UNI(sched) & 0xFF) : ZS_K0, kSecond = ((UNI(sched) >> 8) & 0xFF) ? ((UNI(sched) >> 8) & 0xFF) : ZS_K1;
     const gbytes_t gsrc = (gbytes_t)uni_ptr(src);
     const gwords_t gL = (gwords_t)uni_ptr(hashLong), gS = (gwords_t)uni_ptr(hashSmall);
     ZS_GLOBAL zs_seq* const gseqs = (ZS_GLOBAL zs_seq*)uni_ptr(seqs);
@@ -462,25 +449,6 @@ __device__ ZS_NOINLINE static void match_block(const uint8_t* __restrict__ src, 
                 r1 = ring4(ring, searching ? pos + 1 - off1 : ip);
                 const unsigned long long rb = __ballot(searching && r1 == (uint32_t)(d8 >> 8));
                 if (rb) { const uint32_t fr = (uint32_t)__ffsll((long long)rb) - 1; K = fr - 2; searching = lane >= 3 && lane <= fr; }
-            }
-            // ---- predictor: offer the bytes consumed since the last step to the filter, then ask it about this step's lanes ----
-            if (usePred) {
-                if (gmark < ip) {
-                    const uint32_t from = ip - gmark > LANES ? ip - LANES : gmark;          // (of a long match only the last 64 bytes)
-                    const uint32_t q = from + lane;
-                    if (q < ip && q >= w.lo && q + 4 <= w.hi) { const uint32_t h = ring4(ring, q) * 2654435761u; gram[(h >> 8) & (ZS_GRAM - 1)] = (uint8_t)((h >> 24) | 1u); }
-                    gmark = ip;
-                    WAVE_MEM_SYNC();
-                }
-                if (K > 1) {
-                    const uint32_t h = (uint32_t)(d8 >> 32) * 2654435761u;                   // the 4-gram at pos + 4: the tail of this lane's window
-                    const unsigned long long fire = __ballot(searching && gram[(h >> 8) & (ZS_GRAM - 1)] == (uint8_t)((h >> 24) | 1u));
-                    if (fire) {
-                        const uint32_t fl = (uint32_t)__ffsll((long long)fire) - 1;          // lane 3 + j: the event is expected within j .. j + 3
-                        const uint32_t kp = fl - 3 + 1 + 3;
-                        if (kp < K) { K = kp; searching = lane >= 3 && lane < 3 + K; }
-                    }
-                }
             }
             // ---- two lanes, one bucket: find the first lane with an earlier partner and stop in front of it ----
             bool shadowL0 = false, shadowS0 = false;                  // lane 0's insertion is overwritten by lane 1's / lane 2's
@@ -1664,7 +1632,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
         if (blockSize >= 7) {
             uint32_t rep[3] = {repc[0], repc[1], repc[2]};
             MfState ms;
-            match_block(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, L.p.gram, lane, sched);
+            match_block(src, srcSize, ipos, blockSize, hashLong, hashSmall, cp, dictLimit, rep, seqs, ms, L.p.ring, L.p.scr, lane, sched);
             __threadfence_block();
             __syncthreads();
             gather_literals(lit, src, seqs, ms.nbSeq, ms.anchor, ms.lastLL, lane);
