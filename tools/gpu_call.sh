@@ -2,6 +2,7 @@
 # One parameterised script for the GPU box (run through gpurun from the repo root):  bash tools/gpu_call.sh <tag> <section>...
 # Sections write under gpurun_out/<tag>/ ; copy what is to be judged into profiles/ afterwards.
 #   tests[:expr]   pytest -m gpu (optionally -k expr)
+#   smoke          __graft_entry__.smoke()
 #   bench          the driver's default bench.py line (all legs)
 #   regime         timed-region regime sweep: callers x steps, no side legs
 #   broker         tools/broker_probe.py (10/20/24 callers x 256-chunk batches), device + host memory, GPU_MAX_HW_QUEUES variants
@@ -22,6 +23,8 @@ for sec in "$@"; do
     tests)
       if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$arg" > $O/pytest_gpu.log 2>&1; else timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; fi
       tail -4 $O/pytest_gpu.log ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     bench)
       timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; tail -3 $O/bench_default.err ;;
     regime)
