@@ -33,7 +33,7 @@ template <class T> inline T max(T a, T b) { return a < b ? b : a; }
 typedef int hipError_t;
 typedef struct hipemu_stream* hipStream_t;
 typedef struct hipemu_event* hipEvent_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
+enum { hipErrorNotReady = 600, hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipEventDefault = 0, hipHostRegisterDefault = 0, hipHostRegisterPortable = 1, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };

@@ -790,7 +790,7 @@ static void combiner_submit(tsx_combiner* cb, tsx_zreq& q) {
         for (;;) {
             for (uint32_t i = 0; i < cb->nlanes && li < 0; i++) {
                 tsx_lane& l = cb->lane[i];
-                if (l.busy && hipEventQuery(l.end) == hipSuccess) l.busy = false;
+                if (l.busy && hipEventQuery(l.end) != hipErrorNotReady) l.busy = false;     // done - or failed: the launch on it will say so
                 if (!l.busy) li = (int)i;
             }
             if (li >= 0) break;
