@@ -42,3 +42,88 @@ def test_packed_host_output_on_the_device(gpu, oracle):
         assert (d1["dst_off"].astype(np.int64) == ends - d1["dst_len"]).all()
         for i in (0, 2, 6):
             assert packed[i] == pc.oracle_transform(oracle, flags, chunks[i], i)
+
+
+def test_both_decoder_forms_agree_on_the_device(gpu, oracle, monkeypatch):
+    """Batches of up to 192 chunks decode one workgroup per BLOCK with execution by pointer jumping (csrc/zstd_dec_blocks.hip), larger
+    ones one workgroup per chunk (csrc/zstd_dec.hip); the block form hands what it does not like back to the chunk form.  Full-size
+    frames of stock libzstd (levels 1 / 3 / 19), frames of many mixed blocks, damaged frames and a 10 MiB chunk through both forms on
+    the device: identical statuses and bytes, every undamaged frame decoded by the block form, a 200-chunk batch by the chunk form."""
+    from tests.test_emu_zstd import _fuzzed_frames
+    inputs = _inputs()
+    plain = list(inputs.values()) + [pc.big_chunk("mixed10")]
+    blobs, sizes = [], []
+    for lvl in (1, 3, 19):
+        for v in plain:
+            blobs.append(oracle.zstd_compress_chunk(v.tobytes(), lvl)); sizes.append(int(v.size))
+    good = len(blobs)
+    fb, fs = _fuzzed_frames(oracle, 60, 31)
+    big = bytearray(blobs[0]); big[len(big) // 3] ^= 0x5A; big[len(big) // 2] ^= 0xC3                  # a damaged full-size frame
+    blobs += fb + [bytes(big)]; sizes += fs + [sizes[0]]
+    ctx = gpu.ctx_create(0, 0, 0)
+    try:
+        outs, d = pc.run_detransform(gpu, nat.COMPRESS, blobs, sizes, ctx=ctx)
+        assert pc.blockmode_chunks(gpu, ctx, good) == good
+        monkeypatch.setenv("TSX_DEC_BLOCK_CHUNKS", "0")
+        outs0, d0 = pc.run_detransform(gpu, nat.COMPRESS, blobs, sizes, ctx=ctx)
+        assert pc.blockmode_chunks(gpu, ctx, len(blobs)) == -1
+        monkeypatch.delenv("TSX_DEC_BLOCK_CHUNKS")
+        # above the threshold the batch takes the chunk form by itself
+        many = [blobs[3]] * 200
+        outs2, d2 = pc.run_detransform(gpu, nat.COMPRESS, many, [sizes[3]] * 200, ctx=ctx)
+        assert pc.blockmode_chunks(gpu, ctx, 200) == -1 and (d2["status"] == 0).all() and all(o == plain[3].tobytes() for o in outs2)
+    finally:
+        gpu.ctx_destroy(ctx)
+    assert list(d["status"]) == list(d0["status"]) and (d["status"][:good] == 0).all() and (d["status"][good:] != 0).sum() >= 15
+    for i in range(len(blobs)):
+        if d["status"][i] == 0:
+            assert outs[i] == outs0[i], i
+    for i in range(good):
+        assert outs[i] == plain[i % len(plain)].tobytes(), i
+
+
+def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
+    """16 threads, context-less 64-chunk compressing batches from / to pinned host buffers: every batch equals the single-threaded
+    result, and the device's launch combiner carried them in fewer launches than batches (callers that arrive while the lanes are busy
+    travel as one zstd_compress_segments_kernel)."""
+    import ctypes as C
+    import threading
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    stats = gpu.lib.tsx_debug_combiner_stats
+    stats.restype = C.c_int; stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    T, reps, B = 16, 3, 64
+    CH = 1 << 20
+    chunks = [synth.gen_chunk("K", 77, 0, i, CH) for i in range(B)]
+    ref, dref = pc.run_transform(gpu, flags, chunks, mem="packed")
+    sizes = [CH] * B
+    soff, _, _, st, _ = pc.layout(sizes, flags, gpu)
+    src = np.zeros(st, np.uint8)
+    for c, o_ in zip(chunks, soff):
+        src[o_:o_ + c.size] = c
+    gpu.host_register(src)
+    dsts = [np.zeros(B * (CH + 4096), np.uint8) for _ in range(T)]
+    for h in dsts:
+        gpu.host_register(h)
+    g0, m0 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g0), C.byref(m0))
+    errors = []
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+
+    def worker(t):
+        try:
+            for _ in range(reps):
+                d = pc.make_descs(sizes, soff, [0] * B, [0] * B)
+                gpu.transform_batch(p, d, src, dsts[t], dsts[t].size, nat.MEM_HOST_PACKED)
+                got = [dsts[t][int(d["dst_off"][i]):int(d["dst_off"][i]) + int(d["dst_len"][i])].tobytes() for i in range(B)]
+                if got != ref or (d["status"] != 0).any() or (d["crc32c"] != dref["crc32c"]).any():
+                    errors.append((t, "differs"))
+        except Exception as e:                                          # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    [x.start() for x in th]; [x.join() for x in th]
+    g1, m1 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g1), C.byref(m1))
+    for h in dsts:
+        gpu.host_unregister(h)
+    gpu.host_unregister(src)
+    assert not errors, errors[:4]
+    assert m1.value - m0.value == T * reps and g1.value - g0.value < T * reps, (g1.value - g0.value, m1.value - m0.value)
