@@ -63,7 +63,11 @@ def test_both_decoder_forms_agree_on_the_device(gpu, oracle, monkeypatch):
     ctx = gpu.ctx_create(0, 0, 0)
     try:
         outs, d = pc.run_detransform(gpu, nat.COMPRESS, blobs, sizes, ctx=ctx)
-        assert pc.blockmode_chunks(gpu, ctx, good) == good
+        # the block form takes frames of up to 264 blocks; libzstd 1.5.7's pre-splitter cuts the 10 MiB mixed chunk into 553 at level 3:
+        # that one is the chunk form's by design
+        from tests import zstd_inspect as zi
+        fits = sum(1 for b in blobs[:good] if len(zi.parse_frame(b, decode=False)[1]) <= 264)
+        assert fits >= good - 2 and pc.blockmode_chunks(gpu, ctx, good) == fits
         monkeypatch.setenv("TSX_DEC_BLOCK_CHUNKS", "0")
         outs0, d0 = pc.run_detransform(gpu, nat.COMPRESS, blobs, sizes, ctx=ctx)
         assert pc.blockmode_chunks(gpu, ctx, len(blobs)) == -1
