@@ -21,6 +21,7 @@ struct ZbBlock {
 struct ZbChunk {
     uint32_t mode;                               // 1: the block form is decoding this chunk; 0: left to (or handed back to) zstd_decompress_kernel
     uint32_t nblocks, contentSize, pad;
+    uint32_t live[32];                           // jump round r left unresolved words in this chunk (round r + 1 returns at once when not)
     ZbBlock blk[ZB_MAX_BLOCKS];
 };
 #define ZB_CHUNK_HDR_BYTES ((sizeof(ZbChunk) + 255u) & ~(size_t)255u)

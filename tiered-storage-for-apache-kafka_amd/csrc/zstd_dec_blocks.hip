@@ -92,6 +92,7 @@ __global__ __launch_bounds__(LANES) void zb_index_kernel(const uint8_t* __restri
     __shared__ uint32_t sN, sBad;
     const uint32_t lane = threadIdx.x, chunk = blockIdx.x;
     ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
+    if (lane < 32) C->live[lane] = 0;
     if (lane == 0) C->mode = 0;                                       // "not taken" until the last line of this kernel says otherwise (no memset launch: nothing
                                                                       // else of the header is read before this kernel has written it)
     if (status[chunk] != TSX_OK) return;                              // nothing to decode, nothing to fall back to
@@ -646,11 +647,16 @@ __global__ __launch_bounds__(LANES) void zb_scatter_kernel(const uint8_t* __rest
     if (fail && lane == 0) ZB_STORE_AGENT(&C->mode, 0u);                // the chunk-serial kernel behind this launch redoes the chunk
 }
 
-// one jump round: every unresolved word takes its source's word (four words per thread)
-__global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
+// one jump round: every unresolved word takes its source's word (four words per thread).  Chain depths are small in practice (log-like
+// content: every word resolved after 7 rounds, its matches reach ~100 KB back, not to the previous record) while the launcher must queue
+// the rounds the WORST case needs (a 4 MiB run of one byte: 22): a round notes whether it left anything unresolved, and the rounds behind
+// a round that did not return at their first instruction.
+__global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap, uint32_t seq_cap,
+                                                      uint32_t round) {
     const uint32_t chunk = blockIdx.y;
-    const ZbChunk* const C = (const ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
+    ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
     if (C->mode != 1) return;
+    if (round > 0 && C->live[round - 1] == 0) return;
     const uint32_t n = C->contentSize, p = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (p >= n) return;
     uint32_t* const words = (uint32_t*)(arenas + (size_t)chunk * astride + lit_cap + 12u * (size_t)seq_cap);
@@ -660,8 +666,9 @@ __global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs
         const uint32_t a = (v.x & ZB_LIT) ? v.x : words[v.x], b_ = (v.y & ZB_LIT) ? v.y : words[v.y], c = (v.z & ZB_LIT) ? v.z : words[v.z], d_ = (v.w & ZB_LIT) ? v.w : words[v.w];
         v.x = a; v.y = b_; v.z = c; v.w = d_;
         *reinterpret_cast<uint4*>(words + p) = v;
+        if (!((a & b_ & c & d_) & ZB_LIT) && round < 32) C->live[round] = 1;       // (every writer stores the same value)
     } else {
-        for (uint32_t q = p; q < n; q++) { const uint32_t v = words[q]; if (!(v & ZB_LIT)) words[q] = words[v]; }
+        for (uint32_t q = p; q < n; q++) { const uint32_t v = words[q]; if (!(v & ZB_LIT)) { const uint32_t w = words[v]; words[q] = w; if (!(w & ZB_LIT) && round < 32) C->live[round] = 1; } }
     }
 }
 
@@ -721,7 +728,7 @@ uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames
     uint32_t rounds = 1; while ((1ull << rounds) < (uint64_t)max_out + 1) rounds++;
     const uint32_t tiles = (max_out + 1023) / 1024;                     // 256 threads x 4 words
     for (uint32_t r = 0; r < rounds; r++)
-        hipLaunchKernelGGL(zb_jump_kernel, dim3(tiles, n), dim3(256), 0, st, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
+        hipLaunchKernelGGL(zb_jump_kernel, dim3(tiles, n), dim3(256), 0, st, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap, r);
     hipLaunchKernelGGL(zb_emit_kernel, dim3((max_out + 4095) / 4096, n), dim3(256), 0, st, (const tsx_chunk_desc*)d_descs, dst, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
     return 4 + rounds;
 }
