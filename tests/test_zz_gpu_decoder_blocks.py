@@ -45,7 +45,7 @@ def test_packed_host_output_on_the_device(gpu, oracle):
 
 
 def test_both_decoder_forms_agree_on_the_device(gpu, oracle, monkeypatch):
-    """Batches of up to 192 chunks decode one workgroup per BLOCK with execution by pointer jumping (csrc/zstd_dec_blocks.hip), larger
+    """Batches of up to 256 chunks decode one workgroup per BLOCK with execution by pointer jumping (csrc/zstd_dec_blocks.hip), larger
     ones one workgroup per chunk (csrc/zstd_dec.hip); the block form hands what it does not like back to the chunk form.  Full-size
     frames of stock libzstd (levels 1 / 3 / 19), frames of many mixed blocks, damaged frames and a 10 MiB chunk through both forms on
     the device: identical statuses and bytes, every undamaged frame decoded by the block form, a 200-chunk batch by the chunk form."""

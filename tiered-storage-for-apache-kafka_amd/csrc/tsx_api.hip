@@ -277,10 +277,10 @@ static int grow(T** p, size_t* cap, size_t need) {
 
 // Small detransform batches (a fetch: one chunk, a prefetch window) decode one workgroup per BLOCK instead of per chunk: the
 // chunk-serial decoder needs 25-50 ms for a chunk however idle the chip is.  TSX_DEC_BLOCK_CHUNKS: largest batch that takes this
-// form (default 192, 0 = never).
+// form (default 256, 0 = never).
 static uint32_t dec_block_chunks() {
     if (const char* e = getenv("TSX_DEC_BLOCK_CHUNKS")) { const long v = atol(e); return v < 0 ? 0u : (uint32_t)v; }
-    return 192u;                                            // measured: the two forms meet at ~240 chunks (34 ms), profiles/r03_dec_latency_block_form.jsonl
+    return 256u;                                            // measured: 27.6 ms at 256 chunks against the chunk form's 33, profiles/r03_dec_latency_block_form.jsonl
 }
 static bool dec_use_blocks(uint32_t n, uint32_t max_out) { return n <= dec_block_chunks() && tsx_zstd_blockmode_takes(max_out); }
 
