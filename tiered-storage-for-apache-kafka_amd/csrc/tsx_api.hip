@@ -327,7 +327,7 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
             uint8_t* bp = (uint8_t*)c->d_bwork;
             rc = grow(&bp, &c->bwork_cap, tsx_zstd_blockmode_bytes(n, max_out));
             c->d_bwork = bp;
-            if (rc) return rc;
+            if (rc) { c->d_bwork = nullptr; c->bwork_cap = 0; (void)hipGetLastError(); }   // no room for the fast path: the chunk form decodes the batch
         }
     }
     return TSX_OK;
@@ -644,7 +644,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         if (r.comp) {
             const uint32_t* skip = nullptr; uint32_t skip_stride = 0;
             c->last_used_blocks = false;
-            if (c->d_bwork && dec_use_blocks(r.n, r.max_out) && sb.n == r.n) {
+            if (c->d_bwork && c->bwork_cap >= tsx_zstd_blockmode_bytes(r.n, r.max_out) && dec_use_blocks(r.n, r.max_out) && sb.n == r.n) {
                 c->last_used_blocks = true;
                 // one workgroup per block; what that form does not take (or gives up on) is decoded by the chunk-serial kernel behind it
                 t.unzstd_launches += tsx_launch_zstd_decompress_blocks(st, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.max_out, r.d_dst, ds, c->d_bwork);
