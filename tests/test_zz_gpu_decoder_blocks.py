@@ -48,7 +48,7 @@ def test_both_decoder_forms_agree_on_the_device(gpu, oracle, monkeypatch):
     """Batches of up to 256 chunks decode one workgroup per BLOCK with execution by pointer jumping (csrc/zstd_dec_blocks.hip), larger
     ones one workgroup per chunk (csrc/zstd_dec.hip); the block form hands what it does not like back to the chunk form.  Full-size
     frames of stock libzstd (levels 1 / 3 / 19), frames of many mixed blocks, damaged frames and a 10 MiB chunk through both forms on
-    the device: identical statuses and bytes, every undamaged frame decoded by the block form, a 200-chunk batch by the chunk form."""
+    the device: identical statuses and bytes, every undamaged frame decoded by the block form, a 300-chunk batch by the chunk form."""
     from tests.test_emu_zstd import _fuzzed_frames
     inputs = _inputs()
     plain = list(inputs.values()) + [pc.big_chunk("mixed10")]
@@ -73,9 +73,9 @@ def test_both_decoder_forms_agree_on_the_device(gpu, oracle, monkeypatch):
         assert pc.blockmode_chunks(gpu, ctx, len(blobs)) == -1
         monkeypatch.delenv("TSX_DEC_BLOCK_CHUNKS")
         # above the threshold the batch takes the chunk form by itself
-        many = [blobs[3]] * 200
-        outs2, d2 = pc.run_detransform(gpu, nat.COMPRESS, many, [sizes[3]] * 200, ctx=ctx)
-        assert pc.blockmode_chunks(gpu, ctx, 200) == -1 and (d2["status"] == 0).all() and all(o == plain[3].tobytes() for o in outs2)
+        many = [blobs[3]] * 300
+        outs2, d2 = pc.run_detransform(gpu, nat.COMPRESS, many, [sizes[3]] * 300, ctx=ctx)
+        assert pc.blockmode_chunks(gpu, ctx, 300) == -1 and (d2["status"] == 0).all() and all(o == plain[3].tobytes() for o in outs2)
     finally:
         gpu.ctx_destroy(ctx)
     assert list(d["status"]) == list(d0["status"]) and (d["status"][:good] == 0).all() and (d["status"][good:] != 0).sum() >= 15
