@@ -16,7 +16,7 @@
 //   zb_scatter_kernel  one wave per block.  Chains the block summaries up to its own block (output position = sum of the regenerated
 //                      sizes before it, incoming history = composition of the outgoing ones: O(1) per block) and writes ONE WORD PER
 //                      OUTPUT BYTE: the byte itself for a literal, the position it copies from for a match byte.
-//   zb_jump_kernel     log2(size) rounds of pointer doubling over those words: "where I copy from" becomes "where that copies from"
+//   zb_jump_kernel     log4(size) passes of pointer jumping (two jumps each) over those words: "where I copy from" becomes "where that copies from"
 //                      until every word is a literal - the execution stage without any order between sequences, blocks or
 //                      workgroups (in-order execution is ONE dependency chain through the whole chunk: see the comment there).
 //   zb_emit_kernel     words -> bytes.
@@ -230,6 +230,13 @@ __global__ __launch_bounds__(LANES) void zb_index_kernel(const uint8_t* __restri
 // decode: one workgroup (wave 0 sequences, wave 1 literals) per block
 // ---------------------------------------------------------------------------------------------------
 #define ZB_FAIL() do { if (lane == 0) ZB_STORE_AGENT(&C->mode, 0u); return; } while (0)
+#ifdef TSX_PROF2
+static unsigned long long* g_zbprof_out = nullptr;                    // 8 u64 per (chunk, block): phase laps of zb_decode_kernel (tools/zb_phase_laps.py)
+extern "C" void tsx_debug_set_zbprof(void* dev_ptr) { g_zbprof_out = (unsigned long long*)dev_ptr; }
+#define ZLT(k) do { const unsigned long long n_ = (unsigned long long)clock64(); zlt_[k] += n_ - zlast_; zlast_ = n_; } while (0)
+#else
+#define ZLT(k) do {} while (0)
+#endif
 
 // The 1 or 4 Huffman streams of a literals section, on lanes 0-3 through per-stream LDS windows (zstd_dec.hip's literal stage):
 // payload = the section's bytes behind the tree description.  Returns false (wave-uniform) on a malformed stream.
@@ -343,9 +350,16 @@ __device__ static bool zb_seq_table(DecLds& L, int k, uint32_t mode, const uint8
 
 __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
                                                               const tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas,
-                                                              uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
+                                                              uint64_t astride, uint32_t lit_cap, uint32_t seq_cap
+#ifdef TSX_PROF2
+                                                              , unsigned long long* __restrict__ zbprof
+#endif
+                                                              ) {
     __shared__ DecLds L;
     const uint32_t lane = threadIdx.x & (LANES - 1), role = DUNI(threadIdx.x >> 6), b = blockIdx.x, chunk = blockIdx.y;
+#ifdef TSX_PROF2
+    unsigned long long zlt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, zlast_ = (unsigned long long)clock64();
+#endif
     ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
     if (DUNI(C->mode) != 1 || b >= DUNI(C->nblocks)) return;
     ZbBlock* const B = &C->blk[b];
@@ -380,9 +394,14 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
         huf_buildX_wave(L, lane);
         __threadfence_block();
         WAVE_SYNC();
+        ZLT(6);
         if (h.ltype == 2) t += used;
         if (t > h.hl + h.csize) ZB_FAIL();
         if (!zb_huf_streams(L, blk + t, h.hl + h.csize - t, h.streams, h.litSize, lit, lane)) ZB_FAIL();
+        ZLT(7);
+#ifdef TSX_PROF2
+        if (lane == 0 && zbprof) { unsigned long long* const zp = zbprof + ((size_t)chunk * ZB_MAX_BLOCKS + b) * 8; zp[6] = zlt_[6]; zp[7] = zlt_[7]; }
+#endif
         return;
     }
     // ---- sequences ----
@@ -399,6 +418,7 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
         if (mode == 3 || to > sb) ZB_FAIL();
         if (!zb_seq_table(L, k, mode, src + DUNI(S->off) + to, sb - to, lane)) ZB_FAIL();
     }
+    ZLT(0);
     uint32_t* const sLL = seqArena + DUNI(B->seqAt); uint32_t* const sML = sLL + seq_cap; uint32_t* const sOF = sML + seq_cap;
     const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog);
     const uint8_t* const win = L.swin;
@@ -438,6 +458,7 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
                 Bc = lo;
             }
         }
+        ZLT(1);
         // pass 1: the chain (lanes 0, 1, 2 = the LL, ML, OF state machines; see zstd_dec.hip)
         uint32_t bad = 0;
         const uint32_t Bgroup = Bc;
@@ -469,6 +490,7 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
         if (bad >> 31) ZB_FAIL();
         __threadfence_block();
         WAVE_SYNC();
+        ZLT(2);
         // pass 2: every lane decodes the fields of its own sequence
         const bool valid = lane < cnt;
         uint32_t ll = 0, ml = 0, offBase = 4;
@@ -494,6 +516,7 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
             }
         }
         if (__any(valid && offBase > 3 && offBase - 3 >= ZB_SYM)) ZB_FAIL();     // an offset of 2 GiB or more: not in a frame this form takes
+        ZLT(3);
         // pass 3: repeat offsets, on values that are either offsets or references into the incoming history
         uint32_t off = offBase - 3;
         {
@@ -523,12 +546,17 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
                 prev = j + 1;
             }
         }
+        ZLT(4);
         if (valid) { sLL[g + lane] = ll; sML[g + lane] = ml; sOF[g + lane] = off; }
         uint32_t a = ll, m = ml;
         for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); m += __shfl_xor(m, o); }
         sumLL += DUNI(a); sumML += DUNI(m);
         if (sumLL > litSize || litSize + sumML > ZS_BLOCK_MAX) ZB_FAIL();   // a block regenerates at most Block_Maximum_Size bytes
+        ZLT(5);
     }
+#ifdef TSX_PROF2
+    if (lane == 0 && zbprof) { unsigned long long* const zp = zbprof + ((size_t)chunk * ZB_MAX_BLOCKS + b) * 8; for (int k = 0; k < 6; k++) zp[k] = zlt_[k]; }
+#endif
     if (Bc != 0) ZB_FAIL();                                             // every bit of the stream was used
     if (lane == 0) { B->regen = litSize + sumML; B->endHist[0] = r0; B->endHist[1] = r1; B->endHist[2] = r2; B->ok = 1; }
 }
@@ -547,15 +575,23 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
 // ---------------------------------------------------------------------------------------------------
 #define ZB_LIT 0x80000000u                      /* src word: ZB_LIT | byte (resolved), else the chunk position this byte copies from */
 
-// one wave per block: the chain over the block summaries (positions, incoming repeat-offset history), then one word per output byte
-__global__ __launch_bounds__(LANES) void zb_scatter_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
-                                                           tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas,
-                                                           uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
-    __shared__ uint32_t sStart[ZB_MAX_BLOCKS + 1];                      // output position of every block (exclusive prefix of the regenerated sizes)
+// One workgroup of ZB_SC_WAVES waves per block.  Every wave walks the block summaries (positions, incoming repeat-offset history:
+// O(1) per block, wave-uniform), the waves share out the block's groups of 64 sequences: a first sweep leaves every group's literal
+// and output byte counts in LDS, their prefix sums place the groups, and then every group is scattered on its own - one word per
+// output byte.  (One wave per block took 0.9 ms of a single chunk's 2.7 ms: ~85 groups one after the other, each behind its own
+// loads - profiles/r03_dec_single_chunk_kernel_stats.txt.)
+#define ZB_SC_WAVES 8u
+#define ZB_SC_GROUPS ((ZS_BLOCK_MAX / 3u + LANES - 1) / LANES + 1)      /* a sequence regenerates >= 3 bytes, a block <= 128 KiB */
+__global__ __launch_bounds__(ZB_SC_WAVES * LANES) void zb_scatter_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                                         tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas,
+                                                                         uint64_t astride, uint32_t lit_cap, uint32_t seq_cap) {
+    __shared__ uint32_t sRegen[ZB_MAX_BLOCKS];                          // regenerated size of every block
     __shared__ uint32_t sHist[3][ZB_MAX_BLOCKS];                        // outgoing history of every block (symbolic in its incoming one)
     __shared__ uint8_t sFlag[ZB_MAX_BLOCKS];                            // 1 compressed, 2 decoded fine, 4 has sequences
-    __shared__ uint32_t gStart[LANES + 1], gLL[LANES], gLit[LANES], gSrc[LANES];   // the group of 64 sequences being scattered
-    const uint32_t lane = threadIdx.x, b = blockIdx.x, chunk = blockIdx.y;
+    __shared__ uint32_t sLit[ZB_SC_GROUPS + 1], sTot[ZB_SC_GROUPS + 1]; // per group of 64 sequences: literal / output bytes, then their exclusive prefixes
+    __shared__ uint32_t gStart[ZB_SC_WAVES][LANES + 1], gLL[ZB_SC_WAVES][LANES], gLit[ZB_SC_WAVES][LANES], gSrc[ZB_SC_WAVES][LANES];   // the group a wave is scattering
+    __shared__ uint32_t sFail;
+    const uint32_t tid = threadIdx.x, lane = tid & (LANES - 1), wv = DUNI(tid >> 6), b = blockIdx.x, chunk = blockIdx.y;
     ZbChunk* const C = (ZbChunk*)(hdrs + (size_t)chunk * ZB_CHUNK_HDR_BYTES);
     if (DUNI(ZB_LOAD_AGENT(&C->mode)) != 1) return;
     const uint32_t nb = DUNI(C->nblocks);
@@ -565,22 +601,21 @@ __global__ __launch_bounds__(LANES) void zb_scatter_kernel(const uint8_t* __rest
     const uint8_t* const litArena = arenas + (size_t)chunk * astride;
     const uint32_t* const seqArena = (const uint32_t*)(litArena + lit_cap);
     uint32_t* const words = (uint32_t*)(litArena + lit_cap + 12u * (size_t)seq_cap);      // one per output byte
-    for (uint32_t i = lane; i < nb; i += LANES) {
+    for (uint32_t i = tid; i < nb; i += ZB_SC_WAVES * LANES) {
         const ZbBlock* const S = &C->blk[i];
-        sStart[i] = S->regen;
+        sRegen[i] = S->regen;
         sHist[0][i] = S->endHist[0]; sHist[1][i] = S->endHist[1]; sHist[2][i] = S->endHist[2];
         sFlag[i] = (uint8_t)((S->btype == 2 ? 1 : 0) | (S->ok ? 2 : 0) | (S->nbSeq ? 4 : 0));
     }
+    if (tid == 0) sFail = 0;
     __threadfence_block();
     __syncthreads();
-    uint32_t h0 = 1, h1 = 4, h2 = 8;
+    uint32_t h0 = 1, h1 = 4, h2 = 8, myStart = 0, regen = 0;
     {
         uint32_t pos = 0; bool okAll = true;
-        for (uint32_t i = 0; i < nb; i++) {                             // wave-uniform; O(1) per block
-            const uint32_t rg = sStart[i];
-            WAVE_SYNC();
-            if (lane == 0) sStart[i] = pos;
-            const uint32_t fl = DUNI(sFlag[i]);
+        for (uint32_t i = 0; i < nb; i++) {                             // wave-uniform; O(1) per block; every wave for itself
+            const uint32_t rg = DUNI(sRegen[i]), fl = DUNI(sFlag[i]);
+            if (i == b) { myStart = pos; regen = rg; }
             if (fl & 1) {
                 if (!(fl & 2)) okAll = false;
                 if (i < b && (fl & 4)) {
@@ -592,25 +627,53 @@ __global__ __launch_bounds__(LANES) void zb_scatter_kernel(const uint8_t* __rest
             pos += rg;
             if (pos > ZB_MAX_CHUNK) { okAll = false; break; }
         }
-        if (lane == 0) sStart[nb] = pos;
-        __threadfence_block();
-        __syncthreads();
-        if (!okAll || pos != DUNI(C->contentSize)) { if (lane == 0) ZB_STORE_AGENT(&C->mode, 0u); return; }      // every wave of the chunk sees the same sums
+        if (!okAll || pos != DUNI(C->contentSize)) { if (tid == 0) ZB_STORE_AGENT(&C->mode, 0u); return; }       // every wave of the chunk sees the same sums
     }
     const ZbBlock* const B = &C->blk[b];
-    const uint32_t myStart = DUNI(sStart[b]), regen = DUNI(sStart[b + 1]) - myStart, btype = DUNI(B->btype), boff = DUNI(B->off);
+    const uint32_t btype = DUNI(B->btype), boff = DUNI(B->off);
     const uint32_t contentSize = DUNI(C->contentSize);
-    if (b == 0 && lane == 0) descs[chunk].dst_len = contentSize;
-    if (btype == 0) { for (uint32_t i = lane; i < regen; i += LANES) words[myStart + i] = ZB_LIT | src[boff + i]; return; }
-    if (btype == 1) { const uint32_t v = ZB_LIT | src[boff]; for (uint32_t i = lane; i < regen; i += LANES) words[myStart + i] = v; return; }
+    if (b == 0 && tid == 0) descs[chunk].dst_len = contentSize;
+    if (btype == 0) { for (uint32_t i = tid; i < regen; i += ZB_SC_WAVES * LANES) words[myStart + i] = ZB_LIT | src[boff + i]; return; }
+    if (btype == 1) { const uint32_t v = ZB_LIT | src[boff]; for (uint32_t i = tid; i < regen; i += ZB_SC_WAVES * LANES) words[myStart + i] = v; return; }
     const uint32_t litSize = DUNI(B->litSize), nbSeq = DUNI(B->nbSeq);
     const uint8_t* litPtr = litArena + DUNI(B->litAt);
     if (DUNI(B->ltype) == 0) { const ZbLit h = zb_lit_header(src + boff, DUNI(B->bsize)); litPtr = src + boff + h.hl; }
     const uint32_t* const sLL = seqArena + DUNI(B->seqAt); const uint32_t* const sML = sLL + seq_cap; const uint32_t* const sOF = sML + seq_cap;
-    uint32_t lp = 0, opos = myStart;
+    const uint32_t ngroups = (nbSeq + LANES - 1) / LANES;
+    if (ngroups > ZB_SC_GROUPS) { if (tid == 0) ZB_STORE_AGENT(&C->mode, 0u); return; }   // (the decode kernel bounds the match lengths' sum: cannot happen)
+    // sweep 1: the groups' byte counts
+    for (uint32_t gi = wv; gi < ngroups; gi += ZB_SC_WAVES) {
+        const uint32_t q = gi * LANES + lane;
+        uint32_t a = q < nbSeq ? sLL[q] : 0, t = q < nbSeq ? a + sML[q] : 0;
+        for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); t += __shfl_xor(t, o); }
+        if (lane == 0) { sLit[gi] = a; sTot[gi] = t; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wv == 0) {                                                       // exclusive prefixes, 64 groups per step
+        uint32_t cl = 0, ct = 0;
+        for (uint32_t g0 = 0; g0 <= ngroups; g0 += LANES) {
+            const uint32_t gi = g0 + lane;
+            const uint32_t a = gi < ngroups ? sLit[gi] : 0, t = gi < ngroups ? sTot[gi] : 0;
+            uint32_t ia = a, it = t;
+            for (int o = 1; o < LANES; o <<= 1) {
+                const uint32_t x = __shfl_up(ia, o), y = __shfl_up(it, o);
+                if (lane >= (uint32_t)o) { ia += x; it += y; }
+            }
+            if (gi <= ngroups) { sLit[gi] = cl + ia - a; sTot[gi] = ct + it - t; }
+            cl += (uint32_t)__builtin_amdgcn_readlane(ia, LANES - 1); ct += (uint32_t)__builtin_amdgcn_readlane(it, LANES - 1);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t allLit = DUNI(sLit[ngroups]), allTot = DUNI(sTot[ngroups]);
+    if (allLit > litSize || allTot + (litSize - allLit) != regen) { if (tid == 0) ZB_STORE_AGENT(&C->mode, 0u); return; }    // (sums the decode kernel has checked)
+    // sweep 2: every group on its own
     bool fail = false;
-    for (uint32_t g = 0; g < nbSeq; g += LANES) {
+    for (uint32_t gi = wv; gi < ngroups; gi += ZB_SC_WAVES) {
+        const uint32_t g = gi * LANES;
         const uint32_t cnt = nbSeq - g < LANES ? nbSeq - g : LANES;
+        const uint32_t lp = DUNI(sLit[gi]), opos = myStart + DUNI(sTot[gi]), groupTot = DUNI(sTot[gi + 1]) - DUNI(sTot[gi]);
         const bool valid = lane < cnt;
         const uint32_t ll = valid ? sLL[g + lane] : 0, ml = valid ? sML[g + lane] : 0;
         uint32_t off = valid ? sOF[g + lane] : 0;
@@ -620,31 +683,28 @@ __global__ __launch_bounds__(LANES) void zb_scatter_kernel(const uint8_t* __rest
             const uint32_t a = __shfl_up(litIncl, o), t = __shfl_up(totIncl, o);
             if (lane >= (uint32_t)o) { litIncl += a; totIncl += t; }
         }
-        const uint32_t groupLit = (uint32_t)__builtin_amdgcn_readlane(litIncl, LANES - 1), groupTot = (uint32_t)__builtin_amdgcn_readlane(totIncl, LANES - 1);
-        if (lp + groupLit > litSize || opos + groupTot > myStart + regen) { fail = true; break; }
         const uint32_t myLit = lp + litIncl - ll, myOut = opos + totIncl - (ll + ml), mOut = myOut + ll;
         if (__any(valid && ml && (off == 0 || off > mOut))) { fail = true; break; }
         // the group's ~1.5 KB of output, one word per byte, written by all lanes side by side: position -> its sequence by a
         // binary search over the 64 start positions (a lane walking its own run would serialise a 100 KB match on one lane)
         WAVE_SYNC();
-        gStart[lane] = valid ? myOut : opos + groupTot; gLL[lane] = ll; gLit[lane] = myLit; gSrc[lane] = mOut - off;
-        if (lane == 0) gStart[LANES] = opos + groupTot;
+        gStart[wv][lane] = valid ? myOut : opos + groupTot; gLL[wv][lane] = ll; gLit[wv][lane] = myLit; gSrc[wv][lane] = mOut - off;
+        if (lane == 0) gStart[wv][LANES] = opos + groupTot;
         __threadfence_block();
         WAVE_SYNC();
         for (uint32_t p = opos + lane; p < opos + groupTot; p += LANES) {
             uint32_t i = 0;
-            for (uint32_t s_ = 32; s_; s_ >>= 1) if (gStart[i + s_] <= p) i += s_;      // the last sequence that starts at or before p
-            const uint32_t rel = p - gStart[i], l_ = gLL[i];
-            words[p] = rel < l_ ? (ZB_LIT | litPtr[gLit[i] + rel]) : gSrc[i] + (rel - l_);
+            for (uint32_t s_ = 32; s_; s_ >>= 1) if (gStart[wv][i + s_] <= p) i += s_;     // the last sequence that starts at or before p
+            const uint32_t rel = p - gStart[wv][i], l_ = gLL[wv][i];
+            words[p] = rel < l_ ? (ZB_LIT | litPtr[gLit[wv][i] + rel]) : gSrc[wv][i] + (rel - l_);
         }
-        lp += groupLit; opos += groupTot;
     }
-    if (!fail) {
-        const uint32_t tail = litSize - lp;
-        if (opos + tail != myStart + regen) fail = true;
-        else for (uint32_t k = lane; k < tail; k += LANES) words[opos + k] = ZB_LIT | litPtr[lp + k];
-    }
-    if (fail && lane == 0) ZB_STORE_AGENT(&C->mode, 0u);                // the chunk-serial kernel behind this launch redoes the chunk
+    if (fail && lane == 0) sFail = 1;
+    // the literals behind the last sequence
+    for (uint32_t k = tid; k < litSize - allLit; k += ZB_SC_WAVES * LANES) words[myStart + allTot + k] = ZB_LIT | litPtr[allLit + k];
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0 && sFail) ZB_STORE_AGENT(&C->mode, 0u);                // the chunk-serial kernel behind this launch redoes the chunk
 }
 
 // one jump round: every unresolved word takes its source's word (four words per thread).  Chain depths are small in practice (log-like
@@ -663,12 +723,20 @@ __global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs
     if (p + 4 <= n) {
         uint4 v = *reinterpret_cast<const uint4*>(words + p);
         if ((v.x & v.y & v.z & v.w) & ZB_LIT) return;                   // all four resolved already
-        const uint32_t a = (v.x & ZB_LIT) ? v.x : words[v.x], b_ = (v.y & ZB_LIT) ? v.y : words[v.y], c = (v.z & ZB_LIT) ? v.z : words[v.z], d_ = (v.w & ZB_LIT) ? v.w : words[v.w];
+        // two jumps per pass: a word that is still a position after the first takes its source's word once more (a pass costs one
+        // read and one write of the word array whatever it resolves: log4 instead of log2 passes)
+        uint32_t a = (v.x & ZB_LIT) ? v.x : words[v.x], b_ = (v.y & ZB_LIT) ? v.y : words[v.y], c = (v.z & ZB_LIT) ? v.z : words[v.z], d_ = (v.w & ZB_LIT) ? v.w : words[v.w];
+        if (!((a & b_ & c & d_) & ZB_LIT)) {
+            a = (a & ZB_LIT) ? a : words[a]; b_ = (b_ & ZB_LIT) ? b_ : words[b_]; c = (c & ZB_LIT) ? c : words[c]; d_ = (d_ & ZB_LIT) ? d_ : words[d_];
+        }
         v.x = a; v.y = b_; v.z = c; v.w = d_;
         *reinterpret_cast<uint4*>(words + p) = v;
         if (!((a & b_ & c & d_) & ZB_LIT) && round < 32) C->live[round] = 1;       // (every writer stores the same value)
     } else {
-        for (uint32_t q = p; q < n; q++) { const uint32_t v = words[q]; if (!(v & ZB_LIT)) { const uint32_t w = words[v]; words[q] = w; if (!(w & ZB_LIT) && round < 32) C->live[round] = 1; } }
+        for (uint32_t q = p; q < n; q++) {
+            const uint32_t v = words[q];
+            if (!(v & ZB_LIT)) { uint32_t w = words[v]; if (!(w & ZB_LIT)) w = words[w]; words[q] = w; if (!(w & ZB_LIT) && round < 32) C->live[round] = 1; }
+        }
     }
 }
 
@@ -722,10 +790,16 @@ uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames
     const size_t astride = zb_arena_stride(max_out);
     const uint32_t lit_cap = zb_lit_cap(max_out), seq_cap = zb_seq_cap(max_out);
     hipLaunchKernelGGL(zb_index_kernel, dim3(n), dim3(LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, (const int32_t*)d_status, hdrs, lit_cap, seq_cap);
-    hipLaunchKernelGGL(zb_decode_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(2 * LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
-    hipLaunchKernelGGL(zb_scatter_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(LANES), 0, st, frames, from_mid, mid_stride, d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
-    // a copy chain is at most as long as the chunk: ceil(log2(max_out)) doublings resolve every word (a round over resolved words is a read)
-    uint32_t rounds = 1; while ((1ull << rounds) < (uint64_t)max_out + 1) rounds++;
+    hipLaunchKernelGGL(zb_decode_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(2 * LANES), 0, st, frames, from_mid, mid_stride, (const tsx_chunk_desc*)d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap
+#ifdef TSX_PROF2
+                       , g_zbprof_out
+#endif
+                       );
+    hipLaunchKernelGGL(zb_scatter_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(ZB_SC_WAVES * LANES), 0, st, frames, from_mid, mid_stride, d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
+    // a copy chain is at most as long as the chunk and a pass makes two jumps: ceil(log4(max_out)) + 1 passes resolve every word (the passes
+    // behind one that resolved everything return at once)
+    uint32_t bits = 1; while ((1ull << bits) < (uint64_t)max_out + 1) bits++;
+    const uint32_t rounds = (bits + 1) / 2 + 1;
     const uint32_t tiles = (max_out + 1023) / 1024;                     // 256 threads x 4 words
     for (uint32_t r = 0; r < rounds; r++)
         hipLaunchKernelGGL(zb_jump_kernel, dim3(tiles, n), dim3(256), 0, st, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap, r);

@@ -53,6 +53,13 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained > $O/bench_under_rocprofv3.json 2> $O/trace.err )
       f=$(find $O/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/bench_rocprofv3_kernel_stats.csv && head -8 $f
       find $O/trace -name "*kernel_trace.csv" -delete ;;
+    dectrace)
+      # per-kernel time of a single-chunk (or arg-chunk) inverse call, both decoder forms (kernel names tell them apart)
+      ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/dectrace -o dec --output-format csv -- python $R/tools/dec_latency.py ${arg:-1} > $O/dec_under_rocprofv3.jsonl 2> $O/dectrace.err )
+      f=$(find $O/dectrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/dec_rocprofv3_kernel_stats.csv && head -20 $f
+      find $O/dectrace -name "*kernel_trace.csv" -delete ;;
+    zblaps)
+      timeout 300 python tools/zb_phase_laps.py ${arg:-4} 2>&1 | grep -v amdgpu.ids | tee $O/zb_phase_laps.txt ;;
     dec)
       timeout 600 python tools/dec_latency.py ${arg:-256} > $O/dec_latency.jsonl 2> $O/dec_latency.err; cat $O/dec_latency.jsonl; tail -3 $O/dec_latency.err ;;
     prio)
