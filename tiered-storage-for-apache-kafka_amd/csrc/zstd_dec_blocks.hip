@@ -421,7 +421,7 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
     ZLT(0);
     uint32_t* const sLL = seqArena + DUNI(B->seqAt); uint32_t* const sML = sLL + seq_cap; uint32_t* const sOF = sML + seq_cap;
     const uint32_t llLog = DUNI(L.llLog), ofLog = DUNI(L.ofLog), mlLog = DUNI(L.mlLog);
-    const uint8_t* const win = L.swin;
+    const uint8_t* const win = L.swin + ZS_DPAD;
     const uint32_t t = DUNI(B->streamOff);
     const uint32_t n = bsize - t;                                       // >= 1 (index kernel)
     const uint8_t* const stream = blk + t;
@@ -444,8 +444,9 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
                 uint4 v;
                 if (wbase + k + 16 <= n) __builtin_memcpy(&v, stream + wbase + k, 16);
                 else { uint8_t tmp[16]; for (uint32_t j = 0; j < 16; j++) tmp[j] = wbase + k + j < n ? stream[wbase + k + j] : 0; __builtin_memcpy(&v, tmp, 16); }
-                *reinterpret_cast<uint4*>(&L.swin[k]) = v;
+                *reinterpret_cast<uint4*>(&L.swin[ZS_DPAD + k]) = v;
             }
+            if (lane < ZS_DPAD / 4) reinterpret_cast<uint32_t*>(L.swin)[lane] = 0;      // the margin in front of the window
             __threadfence_block();
             WAVE_SYNC();
             if (!filled) {
@@ -463,22 +464,12 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
         uint32_t bad = 0;
         const uint32_t Bgroup = Bc;
         const uint32_t upd = g + cnt < nbSeq ? cnt : cnt - 1;
-        for (uint32_t j = 0; j < upd; j++) {
-            const uint32_t p8 = (Bc >> 3) > 7 ? (Bc >> 3) - 7 : 0;
-            uint64_t c8 = wld64(win, wbase, p8);
-            const uint32_t e_ = tbl[st];
-            recp[j * 4] = (uint16_t)st;
-            TSX_SCHED_BARRIER();
-            const uint32_t pc = SEQD_COUNTS(e_);
-            const uint32_t qc = pc + DPP_SHL(pc, 1) + DPP_SHL(pc, 2);
-            const int32_t raw = (int32_t)(Bc - DUNI(qc >> 5));
-            bad |= (uint32_t)raw;
-            const uint32_t lo = (uint32_t)(raw < 0 ? 0 : raw);
-            uint32_t sh = lo - 8 * p8;
-            if (lo < 8 * p8) { c8 = wld64(win, wbase, lo >> 3); sh = lo & 7; }
-            st = SEQD_BASE(e_) + ((uint32_t)(c8 >> (sh + ((qc - pc) & 31))) & ((1u << (pc & 31)) - 1));
-            Bc = lo;
+        uint32_t j = 0;
+        for (; j + 2 <= upd; j += 2) {                                    // two steps per trip: rec offsets become immediates, half the loop control
+            seq_chain_step(tbl, recp + j * 4, win, wbase, st, Bc, bad);
+            seq_chain_step(tbl, recp + j * 4 + 4, win, wbase, st, Bc, bad);
         }
+        if (j < upd) seq_chain_step(tbl, recp + j * 4, win, wbase, st, Bc, bad);
         if (upd < cnt) {
             const uint32_t e_ = tbl[st];
             recp[upd * 4] = (uint16_t)st;

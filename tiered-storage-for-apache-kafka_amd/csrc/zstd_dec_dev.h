@@ -19,6 +19,7 @@ __device__ static inline uint32_t dhb32(uint32_t v) { return 31u - (uint32_t)__c
 __device__ static inline uint64_t dld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
 #define ZS_DWIN 2048u
+#define ZS_DPAD 16u
 #define ZS_HWIN 256u
 struct FseD { uint16_t base; uint8_t sym; uint8_t nb; };
 // sequence decoding entry, one dword: next-state base (bits 0-8) | nbBits (9-13) | nbBits + the symbol's number of extra
@@ -83,7 +84,7 @@ struct DecLds {
     uint32_t nseq[2];            // sequence stage -> execution stage: number of sequences of block k in slot k & 1
     int32_t err;                 // first error of either wave
     alignas(16) uint8_t hwin[4 * (ZS_HWIN + 16)];   // one window per Huffman stream
-    alignas(16) uint8_t swin[ZS_DWIN + 32];        // the sequence bit stream's window
+    alignas(16) uint8_t swin[ZS_DPAD + ZS_DWIN + 32];   // the sequence bit stream's window behind ZS_DPAD zero bytes (seq_chain_step reads up to 7 bytes in front of the stream)
 };
 
 // ---- backward bit reader (BIT_DStream) -----------------------------------------------------------------
@@ -128,6 +129,34 @@ __device__ static inline bool br_reload(BitR& b) {
 // An 8-byte read from a window of a bit stream held in LDS: win[0 ..) = stream bytes [wbase ..), positions are offsets in the
 // stream, so no pointer ever leaves the window array.
 __device__ static inline uint64_t wld64(const uint8_t* win, uint32_t wbase, uint32_t pos) { return dld64(win + (pos - wbase)); }
+
+// One step of the sequence chain (pass 1 of the sequence stage in zstd_dec.hip and zstd_dec_blocks.hip), on the vector unit.  Lanes 0, 1, 2
+// run the LL, ML and OF state machines (that is the order in which a sequence's state-update bits sit in the stream, highest first); the
+// other lanes carry state 0 through an all-zero entry.  One table read serves all three, two DPP adds give every machine the bits below
+// its own field and lane 0 the sequence's bit total, and the 8 bytes that hold the update bits are read together with the entries from
+// the cursor alone ([B - 56.., B)): only a sequence that reads more than 56 bits needs a second, dependent read.  win = the window
+// behind its ZS_DPAD zero bytes: near the stream's start the 8 bytes begin up to 7 bytes in front of it, which costs no select.  The
+// state goes to *rec for pass 2; an over-read shows as a negative cursor (collected in bad, checked once per group) and is clamped so that
+// no load leaves the window.  The wave is alone on its SIMD, so a step costs its instruction count (~5 cycles each) plus one LDS latency:
+// profiles/r03_zb_phase_laps.txt.
+__device__ __forceinline__ void seq_chain_step(const SeqD* __restrict__ tbl, uint16_t* __restrict__ rec, const uint8_t* __restrict__ win, uint32_t wbase,
+                                               uint32_t& st, uint32_t& B, uint32_t& bad) {
+    const int32_t p8 = (int32_t)(B >> 3) - 7;                           // >= wbase when wbase != 0 (the window's margin), >= -7 else
+    const uint32_t e_ = tbl[st];                                        // first: LDS answers in order, and this is the read the chain waits for
+    uint64_t c8 = dld64(win + (p8 - (int32_t)wbase));
+    *rec = (uint16_t)st;
+    TSX_SCHED_BARRIER();                                                // both reads are in flight before anything waits
+    const uint32_t pc = SEQD_COUNTS(e_);
+    const uint32_t below = DPP_SHL(pc, 1) + DPP_SHL(pc, 2);             // the machines below this one
+    // extra bits of the offset, match length, literal length, then the state updates: LL, ML, OF (ZSTD_decodeSequence order)
+    const int32_t raw = (int32_t)(B - DUNI((pc + below) >> 5));
+    bad |= (uint32_t)raw;
+    const uint32_t lo = (uint32_t)(raw < 0 ? 0 : raw);
+    int32_t sh = (int32_t)lo - 8 * p8;
+    if (__builtin_expect(sh < 0, 0)) { c8 = wld64(win, wbase, lo >> 3); sh = (int32_t)(lo & 7); }       // rare
+    st = SEQD_BASE(e_) + ((uint32_t)(c8 >> ((uint32_t)sh + (below & 31))) & ((1u << (pc & 31)) - 1));
+    B = lo;
+}
 
 // ---- FSE table description + decoding table (lane 0) ---------------------------------------------------------
 // returns bytes consumed, 0 on error

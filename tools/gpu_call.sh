@@ -9,6 +9,7 @@
 #   pmc            PMC passes over the compressor + decoder (tools/pmc_zstd.sh, tools/pmc_dec.sh)
 #   trace          rocprofv3 --kernel-trace --stats of the bench's timed region
 #   prio           per-block wave priority modes in the sustained regime (tools/steady_state_probe.py)
+#   detr[:n]       big-batch inverse chain (tools/detransform_bench.py);  pmcdec: PMC passes over the decoder only;  zblaps[:n] / dectrace[:n]: block-form laps / kernel stats
 #   dec[:nmax]     fetch-side latency of 1 .. nmax chunks, block-parallel vs chunk-serial decoder form (tools/dec_latency.py)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
@@ -58,6 +59,10 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/dectrace -o dec --output-format csv -- python $R/tools/dec_latency.py ${arg:-1} > $O/dec_under_rocprofv3.jsonl 2> $O/dectrace.err )
       f=$(find $O/dectrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/dec_rocprofv3_kernel_stats.csv && head -20 $f
       find $O/dectrace -name "*kernel_trace.csv" -delete ;;
+    detr)
+      timeout 300 python tools/detransform_bench.py ${arg:-2048} 2>&1 | grep -v amdgpu.ids | tee $O/detransform_bench.txt ;;
+    pmcdec)
+      bash tools/pmc_dec.sh > $O/pmc_dec.log 2>&1; python tools/show_pmc.py gpurun_out/pmc_dec | sed 's/^/dec /' | tee $O/pmc_dec_summary.txt ;;
     zblaps)
       timeout 300 python tools/zb_phase_laps.py ${arg:-4} 2>&1 | grep -v amdgpu.ids | tee $O/zb_phase_laps.txt ;;
     dec)
