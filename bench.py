@@ -57,6 +57,7 @@ def parse():
                     help="with --split-segments: rank 0 (the owner of the upload stream) also receives every rank's slice of the transformed object inside the step (send / recv)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the continuously-fed measurement (5 callers, 10 batches each) after the timed region")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host->host (PCIe-inclusive) measurement after the timed region")
+    ap.add_argument("--broker-in-process", action="store_true", help="run the broker-shaped leg in this process (torch's bundled HIP runtime) instead of tools/broker_leg.py (the system's)")
     ap.add_argument("--no-broker", action="store_true", help="skip the broker-shaped leg of end_to_end (10 / 20 callers x 256-chunk segments, pooled contexts, registered buffers)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
@@ -633,70 +634,46 @@ def main():
         # TSX_MEM_HOST_PACKED from a registered source into a registered per-thread output buffer - what GpuTransformChunkEnumeration
         # issues (20 callers = 10 threads with one batch of read-ahead each; 32 = 16 such threads).  The loop is closed - a caller's next
         # call follows its last - so the row is bounded by the chunks the callers OFFER: 2560 / 5120 / 8192 against the 6144 the chip holds.
+        # The leg lives in tools/broker_leg.py and runs in a process of its own, WITHOUT torch: this process's HIP runtime is the one torch
+        # bundles (7.0.2), which moves device -> host copies with blit kernels - they wait for CU slots behind the compressor's waves - where
+        # the system's runtime (what a broker's JVM loads) uses the SDMA engines (profiles/r03_copy_engine_probe.txt).  The device stays
+        # this process's too: it is idle while the child runs.  --broker-in-process keeps the leg here (torch's runtime).
         broker = None
         if T > 1 and n >= 256 and not args.no_broker:
-            broker = []
             B = 256
-            cap = B * (2 << 20)                                           # packed output of one segment: 0.33 GiB at r = 0.31, 0.5 GiB of room
-            N.host_register(hsrc)
-            bufs = []
-            try:
-                for callers in (10, 20, 32):
-                    while len(bufs) < callers:
-                        hb = np.zeros(cap, np.uint8); N.host_register(hb); bufs.append(hb)
-                    segs = [hsrc[(t % (n // B)) * B * CH:((t % (n // B)) + 1) * B * CH] for t in range(callers)]
-                    des = []
-                    for t in range(callers):
-                        dd = np.zeros(B, nat.DESC_DTYPE)
-                        dd["src_off"] = np.arange(B, dtype=np.uint64) * CH; dd["src_len"] = CH
-                        dd["iv"] = d["iv"][(t % (n // B)) * B:((t % (n // B)) + 1) * B]
-                        des.append(dd)
-                    window = 8.0                                          # seconds of continuous calling per row (closed loop: a caller's next call follows its last)
-                    lat = [[] for _ in range(callers)]
-                    stamps = []
-                    stop_at = [0.0]
-
-                    def bworker(t, warm):
-                        while True:
-                            a = time.perf_counter()
-                            N.transform_batch(params, des[t], segs[t], bufs[t], cap, nat.MEM_HOST_PACKED, ctx=None)
-                            b_ = time.perf_counter()
-                            if warm:
-                                return
-                            lat[t].append(b_ - a)
-                            with lock:
-                                stamps.append(b_)
-                            if b_ >= stop_at[0]:
-                                return
-
-                    th = [threading.Thread(target=bworker, args=(t, True)) for t in range(callers)]     # pooled contexts and their workspaces exist
-                    [x.start() for x in th]; [x.join() for x in th]
-                    t1 = time.perf_counter()
-                    stop_at[0] = t1 + window
-                    th = [threading.Thread(target=bworker, args=(t, False)) for t in range(callers)]
-                    [x.start() for x in th]; [x.join() for x in th]
-                    ok = all(bool((dd["status"] == 0).all()) and bool((dd["dst_len"] == d["dst_len"][(t % (n // B)) * B:((t % (n // B)) + 1) * B]).all())
-                             for t, dd in enumerate(des))
-                    # rate = least-squares slope of completions over time across the middle 60 % of the run (no ramp, no drain; counting the
-                    # calls that end inside a fixed window would quantise: at 2.5 s per call a caller completes one or two calls in it)
-                    done_at = np.sort(np.asarray(stamps)) - t1
-                    done = len(done_at)
-                    k0, k1 = int(done * 0.2), max(int(done * 0.8), int(done * 0.2) + 2)
-                    slope = float(np.polyfit(done_at[k0:k1], np.arange(k0, min(k1, done)), 1)[0]) if done >= 4 else done / max(float(done_at[-1]), 1e-9)
-                    gibs = slope * B * CH / GiB
-                    broker.append({"callers": callers, "batch_chunks": B, "chunks_offered": callers * B, "calls": done, "seconds": round(float(done_at[-1]), 2), "method": "slope of completions, middle 60 %",
-                                   "context": "pooled (ctx = NULL), launch combiner", "dst_layout": "packed",
-                                   "host_memory": "source and outputs registered", "gibs": round(gibs, 4), "frac_of_device_resident_value": round(gibs / value, 3),
-                                   "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat if x]))) * 1e3, 1),
-                                   "same_sizes_as_device_run": ok})
-            finally:
-                for hb in bufs:
-                    N.host_unregister(hb)
-                N.host_unregister(hsrc)
-            del bufs
+            bseg = min(2, n // B)                                         # two distinct segments, the callers alternate
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import broker_leg
+            if args.broker_in_process:
+                broker = broker_leg.run(N, nat, params, hsrc[:bseg * B * CH], d["iv"][:bseg * B], d["dst_len"][:bseg * B], (10, 20, 32), B, CH, 8.0)
+            else:
+                import subprocess
+                import tempfile
+                shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+                tmpd = tempfile.mkdtemp(prefix="tsx_broker_", dir=shm)
+                try:
+                    np.save(os.path.join(tmpd, "src.npy"), hsrc[:bseg * B * CH]); np.save(os.path.join(tmpd, "ivs.npy"), d["iv"][:bseg * B])
+                    np.save(os.path.join(tmpd, "expect.npy"), d["dst_len"][:bseg * B])
+                    cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "broker_leg.py"), "--src", os.path.join(tmpd, "src.npy"),
+                                         "--ivs", os.path.join(tmpd, "ivs.npy"), "--expect", os.path.join(tmpd, "expect.npy"), "--callers", "10,20,32",
+                                         "--batch", str(B), "--chunk", str(CH), "--profile", str(profile)], capture_output=True, text=True, timeout=600)
+                    lines = [ln for ln in cp.stdout.strip().splitlines() if ln.startswith("[")]
+                    if cp.returncode == 0 and lines:
+                        broker = json.loads(lines[-1])
+                    else:
+                        broker = [{"error": "tools/broker_leg.py failed (rc %d): %s" % (cp.returncode, cp.stderr.strip()[-300:])}]
+                except (OSError, subprocess.SubprocessError, ValueError) as e:
+                    broker = [{"error": "tools/broker_leg.py: %r" % (e,)}]
+                finally:
+                    import shutil
+                    shutil.rmtree(tmpd, ignore_errors=True)
+            for b_ in broker:
+                if "gibs" in b_:
+                    b_["frac_of_device_resident_value"] = round(b_["gibs"] / value, 3)
+                    b_["process"] = "this one (torch's HIP runtime)" if args.broker_in_process else "tools/broker_leg.py, no torch: the system's HIP runtime, as a JVM loads it"
         e2e = {"metric": "GiB/s of original bytes, host buffers in -> host buffers out (PCIe inclusive)",
                "chunks": n, "pcie_peak_GBs_per_direction": PCIE, "one_batch_at_a_time": rows, "batches_in_flight": conc, "broker": broker,
-               "value": max([r["gibs"] for r in rows] + [c_["gibs"] for c_ in (conc or [])] + [b_["gibs"] for b_ in (broker or [])]) if rows else None, "unit": "GiB/s"}
+               "value": max([r["gibs"] for r in rows] + [c_["gibs"] for c_ in (conc or [])] + [b_["gibs"] for b_ in (broker or []) if "gibs" in b_]) if rows else None, "unit": "GiB/s"}
         del hsrc, hdst
 
     if rank == 0:

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""The broker-shaped leg of bench.py's `end_to_end` object, runnable in a process of its own WITHOUT torch.
+
+Shape (reference README.md:218-222, RemoteStorageManager.java:400-432: >= 10 RLM upload threads, one segment each): `callers`
+threads, every call ONE B-chunk segment, context-less (pooled contexts, as the JNI shim calls), TSX_MEM_HOST_PACKED from a registered
+source into a registered per-thread output buffer - what GpuTransformChunkEnumeration issues.  The loop is closed: a caller's next
+call follows its last.
+
+Why a process of its own: a process has ONE HIP runtime - the first one loaded.  bench.py imports torch, and torch brings its own
+(HIP 7.0.2 in this image), which moves device -> host copies with blit KERNELS; the system's runtime (7.2, what a broker's JVM loads
+through libtsxform.so) uses the SDMA engines.  A copy kernel needs CU slots, and on a chip full of second-long compressor waves it
+waits for them: with torch in the process 32 callers moved 11.7 GiB/s, without it 14.3 (profiles/r03_copy_engine_probe.txt,
+r03_broker_with_and_without_torch.jsonl).  bench.py therefore runs this leg as `python tools/broker_leg.py ...` and quotes its rows.
+
+  broker_leg.py --src S.npy --ivs I.npy --expect L.npy --callers 10,20,32 [--batch 256] [--chunk 4194304] [--window 8] [--lib path]
+prints one JSON line: the list of rows."""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GiB = float(1 << 30)
+
+
+def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_note=""):
+    """hsrc: nseg * B * CH source bytes (registered here), ivs: (nseg * B, 12), expect: dst_len of every chunk from the device-resident run."""
+    nseg = hsrc.size // (B * CH)
+    cap = B * (CH // 2 + (64 << 10))                                     # packed output of one segment: 0.33 of the input at r = 0.31, half of it of room
+    lock = threading.Lock()
+    rows = []
+    N.host_register(hsrc)
+    bufs = []
+    try:
+        for callers in callers_list:
+            while len(bufs) < callers:
+                hb = np.zeros(cap, np.uint8); N.host_register(hb); bufs.append(hb)
+            segs = [hsrc[(t % nseg) * B * CH:((t % nseg) + 1) * B * CH] for t in range(callers)]
+            des = []
+            for t in range(callers):
+                dd = np.zeros(B, nat.DESC_DTYPE)
+                dd["src_off"] = np.arange(B, dtype=np.uint64) * CH; dd["src_len"] = CH
+                dd["iv"] = ivs[(t % nseg) * B:((t % nseg) + 1) * B]
+                des.append(dd)
+            lat = [[] for _ in range(callers)]
+            stamps = []
+            stop_at = [0.0]
+
+            def bworker(t, warm):
+                while True:
+                    a = time.perf_counter()
+                    N.transform_batch(params, des[t], segs[t], bufs[t], cap, nat.MEM_HOST_PACKED, ctx=None)
+                    b_ = time.perf_counter()
+                    if warm:
+                        return
+                    lat[t].append(b_ - a)
+                    with lock:
+                        stamps.append(b_)
+                    if b_ >= stop_at[0]:
+                        return
+
+            th = [threading.Thread(target=bworker, args=(t, True)) for t in range(callers)]     # pooled contexts and their workspaces exist
+            [x.start() for x in th]; [x.join() for x in th]
+            t1 = time.perf_counter()
+            stop_at[0] = t1 + window
+            th = [threading.Thread(target=bworker, args=(t, False)) for t in range(callers)]
+            [x.start() for x in th]; [x.join() for x in th]
+            ok = all(bool((dd["status"] == 0).all()) and bool((dd["dst_len"] == expect[(t % nseg) * B:((t % nseg) + 1) * B]).all())
+                     for t, dd in enumerate(des))
+            # rate = least-squares slope of completions over time across the middle 60 % of the run (no ramp, no drain; counting the
+            # calls that end inside a fixed window would quantise: at 2.5 s per call a caller completes one or two calls in it)
+            done_at = np.sort(np.asarray(stamps)) - t1
+            done = len(done_at)
+            k0, k1 = int(done * 0.2), max(int(done * 0.8), int(done * 0.2) + 2)
+            slope = float(np.polyfit(done_at[k0:k1], np.arange(k0, min(k1, done)), 1)[0]) if done >= 4 else done / max(float(done_at[-1]), 1e-9)
+            gibs = slope * B * CH / GiB
+            rows.append({"callers": callers, "batch_chunks": B, "chunks_offered": callers * B, "calls": done, "seconds": round(float(done_at[-1]), 2),
+                         "method": "slope of completions, middle 60 %", "context": "pooled (ctx = NULL), launch combiner", "dst_layout": "packed",
+                         "host_memory": "source and outputs registered", "gibs": round(gibs, 4),
+                         "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat if x]))) * 1e3, 1),
+                         "same_sizes_as_device_run": ok, "torch_in_process": "torch" in sys.modules})
+    finally:
+        for hb in bufs:
+            N.host_unregister(hb)
+        N.host_unregister(hsrc)
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--src", required=True); ap.add_argument("--ivs", required=True); ap.add_argument("--expect", required=True)
+    ap.add_argument("--callers", default="10,20,32")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--chunk", type=int, default=4 << 20)
+    ap.add_argument("--window", type=float, default=8.0)
+    ap.add_argument("--profile", type=int, default=0)
+    ap.add_argument("--lib", default="")
+    args = ap.parse_args()
+    import tsxform
+    from tsxform import synth
+    nat = tsxform._native
+    N = nat.Native(args.lib) if args.lib else nat.Native()
+    N.init(1, [0])
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=args.profile)
+    hsrc = np.load(args.src); ivs = np.load(args.ivs); expect = np.load(args.expect)
+    rows = run(N, nat, params, hsrc, ivs, expect, [int(x) for x in args.callers.split(",")], args.batch, args.chunk, args.window)
+    print(json.dumps(rows), flush=True)
+
+
+if __name__ == "__main__":
+    main()

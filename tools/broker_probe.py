@@ -29,25 +29,39 @@ def main():
     ap.add_argument("--seconds", type=float, default=6.0, help="approximate run time per configuration")
     ap.add_argument("--pool-chunks", type=int, default=2048, help="distinct source chunks generated (threads take slices)")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--src-file", default="", help=".npy of the source chunks: written if missing (needs torch), loaded otherwise - with --mem host the process then "
+                    "runs WITHOUT torch, i.e. on the system's HIP runtime as a broker's JVM does (torch bundles its own, older one: profiles/r03_copy_engine_probe.txt)")
+    ap.add_argument("--gen-only", action="store_true")
     args = ap.parse_args()
-    import torch
     import tsxform
     from tsxform import synth
     nat = tsxform._native
+    CH = synth.CHUNK
+    P = args.pool_chunks
+    torch = None
+    hsrc = None
+    if args.mem == "host" and args.src_file and os.path.exists(args.src_file):
+        hsrc = np.load(args.src_file)
+        assert hsrc.size == P * CH
+    if hsrc is None:
+        import torch                                   # before libtsxform: a process has ONE HIP runtime, the first one loaded (torch bundles its own)
     N = nat.Native()
     N.init(1, [0])
-    dev = torch.device("cuda", 0)
-    CH = synth.CHUNK
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
-    P = args.pool_chunks
-    src = torch.empty(P * CH, dtype=torch.uint8, device=dev)
-    for i in range(P):
-        src[i * CH:(i + 1) * CH] = synth.gen_chunk("K", 1000 + i // 256, i // 256, i % 256, CH, device=dev)
-    torch.cuda.synchronize()
-    hsrc = None
+    if hsrc is None:
+        dev = torch.device("cuda", 0)
+        src = torch.empty(P * CH, dtype=torch.uint8, device=dev)
+        for i in range(P):
+            src[i * CH:(i + 1) * CH] = synth.gen_chunk("K", 1000 + i // 256, i // 256, i % 256, CH, device=dev)
+        torch.cuda.synchronize()
+        if args.mem == "host" or args.gen_only:
+            hsrc = src.cpu().numpy()
+            if args.src_file:
+                np.save(args.src_file, hsrc)
+        if args.gen_only:
+            return
     if args.mem == "host":
-        hsrc = src.cpu().numpy()
         N.host_register(hsrc)
     params = nat.Native.make_params(flags, synth.KEY, synth.AAD)
     for cfg in args.configs.split(","):
@@ -79,7 +93,8 @@ def main():
 
         for t in range(min(T, 4)):                       # workspaces / pools exist before the clock starts
             call(t)
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         done = [0] * T
         lat = [[] for _ in range(T)]
         stop_at = [0.0]
@@ -96,11 +111,12 @@ def main():
         th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
         [x.start() for x in th]
         [x.join() for x in th]
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         el = time.perf_counter() - t0
         ok = all(bool((d["status"] == 0).all()) for d in descs)
         allat = np.concatenate([np.asarray(x) for x in lat]) if sum(done) else np.zeros(1)
-        print(json.dumps({"tag": args.tag, "threads": T, "batch_chunks": B, "mem": args.mem, "ctxless": args.ctxless,
+        print(json.dumps({"tag": args.tag, "torch_in_process": "torch" in sys.modules, "threads": T, "batch_chunks": B, "mem": args.mem, "ctxless": args.ctxless,
                           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "batches": int(sum(done)), "seconds": round(el, 3),
                           "gibs": round(sum(done) * B * CH / GiB / el, 3), "ms_per_call_median": round(float(np.median(allat)) * 1e3, 1),
                           "ms_per_call_p95": round(float(np.percentile(allat, 95)) * 1e3, 1), "ok": ok}), flush=True)
@@ -111,7 +127,8 @@ def main():
             for h in dsts:
                 N.host_unregister(h)
         del dsts
-        torch.cuda.empty_cache()
+        if torch is not None:
+            torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

@@ -59,6 +59,76 @@ PY
       ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/dectrace -o dec --output-format csv -- python $R/tools/dec_latency.py ${arg:-1} > $O/dec_under_rocprofv3.jsonl 2> $O/dectrace.err )
       f=$(find $O/dectrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/dec_rocprofv3_kernel_stats.csv && head -20 $f
       find $O/dectrace -name "*kernel_trace.csv" -delete ;;
+    brokernt)
+      # the broker shape in a process WITHOUT torch (the system's HIP runtime, as a JVM loads it) and, for comparison, with it
+      export GPU_MAX_HW_QUEUES=16
+      timeout 200 python tools/broker_probe.py --mem host --ctxless --pool-chunks 512 --src-file /dev/shm/tsx_k512.npy --gen-only > /dev/null 2> $O/brokernt.err
+      timeout 300 python tools/broker_probe.py --mem host --ctxless --configs ${arg:-10x256,20x256,32x256} --pool-chunks 512 --seconds 6 --src-file /dev/shm/tsx_k512.npy --tag notorch 2>> $O/brokernt.err | tee $O/brokernt.jsonl
+      timeout 300 python tools/broker_probe.py --mem host --ctxless --configs ${arg:-10x256,20x256,32x256} --pool-chunks 512 --seconds 6 --tag torch 2>> $O/brokernt.err | tee -a $O/brokernt.jsonl
+      rm -f /dev/shm/tsx_k512.npy; unset GPU_MAX_HW_QUEUES ;;
+    copytorch)
+      for mode in registered torchpinned; do
+        D=$O/ct_$mode
+        ( cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $D -o c --output-format csv -- python $R/tools/ubench/copy_engine_torch.py $mode 2> /dev/null | grep "GB/s" )
+        k=$(grep -h copyBuffer $D/*kernel_stats.csv 2>/dev/null | awk -F, '{s+=$2} END {print s+0}' | tr -d '"'); m=$(grep -hc MEMORY_COPY $D/*memory_copy_trace.csv 2>/dev/null | awk '{s+=$1} END {print s+0}')
+        echo "   -> blit kernels: $k   SDMA copies: $m"; rm -rf $D
+      done 2>&1 | tee $O/copy_engine_torch.txt ;;
+    copyenv)
+      # ... with hipHostRegisterPortable (what tsx_host_register asks for) and with GPU_MAX_HW_QUEUES=16 (what bench.py / a broker's launcher set)
+      for cfg in "registered 4" "registered 16" "portable 4" "portable 16"; do set -- $cfg
+        D=$O/cv_$1_$2
+        ( cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=$2 && timeout 60 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $D -o c --output-format csv -- $R/tools/ubench/copy_engine d2h $1 1300000 256 2> /dev/null | grep "GB/s" | sed "s/^/GPU_MAX_HW_QUEUES=$2 /" )
+        k=$(grep -h copyBuffer $D/*kernel_stats.csv 2>/dev/null | awk -F, '{s+=$2} END {print s+0}' | tr -d '"'); m=$(grep -hc MEMORY_COPY $D/*memory_copy_trace.csv 2>/dev/null | awk '{s+=$1} END {print s+0}')
+        echo "   -> blit kernels: $k   SDMA copies: $m"; rm -rf $D
+      done 2>&1 | tee $O/copy_engine_env.txt ;;
+    copybg)
+      # ... and with the other direction busy on another stream (bg 1) / a kernel holding every CU slot (bg 2)
+      for cfg in ${arg:-"d2h,1300000,0,1 d2h,1300001,3,1 h2d,1300000,0,1 d2h,1300000,0,2 d2h,1300001,3,2 h2d,1300000,0,2"}; do set -- ${cfg//,/ }
+        D=$O/cb_$1_$2_$4
+        ( cd /tmp && export TMPDIR=/tmp && timeout 60 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $D -o c --output-format csv -- $R/tools/ubench/copy_engine $1 registered $2 256 0 $3 $4 2> /dev/null | grep "GB/s" )
+        k=$(grep -h copyBuffer $D/*kernel_stats.csv 2>/dev/null | awk -F, '{s+=$2} END {print s+0}' | tr -d '"'); m=$(grep -hc MEMORY_COPY $D/*memory_copy_trace.csv 2>/dev/null | awk '{s+=$1} END {print s+0}')
+        echo "   -> blit kernels: $k   SDMA copies: $m"; rm -rf $D
+      done 2>&1 | tee $O/copy_engine_bg.txt ;;
+    copyalign)
+      # ... and when sizes / host addresses are not multiples of 4 (packed output)
+      for cfg in "1300000 0" "1300001 0" "1300002 0" "1300000 1" "1300000 2" "1300001 3" "1300032 0" "1300000 32"; do set -- $cfg; for dir in d2h h2d; do
+        D=$O/ca_${dir}_$1_$2
+        ( cd /tmp && export TMPDIR=/tmp && timeout 60 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $D -o c --output-format csv -- $R/tools/ubench/copy_engine $dir registered $1 256 0 $2 2> /dev/null | grep "GB/s" )
+        k=$(grep -h copyBuffer $D/*kernel_stats.csv 2>/dev/null | awk -F, '{s+=$2} END {print s+0}' | tr -d '"'); m=$(grep -hc MEMORY_COPY $D/*memory_copy_trace.csv 2>/dev/null | awk '{s+=$1} END {print s+0}')
+        echo "   -> blit kernels: $k   SDMA copies: $m"; rm -rf $D
+      done; done 2>&1 | tee $O/copy_engine_align.txt ;;
+    copyhog)
+      # ... and when other streams of the process have copied before (do they keep the SDMA engines?)
+      for hog in 0 1 2 4 8; do for dir in d2h h2d; do
+        D=$O/ch_${dir}_$hog
+        ( cd /tmp && export TMPDIR=/tmp && timeout 60 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $D -o c --output-format csv -- $R/tools/ubench/copy_engine $dir registered 1300000 256 $hog 2> /dev/null | grep "GB/s" )
+        k=$(grep -h copyBuffer $D/*kernel_stats.csv 2>/dev/null | awk -F, '{s+=$2} END {print s+0}' | tr -d '"'); m=$(grep -hc MEMORY_COPY $D/*memory_copy_trace.csv 2>/dev/null | awk '{s+=$1} END {print s+0}')
+        echo "   -> blit kernels: $k   SDMA copies: $m"; rm -rf $D
+      done; done 2>&1 | tee $O/copy_engine_hog.txt ;;
+    copyengine)
+      # SDMA or blit kernel?  tools/ubench/copy_engine per direction / host memory kind / size under rocprofv3 (kernel + memory-copy trace)
+      for dir in d2h h2d; do for kind in malloc registered; do for sz in 65536 1300000 16777216 268435456; do
+        cnt=256; [ $sz -ge 16777216 ] && cnt=16; [ $sz -ge 268435456 ] && cnt=4
+        D=$O/ce_${dir}_${kind}_$sz
+        ( cd /tmp && export TMPDIR=/tmp && timeout 60 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $D -o c --output-format csv -- $R/tools/ubench/copy_engine $dir $kind $sz $cnt 2> /dev/null | grep "GB/s" )
+        k=$(grep -h copyBuffer $D/*kernel_stats.csv 2>/dev/null | awk -F, '{s+=$2} END {print s+0}' | tr -d '"'); m=$(grep -hc MEMORY_COPY $D/*memory_copy_trace.csv 2>/dev/null | awk '{s+=$1} END {print s+0}')
+        echo "   -> blit kernels: $k   SDMA copies: $m"; rm -rf $D
+      done; done; done 2>&1 | tee $O/copy_engine_probe.txt ;;
+    brokertrace)
+      # kernel + memory-copy trace of the broker shape (default 32 callers x 256 chunks, ctx-less, registered host buffers): who runs when
+      ( cd /tmp && export TMPDIR=/tmp GPU_MAX_HW_QUEUES=16 && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O/btrace -o b --output-format csv -- python $R/tools/broker_probe.py --mem host --ctxless --configs ${arg:-32x256} --pool-chunks 512 --seconds 6 > $O/btrace.jsonl 2> $O/btrace.err )
+      cat $O/btrace.jsonl; for f in $(find $O/btrace -name "*kernel_trace.csv" -o -name "*memory_copy_trace.csv"); do gzip -c $f > $O/$(basename $f).gz; done
+      rm -rf $O/btrace; ls -la $O ;;
+    e2e)
+      # the host-path legs of the bench line only (one batch at a time, batches in flight, broker rows)
+      timeout 600 python bench.py --steps ${arg:-10} --no-cpu-baseline --no-inverse --no-sustained --no-verify > $O/bench_e2e.json 2> $O/bench_e2e.err
+      python - <<PY
+import json
+j = json.loads(open("$O/bench_e2e.json").read().strip().splitlines()[-1]); e = j["end_to_end"]
+print("value", j["value"]); print("one at a time", [(r.get("mem"), r.get("ms"), r.get("gibs")) for r in e["one_batch_at_a_time"]]); print("in flight", [(c.get("callers"), c.get("gibs")) for c in e["batches_in_flight"] or []])
+for b in e["broker"] or []: print("broker", b["callers"], b["gibs"], b["frac_of_device_resident_value"], b["ms_per_call_median"], b["calls"])
+PY
+      ;;
     detr)
       timeout 300 python tools/detransform_bench.py ${arg:-2048} 2>&1 | grep -v amdgpu.ids | tee $O/detransform_bench.txt ;;
     pmcdec)
