@@ -57,7 +57,8 @@ def parse():
                     help="with --split-segments: rank 0 (the owner of the upload stream) also receives every rank's slice of the transformed object inside the step (send / recv)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the continuously-fed measurement (5 callers, 10 batches each) after the timed region")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host->host (PCIe-inclusive) measurement after the timed region")
-    ap.add_argument("--broker-in-process", action="store_true", help="run the broker-shaped leg in this process (torch's bundled HIP runtime) instead of tools/broker_leg.py (the system's)")
+    ap.add_argument("--broker-subprocess", action="store_true", help="run the broker-shaped leg as tools/broker_leg.py in a child process without torch (the system's HIP runtime "
+                    "instead of the one torch bundles); slower while this process holds the device too - see the comment at the leg")
     ap.add_argument("--no-broker", action="store_true", help="skip the broker-shaped leg of end_to_end (10 / 20 callers x 256-chunk segments, pooled contexts, registered buffers)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
@@ -634,17 +635,21 @@ def main():
         # TSX_MEM_HOST_PACKED from a registered source into a registered per-thread output buffer - what GpuTransformChunkEnumeration
         # issues (20 callers = 10 threads with one batch of read-ahead each; 32 = 16 such threads).  The loop is closed - a caller's next
         # call follows its last - so the row is bounded by the chunks the callers OFFER: 2560 / 5120 / 8192 against the 6144 the chip holds.
-        # The leg lives in tools/broker_leg.py and runs in a process of its own, WITHOUT torch: this process's HIP runtime is the one torch
-        # bundles (7.0.2), which moves device -> host copies with blit kernels - they wait for CU slots behind the compressor's waves - where
-        # the system's runtime (what a broker's JVM loads) uses the SDMA engines (profiles/r03_copy_engine_probe.txt).  The device stays
-        # this process's too: it is idle while the child runs.  --broker-in-process keeps the leg here (torch's runtime).
+        # The leg lives in tools/broker_leg.py.  One thing about THIS process distorts it: a process has one HIP runtime, the first one loaded,
+        # and here that is the one torch bundles (7.0.2), which moves device -> host copies with blit KERNELS; the system's runtime (7.2, what a
+        # broker's JVM loads through libtsxform.so) uses the SDMA engines.  A copy kernel needs CU slots and waits for them on a chip full of
+        # second-long compressor waves: standalone, the same leg at 32 callers reads 11.7 GiB/s with torch in the process and 14.3 without, and
+        # no longer falls below the 20-caller row (profiles/r03_broker_with_and_without_torch.jsonl, r03_copy_engine_probe.txt).
+        # --broker-subprocess runs the leg as a torch-free child - but while this process holds the device as well the child is slower than
+        # either (two processes' queues are time-sliced: 8.9 / 13.5 / 12.8), so the default stays in-process: the rows are a LOWER bound of
+        # what a torch-free process sees from 32 callers up.
         broker = None
         if T > 1 and n >= 256 and not args.no_broker:
             B = 256
-            bseg = min(2, n // B)                                         # two distinct segments, the callers alternate
+            bseg = min(2, n // B) if args.broker_subprocess else n // B    # distinct segments, the callers take them in turn
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import broker_leg
-            if args.broker_in_process:
+            if not args.broker_subprocess:
                 broker = broker_leg.run(N, nat, params, hsrc[:bseg * B * CH], d["iv"][:bseg * B], d["dst_len"][:bseg * B], (10, 20, 32), B, CH, 8.0)
             else:
                 import subprocess
@@ -670,7 +675,7 @@ def main():
             for b_ in broker:
                 if "gibs" in b_:
                     b_["frac_of_device_resident_value"] = round(b_["gibs"] / value, 3)
-                    b_["process"] = "this one (torch's HIP runtime)" if args.broker_in_process else "tools/broker_leg.py, no torch: the system's HIP runtime, as a JVM loads it"
+                    b_["process"] = "tools/broker_leg.py, no torch: the system's HIP runtime, as a JVM loads it" if args.broker_subprocess else "this one (torch's bundled HIP runtime: D2H copies are blit kernels)"
         e2e = {"metric": "GiB/s of original bytes, host buffers in -> host buffers out (PCIe inclusive)",
                "chunks": n, "pcie_peak_GBs_per_direction": PCIE, "one_batch_at_a_time": rows, "batches_in_flight": conc, "broker": broker,
                "value": max([r["gibs"] for r in rows] + [c_["gibs"] for c_ in (conc or [])] + [b_["gibs"] for b_ in (broker or []) if "gibs" in b_]) if rows else None, "unit": "GiB/s"}

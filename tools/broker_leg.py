@@ -6,11 +6,12 @@ threads, every call ONE B-chunk segment, context-less (pooled contexts, as the J
 source into a registered per-thread output buffer - what GpuTransformChunkEnumeration issues.  The loop is closed: a caller's next
 call follows its last.
 
-Why a process of its own: a process has ONE HIP runtime - the first one loaded.  bench.py imports torch, and torch brings its own
-(HIP 7.0.2 in this image), which moves device -> host copies with blit KERNELS; the system's runtime (7.2, what a broker's JVM loads
-through libtsxform.so) uses the SDMA engines.  A copy kernel needs CU slots, and on a chip full of second-long compressor waves it
-waits for them: with torch in the process 32 callers moved 11.7 GiB/s, without it 14.3 (profiles/r03_copy_engine_probe.txt,
-r03_broker_with_and_without_torch.jsonl).  bench.py therefore runs this leg as `python tools/broker_leg.py ...` and quotes its rows.
+Why it can run in a process of its own: a process has ONE HIP runtime - the first one loaded.  bench.py imports torch, and torch
+brings its own (HIP 7.0.2 in this image), which moves device -> host copies with blit KERNELS; the system's runtime (7.2, what a
+broker's JVM loads through libtsxform.so) uses the SDMA engines.  A copy kernel needs CU slots, and on a chip full of second-long
+compressor waves it waits for them: standalone, 32 callers moved 11.7 GiB/s with torch in the process and 14.3 without
+(profiles/r03_copy_engine_probe.txt, r03_broker_with_and_without_torch.jsonl).  As a CHILD of bench.py it shares the device with the
+parent's queues and is slower than either, so bench.py calls run() in-process by default (--broker-subprocess for the child).
 
   broker_leg.py --src S.npy --ivs I.npy --expect L.npy --callers 10,20,32 [--batch 256] [--chunk 4194304] [--window 8] [--lib path]
 prints one JSON line: the list of rows."""
