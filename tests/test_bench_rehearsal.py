@@ -103,3 +103,36 @@ def test_single_rank_line_has_every_leg(emu, oracle):
     s = j["sustained"]
     assert s["callers"] == 5 and s["batches"] == 15 and s["value"] >= 0 and "slope" in s["method"]
     assert j["detransform"]["round_trip_exact"] is True and j["roofline"]["bound"] == "hbm"
+
+
+def test_broker_leg_runs_without_torch_and_checks_sizes(emu, tmp_path):
+    """tools/broker_leg.py - the broker-shaped leg of bench.py's end_to_end object - as the child process bench.py --broker-subprocess
+    starts: no torch in the process (a process has one HIP runtime; torch's bundled one moves D2H copies with kernels), pooled contexts,
+    packed output between registered buffers, sizes checked against the run that produced `expect`.  Here on the emulated library with
+    tiny chunks; a wrong expectation must show in same_sizes_as_device_run."""
+    import tsxform
+    from tsxform import synth
+    nat = tsxform._native
+    CH, B, nseg = 32768, 3, 2
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=0)
+    src = np.concatenate([synth.gen_chunk("K", 1000, 0, i, CH) for i in range(nseg * B)])
+    ivs = np.stack([np.frombuffer(synth.iv_for(0, i), np.uint8) for i in range(nseg * B)])
+    d = np.zeros(nseg * B, nat.DESC_DTYPE); d["src_off"] = np.arange(nseg * B, dtype=np.uint64) * CH; d["src_len"] = CH; d["iv"] = ivs
+    slot = (emu.transformed_bound(CH, flags) + 63) // 64 * 64
+    d["dst_off"] = np.arange(nseg * B, dtype=np.uint64) * slot; d["dst_cap"] = slot
+    dst = np.zeros(nseg * B * slot, np.uint8)
+    emu.transform_batch(params, d, src, dst, dst.size, nat.MEM_HOST, ctx=None)
+    assert (d["status"] == 0).all()
+    lib = [m for m in open("/proc/self/maps").read().split() if m.endswith("libtsxform_emu.so")][0]
+    for name, arr in (("src", src), ("ivs", ivs), ("expect", d["dst_len"]), ("wrong", d["dst_len"] + 1)):
+        np.save(str(tmp_path / (name + ".npy")), arr)
+    for expect, ok in (("expect", True), ("wrong", False)):
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "broker_leg.py"), "--src", str(tmp_path / "src.npy"), "--ivs", str(tmp_path / "ivs.npy"),
+                             "--expect", str(tmp_path / (expect + ".npy")), "--callers", "2,3", "--batch", str(B), "--chunk", str(CH), "--window", "0.5", "--lib", lib],
+                            cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert cp.returncode == 0, cp.stderr[-2000:]
+        rows = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("[")][-1])
+        assert [r["callers"] for r in rows] == [2, 3]
+        for r in rows:
+            assert r["same_sizes_as_device_run"] is ok and r["torch_in_process"] is False and r["calls"] >= r["callers"] and r["gibs"] > 0
