@@ -13,9 +13,10 @@
 //                      it from the earlier block's bytes, and repeat offsets are resolved SYMBOLICALLY: a block does not know the
 //                      history it starts from, so an offset that comes out of the history is recorded as "incoming entry i minus d"
 //                      and the block's outgoing history is a function of the incoming one.
-//   zb_scatter_kernel  one wave per block.  Chains the block summaries up to its own block (output position = sum of the regenerated
-//                      sizes before it, incoming history = composition of the outgoing ones: O(1) per block) and writes ONE WORD PER
-//                      OUTPUT BYTE: the byte itself for a literal, the position it copies from for a match byte.
+//   zb_scatter_kernel  one workgroup (8 waves) per block.  Chains the block summaries up to its own block (output position = sum of the
+//                      regenerated sizes before it, incoming history = composition of the outgoing ones: O(1) per block), shares the
+//                      block's groups of 64 sequences out over its waves and writes ONE WORD PER OUTPUT BYTE: the byte itself for a
+//                      literal, the position it copies from for a match byte.
 //   zb_jump_kernel     log4(size) passes of pointer jumping (two jumps each) over those words: "where I copy from" becomes "where that copies from"
 //                      until every word is a literal - the execution stage without any order between sequences, blocks or
 //                      workgroups (in-order execution is ONE dependency chain through the whole chunk: see the comment there).
@@ -698,10 +699,10 @@ __global__ __launch_bounds__(ZB_SC_WAVES * LANES) void zb_scatter_kernel(const u
     if (tid == 0 && sFail) ZB_STORE_AGENT(&C->mode, 0u);                // the chunk-serial kernel behind this launch redoes the chunk
 }
 
-// one jump round: every unresolved word takes its source's word (four words per thread).  Chain depths are small in practice (log-like
-// content: every word resolved after 7 rounds, its matches reach ~100 KB back, not to the previous record) while the launcher must queue
-// the rounds the WORST case needs (a 4 MiB run of one byte: 22): a round notes whether it left anything unresolved, and the rounds behind
-// a round that did not return at their first instruction.
+// one jump pass: every unresolved word takes its source's word, twice (four words per thread).  Chain depths are small in practice
+// (log-like content: every word resolved after 7 jumps = 4 passes, its matches reach ~100 KB back, not to the previous record) while the
+// launcher must queue the passes the WORST case needs (a 4 MiB run of one byte: 22 jumps, 13 passes queued): a pass notes whether it left
+// anything unresolved, and the passes behind one that did not return at their first instruction.
 __global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap, uint32_t seq_cap,
                                                       uint32_t round) {
     const uint32_t chunk = blockIdx.y;
