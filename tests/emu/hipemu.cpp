@@ -31,6 +31,21 @@ hipemu_switch:
 .size hipemu_switch,.-hipemu_switch
 )");
 
+// ThreadSanitizer flavour (make emu-tsan): the lane fibers are announced to the tool, or it would take a stack switch for a wild jump
+#if defined(__SANITIZE_THREAD__)
+extern "C" { void* __tsan_get_current_fiber(void); void* __tsan_create_fiber(unsigned flags); void __tsan_destroy_fiber(void* fiber);
+             void __tsan_switch_to_fiber(void* fiber, unsigned flags); }
+#define TSAN_FIBER_NEW() __tsan_create_fiber(0)
+#define TSAN_FIBER_FREE(f_) __tsan_destroy_fiber(f_)
+#define TSAN_FIBER_GO(f_) __tsan_switch_to_fiber(f_, 0)
+#define TSAN_FIBER_SELF() __tsan_get_current_fiber()
+#else
+#define TSAN_FIBER_NEW() nullptr
+#define TSAN_FIBER_FREE(f_) do {} while (0)
+#define TSAN_FIBER_GO(f_) do {} while (0)
+#define TSAN_FIBER_SELF() nullptr
+#endif
+
 namespace hipemu {
 
 static const size_t kStack = 256 * 1024;
@@ -39,6 +54,7 @@ struct Fiber {
     void* sp = nullptr;
     char* stack = nullptr;
     bool done = false;
+    void* tsan = nullptr;
     Ctx ctx{};
 };
 struct Wave {
@@ -57,9 +73,10 @@ Ctx* g_ctx = nullptr;
 static Block* g_blk = nullptr;
 static Fiber* g_cur = nullptr;
 static void* g_sched_sp = nullptr;
+static void* g_sched_tsan = nullptr;
 static std::vector<char*> g_stack_pool;
 
-static void yield() { hipemu_switch(&g_cur->sp, g_sched_sp); }
+static void yield() { TSAN_FIBER_GO(g_sched_tsan); hipemu_switch(&g_cur->sp, g_sched_sp); }
 
 static void release_block_barrier_if_complete() {
     Block& b = *g_blk;
@@ -79,6 +96,7 @@ static void trampoline() {
     b.live--;
     release_wave_barrier_if_complete(w);
     release_block_barrier_if_complete();
+    TSAN_FIBER_GO(g_sched_tsan);
     hipemu_switch(&f->sp, g_sched_sp);
     std::abort();  // never resumed
 }
@@ -126,6 +144,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry) {
     blk.entry = &entry;
     Block* saved_blk = g_blk;
     g_blk = &blk;
+    g_sched_tsan = TSAN_FIBER_SELF();
     for (unsigned bz = 0; bz < grid.z; bz++)
         for (unsigned by = 0; by < grid.y; by++)
             for (unsigned bx = 0; bx < grid.x; bx++) {
@@ -134,6 +153,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry) {
                 for (unsigned t = 0; t < nthreads; t++) {
                     Fiber& f = blk.fibers[t];
                     init_fiber(f);
+                    if (!f.tsan) f.tsan = TSAN_FIBER_NEW();
                     f.ctx.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
                     f.ctx.bid = {bx, by, bz};
                     f.ctx.bdim = block; f.ctx.gdim = grid; f.ctx.flat_tid = t;
@@ -147,12 +167,13 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry) {
                         Fiber& f = blk.fibers[t];
                         if (f.done) continue;
                         g_cur = &f; g_ctx = &f.ctx;
+                        TSAN_FIBER_GO(f.tsan);
                         hipemu_switch(&g_sched_sp, f.sp);
                         if (f.done) remaining--;
                     }
                 }
             }
-    for (auto& f : blk.fibers) if (f.stack) g_stack_pool.push_back(f.stack);
+    for (auto& f : blk.fibers) { if (f.stack) g_stack_pool.push_back(f.stack); if (f.tsan) TSAN_FIBER_FREE(f.tsan); }
     g_blk = saved_blk; g_cur = nullptr; g_ctx = nullptr;
 }
 
