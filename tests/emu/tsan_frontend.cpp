@@ -63,8 +63,10 @@ int main(int argc, char** argv) {
         for (auto& d : j.dref) if (d.status != TSX_OK) { fprintf(stderr, "reference status %d\n", d.status); return 2; }
     }
     std::atomic<int> bad{0};
+    static int racy = 0;                                                // TSAN_SELFTEST=1: a deliberate race, to see that the tool is awake in this build
     auto worker = [&](int t) {
         Job& j = jobs[t];
+        if (getenv("TSAN_SELFTEST")) racy++;
         tsx_ctx* own = nullptr;
         if (t % 4 == 3 && tsx_ctx_create(0, 8, 40000, &own) != TSX_OK) { bad++; return; }
         for (int r = 0; r < REPS; r++) {
