@@ -41,8 +41,8 @@ int main(int argc, char** argv) {
     std::vector<Job> jobs(T);
     for (int t = 0; t < T; t++) {
         Job& j = jobs[t];
-        const uint32_t sizes[5] = {(20000u + 977u * t) / scale, 1, 0, 33000 / scale, 4096 / scale};
-        const uint32_t n = 3 + t % 3;
+        const uint32_t sizes[5] = {(20000u + 977u * t) / scale, 1, 33000 / scale, 0, 4096 / scale};
+        const uint32_t n = 2 + t % 3;                                   // (every chunk costs the emulated wave its table set-up: keep them few)
         uint64_t off = 0;
         memset(&j.prm, 0, sizeof j.prm);
         j.prm.flags = TSX_COMPRESS | TSX_ENCRYPT | TSX_CRC; j.prm.aad_len = 32; j.prm.zstd_profile = t & 1;
