@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--broker-subprocess", action="store_true", help="run the broker-shaped leg as tools/broker_leg.py in a child process without torch (the system's HIP runtime "
                     "instead of the one torch bundles); slower while this process holds the device too - see the comment at the leg")
     ap.add_argument("--no-broker", action="store_true", help="skip the broker-shaped leg of end_to_end (10 / 20 callers x 256-chunk segments, pooled contexts, registered buffers)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the barrier / max-over-ranks reduction (and, with --split-segments / --gather-object, the "
+                         "size all-gather and a point-to-point loop-back) even with ONE rank: RCCL on a single GPU (tests/test_gpu_parity.py)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
     return ap.parse_args()
@@ -138,7 +141,12 @@ def main():
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback; --rehearse is a logic rehearsal, not a measurement)"
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        if "MASTER_ADDR" not in os.environ:                                # --force-dist without a launcher: a one-rank rendezvous on loopback
+            import socket
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # NCCL = RCCL on ROCm
         else:
@@ -237,18 +245,18 @@ def main():
             # .log object and build the whole chunk index (AbstractChunkIndex.java:52-72)
             at = 0
             for s_, (lo, hi) in zip(range(nseg), ranges):
-                index[s_] = shard.exchange_transformed_sizes(ds[t]["dst_len"][at:at + hi - lo], cps, rank, world, dist if world > 1 else None,
+                index[s_] = shard.exchange_transformed_sizes(ds[t]["dst_len"][at:at + hi - lo], cps, rank, world, dist if dist_on else None,
                                                              device="cpu" if args.backend == "gloo" else dev)
                 if args.gather_object:
                     # the optional second exchange: this rank's slice, packed, straight into its place on the owner rank
                     mine = shard.pack_slice(dsts[t], ds[t]["dst_off"][at:at + hi - lo], ds[t]["dst_len"][at:at + hi - lo])
-                    objects[s_] = shard.gather_object_to_owner(mine, index[s_][0], cps, rank, world, 0, dist if world > 1 else None,
+                    objects[s_] = shard.gather_object_to_owner(mine, index[s_][0], cps, rank, world, 0, dist if dist_on else None,
                                                                device="cpu" if args.backend == "gloo" else dev)
                 at += hi - lo
 
     def fence():
         Mem.sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         Mem.sync()
 
@@ -341,7 +349,7 @@ def main():
     del ctxs[1:], dsts[1:], ds[1:]
     if not rehearse:
         torch.cuda.empty_cache()
-    if world > 1:
+    if dist_on:
         elapsed = Mem.max_over_ranks(elapsed)
     assert (d["status"] == 0).all(), "chunk failures: %s" % d["status"][d["status"] != 0][:8]
     # whole-job bytes: weak scaling - every rank has nseg segments; split mode - the job is nseg segments in total
@@ -388,11 +396,11 @@ def main():
                 N.detransform_batch(params, e, Mem.ptr(dst), Mem.ptr(back), bsz, MEM, ctx=ctx)
         fence()
         inv_s = (time.perf_counter() - t1) / reps
-        if world > 1:
+        if dist_on:
             inv_s = Mem.max_over_ranks(inv_s)
         tm = N.ctx_timing(ctx)
         exact = bool((e["status"] == 0).all() and (e["dst_len"] == CH).all() and (e["crc32c"] == d["crc32c"]).all() and Mem.equal(back, src))
-        if world > 1:
+        if dist_on:
             exact = Mem.max_over_ranks(0.0 if exact else 1.0) == 0.0                      # every rank's round trip
         # reported, not asserted: a fetch-side failure must not take the forward measurement's line with it
         inverse = {"metric": "GiB/s of restored bytes, tsx_detransform_batch (GCM verify+decrypt, Zstd decode, CRC32C), one batch at a time",
@@ -703,13 +711,16 @@ def main():
                            b"".join((objects[k].cpu().numpy() if hasattr(objects[k], "cpu") else np.asarray(objects[k])).tobytes() for k in sorted(objects))).hexdigest()[:16],
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
                        "hip_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "process_group": None if not dist_on else {
+                           "backend": args.backend + (" (= RCCL)" if args.backend == "nccl" else ""), "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1),
+                           "ran": ["barrier", "all_reduce(MAX)"] + (["all_gather(sizes)"] if split else []) + (["p2p slice -> owner"] if split and args.gather_object and (world > 1 or args.backend == "nccl") else [])},
                        "verified_chunks_vs_oracle": verified},
             "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "end_to_end": e2e, "detransform": inverse,
         }
         print(json.dumps(line))
     for c in ctxs:
         N.ctx_destroy(c)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -35,6 +35,7 @@ import java.util.concurrent.CompletableFuture;
 import java.util.concurrent.ExecutionException;
 import java.util.concurrent.ExecutorService;
 import java.util.concurrent.Executors;
+import java.util.concurrent.RejectedExecutionException;
 import java.util.concurrent.TimeUnit;
 import java.util.concurrent.atomic.AtomicInteger;
 import java.util.concurrent.TimeoutException;
@@ -74,6 +75,9 @@ public class GpuChunkCache extends ChunkCache<byte[]> implements AutoCloseable {
     private long maxBytes = Long.MAX_VALUE;
     private long getTimeoutMs = 10_000;
     private long coalesceWaitMicros = 200;
+    private long retentionMs = Long.MAX_VALUE;
+    /** last access of every cached chunk (retention.ms); same keys as {@code cached}. */
+    private final Map<ChunkKey, Long> touched = new HashMap<>();
     private ExecutorService executor;
 
     private final Object lock = new Object();
@@ -131,7 +135,14 @@ public class GpuChunkCache extends ChunkCache<byte[]> implements AutoCloseable {
                 throw new IllegalArgumentException(COALESCE_WAIT_US_CONFIG + " must lie in [0, get.timeout.ms / 2]");
             }
         }
+        // retention.ms: the reference's caches expire an entry that has not been read for that long (Caffeine expireAfterAccess,
+        // ChunkCache.java:146-150); here entries carry their last-access time and are dropped on the next insert / lookup after it
+        this.retentionMs = config.cacheRetention().map(java.time.Duration::toMillis).orElse(Long.MAX_VALUE);
+        final ExecutorService old = this.executor;
         this.executor = newExecutor(config.threadPoolSize().orElse(Runtime.getRuntime().availableProcessors()));
+        if (old != null) {
+            old.shutdown();                                            // a re-configured cache does not leak its first pool's threads
+        }
     }
 
     private static ExecutorService newExecutor(final int threads) {
@@ -181,55 +192,114 @@ public class GpuChunkCache extends ChunkCache<byte[]> implements AutoCloseable {
     }
 
     private void insert(final ChunkKey key, final byte[] value) {          // under lock
+        final long now = System.currentTimeMillis();
         final byte[] old = cached.put(key, value);
+        touched.put(key, now);
         bytes += value.length - (old != null ? old.length : 0);
-        final var it = cached.entrySet().iterator();
-        while (bytes > maxBytes && cached.size() > 1 && it.hasNext()) {
+        final var it = cached.entrySet().iterator();                       // least recently used first
+        while (it.hasNext()) {
             final var eldest = it.next();
             if (eldest.getKey().equals(key)) {
                 continue;
             }
+            final boolean expired = retentionMs != Long.MAX_VALUE && now - touched.getOrDefault(eldest.getKey(), now) > retentionMs;
+            if (!expired && !(bytes > maxBytes && cached.size() > 1)) {
+                break;                                                     // access order = age order: nothing behind it is older
+            }
             bytes -= eldest.getValue().length;
+            touched.remove(eldest.getKey());
             it.remove();
         }
     }
 
-    /** One ranged fetch + one device batch; on failure every chunk on its own, so that only the bad one fails. */
+    /** A cached chunk, unless retention.ms has passed since its last read (then it is dropped, as an expired Caffeine entry is). */
+    private byte[] lookup(final ChunkKey key) {                           // under lock
+        final byte[] hit = cached.get(key);
+        if (hit == null) {
+            return null;
+        }
+        final long now = System.currentTimeMillis();
+        if (retentionMs != Long.MAX_VALUE && now - touched.getOrDefault(key, now) > retentionMs) {
+            bytes -= hit.length;
+            cached.remove(key);
+            touched.remove(key);
+            return null;
+        }
+        touched.put(key, now);
+        return hit;
+    }
+
+    /**
+     * One ranged fetch + one device batch; on failure every chunk on its own, so that only the bad one fails.  Runs on the executor:
+     * EVERY Throwable is captured (an OutOfMemoryError "Direct buffer memory" of the per-thread buffers, an UnsatisfiedLinkError of
+     * the JNI pair ...) the way CompletableFuture.supplyAsync does for the reference (ChunkCache.java:76-129), and whatever happens no
+     * slot stays open and no key stays in {@code pending}: later getChunk calls for these ids must start a new load, not wait
+     * get.timeout.ms for a task that died.
+     */
     private void runBatch(final Batch batch, final SegmentManifest manifest) {
         final int count = batch.slots.size();
-        List<byte[]> got = null;
-        Throwable batchError = null;
+        Throwable fatal = null;
         try {
-            got = manager.getChunks(batch.object, manifest, batch.first, count);
-        } catch (final StorageBackendException | RuntimeException e) {
-            batchError = e;
-        }
-        for (int i = 0; i < count; i++) {
-            final ChunkKey key = new ChunkKey(batch.object.value(), batch.first + i);
-            byte[] value = null;
-            Throwable error = null;
-            if (batchError == null) {
-                value = got.get(i);
-            } else if (count == 1) {
-                error = batchError;
-            } else {
-                try {
-                    value = manager.getChunks(batch.object, manifest, batch.first + i, 1).get(0);
-                } catch (final StorageBackendException | RuntimeException e) {
-                    error = e;
-                }
+            List<byte[]> got = null;
+            Throwable batchError = null;
+            try {
+                got = manager.getChunks(batch.object, manifest, batch.first, count);
+            } catch (final Throwable e) {
+                batchError = e;
             }
-            synchronized (lock) {
+            for (int i = 0; i < count; i++) {
+                final ChunkKey key = new ChunkKey(batch.object.value(), batch.first + i);
+                byte[] value = null;
+                Throwable error = null;
+                if (batchError == null) {
+                    value = got.get(i);
+                } else if (count == 1 || batchError instanceof Error) {
+                    error = batchError;                            // an Error is not a property of one chunk: no chunk-by-chunk retry
+                } else {
+                    try {
+                        value = manager.getChunks(batch.object, manifest, batch.first + i, 1).get(0);
+                    } catch (final Throwable e) {
+                        error = e;
+                    }
+                }
+                synchronized (lock) {
+                    if (error == null) {
+                        insert(key, value);
+                    }
+                    pending.remove(key);
+                }
                 if (error == null) {
-                    insert(key, value);
+                    batch.slots.get(i).complete(value);
+                } else {
+                    batch.slots.get(i).completeExceptionally(error);
                 }
-                pending.remove(key);
             }
-            if (error == null) {
-                batch.slots.get(i).complete(value);
-            } else {
-                batch.slots.get(i).completeExceptionally(error);
+        } catch (final Throwable e) {
+            fatal = e;
+        } finally {
+            abandon(batch, fatal != null ? fatal : new IllegalStateException("chunk load ended without a result"));
+        }
+    }
+
+    /** Fails every slot of the batch that has no result yet and forgets its keys (no-op for slots that are done). */
+    private void abandon(final Batch batch, final Throwable cause) {
+        for (int i = 0; i < batch.slots.size(); i++) {
+            final CompletableFuture<byte[]> slot = batch.slots.get(i);
+            if (!slot.isDone()) {
+                synchronized (lock) {
+                    pending.remove(new ChunkKey(batch.object.value(), batch.first + i), slot);
+                }
+                slot.completeExceptionally(cause);
             }
+        }
+    }
+
+    /** executor.execute that cannot leave a batch behind: a closed (or saturated) executor fails the batch's waiters at once. */
+    private void submit(final Batch batch, final SegmentManifest manifest) {
+        try {
+            executor.execute(() -> runBatch(batch, manifest));
+        } catch (final RejectedExecutionException e) {
+            abandon(batch, e);
         }
     }
 
@@ -253,7 +323,7 @@ public class GpuChunkCache extends ChunkCache<byte[]> implements AutoCloseable {
         Batch lead = null;
         synchronized (lock) {
             final ChunkKey key = new ChunkKey(objectKey.value(), chunkId);
-            final byte[] hit = cached.get(key);
+            final byte[] hit = lookup(key);
             if (hit == null) {
                 mine = pending.get(key);
             }
@@ -287,7 +357,7 @@ public class GpuChunkCache extends ChunkCache<byte[]> implements AutoCloseable {
                         openBatch.put(objectKey.value(), batch);
                     } else {
                         batch.open = false;                    // pure prefetch: nobody waits for it here
-                        executor.execute(() -> runBatch(batch, manifest));
+                        submit(batch, manifest);
                     }
                 }
                 i = j;
@@ -309,7 +379,7 @@ public class GpuChunkCache extends ChunkCache<byte[]> implements AutoCloseable {
                 openBatch.remove(objectKey.value(), lead);
             }
             final Batch leaving = lead;
-            executor.execute(() -> runBatch(leaving, manifest));      // on the executor like every load: get.timeout.ms bounds the leader too
+            submit(leaving, manifest);                                 // on the executor like every load: get.timeout.ms bounds the leader too
         }
         try {
             return new ByteArrayInputStream(mine.get(getTimeoutMs, TimeUnit.MILLISECONDS));

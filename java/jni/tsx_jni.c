@@ -11,8 +11,12 @@
 
 #include "tsxform.h"
 
+/* The shim was compiled against ONE version of tsxform.h; ABI 3 put src_size in the middle of the batch entry points, so a
+ * libtsxform.so of another ABI would be called with shifted arguments (a size taken for a pointer).  init() is the first native
+ * call TsxNative's static initialiser makes: a mismatched pair fails there, before any batch call exists. */
 JNIEXPORT jint JNICALL Java_io_aiven_kafka_tieredstorage_gpu_TsxNative_init(JNIEnv* env, jclass cls) {
     (void)env; (void)cls;
+    if (tsx_abi_version() != TSX_ABI_VERSION) return TSX_E_UNSUPPORTED;
     return tsx_init(0, NULL);
 }
 

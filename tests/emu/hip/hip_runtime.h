@@ -182,6 +182,7 @@ hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void* p);

@@ -210,6 +210,7 @@ hipError_t hipMalloc(void** p, size_t n) {
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)6 << 30; *total_b = (size_t)8 << 30; return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }

@@ -28,7 +28,7 @@ def make_descs(sizes, soff, doff, caps, segment=0):
     return d
 
 
-def run_transform(N, flags, chunks, key=synth.KEY, aad=synth.AAD, mem=None, profile=nat.ZSTD_PROFILE_1_5_7, dst_caps=None):
+def run_transform(N, flags, chunks, key=synth.KEY, aad=synth.AAD, mem=None, profile=nat.ZSTD_PROFILE_1_5_7, dst_caps=None, ctx=None):
     """chunks: list of numpy uint8 arrays.  Returns (list of transformed bytes, descs).  dst_caps: per-chunk override of the
     slot capacity handed to the library (None = the library's own bound)."""
     sizes = [int(c.size) for c in chunks]
@@ -51,7 +51,7 @@ def run_transform(N, flags, chunks, key=synth.KEY, aad=synth.AAD, mem=None, prof
         N.transform_batch(p, d, src, dst, dst.size, nat.MEM_HOST_PACKED)
         return [dst[int(d["dst_off"][i]):int(d["dst_off"][i]) + int(d["dst_len"][i])].tobytes() for i in range(len(sizes))], d
     else:
-        N.transform_batch(p, d, src, dst, dst.size)
+        N.transform_batch(p, d, src, dst, dst.size, ctx=ctx)
     outs = [dst[doff[i]:doff[i] + d["dst_len"][i]].tobytes() for i in range(len(sizes))]
     return outs, d
 

@@ -136,3 +136,29 @@ def test_broker_leg_runs_without_torch_and_checks_sizes(emu, tmp_path):
         assert [r["callers"] for r in rows] == [2, 3]
         for r in rows:
             assert r["same_sizes_as_device_run"] is ok and r["torch_in_process"] is False and r["calls"] >= r["callers"] and r["gibs"] > 0
+
+
+def _force_dist_cmd(extra):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--split-segments", "--gather-object",
+            "--segments", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sustained", "--no-end-to-end"] + extra
+
+
+def test_force_dist_runs_the_collectives_with_one_rank(emu, oracle):
+    """--force-dist makes ONE rank initialise the process group and run the barrier, the max-over-ranks all-reduce, the
+    all-gather of transformed sizes and the point-to-point path of --gather-object (a grouped send + recv to itself) - here with gloo on
+    the emulator; tests/test_gpu_parity.py::test_rccl_collectives_run_on_one_gpu is the same command with the nccl backend on the device."""
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    from tsxform import synth
+    CH, cps = 20000, 4
+    r = subprocess.run(_force_dist_cmd(["--rehearse", "--backend", "gloo", "--chunk-bytes", str(CH), "--chunks-per-segment", str(cps)]),
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    pg = j["config"]["process_group"]
+    assert pg["forced_on_one_rank"] is True and pg["ran"] == ["barrier", "all_reduce(MAX)", "all_gather(sizes)"]     # (gloo has no pair to itself: the p2p loop-back is nccl only)
+    of = oracle.COMPRESS | oracle.ENCRYPT
+    whole = b"".join(oracle.transform_chunk(of, synth.KEY, synth.AAD, synth.iv_for(0, k), synth.gen_chunk("K", 1000, 0, k, CH).tobytes())[0] for k in range(cps))
+    assert j["config"]["object_gathered_on_rank0_sha"] == hashlib.sha256(whole).hexdigest()[:16]     # what came back through the loop-back IS the object
+    assert j["detransform"]["round_trip_exact"] is True

@@ -42,8 +42,14 @@ def test_library_loads_and_exports_every_declared_symbol(product_lib):
     assert b"Invalid decompressed size" in lib.tsx_strerror(-7)
 
 
-def test_library_contains_gfx950_code_only(product_lib):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", product_lib], capture_output=True, text=True).stdout
+def test_library_contains_gfx950_code_only(product_lib, tmp_path):
+    # llvm-objdump --offloading also EXTRACTS every bundle entry next to the path it was given: hand it a link in a scratch directory
+    # so that nothing lands in the package directory (hygiene)
+    link = tmp_path / os.path.basename(product_lib)
+    os.symlink(os.path.abspath(product_lib), link)
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(link)], capture_output=True, text=True, cwd=tmp_path).stdout
+    pkg = os.path.dirname(os.path.abspath(product_lib))
+    assert not [f for f in os.listdir(pkg) if ".hipv4-" in f or ".host-x86_64-" in f], "offload-bundle pieces in the package directory"
     archs = set(re.findall(r"gfx[0-9a-f]+", out))
     assert archs == {"gfx950"}, archs
 
@@ -160,3 +166,16 @@ def test_gpu_chunk_cache_meets_the_references_cache_selection_contract():
     # the upload side gives its device hint back
     t = open(os.path.join(jdir, "GpuTransformChunkEnumeration.java")).read()
     assert "TsxNative.setThreadDevice(-1)" in t
+
+
+def test_stale_abi_is_refused(tmp_path):
+    """ABI 3 put src_size in the middle of the batch entry points; a library of another ABI must be refused at load, not
+    called with shifted arguments."""
+    c = tmp_path / "stale.c"
+    c.write_text("unsigned tsx_abi_version(void) { return 2; }\n")
+    so = tmp_path / "libtsxform_stale.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(c)])
+    with pytest.raises(RuntimeError, match="ABI 2"):
+        nat.Native(str(so))
+    shim = open(os.path.join(ROOT, "java", "jni", "tsx_jni.c")).read()
+    assert "tsx_abi_version() != TSX_ABI_VERSION" in shim              # the JNI shim's init() refuses a mismatched pair as well

@@ -17,6 +17,7 @@ MEM_HOST, MEM_DEVICE, MEM_HOST_PACKED = 0, 1, 2
 OK, E_INVAL, E_DEVICE, E_NOMEM, E_DST_TOO_SMALL, E_TAG_MISMATCH, E_BAD_FRAME, E_BAD_SIZE, E_SHORT_CHUNK, E_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 ZSTD_PROFILE_1_5_6, ZSTD_PROFILE_1_5_7 = 0, 1
+ABI_VERSION = 3          # TSX_ABI_VERSION of include/tsxform.h these prototypes were written against
 
 
 class ChunkDesc(C.Structure):
@@ -62,6 +63,11 @@ class Native:
         L = C.CDLL(path)
         vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
         L.tsx_abi_version.restype = u32
+        # ABI 3 put src_size in the MIDDLE of the batch entry points: a stale library called with these prototypes would take src_size
+        # for the dst pointer.  Refuse it before any other symbol is touched (tests/test_boundary.py::test_stale_abi_is_refused).
+        if not hasattr(L, "tsx_abi_version") or L.tsx_abi_version() != ABI_VERSION:
+            raise RuntimeError("tsxform: %s speaks ABI %s, this binding ABI %d - rebuild it (`make -C %s`)"
+                               % (path, L.tsx_abi_version() if hasattr(L, "tsx_abi_version") else "?", ABI_VERSION, os.path.join(_HERE, "csrc")))
         L.tsx_version.restype = C.c_char_p
         L.tsx_strerror.restype = C.c_char_p; L.tsx_strerror.argtypes = [C.c_int]
         L.tsx_init.restype = C.c_int; L.tsx_init.argtypes = [C.c_int, C.POINTER(C.c_int)]

@@ -71,6 +71,7 @@ struct tsx_device {
     // pooled contexts of the ctx-less calls: idle ones, how many are out, batches served (all under g_mu)
     std::vector<tsx_ctx*> idle;
     size_t idle_bytes = 0;
+    size_t idle_cap = 0;                                     // most idle workspace kept (init_devices: a fraction of THIS device's memory)
     std::unique_ptr<tsx_combiner> comb;                      // created with the first ctx-less compressing batch
     uint32_t in_use = 0;
     uint64_t batches = 0;
@@ -79,7 +80,10 @@ struct tsx_device {
 #define TSX_MAX_SUBS 64                 /* sub-batches of one host-memory batch (staging pipeline) */
 #define TSX_SUB_BYTES ((size_t)64 << 20) /* input bytes per sub-batch: >= 1000 workgroups of the GCM / CRC kernels */
 #define TSX_POOL_MAX_IDLE 32            /* idle pooled contexts kept per device (a broker: >= 10 RLM threads + read-ahead helpers + the fetch pool) ... */
-#define TSX_POOL_MAX_IDLE_BYTES ((size_t)128 << 30) /* ... as long as their workspaces together stay under 128 of the 288 GB; the rest are destroyed on release */
+// ... as long as their workspaces together stay under tsx_device.idle_cap = 4/9 of the device's memory (128 of the MI355X's 288 GB; a smaller
+// device or several processes per GPU get their share: TSX_POOL_IDLE_BYTES overrides); the rest are destroyed on release, and an
+// allocation that fails drains the idle pool and is tried again (reserve_or_drain) - cached memory is never the reason for TSX_E_NOMEM.
+#define TSX_POOL_MAX_IDLE_BWORK 4       /* idle contexts that keep their block-form decoder workspace (37 MiB per 4 MiB chunk: 9.4 GiB for a segment) */
 #define TSX_COMP_PIECES 4               /* pieces of a host-memory batch on the compress path: one compute stream each (they must co-reside) */
 
 struct tsx_ctx {
@@ -182,6 +186,11 @@ static int init_devices(std::vector<tsx_device>& devs, int want, const int* devi
             return TSX_E_DEVICE;
         }
         HIPCHK(hipSetDevice(d.hip_id));
+        {   size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) { (void)hipGetLastError(); total_b = prop.totalGlobalMem; }
+            d.idle_cap = total_b / 9 * 4;
+            if (const char* e = getenv("TSX_POOL_IDLE_BYTES")) { const long long v = atoll(e); if (v >= 0) d.idle_cap = (size_t)v; }
+        }
         HIPCHK(hipMalloc((void**)&d.d_crc, sizeof(tsx_crc_tables)));
         HIPCHK(hipMalloc((void**)&d.d_aes, sizeof(tsx_aes_tables)));
         HIPCHK(hipMalloc((void**)&d.d_zc, tsx_zstd_consts_bytes()));
@@ -433,13 +442,44 @@ static tsx_ctx* pool_acquire(int* rc) {
     c->pooled = true;
     return c;
 }
-static void pool_release(tsx_ctx* c) {
+// Idle pooled contexts of device di give their memory back (an allocation has just failed: what is cached must not be the reason).
+static bool pool_drain(tsx_device* dev) {
+    std::vector<tsx_ctx*> dead;
     {
         std::lock_guard<std::mutex> lk(g_mu);
+        dead.swap(dev->idle); dev->idle_bytes = 0;
+    }
+    if (dead.empty()) return false;
+    tsx_device_scope keep;
+    for (tsx_ctx* c : dead) { ctx_free_device_mem(c); delete c; }
+    return true;
+}
+static int reserve_or_drain(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_out, uint32_t flags, bool host_mem, size_t in_bytes, size_t out_bytes) {
+    int rc = ctx_reserve(c, n, max_len, max_out, flags, host_mem, in_bytes, out_bytes);
+    if (rc != TSX_E_NOMEM) return rc;
+    (void)hipGetLastError();
+    if (!pool_drain(c->dev)) return rc;                                 // nothing was cached: the device really is full
+    return ctx_reserve(c, n, max_len, max_out, flags, host_mem, in_bytes, out_bytes);
+}
+static void pool_release(tsx_ctx* c) {
+    {
+        std::unique_lock<std::mutex> lk(g_mu);
         tsx_device& d = *c->dev;
         d.in_use--;
+        if (c->d_bwork) {
+            // the fetch side's ForkJoinPool issues from dozens of threads (ChunkCache.java:140): without a bound every idle context would
+            // park a block-form workspace; beyond a few the next small fetch on such a context re-allocates it (~1 ms) instead
+            uint32_t with = 0;
+            for (const tsx_ctx* o : d.idle) if (o->d_bwork) with++;
+            if (with >= TSX_POOL_MAX_IDLE_BWORK) {
+                lk.unlock();
+                { tsx_device_scope keep; hipSetDevice(d.hip_id); hipFree(c->d_bwork); }
+                c->d_bwork = nullptr; c->bwork_cap = 0;
+                lk.lock();
+            }
+        }
         const size_t b = ctx_workspace_bytes(c);
-        if (d.idle.size() < TSX_POOL_MAX_IDLE && (d.idle.empty() || d.idle_bytes + b <= TSX_POOL_MAX_IDLE_BYTES)) { d.idle.push_back(c); d.idle_bytes += b; return; }
+        if (d.idle.size() < TSX_POOL_MAX_IDLE && (d.idle.empty() || d.idle_bytes + b <= d.idle_cap)) { d.idle.push_back(c); d.idle_bytes += b; return; }
     }
     tsx_device_scope keep;
     ctx_free_device_mem(c);                                            // a burst of callers does not pin its workspaces forever
@@ -588,8 +628,12 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     // engines move other callers' gigabytes waits for them (measured: +550 ms per 256-chunk call with 10 callers), a small kernel
     // waits for a slot on a chip full of compressor waves.
     const bool lean = r.mode == 0 && r.comp && r.enc && r.fuse_stages;
-    if (lean) dd = c->hd_descs + lo;
-    else {
+    if (lean) {
+        dd = c->hd_descs + lo;
+        // the waves are the only writers of status / dst_len here and no init or publish kernel runs: what the caller handed in (often a
+        // stale TSX_OK) must not survive a launch that never ran
+        for (uint32_t i = lo; i < lo + n; i++) { c->h_descs[i].status = TSX_E_DEVICE; c->h_descs[i].dst_len = 0; }
+    } else {
         HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
     }
@@ -613,8 +657,11 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
             if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
             if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->hd_key; fuse.out = r.d_dst; fuse.self_status = 1; fuse.key_on_host = 1; }
             const uint32_t sched = zstd_sched_from_env();
+            (void)hipGetLastError();
             t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
                                                        r.params->zstd_profile, sched, fuse);
+            // hipLaunchKernelGGL reports through the last-error slot only; a lean batch has nothing behind the launch that would notice
+            if (hipGetLastError() != hipSuccess) return TSX_E_DEVICE;
         }
         HIPCHK(hipEventRecord(e[2], st));
         if (fused) {
@@ -745,8 +792,10 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
         memcpy(c->h_descs, r.descs, (size_t)n * sizeof(tsx_chunk_desc));
         // with encryption the launch is the group's ONLY operation on the lane: descriptors and key schedules stay in the members' pinned
         // memory (the waves read and write them in place), statuses are owned by the waves
-        if (r.enc) tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
-        else {
+        if (r.enc) {
+            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
+            for (uint32_t i = 0; i < n; i++) { c->h_descs[i].status = TSX_E_DEVICE; c->h_descs[i].dst_len = 0; }      // the waves own them from here
+        } else {
             HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, ls));
             hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_status, n);
         }
@@ -759,7 +808,9 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
         if (r.enc) { sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->hd_key; sg.fuse.out = r.d_dst; sg.fuse.self_status = 1; sg.fuse.key_on_host = 1; }
         first += n;
     }
+    (void)hipGetLastError();                                             // (hipErrorNotReady of the leader's lane queries)
     tsx_launch_zstd_compress_segments(ls, l.d_segs, l.h_segs, (uint32_t)grp.size(), first, zstd_sched_from_env());
+    if (hipGetLastError() != hipSuccess) return TSX_E_DEVICE;           // every member gets the rc (combiner_submit)
     for (tsx_zreq* q : grp) {
         tsx_ctx* c = q->c; const tsx_run& r = *q->r;
         const uint32_t n = r.n;
@@ -839,7 +890,7 @@ static int run_combined(tsx_run& r) {
         out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
     }
     r.max_len = max_len; r.max_out = max_out;
-    rc = ctx_reserve(c, n, max_len, 0, r.flags, r.host, in_bytes, out_bytes);
+    rc = reserve_or_drain(c, n, max_len, 0, r.flags, r.host, in_bytes, out_bytes);
     if (rc) return rc;
     tsx_combiner* cb = nullptr;
     if ((rc = combiner_get(c->dev, &cb))) return rc;
@@ -888,7 +939,7 @@ static int run_batch_inner(tsx_run& r) {
         out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
     }
     r.max_len = max_len; r.max_out = max_out;
-    rc = ctx_reserve(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, out_bytes);
+    rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, out_bytes);
     if (rc) return rc;
     r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
     r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
@@ -1121,6 +1172,14 @@ extern "C" int tsx_debug_combiner_stats(int device_index, uint64_t* groups, uint
 
 // Test hook (not part of the ABI): how many of the first n chunks of the context's LAST detransform batch were decoded by the
 // block-parallel form (the rest went through the chunk-serial kernel); -1 when that batch did not use the form at all.
+// test hook: how many idle pooled contexts of a device hold a block-form decoder workspace (bounded by TSX_POOL_MAX_IDLE_BWORK)
+extern "C" int tsx_debug_pool_bwork(int device_index) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL;
+    int k = 0;
+    for (const tsx_ctx* c : g_devs[device_index].idle) if (c->d_bwork) k++;
+    return k;
+}
 extern "C" int tsx_debug_blockmode_chunks(tsx_ctx* c, uint32_t n) {
     if (!c) return TSX_E_INVAL;
     if (!c->d_bwork || !c->last_used_blocks) return -1;

@@ -33,9 +33,9 @@ def exchange_transformed_sizes(local_sizes, n_chunks: int, rank: int, world: int
     lo, hi = chunk_range_of_rank(n_chunks, rank, world)
     local = np.asarray(local_sizes, dtype=np.int32)
     assert local.shape == (hi - lo,)
-    if world == 1:
+    if world == 1 and dist is None:
         sizes = local.astype(np.int64)
-    else:
+    else:                                                # (world 1 with a process group: bench.py --force-dist runs the collective on one GPU)
         import torch
         per = max(chunk_range_of_rank(n_chunks, r, world)[1] - chunk_range_of_rank(n_chunks, r, world)[0] for r in range(world))
         buf = torch.zeros(per, dtype=torch.int32, device=device)
@@ -83,7 +83,18 @@ def gather_object_to_owner(my_slice, sizes, n_chunks: int, rank: int, world: int
     mine = my_slice if isinstance(my_slice, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(my_slice)).to(device)
     assert mine.numel() == slice_bytes[rank], (mine.numel(), slice_bytes[rank])
     if world == 1:
-        return mine
+        if dist is None:
+            return mine
+        # bench.py --force-dist: one rank, one GPU - the slice travels through the process group's point-to-point path to this same
+        # rank (a grouped send + recv to self: ncclSend / ncclRecv on the device), so that the first multi-GPU run is not the first time
+        # that code executes
+        if dist.get_backend() != "nccl":                 # gloo has no pair to itself: the CPU rehearsal keeps the slice as it is
+            return mine
+        obj = torch.empty_like(mine)
+        if mine.numel():
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), 0), dist.P2POp(dist.irecv, obj, 0)]):
+                w.wait()
+        return obj
     if rank != owner:
         if slice_bytes[rank]:
             dist.send(mine.contiguous(), dst=owner)

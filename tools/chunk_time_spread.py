@@ -11,7 +11,7 @@ import torch
 import tsxform
 from tsxform import synth
 nat = tsxform._native
-N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), "libtsxform_prof.so")); N.init(1, [0])
+N = nat.Native(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", "libtsxform_prof.so")); N.init(1, [0])
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n, CH = 2048, synth.CHUNK
 dev = torch.device("cuda", 0)

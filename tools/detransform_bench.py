@@ -9,7 +9,7 @@ import tsxform
 from tsxform import synth
 nat = tsxform._native
 LIBNAME = sys.argv[2] if len(sys.argv) > 2 else "libtsxform.so"
-N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), LIBNAME)); N.init(1, [0])
+N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), LIBNAME) if LIBNAME == "libtsxform.so" else os.path.join(ROOT, "tools", "_libs", LIBNAME)); N.init(1, [0])
 n, CH = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, synth.CHUNK
 dev = torch.device("cuda", 0)
 src = torch.empty(n * CH, dtype=torch.uint8, device=dev)

@@ -7,7 +7,7 @@ rm -rf $O; mkdir -p $O
 cd $R
 timeout 170 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 timeout 120 python tools/detransform_bench.py 2048 libtsxform.so > $O/detransform_new.txt 2>&1; tail -4 $O/detransform_new.txt
-[ -f tiered-storage-for-apache-kafka_amd/libtsxform_prof2.so ] && timeout 100 python tools/detransform_bench.py 2048 libtsxform_prof2.so > $O/detransform_prof2.txt 2>&1; tail -9 $O/detransform_prof2.txt
+[ -f tools/_libs/libtsxform_prof2.so ] && timeout 100 python tools/detransform_bench.py 2048 libtsxform_prof2.so > $O/detransform_prof2.txt 2>&1; tail -9 $O/detransform_prof2.txt
 timeout 240 python bench.py --steps 9 --warmup 1 2> $O/bench_full.err | tail -1 > $O/bench_full.json; cat $O/bench_full.json | cut -c1-400
 cd /tmp
 timeout 150 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $O/stats.log 2>&1

@@ -31,7 +31,7 @@ def main():
     import tsxform
     from tsxform import synth
     nat = tsxform._native
-    N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), args.lib))
+    N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), args.lib) if args.lib == "libtsxform.so" else os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", args.lib))
     has_prof = "_prof" in args.lib
     N.init(1, [0])
     n, CH = args.chunks, synth.CHUNK

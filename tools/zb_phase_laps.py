@@ -15,7 +15,7 @@ import tsxform  # noqa: E402
 from tsxform import synth  # noqa: E402
 
 nat = tsxform._native
-N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), "libtsxform_prof2.so")); N.init(1, [0])
+N = nat.Native(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", "libtsxform_prof2.so")); N.init(1, [0])
 dev = torch.device("cuda", 0)
 CH = synth.CHUNK
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
