@@ -21,8 +21,13 @@ N.lib.hipemu_alloc_calls.restype = ctypes.c_long
 flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
 small = [synth.gen_chunk("K", 3, 0, 0, 900)]
 large = [synth.gen_chunk("K", 4, 0, i, 3000 + 20 * i) for i in range(18)]         # more chunks, longer chunks: every workspace regrows
-want_small, _ = pc.run_transform(N, flags, small)
-want_large, _ = pc.run_transform(N, flags, large)
+# (references through an explicit context: an idle POOLED context would be drained to retry a failed allocation - tsx_api.hip
+#  reserve_or_drain, tests/test_emu_boundary.py::test_cached_workspaces_are_not_a_reason_for_nomem - and this script wants the failures)
+_c = N.ctx_create(0, 0, 0)
+want_small, _ = pc.run_transform(N, flags, small, ctx=_c)
+want_large, _ = pc.run_transform(N, flags, large, ctx=_c)
+N.ctx_destroy(_c)
+assert N.pool_stats(0)["idle"] == 0
 
 
 def attempt(ctx, chunks, mem):

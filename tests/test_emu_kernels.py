@@ -143,3 +143,13 @@ def test_packed_host_output_is_the_object_bytes(emu):
     assert dst[:len(ref[0])].tobytes() == ref[0] and (dst[room:] == 0xEE).all()
     with pytest.raises(Exception):
         N.detransform_batch(p, d, src, dst, dst.size, nat.MEM_HOST_PACKED)             # transform only
+
+
+def test_host_carryless_multiplier_equals_the_bit_loop(emu):
+    """tsx_gcm_key_build_host takes its 541 GF(2^128) products through PCLMULQDQ when the host has it (the per-batch key schedule is on the
+    fetch path's latency: VERDICT r3 #6); the bit loop it replaces is the reference - 200 000 pseudo-random products, edge operands included."""
+    import ctypes
+    f = emu.lib.tsx_debug_hmul_selftest
+    f.argtypes = [ctypes.c_uint32]; f.restype = ctypes.c_int
+    r = f(200000)
+    assert r in (0, -1), "%d products differ" % r

@@ -86,6 +86,29 @@ def test_both_decoder_forms_agree_on_the_device(gpu, oracle, monkeypatch):
         assert outs[i] == plain[i % len(plain)].tobytes(), i
 
 
+def test_block_form_takes_deep_copy_chains_on_the_device(gpu, oracle):
+    """4 MiB chunks whose copy chains are 4 Mi / 2 Mi / 600 k hops deep (runs at offset 1, 2 and 7), frames of stock libzstd and of the
+    product compressor: exact bytes, and the block form keeps every one of them - with in-place pointer jumping a pass guarantees three
+    hops, so ceil(log3(size)) + 1 passes are queued (round 3 queued log4 + 1 = 13: a 2 Mi-hop chain could end up in the 31 ms path)."""
+    from tests.test_emu_zstd import _deep_chain_inputs
+    inputs = _deep_chain_inputs(synth.CHUNK)
+    vals = list(inputs.values())
+    blobs = [oracle.zstd_compress_chunk(v.tobytes(), 3) for v in vals] + [oracle.zstd_compress_chunk(v.tobytes(), 19) for v in vals]
+    ours, d0 = pc.run_transform(gpu, nat.COMPRESS, vals)
+    assert (d0["status"] == 0).all()
+    blobs += ours
+    ctx = gpu.ctx_create(0, 0, 0)
+    try:
+        for rep in range(3):                                            # (the order of the in-place stores differs from launch to launch)
+            outs, d = pc.run_detransform(gpu, nat.COMPRESS, blobs, [synth.CHUNK] * len(blobs), ctx=ctx)
+            assert pc.blockmode_chunks(gpu, ctx, len(blobs)) == len(blobs), "a deep chain fell back to the chunk-serial decoder"
+            assert (d["status"] == 0).all()
+            for i in range(len(blobs)):
+                assert outs[i] == vals[i % 3].tobytes(), (rep, i)
+    finally:
+        gpu.ctx_destroy(ctx)
+
+
 def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
     """16 threads, context-less 64-chunk compressing batches from / to pinned host buffers: every batch equals the single-threaded
     result, and the device's launch combiner carried them in fewer launches than batches (callers that arrive while the lanes are busy

@@ -51,7 +51,8 @@ void tsx_aes_build_tables(tsx_aes_tables* t) {
 
 // ---------------------------------------------------------------------------------------------------
 // per-key setup on the HOST: the arithmetic of gcm_setup_kernel below, word for word, in plain C++ (round keys, H = E_K(0),
-// powers of H, the 4-bit tables of H^256 and the 2-bit tables of H^64).  ~0.1 ms of one core per batch key.
+// powers of H, the 4-bit tables of H^256 and the 2-bit tables of H^64).  ~0.1 ms of one core per batch key with the bit loop, ~10 us
+// with the host's carry-less multiplier.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 struct HostAes { uint32_t te0[256]; std::once_flag once; };
@@ -71,6 +72,32 @@ inline tsx_gf128 h_mul(const tsx_gf128& x, tsx_gf128 v) {
     for (int i = 0; i < 64; i++) { if ((x.lo >> (63 - i)) & 1) { z.hi ^= v.hi; z.lo ^= v.lo; } h_mulx(v); }
     return z;
 }
+// The same product with the host's carry-less multiplier (x86-64 PCLMULQDQ: every host a broker runs on has it; the bit loop above stays
+// as the fallback and as the reference the self-test compares with).  With integer bit 127 - i holding the coefficient of x^i, the
+// carry-less product C of the two integers is the bit-reversed polynomial product one place to the right: C << 1 = rev256(P).  Its high
+// half H is rev(P mod x^128) and its low half L is rev(P div x^128), which folds in through x^128 = x^7 + x^2 + x + 1 (a right shift in
+// this bit order) - the bits those right shifts drop are the second fold W.
+#if defined(__x86_64__)
+typedef long long tsx_v2di __attribute__((vector_size(16)));
+__attribute__((target("pclmul,sse2"))) inline tsx_gf128 h_mul_clmul(const tsx_gf128& x, const tsx_gf128& y) {
+    typedef unsigned __int128 u128;
+    const tsx_v2di a = {(long long)x.lo, (long long)x.hi}, b = {(long long)y.lo, (long long)y.hi};
+    auto prod = [](tsx_v2di v) { return ((u128)(uint64_t)v[1] << 64) | (uint64_t)v[0]; };
+    const u128 p00 = prod(__builtin_ia32_pclmulqdq128(a, b, 0x00)), p11 = prod(__builtin_ia32_pclmulqdq128(a, b, 0x11));
+    const u128 mid = prod(__builtin_ia32_pclmulqdq128(a, b, 0x10)) ^ prod(__builtin_ia32_pclmulqdq128(a, b, 0x01));
+    u128 lo = p00 ^ (mid << 64), hi = p11 ^ (mid >> 64);              // C = hi : lo
+    hi = (hi << 1) | (lo >> 127); lo <<= 1;                            // C << 1
+    const u128 m = lo ^ (lo << 127) ^ (lo << 126) ^ (lo << 121);
+    const u128 r = hi ^ m ^ (m >> 1) ^ (m >> 2) ^ (m >> 7);
+    tsx_gf128 z; z.hi = (uint64_t)(r >> 64); z.lo = (uint64_t)r;
+    return z;
+}
+inline bool h_have_clmul() { static const bool v = __builtin_cpu_supports("pclmul") && !getenv("TSX_NO_PCLMUL"); return v; }
+#else
+inline tsx_gf128 h_mul_clmul(const tsx_gf128& x, const tsx_gf128& y) { return h_mul(x, y); }
+inline bool h_have_clmul() { return false; }
+#endif
+inline tsx_gf128 h_mulf(const tsx_gf128& x, const tsx_gf128& y) { return h_have_clmul() ? h_mul_clmul(x, y) : h_mul(x, y); }
 // one AES-256 block through the Te0 table (little-endian state words, as aes256_encrypt in gcm_dev.h)
 inline void h_aes256(const uint32_t* rk, uint32_t& w0, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
     const uint32_t* T = g_host_aes.te0;
@@ -114,10 +141,10 @@ void tsx_gcm_key_build_host(const uint8_t key32[32], const uint8_t* aad, uint32_
     out->h = h; out->aad_len = aad_len;
     for (uint32_t t = 0; t < 64; t++) out->aad[t] = t < aad_len ? aad[t] : 0;
     out->hpow2[0] = h;
-    for (int k = 1; k < 32; k++) out->hpow2[k] = h_mul(out->hpow2[k - 1], out->hpow2[k - 1]);
+    for (int k = 1; k < 32; k++) out->hpow2[k] = h_mulf(out->hpow2[k - 1], out->hpow2[k - 1]);
     tsx_gf128 one; one.hi = 0x8000000000000000ull; one.lo = 0;
     out->hpow[0] = one; out->hpow[1] = h;
-    for (int k = 1; k < 9; k++) { const uint32_t half = 1u << k; for (uint32_t d = 0; d < half; d++) out->hpow[half + d] = h_mul(out->hpow[d], out->hpow2[k]); }
+    for (int k = 1; k < 9; k++) { const uint32_t half = 1u << k; for (uint32_t d = 0; d < half; d++) out->hpow[half + d] = h_mulf(out->hpow[d], out->hpow2[k]); }
     tsx_gf128 sv[128];
     { tsx_gf128 v = out->hpow2[8]; for (int i = 0; i < 128; i++) { sv[i] = v; h_mulx(v); } }
     for (uint32_t e = 0; e < 512; e++) {                               // 4-bit (Shoup) tables of H^256
@@ -138,6 +165,21 @@ void tsx_gcm_key_build_host(const uint8_t key32[32], const uint8_t* aad, uint32_
             }
         }
     }
+}
+
+// test hook: n pseudo-random products through the carry-less multiplier and through the bit loop; returns the number that differ
+// (-1: this host has no carry-less multiplier, nothing compared)
+extern "C" int tsx_debug_hmul_selftest(uint32_t n) {
+    if (!h_have_clmul()) return -1;
+    uint64_t s_ = 0x9E3779B97F4A7C15ull; int bad = 0;
+    auto next = [&] { s_ ^= s_ << 13; s_ ^= s_ >> 7; s_ ^= s_ << 17; return s_; };
+    for (uint32_t i = 0; i < n; i++) {
+        tsx_gf128 a, b; a.hi = next(); a.lo = next(); b.hi = next(); b.lo = next();
+        if (i % 7 == 0) { a.lo = 0; } if (i % 11 == 0) { b.hi = 0x8000000000000000ull; b.lo = 0; } if (i % 13 == 0) { a.hi = 0; a.lo = 1; }
+        const tsx_gf128 p = h_mul(a, b), q = h_mul_clmul(a, b);
+        if (p.hi != q.hi || p.lo != q.lo) bad++;
+    }
+    return bad;
 }
 
 #include "gcm_dev.h"

@@ -17,7 +17,7 @@
 //                      regenerated sizes before it, incoming history = composition of the outgoing ones: O(1) per block), shares the
 //                      block's groups of 64 sequences out over its waves and writes ONE WORD PER OUTPUT BYTE: the byte itself for a
 //                      literal, the position it copies from for a match byte.
-//   zb_jump_kernel     log4(size) passes of pointer jumping (two jumps each) over those words: "where I copy from" becomes "where that copies from"
+//   zb_jump_kernel     <= log3(size) + 1 passes of pointer jumping (two jumps each, in place: three hops guaranteed) over those words: "where I copy from" becomes "where that copies from"
 //                      until every word is a literal - the execution stage without any order between sequences, blocks or
 //                      workgroups (in-order execution is ONE dependency chain through the whole chunk: see the comment there).
 //   zb_emit_kernel     words -> bytes.
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(ZB_SC_WAVES * LANES) void zb_scatter_kernel(const u
 
 // one jump pass: every unresolved word takes its source's word, twice (four words per thread).  Chain depths are small in practice
 // (log-like content: every word resolved after 7 jumps = 4 passes, its matches reach ~100 KB back, not to the previous record) while the
-// launcher must queue the passes the WORST case needs (a 4 MiB run of one byte: 22 jumps, 13 passes queued): a pass notes whether it left
+// launcher must queue the passes the WORST case needs (a 4 MiB chain at offset 1 or 2: three guaranteed hops per pass, 15 passes queued): a pass notes whether it left
 // anything unresolved, and the passes behind one that did not return at their first instruction.
 __global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap, uint32_t seq_cap,
                                                       uint32_t round) {
@@ -788,10 +788,14 @@ uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames
 #endif
                        );
     hipLaunchKernelGGL(zb_scatter_kernel, dim3(ZB_MAX_BLOCKS, n), dim3(ZB_SC_WAVES * LANES), 0, st, frames, from_mid, mid_stride, d_descs, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
-    // a copy chain is at most as long as the chunk and a pass makes two jumps: ceil(log4(max_out)) + 1 passes resolve every word (the passes
-    // behind one that resolved everything return at once)
-    uint32_t bits = 1; while ((1ull << bits) < (uint64_t)max_out + 1) bits++;
-    const uint32_t rounds = (bits + 1) / 2 + 1;
+    // A copy chain is at most as long as the chunk.  A pass makes two jumps IN PLACE: the first reads its source's word, the second the
+    // word of what that named - either may still hold its value from before the pass (another thread has not stored yet), so what a pass
+    // guarantees is old[old[old[q]]]: three hops of the chain as it was, not four.  ceil(log3(max_out)) + 1 passes therefore resolve every
+    // word whatever the order of the stores (14 + 1 for a 4 MiB run at offset 1; round 3 queued log4 + 1 = 13 and such chunks silently
+    // took the chunk-serial kernel as well).  The passes behind one that resolved everything return at their first instruction.
+    uint32_t rounds = 1;
+    for (uint64_t reach = 1; reach < (uint64_t)max_out; reach *= 3) rounds++;
+    static_assert(sizeof(((ZbChunk*)0)->live) / sizeof(((ZbChunk*)0)->live[0]) >= 18, "live[] covers the passes of a 16 MiB chunk");
     const uint32_t tiles = (max_out + 1023) / 1024;                     // 256 threads x 4 words
     for (uint32_t r = 0; r < rounds; r++)
         hipLaunchKernelGGL(zb_jump_kernel, dim3(tiles, n), dim3(256), 0, st, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap, r);
