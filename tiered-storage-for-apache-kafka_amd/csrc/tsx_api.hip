@@ -352,8 +352,11 @@ static int ctx_init_device_objects(tsx_ctx* c) {
     for (auto& e : c->sub_ev[0]) HIPCHK(hipEventCreate(&e));      // the other rows are created by the first pipelined batch
     HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
     HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
-    HIPCHK(hipMemset(c->d_key, 0, sizeof(tsx_gcm_key)));                // (the raw-key buffer is only written with TSX_GCM_SETUP_KERNEL: what
-    HIPCHK(hipMemset(c->d_keyraw, 0, 128));                             //  tsx_debug_key_residue reads must never be an allocator's leftovers)
+    // the raw-key buffer is only written with TSX_GCM_SETUP_KERNEL: what tsx_debug_key_residue reads must never be an allocator's leftovers.
+    // On the context's OWN stream: it is non-blocking, a memset on the null stream could land behind the first batch's key copy
+    // (seen on the device: the first batch of a fresh pooled context encrypted with a zeroed schedule).
+    HIPCHK(hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st));
+    HIPCHK(hipMemsetAsync(c->d_keyraw, 0, 128, c->st));
     HIPCHK(hipHostMalloc((void**)&c->h_keyraw, 128, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&c->h_key, sizeof(tsx_gcm_key), hipHostMallocMapped | hipHostMallocPortable));
     HIPCHK(hipHostGetDevicePointer((void**)&c->hd_key, c->h_key, 0));
@@ -612,6 +615,9 @@ struct tsx_run {                                              // what one batch 
 };
 
 static uint32_t zstd_sched_from_env();
+#ifndef TSX_ZSTD_QUAD_DEFAULT
+#define TSX_ZSTD_QUAD_DEFAULT 0         /* which compressor kernel a batch gets when TSX_ZSTD_QUAD is not set */
+#endif
 // Enqueues the kernels of chunks [lo, lo + n) on compute stream st; e[0..3] are recorded at the stage boundaries.
 static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st) {
     tsx_ctx* c = r.c;
@@ -748,6 +754,9 @@ static uint32_t zstd_sched_from_env() {
         unsigned a = 0, b = 0;
         if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) sched = a | b << 8;
     }
+    // four chunks per wave (csrc/zstd_match4.h): TSX_ZSTD_QUAD=1 / 0 (A/B measurements; same bytes either way)
+    if (const char* q = getenv("TSX_ZSTD_QUAD")) { if (atoi(q) != 0) sched |= TSX_ZSTD_SCHED_QUAD; }
+    else if (TSX_ZSTD_QUAD_DEFAULT) sched |= TSX_ZSTD_SCHED_QUAD;
     return sched;
 }
 

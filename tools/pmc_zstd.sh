@@ -3,7 +3,7 @@
 # The synthetic chunks are generated once outside rocprofv3 (thousands of tiny generator kernels would each be serialized).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc
+OUT=$R/gpurun_out/${PMC_DIR:-pmc}       # PMC_DIR=pmc_quad TSX_ZSTD_QUAD=1 bash tools/pmc_zstd.sh: the four-chunks-per-wave kernel
 mkdir -p $OUT
 python $R/tools/prof_zstd.py --chunks 256 --lib libtsxform.so --data /tmp/k256.npy > /dev/null 2>&1
 CMD="python $R/tools/prof_zstd.py --chunks 2048 --dist K --lib libtsxform.so --data /tmp/k256.npy"
