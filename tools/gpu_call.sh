@@ -166,9 +166,10 @@ PY
       if [ "$arg" = "both" ]; then PMC_DIR=pmc_one TSX_ZSTD_QUAD=0 bash tools/pmc_zstd.sh > $O/pmc_one.log 2>&1; python tools/show_pmc.py gpurun_out/pmc_one | tee $O/pmc_one_summary.txt; fi ;;
     quadfly)
       # the quad kernel against callers in flight (is it bound by latency cover or by the memory system?)
-      for cfg in ${arg:-1:3 1:5 1:8 0:5}; do q=${cfg%:*}; t=${cfg#*:}
-        echo -n "TSX_ZSTD_QUAD=$q inflight $t: "
-        TSX_ZSTD_QUAD=$q timeout 400 python bench.py --inflight $t --steps $((t * 4)) --warmup 5 --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained --no-verify 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['gibs_one_batch_at_a_time'])"
+      # cfg = quad:callers[:k0,k1]
+      for cfg in ${arg:-1:3 1:5 1:8 0:5}; do q=${cfg%%:*}; rest=${cfg#*:}; t=${rest%%:*}; sch=""; [[ "$rest" == *:* ]] && sch=${rest#*:}
+        echo -n "TSX_ZSTD_QUAD=$q inflight $t sched '$sch': "
+        TSX_ZSTD_SCHED=$sch TSX_ZSTD_QUAD=$q timeout 400 python bench.py --inflight $t --steps $((t * 4)) --warmup 5 --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained --no-verify 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['gibs_one_batch_at_a_time'])"
       done | tee $O/quad_inflight.txt ;;
     *) echo "unknown section $name" ;;
   esac
