@@ -48,7 +48,6 @@ extern Ctx* g_ctx;  // context of the running fiber
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry);
 void block_barrier();
 void wave_barrier();
-void group_barrier();        // rendezvous of the live lanes of the current 16-lane group (lane >> 4) of the wave
 uint64_t* wave_slots();      // 64 x u64 scratch for the current wave
 uint64_t wave_live_mask();   // lanes of the current wave that have not exited
 unsigned lane_id();
@@ -117,34 +116,6 @@ inline unsigned long long __ballot(int pred) {
     for (int i = 0; i < 64; i++) if (((live >> i) & 1) && s[i]) m |= 1ull << i;
     hipemu::wave_barrier();
     return m;
-}
-// ---- 16-lane group collectives (csrc/zstd_match4.h: four chunks per wave, one per DPP row) -------------------------------
-// On hardware the four groups of a wave share one instruction stream and diverge by exec mask; a __ballot / ds_bpermute executed by
-// one group's lanes sees only that group.  Fibers model this with a rendezvous per GROUP: groups advance independently of each other.
-inline unsigned hipemu_group_ballot16(int pred) {
-    uint64_t* s = hipemu::wave_slots();
-    const unsigned l = hipemu::lane_id(), g0 = l & 48u;
-    s[l] = pred ? 1 : 0;
-    hipemu::group_barrier();
-    unsigned m = 0; const unsigned long long live = hipemu::wave_live_mask();
-    for (unsigned i = 0; i < 16; i++) if (((live >> (g0 + i)) & 1) && s[g0 + i]) m |= 1u << i;
-    hipemu::group_barrier();
-    return m;
-}
-template <class T>
-inline T hipemu_group_xchg16(T v, int src_in_group) {
-    static_assert(sizeof(T) <= 8, "payload");
-    uint64_t bits = 0;
-    std::memcpy(&bits, &v, sizeof(T));
-    uint64_t* s = hipemu::wave_slots();
-    const unsigned l = hipemu::lane_id(), g0 = l & 48u;
-    s[l] = bits;
-    hipemu::group_barrier();
-    const uint64_t r = s[g0 + ((unsigned)src_in_group & 15u)];
-    hipemu::group_barrier();
-    T out;
-    std::memcpy(&out, &r, sizeof(T));
-    return out;
 }
 inline int __any(int p) { return __ballot(p) != 0; }
 inline int __all(int p) { return __ballot(!p) == 0; }

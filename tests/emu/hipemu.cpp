@@ -59,7 +59,6 @@ struct Fiber {
 };
 struct Wave {
     unsigned arrive = 0, gen = 0, live = 0;
-    unsigned garrive[4] = {0, 0, 0, 0}, ggen[4] = {0, 0, 0, 0}, glive[4] = {0, 0, 0, 0};     // per 16-lane group
     uint64_t live_mask = 0;
     uint64_t slots[64];
 };
@@ -87,10 +86,6 @@ static void release_wave_barrier_if_complete(Wave& w) {
     if (w.live && w.arrive == w.live) { w.arrive = 0; w.gen++; }
 }
 
-static void release_group_barrier_if_complete(Wave& w, unsigned g) {
-    if (w.glive[g] && w.garrive[g] == w.glive[g]) { w.garrive[g] = 0; w.ggen[g]++; }
-}
-
 static void trampoline() {
     Fiber* f = g_cur;
     (*g_blk->entry)();
@@ -98,10 +93,8 @@ static void trampoline() {
     Block& b = *g_blk;
     Wave& w = b.waves[f->ctx.flat_tid / 64];
     w.live--; w.live_mask &= ~(1ull << (f->ctx.flat_tid & 63));
-    w.glive[(f->ctx.flat_tid & 63) >> 4]--;
     b.live--;
     release_wave_barrier_if_complete(w);
-    release_group_barrier_if_complete(w, (f->ctx.flat_tid & 63) >> 4);
     release_block_barrier_if_complete();
     TSAN_FIBER_GO(g_sched_tsan);
     hipemu_switch(&f->sp, g_sched_sp);
@@ -121,14 +114,6 @@ void wave_barrier() {
     w.arrive++;
     release_wave_barrier_if_complete(w);
     while (w.gen == gen) yield();
-}
-void group_barrier() {
-    Wave& w = g_blk->waves[g_cur->ctx.flat_tid / 64];
-    const unsigned g = (g_cur->ctx.flat_tid & 63) >> 4;
-    const unsigned gen = w.ggen[g];
-    w.garrive[g]++;
-    release_group_barrier_if_complete(w, g);
-    while (w.ggen[g] == gen) yield();
 }
 uint64_t* wave_slots() { return g_blk->waves[g_cur->ctx.flat_tid / 64].slots; }
 uint64_t wave_live_mask() { return g_blk->waves[g_cur->ctx.flat_tid / 64].live_mask; }
@@ -174,7 +159,6 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry) {
                     f.ctx.bdim = block; f.ctx.gdim = grid; f.ctx.flat_tid = t;
                     Wave& w = blk.waves[t / 64];
                     w.live++; w.live_mask |= 1ull << (t & 63);
-                    w.glive[(t & 63) >> 4]++;
                 }
                 unsigned remaining = nthreads;
                 while (remaining) {

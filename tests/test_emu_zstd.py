@@ -60,59 +60,6 @@ def test_speculation_schedule_never_changes_the_bytes(emu, oracle, sched, monkey
         assert outs[i] == oracle.zstd_compress_chunk(CASES[n].tobytes()), (n, sched)
 
 
-def _quad_launches(N):
-    import ctypes
-    f = N.lib.tsx_debug_quad_launches
-    f.restype = ctypes.c_ulonglong
-    return f()
-
-
-@pytest.mark.parametrize("sched", ["", "1,1", "2,8", "11,11"])
-def test_four_chunks_per_wave_kernel_never_changes_the_bytes(emu, oracle, sched, monkeypatch):
-    """csrc/zstd_match4.h: TSX_ZSTD_QUAD=1 parses four chunks per wavefront, one per 16-lane group - the same serial algorithm, so the same
-    frames.  The whole case set in an order that puts chunks of very different lengths (and the empty one) into one wave, full chain, both
-    profiles, ragged last wave; every frame equals libzstd's, every chunk the oracle chain's bytes, and the quad kernel really ran."""
-    _need157(oracle)
-    monkeypatch.setenv("TSX_ZSTD_QUAD", "1")
-    if sched:
-        monkeypatch.setenv("TSX_ZSTD_SCHED", sched)
-    names = list(CASES)
-    names = names[::3] + names[1::3] + names[2::3]                    # neighbours in a wave differ in size and kind
-    before = _quad_launches(emu)
-    outs, d = pc.run_transform(emu, nat.COMPRESS, [CASES[n] for n in names])
-    assert _quad_launches(emu) > before, "TSX_ZSTD_QUAD=1 did not select the quad kernel"
-    for i, n in enumerate(names):
-        assert d["status"][i] == 0, n
-        assert outs[i] == oracle.zstd_compress_chunk(CASES[n].tobytes()), "%s: frame differs from libzstd %s" % (n, oracle.zstd_version())
-    if not sched:
-        some = [CASES[n] for n in ("K70000", "empty", "R50000", "K1000", "one", "K200000", "zeros")]
-        pc.check_transform_vs_oracle(emu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, some)
-        pc.check_roundtrip(emu, nat.COMPRESS | nat.ENCRYPT | nat.CRC, some)
-        outs0, _ = pc.run_transform(emu, nat.COMPRESS, some[:5], profile=nat.ZSTD_PROFILE_1_5_6)
-        for x, y in zip(outs0, some[:5]):
-            assert x == oracle.zstd_l3_compress(y.tobytes(), 0)
-        # a slot that cannot hold a chunk's output fails that chunk only, its three wave neighbours are unaffected
-        outs1, d1 = pc.run_transform(emu, nat.COMPRESS | nat.ENCRYPT, [CASES["K1000"], CASES["R50000"], CASES["K7"], CASES["K4096"]], dst_caps=[None, 50000, None, None])
-        assert list(d1["status"]) == [0, nat.E_DST_TOO_SMALL, 0, 0] and d1["dst_len"][1] == 0
-        assert outs1[3] == pc.oracle_transform(oracle, nat.COMPRESS | nat.ENCRYPT, CASES["K4096"], 3)
-
-
-def test_four_chunks_per_wave_kernel_fuzz(emu, oracle, monkeypatch):
-    """40 fuzzed inputs (tests/fuzz_cases.py: runs, periodic stretches, far repeats, alphabet changes) through both kernels: identical
-    frames, identical to libzstd."""
-    _need157(oracle)
-    from tests import fuzz_cases
-    rng = np.random.default_rng(44)
-    cases = [fuzz_cases.gen_case(rng) for _ in range(40)]
-    monkeypatch.setenv("TSX_ZSTD_QUAD", "1")
-    outs, d = pc.run_transform(emu, nat.COMPRESS, cases)
-    monkeypatch.setenv("TSX_ZSTD_QUAD", "0")
-    outs1, d1 = pc.run_transform(emu, nat.COMPRESS, cases)
-    assert (d["status"] == 0).all() and outs == outs1
-    for i, x in enumerate(cases):
-        assert outs[i] == oracle.zstd_compress_chunk(x.tobytes()), i
-
-
 @pytest.mark.parametrize("kind", ["mixed10", "sparse64"])
 def test_chunks_beyond_4_MiB(emu, oracle, kind):
     """chunk.size above 4 MiB (up to a whole segment as one chunk): frames equal libzstd's and decode back.  Content chosen so that the

@@ -615,9 +615,6 @@ struct tsx_run {                                              // what one batch 
 };
 
 static uint32_t zstd_sched_from_env();
-#ifndef TSX_ZSTD_QUAD_DEFAULT
-#define TSX_ZSTD_QUAD_DEFAULT 0         /* which compressor kernel a batch gets when TSX_ZSTD_QUAD is not set */
-#endif
 // Enqueues the kernels of chunks [lo, lo + n) on compute stream st; e[0..3] are recorded at the stage boundaries.
 static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st) {
     tsx_ctx* c = r.c;
@@ -754,9 +751,6 @@ static uint32_t zstd_sched_from_env() {
         unsigned a = 0, b = 0;
         if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) sched = a | b << 8;
     }
-    // four chunks per wave (csrc/zstd_match4.h): TSX_ZSTD_QUAD=1 / 0 (A/B measurements; same bytes either way)
-    if (const char* q = getenv("TSX_ZSTD_QUAD")) { if (atoi(q) != 0) sched |= TSX_ZSTD_SCHED_QUAD; }
-    else if (TSX_ZSTD_QUAD_DEFAULT) sched |= TSX_ZSTD_SCHED_QUAD;
     return sched;
 }
 

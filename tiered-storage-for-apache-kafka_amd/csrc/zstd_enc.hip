@@ -651,8 +651,6 @@ __device__ ZS_NOINLINE static void match_block(const uint8_t* __restrict__ src, 
     PT(4);
 }
 
-#include "zstd_match4.h"
-
 // Per-lane copy of a short run with up to 32 bytes of loads in flight before the first store (a byte loop would pay one
 // memory round trip per byte).
 __device__ static inline void copy_run(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n) {
@@ -1692,264 +1690,6 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Four chunks per wave (zstd_match4.h): workgroup b owns chunks 4b .. 4b + 3 of its batch.  The serial parse of the four chunks'
-// current blocks runs as ONE instruction stream (match_block4, a chunk per 16-lane group); everything else - CRC head, table reset, block
-// size decision, literal gathering, the entropy stage, block emission, the GCM tail - is the code of the one-chunk kernel, run chunk
-// after chunk with all 64 lanes.  A chunk's state between those passes lives in LDS (QChunk).
-// ---------------------------------------------------------------------------------------------------
-struct QChunk {
-    uint32_t live;              // 0: nothing (more) to do for this slot (no such chunk, failed earlier, empty, finished)
-    uint32_t srcSize, ipos, remaining, dictLimit, blockSize, lastBlock, hasBlock, first, cur;
-    uint32_t repc[3];
-    int hufRepeat[2];
-    long long savings;
-    uint32_t opOff;             // bytes of the frame written so far
-};
-struct QLds {
-    union {
-        EncLds L;               // per-chunk passes (entropy stage, CRC head, GCM tail): exactly the one-chunk kernel's LDS
-        struct {
-            uint32_t head_[20];                                         // (EncLds::hufRepeat, scal: not aliased)
-            uint32_t rings[Q_GROUPS * (Q_RING / 4 + 4)];
-            uint8_t scrs[Q_GROUPS * 2 * Q_SCR];
-        } q;                    // joint parse of four blocks
-    };
-    QArg qa[Q_GROUPS];
-    QChunk st[Q_GROUPS];
-};
-#ifndef ZS_QUAD_WAVES_PER_SIMD
-#define ZS_QUAD_WAVES_PER_SIMD 3  /* 12 waves = 48 chunks per CU: 170 VGPRs, <= 13.3 KB of LDS per wave */
-#endif
-static_assert(offsetof(QLds, q.rings) >= offsetof(EncLds, scal) + sizeof(((EncLds*)0)->scal), "the rings leave EncLds' header alone");
-static_assert(sizeof(QLds) * 4 * ZS_QUAD_WAVES_PER_SIMD <= 160u * 1024, "LDS of the quad kernel's waves fits the CU");
-
-template <bool SEG>
-__device__ __forceinline__ static void zstd_compress_body4(const uint8_t* __restrict__ src_base_, tsx_chunk_desc* __restrict__ descs_,
-                                                               uint8_t* __restrict__ mid_, uint64_t mid_stride_, uint32_t* __restrict__ zlen_,
-                                                               int32_t* __restrict__ status_, uint8_t* __restrict__ work_, uint32_t profile_, uint32_t sched, uint32_t n_,
-                                                               const tsx_chain_fuse fuse_, const tsx_zseg* __restrict__ segs, const tsx_zfirsts& firsts, uint32_t nsegs) {
-    __shared__ QLds Q;
-    EncLds& L = Q.L;
-    const uint32_t lane = threadIdx.x;
-    uint32_t wg = blockIdx.x, n = n_;
-    const uint8_t* __restrict__ src_base = src_base_; tsx_chunk_desc* __restrict__ descs = descs_; uint8_t* __restrict__ mid = mid_;
-    uint64_t mid_stride = mid_stride_; uint32_t* __restrict__ zlen = zlen_; int32_t* __restrict__ status = status_; uint8_t* __restrict__ work = work_;
-    uint32_t profile = profile_; tsx_chain_fuse fuse = fuse_;
-    if (SEG) {
-        uint32_t k = 0;                                                  // .first values (in workgroups) come with the kernel arguments
-#pragma unroll
-        for (uint32_t i = 1; i < 64; i++) if (i < nsegs && firsts.first[i] <= blockIdx.x) k = i;
-        const tsx_zseg sg = segs[k];
-        wg = blockIdx.x - sg.first; n = sg.n;
-        src_base = sg.src_base; descs = sg.descs; mid = sg.mid; mid_stride = sg.mid_stride; zlen = sg.zlen; status = sg.status; work = sg.work;
-        profile = sg.profile; fuse = sg.fuse;
-    }
-    const uint32_t chunk0 = wg * Q_GROUPS;
-    const uint32_t mine = chunk0 >= n ? 0u : (n - chunk0 < Q_GROUPS ? n - chunk0 : Q_GROUPS);
-    // ---- per chunk: CRC head, status, fresh tables, frame header ----
-    for (uint32_t c = 0; c < Q_GROUPS; c++) {
-        if (c >= mine) { if (lane == 0) { Q.st[c].live = 0; Q.st[c].remaining = 0; } continue; }
-        const uint32_t chunk = chunk0 + c;
-        const uint8_t* __restrict__ src = src_base + descs[chunk].src_off;
-        const uint32_t srcSize = descs[chunk].src_len;
-        uint8_t* const frame = mid + (uint64_t)chunk * mid_stride;
-        uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
-        uint32_t* const hashLong = (uint32_t*)(ws + ZS_WS_HASHLONG);
-        uint32_t* const hashSmall = (uint32_t*)(ws + ZS_WS_HASHSMALL);
-        __syncthreads();                                                // (the LDS of the previous chunk's passes is free)
-        if (fuse.crc) {
-            const uint32_t crc = crc32c_wave(fuse.crc, src, srcSize, L.crcTab, lane);
-            if (lane == 0) descs[chunk].crc32c = crc;
-        }
-        bool live = true;
-        if (fuse.self_status) { if (lane == 0) status[chunk] = TSX_OK; }
-        else if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } live = false; }
-        uint32_t hdr = 0;
-        const zs_cparams cp = zs_level3_cparams(srcSize);
-        if (live) {
-            {   uint4 z; z.x = z.y = z.z = z.w = 0;
-                uint4* a = (uint4*)hashLong; uint4* b = (uint4*)hashSmall;
-                for (uint32_t i = lane; i < (1u << cp.hashLog) / 4; i += LANES) a[i] = z;
-                for (uint32_t i = lane; i < (1u << cp.chainLog) / 4; i += LANES) b[i] = z;
-            }
-            {   const uint32_t windowSize = 1u << cp.windowLog;
-                const uint32_t single = windowSize >= srcSize;
-                const uint32_t fcs = (srcSize >= 256) + (srcSize >= 65536 + 256);
-                uint8_t h[16]; uint32_t k = 0;
-                h[k++] = 0x28; h[k++] = 0xB5; h[k++] = 0x2F; h[k++] = 0xFD;
-                h[k++] = (uint8_t)((single << 5) + (fcs << 6));
-                if (!single) h[k++] = (uint8_t)((cp.windowLog - 10) << 3);
-                if (fcs == 0) { if (single) h[k++] = (uint8_t)srcSize; }
-                else if (fcs == 1) { h[k++] = (uint8_t)(srcSize - 256); h[k++] = (uint8_t)((srcSize - 256) >> 8); }
-                else { h[k++] = (uint8_t)srcSize; h[k++] = (uint8_t)(srcSize >> 8); h[k++] = (uint8_t)(srcSize >> 16); h[k++] = (uint8_t)(srcSize >> 24); }
-                hdr = k;
-                if (lane == 0) for (uint32_t i = 0; i < k; i++) frame[i] = h[i];
-            }
-            if (srcSize == 0) {
-                if (lane == 0) { frame[hdr] = 1; frame[hdr + 1] = 0; frame[hdr + 2] = 0; }
-                finish_frame(descs, chunk, frame, hdr + 3, zlen, status, fuse, ws + ZS_WS_KEYCOPY, L, lane);
-                live = false;
-            } else {
-                uint32_t* const hufSave = (uint32_t*)(ws + ZS_WS_HUFSAVE);
-                __syncthreads();
-                if (lane == 0) { L.huf[0].maxSym = 0; L.huf[1].maxSym = 0; }
-                __syncthreads();
-                for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) hufSave[i] = reinterpret_cast<const uint32_t*>(&L.huf[0])[i];
-                __threadfence_block();
-            }
-        }
-        if (lane == 0) {
-            QChunk& S = Q.st[c];
-            S.live = live ? 1u : 0u; S.srcSize = srcSize; S.ipos = 0; S.remaining = live ? srcSize : 0u; S.dictLimit = 2; S.blockSize = 0; S.lastBlock = 0; S.hasBlock = 0;
-            S.first = 1; S.cur = 0; S.repc[0] = 1; S.repc[1] = 4; S.repc[2] = 8; S.hufRepeat[0] = 0; S.hufRepeat[1] = 0; S.savings = 0; S.opOff = hdr;
-        }
-    }
-    __syncthreads();
-    // ---- rounds: block k of every chunk that still has one ----
-    for (;;) {
-        bool any = false;
-        for (uint32_t c = 0; c < Q_GROUPS; c++) {
-            __syncthreads();
-            const uint32_t remaining = UNI(Q.st[c].remaining);
-            if (lane == 0) { Q.qa[c].active = 0; Q.st[c].hasBlock = 0; }
-            if (!remaining) continue;
-            any = true;
-            const uint32_t chunk = chunk0 + c;
-            const uint8_t* __restrict__ src = src_base + descs[chunk].src_off;
-            uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
-            const uint32_t srcSize = UNI(Q.st[c].srcSize), ipos = UNI(Q.st[c].ipos);
-            uint32_t dictLimit = UNI(Q.st[c].dictLimit);
-            const long long savings = Q.st[c].savings;
-            const zs_cparams cp = zs_level3_cparams(srcSize);
-            const uint32_t blockSizeMax = (1u << cp.windowLog) < ZS_BLOCK_MAX ? (1u << cp.windowLog) : ZS_BLOCK_MAX;
-            uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
-            if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
-                blockSize = UNI(split_block_1_5_7(src + ipos, L, lane));
-            {   const uint32_t blockEndIdx = ipos + 2, maxDist = 1u << cp.windowLog;
-                if (blockEndIdx > maxDist && dictLimit < blockEndIdx - maxDist) dictLimit = blockEndIdx - maxDist;
-            }
-            __syncthreads();
-            if (lane == 0) {
-                QChunk& S = Q.st[c];
-                S.blockSize = blockSize; S.lastBlock = blockSize == remaining; S.dictLimit = dictLimit; S.hasBlock = 1;
-                QArg& A = Q.qa[c];
-                A.src = src; A.hashLong = (uint32_t*)(ws + ZS_WS_HASHLONG); A.hashSmall = (uint32_t*)(ws + ZS_WS_HASHSMALL); A.seqs = (zs_seq*)(ws + ZS_WS_SEQS);
-                A.srcSize = srcSize; A.blockStart = ipos; A.blockSize = blockSize; A.dictLimit = dictLimit;
-                A.rep[0] = S.repc[0]; A.rep[1] = S.repc[1]; A.rep[2] = S.repc[2];
-                A.active = blockSize >= 7 ? 1u : 0u;
-                A.nbSeq = 0; A.litSize = 0; A.lastLL = 0; A.anchor = ipos;
-            }
-        }
-        if (!any) break;
-        __threadfence_block();
-        __syncthreads();
-        match_block4(Q.qa, Q.q.rings, Q.q.scrs, lane, sched);
-        __threadfence_block();
-        __syncthreads();
-        for (uint32_t c = 0; c < Q_GROUPS; c++) {
-            __syncthreads();
-            if (!UNI(Q.st[c].hasBlock)) continue;
-            const uint32_t chunk = chunk0 + c;
-            const uint8_t* __restrict__ src = src_base + descs[chunk].src_off;
-            uint8_t* const frame = mid + (uint64_t)chunk * mid_stride;
-            uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
-            zs_seq* const seqs = (zs_seq*)(ws + ZS_WS_SEQS);
-            uint8_t* const lit = ws + ZS_WS_LIT;
-            uint8_t* const codes = ws + ZS_WS_CODES;
-            uint8_t* const blockout = ws + ZS_WS_BLOCKOUT;
-            uint32_t* const huftmp = (uint32_t*)(blockout + (256u << 10));
-            uint32_t* const hufSave = (uint32_t*)(ws + ZS_WS_HUFSAVE);
-            const uint32_t ipos = UNI(Q.st[c].ipos), blockSize = UNI(Q.st[c].blockSize), lastBlock = UNI(Q.st[c].lastBlock), first = UNI(Q.st[c].first);
-            uint32_t cur = UNI(Q.st[c].cur);
-            uint8_t* op = frame + UNI(Q.st[c].opOff);
-            const bool parsed = UNI(Q.qa[c].active) != 0;
-            MfState ms; ms.nbSeq = UNI(Q.qa[c].nbSeq); ms.litSize = UNI(Q.qa[c].litSize); ms.lastLL = UNI(Q.qa[c].lastLL); ms.anchor = UNI(Q.qa[c].anchor);
-            const uint32_t rep0 = UNI(Q.qa[c].rep[0]), rep1 = UNI(Q.qa[c].rep[1]), rep2 = UNI(Q.qa[c].rep[2]);
-            const int hr0 = Q.st[c].hufRepeat[0], hr1 = Q.st[c].hufRepeat[1];
-            __syncthreads();                                            // everything of the joint pass has been read: the union is this chunk's now
-            uint32_t cSize = 0;                                         // 0 -> raw block
-            bool confirm = false;
-            if (parsed) {
-                gather_literals(lit, src, seqs, ms.nbSeq, ms.anchor, ms.lastLL, lane);
-                __threadfence_block();
-                __syncthreads();
-                if (lane == 0) { L.scal[8] = 0; L.hufRepeat[0] = hr0; L.hufRepeat[1] = hr1; }
-                __syncthreads();
-                const bool suspect = ms.nbSeq == 0 || (ms.litSize / ms.nbSeq >= 20);
-                for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) reinterpret_cast<uint32_t*>(&L.huf[0])[i] = hufSave[i];     // back from the workspace
-                __threadfence_block();
-                __syncthreads();
-                uint32_t litBytes = UNI(compress_literals(blockout, lit, ms.litSize, L, (int)cur, suspect, huftmp, (HufScratch*)(codes + 3 * ZS_WS_CODE_STRIDE), lane));
-                __threadfence_block();
-                __syncthreads();
-                for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) hufSave[i] = reinterpret_cast<const uint32_t*>(&L.huf[0])[i];     // the LL table takes their place
-                __threadfence_block();
-                __syncthreads();
-                uint32_t seqBytes = UNI(compress_sequences(blockout + litBytes, blockout + (255u << 10), seqs, ms.nbSeq, codes, L, huftmp, (ZS_BLOCKOUT_CAP - (256u << 10)) - 64, lane));
-                const bool newHuf = UNI(L.scal[8]) != 0;
-                if (seqBytes != 0xFFFFFFFFu) {
-                    cSize = litBytes + seqBytes;
-                    const uint32_t maxCSize = blockSize - ((blockSize >> 6) + 2);
-                    if (cSize >= maxCSize) cSize = 0;
-                }
-                if (!first && ms.nbSeq < 4 && ms.litSize < 10 && wave_is_rle(src + ipos, blockSize, lane)) cSize = 1;
-                if (cSize > 1) {                                        // confirm repcodes + entropy tables
-                    confirm = true;
-                    if (newHuf) { cur ^= 1; if (lane == 0) L.hufRepeat[cur] = 1; }      // HUF_repeat_check for the next block
-                    __syncthreads();
-                }
-            }
-            // ---- emit the block ----
-            if (cSize == 0) {
-                if (lane == 0) { const uint32_t h = lastBlock + (0u << 1) + (blockSize << 3); op[0] = (uint8_t)h; op[1] = (uint8_t)(h >> 8); op[2] = (uint8_t)(h >> 16); }
-                wave_copy(op + 3, src + ipos, blockSize, lane);
-                cSize = 3 + blockSize;
-            } else if (cSize == 1) {
-                if (lane == 0) { const uint32_t h = lastBlock + (1u << 1) + (blockSize << 3); op[0] = (uint8_t)h; op[1] = (uint8_t)(h >> 8); op[2] = (uint8_t)(h >> 16); op[3] = src[ipos]; }
-                cSize = 4;
-            } else {
-                if (lane == 0) { const uint32_t h = lastBlock + (2u << 1) + (cSize << 3); op[0] = (uint8_t)h; op[1] = (uint8_t)(h >> 8); op[2] = (uint8_t)(h >> 16); }
-                wave_copy(op + 3, blockout, cSize, lane);
-                cSize += 3;
-            }
-            __syncthreads();
-            if (lane == 0) {
-                QChunk& S = Q.st[c];
-                if (parsed) { S.hufRepeat[0] = L.hufRepeat[0]; S.hufRepeat[1] = L.hufRepeat[1]; }
-                if (confirm) { S.repc[0] = rep0; S.repc[1] = rep1; S.repc[2] = rep2; }
-                S.cur = cur;
-                S.savings += (long long)blockSize - (long long)cSize;
-                S.ipos = ipos + blockSize; S.remaining -= blockSize; S.opOff += cSize; S.first = 0;
-            }
-            __syncthreads();
-        }
-    }
-    // ---- frames complete: sizes, GCM tails ----
-    for (uint32_t c = 0; c < mine; c++) {
-        __syncthreads();
-        if (!UNI(Q.st[c].live)) continue;
-        const uint32_t chunk = chunk0 + c;
-        uint8_t* const frame = mid + (uint64_t)chunk * mid_stride;
-        uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
-        const uint32_t flen = UNI(Q.st[c].opOff);
-        __syncthreads();
-        finish_frame(descs, chunk, frame, flen, zlen, status, fuse, ws + ZS_WS_KEYCOPY, L, lane);
-    }
-}
-__global__ __launch_bounds__(LANES, ZS_QUAD_WAVES_PER_SIMD) void zstd_compress4_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
-                                                              uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
-                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched, uint32_t n,
-                                                              const tsx_chain_fuse fuse) {
-    const tsx_zfirsts nofirsts{};
-    zstd_compress_body4<false>(src_base, descs, mid, mid_stride, zlen, status, work, profile, sched, n, fuse, nullptr, nofirsts, 0u);
-}
-__global__ __launch_bounds__(LANES, ZS_QUAD_WAVES_PER_SIMD) void zstd_compress4_segments_kernel(const tsx_zseg* __restrict__ segs, const tsx_zfirsts firsts, uint32_t nsegs,
-                                                                                           uint32_t sched) {
-    const tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr, 0, 0};
-    zstd_compress_body4<true>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0u, sched, 0u, none, segs, firsts, nsegs);
-}
-
 #ifdef TSX_PROF
 #define ZS_PROF_PARAM , unsigned long long* __restrict__ prof_out
 #define ZS_PROF_ARG , prof_out
@@ -1973,25 +1713,14 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segmen
 // ---------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------
-// test hook: launches of the four-chunks-per-wave kernels so far (tests assert that a quad run really was one)
-static unsigned long long g_quad_launches = 0;
-extern "C" unsigned long long tsx_debug_quad_launches(void) { return __atomic_load_n(&g_quad_launches, __ATOMIC_RELAXED); }
 size_t tsx_zstd_consts_bytes(void) { return sizeof(tsx_zstd_consts); }
 void tsx_zstd_build_consts(tsx_zstd_consts* h) { h->abi = 1; h->pad[0] = h->pad[1] = h->pad[2] = 0; }
 size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size_t)n * ZS_WS_BYTES; }
 
 // Several callers' batches in one launch: d_segs[0 .. nsegs) (device memory, ascending .first, segment k = workgroups [first, first + n)).
-uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched) {
+uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, const tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched) {
     if (!total_chunks || !nsegs || nsegs > 64) return 0;
     tsx_zfirsts f{};
-    if (sched & TSX_ZSTD_SCHED_QUAD) {
-        // four chunks per workgroup: a segment's chunks stay together, so the table counts in workgroups (the kernel reads .first back)
-        uint32_t wg = 0;
-        for (uint32_t k = 0; k < nsegs; k++) { f.first[k] = wg; h_segs[k].first = wg; wg += (h_segs[k].n + Q_GROUPS - 1) / Q_GROUPS; }
-        __atomic_fetch_add(&g_quad_launches, 1ull, __ATOMIC_RELAXED);
-        hipLaunchKernelGGL(zstd_compress4_segments_kernel, dim3(wg), dim3(LANES), 0, st, d_segs, f, nsegs, sched & 0xFFFFu);
-        return 1;
-    }
     for (uint32_t k = 0; k < nsegs; k++) f.first[k] = h_segs[k].first;
     hipLaunchKernelGGL(zstd_compress_segments_kernel, dim3(total_chunks), dim3(LANES), 0, st, d_segs, f, nsegs, sched
 #ifdef TSX_PROF
@@ -2005,12 +1734,6 @@ uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*
                                   uint32_t /*max_len*/, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status, void* d_work,
                                   uint32_t profile, uint32_t sched, tsx_chain_fuse fuse) {
     if (!n) return 0;
-    if (sched & TSX_ZSTD_SCHED_QUAD) {
-        __atomic_fetch_add(&g_quad_launches, 1ull, __ATOMIC_RELAXED);
-        hipLaunchKernelGGL(zstd_compress4_kernel, dim3((n + Q_GROUPS - 1) / Q_GROUPS), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
-                           (uint8_t*)d_work, profile, sched & 0xFFFFu, n, fuse);
-        return 1;
-    }
     hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
                        (uint8_t*)d_work, profile, sched, fuse
 #ifdef TSX_PROF

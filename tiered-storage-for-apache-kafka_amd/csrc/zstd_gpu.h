@@ -18,10 +18,7 @@ uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* d_zc, c
 // Several callers' batches in ONE launch (the front end's launch combiner): segment k of the table covers workgroups [first, first + n)
 // and names that caller's buffers, key and profile.  d_segs: the table as the DEVICE reads it (device memory, or the device alias of
 // pinned host memory - a wave reads one entry); h_segs: the same table as the host reads it (its .first values travel as kernel arguments).
-uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched);
-// sched: bits 0-7 / 8-15 = search positions of the first / second step of a search run (0 = the kernel's default); TSX_ZSTD_SCHED_QUAD
-// selects the four-chunks-per-wave kernel (zstd_match4.h).  Never changes the bytes.
-#define TSX_ZSTD_SCHED_QUAD 0x10000u
+uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, const tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched);
 // Inverse (DecompressionChunkEnumeration.java:39-46): frame i at (from_mid ? frames + i*mid_stride :
 // frames + descs[i].src_off), length descs[i].src_len - (from_mid ? 28 : 0); output to dst + descs[i].dst_off,
 // descs[i].dst_len set; status TSX_E_BAD_SIZE / TSX_E_BAD_FRAME / TSX_E_DST_TOO_SMALL on failure.

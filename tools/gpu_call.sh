@@ -150,27 +150,6 @@ PY
           TSX_ZSTD_SCHED=$m timeout 400 python bench.py --steps 40 --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained --no-verify 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['gibs_one_batch_at_a_time'])"
         done
       done | tee $O/sched_ab.txt ;;
-    quad)
-      # four chunks per wave (csrc/zstd_match4.h) against one: a short parity run first, then alternating processes on the driver's command
-      timeout 200 python tools/quad_smoke.py > $O/quad_smoke.log 2>&1; tail -2 $O/quad_smoke.log
-      if ! grep -q "quad smoke ok" $O/quad_smoke.log; then echo "quad smoke FAILED - skipping the A/B"; continue; fi
-      for round in 1 2 3; do
-        for q in ${arg:-0 1}; do
-          echo -n "round $round TSX_ZSTD_QUAD=$q: "
-          TSX_ZSTD_QUAD=$q timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained --verify-chunks 8 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['gibs_one_batch_at_a_time'], j['config']['verified_chunks_vs_oracle'])"
-        done
-      done | tee $O/quad_ab.txt ;;
-    quadpmc)
-      # instruction mix and line traffic of the quad kernel (lone 2048-chunk batch), next to the one-chunk kernel's
-      PMC_DIR=pmc_quad TSX_ZSTD_QUAD=1 bash tools/pmc_zstd.sh > $O/pmc_quad.log 2>&1; python tools/show_pmc.py gpurun_out/pmc_quad | tee $O/pmc_quad_summary.txt
-      if [ "$arg" = "both" ]; then PMC_DIR=pmc_one TSX_ZSTD_QUAD=0 bash tools/pmc_zstd.sh > $O/pmc_one.log 2>&1; python tools/show_pmc.py gpurun_out/pmc_one | tee $O/pmc_one_summary.txt; fi ;;
-    quadfly)
-      # the quad kernel against callers in flight (is it bound by latency cover or by the memory system?)
-      # cfg = quad:callers[:k0,k1]
-      for cfg in ${arg:-1:3 1:5 1:8 0:5}; do q=${cfg%%:*}; rest=${cfg#*:}; t=${rest%%:*}; sch=""; [[ "$rest" == *:* ]] && sch=${rest#*:}
-        echo -n "TSX_ZSTD_QUAD=$q inflight $t sched '$sch': "
-        TSX_ZSTD_SCHED=$sch TSX_ZSTD_QUAD=$q timeout 400 python bench.py --inflight $t --steps $((t * 4)) --warmup 5 --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained --no-verify 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['gibs_one_batch_at_a_time'])"
-      done | tee $O/quad_inflight.txt ;;
     *) echo "unknown section $name" ;;
   esac
 done
