@@ -57,6 +57,8 @@ def parse():
                     help="with --split-segments: rank 0 (the owner of the upload stream) also receives every rank's slice of the transformed object inside the step (send / recv)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the continuously-fed measurement (5 callers, 10 batches each) after the timed region")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host->host (PCIe-inclusive) measurement after the timed region")
+    ap.add_argument("--broker-inprocess", action="store_true", help="run the broker-shaped leg in THIS process, after the timed region (torch's bundled HIP runtime: D2H copies "
+                    "are blit kernels), instead of first, in a torch-free child that owns the device alone (the default since round 4)")
     ap.add_argument("--broker-subprocess", action="store_true", help="run the broker-shaped leg as tools/broker_leg.py in a child process without torch (the system's HIP runtime "
                     "instead of the one torch bundles); slower while this process holds the device too - see the comment at the leg")
     ap.add_argument("--no-broker", action="store_true", help="skip the broker-shaped leg of end_to_end (10 / 20 callers x 256-chunk segments, pooled contexts, registered buffers)")
@@ -121,6 +123,37 @@ def relaunch_under_torchrun(args):
     os.execv(sys.executable, cmd)
 
 
+def broker_leg_first(args):
+    """The broker-shaped leg, BEFORE this process touches the device: a helper child generates two source segments on the GPU (torch, exits),
+    then tools/broker_leg.py runs without torch - the system's HIP runtime, as a broker's JVM loads it through libtsxform.so - and owns the
+    device alone.  (In this process the first HIP runtime loaded is the one torch bundles, whose device -> host copies are blit KERNELS that
+    wait for wave slots on a chip full of compressor waves; and a child that shares the device with a parent that holds queues on it is
+    time-sliced against them: profiles/r03_broker_with_and_without_torch.jsonl.)  Returns (rows, sizes) - sizes = the dst_len of the two
+    segments' chunks as the child's callers saw them, compared with this process's own run later - or (error rows, None)."""
+    import shutil
+    import subprocess
+    import tempfile
+    B, CH = 256, 4 << 20
+    tmpd = tempfile.mkdtemp(prefix="tsx_broker_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    env = dict(os.environ)
+    try:
+        src, ivs, sizes = (os.path.join(tmpd, f) for f in ("src.npy", "ivs.npy", "sizes.npy"))
+        leg = os.path.join(ROOT, "tools", "broker_leg.py")
+        g = subprocess.run([sys.executable, leg, "--gen", src, ivs, "2", str(B), str(CH), args.dist], capture_output=True, text=True, timeout=300, env=env)
+        if g.returncode != 0:
+            return [{"error": "source generation failed (rc %d): %s" % (g.returncode, g.stderr.strip()[-300:])}], None
+        cp = subprocess.run([sys.executable, leg, "--src", src, "--ivs", ivs, "--sizes-out", sizes, "--callers", "10,20,32", "--batch", str(B), "--chunk", str(CH),
+                             "--profile", "1" if args.profile == "1.5.7" else "0"], capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in cp.stdout.strip().splitlines() if ln.startswith("[")]
+        if cp.returncode != 0 or not lines:
+            return [{"error": "tools/broker_leg.py failed (rc %d): %s" % (cp.returncode, cp.stderr.strip()[-300:])}], None
+        return json.loads(lines[-1]), np.load(sizes)
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return [{"error": "tools/broker_leg.py: %r" % (e,)}], None
+    finally:
+        shutil.rmtree(tmpd, ignore_errors=True)
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -132,6 +165,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line would misreport n_gpus" % (args.gpus, world))
+    # the broker-shaped leg of end_to_end comes FIRST, in children, while this process has not initialised HIP yet (see broker_leg_first)
+    broker_first = None
+    if (rank == 0 and world == 1 and not args.rehearse and args.workload in ("auto", "full") and not args.no_broker and not args.no_end_to_end
+            and not args.broker_inprocess and args.inflight > 1 and args.steps > 1 and not args.split_segments):
+        broker_first = broker_leg_first(args)
     import torch  # before libtsxform: one shared HIP runtime
     import torch.distributed as dist
     rehearse = args.rehearse
@@ -418,10 +456,11 @@ def main():
         # in -> host buffers out, registered; small batches take the block-parallel decoder form (csrc/zstd_dec_blocks.hip)
         if rank == 0 and world == 1 and not rehearse and n >= 4:
             try:
-                hfr = dst[:4 * slot].cpu().numpy(); hbk = np.zeros(4 * CH, np.uint8)
+                kmax = 256 if n >= 256 else 4
+                hfr = dst[:kmax * slot].cpu().numpy(); hbk = np.zeros(kmax * CH, np.uint8)
                 N.host_register(hfr); N.host_register(hbk)
                 lat = {}
-                for k_ in (1, 4):
+                for k_ in ((1, 4, 64, 256) if kmax == 256 else (1, 4)):
                     ee = e[:k_].copy(); ee["dst_off"] = np.arange(k_, dtype=np.uint64) * CH
                     tt = []
                     for _ in range(7):
@@ -432,7 +471,12 @@ def main():
                     lat[k_] = (round(float(np.median(tt[2:])) * 1e3, 3), okk)
                 N.host_unregister(hfr); N.host_unregister(hbk)
                 inverse["single_chunk_ms"] = lat[1][0]; inverse["window4_ms"] = lat[4][0]
-                inverse["small_batches_exact"] = bool(lat[1][1] and lat[4][1])
+                if 256 in lat:
+                    # a consumer catching up (ChunkCache.java:159-184 with a large prefetch.max.size): 64 chunks and a whole segment, cut into
+                    # co-resident pieces (copy-in, block-form decode and copy-out overlap: csrc/tsx_api.hip, run_batch_inner)
+                    inverse["window64_ms"] = lat[64][0]; inverse["segment_ms"] = lat[256][0]
+                    inverse["segment_gibs"] = round(256.0 * CH / GiB / (lat[256][0] * 1e-3), 3)
+                inverse["small_batches_exact"] = all(v[1] for v in lat.values())
                 inverse["small_batch_note"] = "host -> host, registered buffers, median of 5; batches of <= 256 chunks decode one workgroup per block"
             except nat.TsxError as ex:
                 inverse["small_batch_error"] = str(ex)
@@ -652,7 +696,16 @@ def main():
         # either (two processes' queues are time-sliced: 8.9 / 13.5 / 12.8), so the default stays in-process: the rows are a LOWER bound of
         # what a torch-free process sees from 32 callers up.
         broker = None
-        if T > 1 and n >= 256 and not args.no_broker:
+        if broker_first is not None:
+            broker, bsizes = broker_first
+            for b_ in broker:
+                if "gibs" in b_:
+                    # the child ran before this process knew the sizes: compare what its callers saw with this process's device-resident run
+                    b_["same_sizes_as_device_run"] = bool(b_.get("same_sizes_as_device_run")) and bsizes is not None and n >= bsizes.size and \
+                        bool((bsizes.astype(np.int64) == d["dst_len"][:bsizes.size].astype(np.int64)).all())
+                    b_["frac_of_device_resident_value"] = round(b_["gibs"] / value, 3)
+                    b_["process"] = "tools/broker_leg.py as a child that ran FIRST and owned the device alone, no torch: the system's HIP runtime, as a JVM loads it"
+        elif T > 1 and n >= 256 and not args.no_broker:
             B = 256
             bseg = min(2, n // B) if args.broker_subprocess else n // B    # distinct segments, the callers take them in turn
             sys.path.insert(0, os.path.join(ROOT, "tools"))

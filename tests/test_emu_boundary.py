@@ -318,3 +318,33 @@ def test_idle_contexts_do_not_all_keep_a_block_form_workspace(emu):
         print("ok")
     """)
     assert out.strip().endswith("ok")
+
+
+def test_mid_size_fetch_batches_decode_in_co_resident_pieces(emu, oracle, monkeypatch):
+    """a host-memory inverse batch of 16 .. 256 chunks is cut into up to 8 pieces on the context's compute streams (copy-in
+    of piece k + 1, block-form decode of piece k, copy-out of piece k - 1 overlap).  40 chunks of mixed sizes incl. an empty one and a
+    forged one: same bytes and statuses as the uncut batch, every good chunk decoded by the block form, CRCs of the restored bytes right."""
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    sizes = [3000 + 977 * i for i in range(40)]; sizes[7] = 0; sizes[23] = 1
+    chunks = [synth.gen_chunk("K" if i % 4 else "R", 31, 0, i, s) for i, s in enumerate(sizes)]
+    blobs, d0 = pc.run_transform(emu, flags, chunks)
+    forged = bytearray(blobs[11]); forged[40] ^= 2; blobs[11] = bytes(forged)
+    ctx = emu.ctx_create(0, 0, 0)
+    try:
+        outs, d = pc.run_detransform(emu, flags, blobs, sizes, ctx=ctx)
+        taken = pc.blockmode_chunks(emu, ctx, len(blobs))
+        import ctypes
+        pieces = emu.lib.tsx_debug_blockmode_pieces; pieces.restype = ctypes.c_int; pieces.argtypes = [ctypes.c_void_p]
+        assert pieces(ctx) == 5, pieces(ctx)                            # 40 chunks: pieces of 8
+        monkeypatch.setenv("TSX_NO_DEC_PIECES", "1")
+        outs1, d1 = pc.run_detransform(emu, flags, blobs, sizes, ctx=ctx)
+        assert pc.blockmode_chunks(emu, ctx, len(blobs)) == taken and pieces(ctx) == 1
+    finally:
+        emu.ctx_destroy(ctx)
+    assert list(d["status"]) == list(d1["status"]) and d["status"][11] == nat.E_TAG_MISMATCH and (np.delete(d["status"], 11) == 0).all()
+    assert taken >= 38                                                  # (the forged chunk never reaches the decoder; the empty frame may go either way)
+    for i, c in enumerate(chunks):
+        if i != 11:
+            assert outs[i] == c.tobytes() == outs1[i], i
+            assert d["crc32c"][i] == oracle.crc32c(c.tobytes())
+    assert outs[11] == b"" or not any(outs[11])

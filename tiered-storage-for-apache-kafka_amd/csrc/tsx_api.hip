@@ -103,7 +103,9 @@ struct tsx_ctx {
     tsx_gcm_chunk* d_gchunks = nullptr;
     int32_t* d_status = nullptr;
     uint32_t* d_zlen = nullptr;
-    uint32_t* d_partials = nullptr; size_t partials_cap = 0;
+    uint32_t* d_partials = nullptr; size_t partials_cap = 0; size_t partials_per_chunk = 0;   // (pieces that run side by side take their own slice)
+    uint32_t last_max_out = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> blk_pieces;  // (first chunk, chunks) of every block-form decoder launch of the last batch
     tsx_gcm_key* d_key = nullptr;
     uint8_t* d_keyraw = nullptr;                 // 32 key + 64 aad
     uint8_t* d_in = nullptr; size_t in_cap = 0;    // staging for TSX_MEM_HOST
@@ -319,6 +321,7 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
     size_t per_chunk = subs * 4 > crc_subs ? subs * 4 : crc_subs;
     int rc = grow(&c->d_partials, &c->partials_cap, (size_t)n * per_chunk);
     if (rc) return rc;
+    c->partials_per_chunk = per_chunk;
     if (host_mem) {
         if ((rc = grow(&c->d_in, &c->in_cap, in_bytes + 64))) return rc;
         if ((rc = grow(&c->d_out, &c->out_cap, out_bytes + 64))) return rc;
@@ -626,6 +629,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     uint8_t* dmid = c->d_mid ? c->d_mid + (size_t)lo * c->mid_stride : nullptr;
     // the Zstd workspace of chunk i is slot i of the batch, whichever piece it travels in: pieces of one batch co-reside
     void* dzw = c->d_zwork ? (uint8_t*)c->d_zwork + (size_t)lo * tsx_zstd_workspace_bytes(1, 0) : nullptr;
+    uint32_t* const dpart = c->d_partials + (size_t)lo * c->partials_per_chunk;     // this piece's slice of the CRC / GHASH partial sums
     tsx_timing& t = c->timing;
     memcpy(c->h_descs + lo, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc));
     // lean: the compressor waves own and publish their chunks' statuses and work on the descriptors and the key schedule where they
@@ -644,7 +648,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     }
     HIPCHK(hipEventRecord(e[0], st));
     if (r.mode == 2) {
-        tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, c->d_partials, 0);
+        tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, dpart, 0);
         HIPCHK(hipEventRecord(e[1], st)); HIPCHK(hipEventRecord(e[2], st));
         t.crc_launches += 2;
         hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);      // a reused descriptor must not keep an old status
@@ -653,7 +657,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         // the finished frame last - one launch per batch.  The batch CRC / GCM kernels want 20 / 40 KiB of LDS per workgroup and, on
         // a chip filled by the compressor waves of the batches in flight, sat hundreds of ms in the queue for a few ms of work.
         // TSX_STAGES_SEPARATE=1 keeps one launch per stage (A/B measurements, tests of the stand-alone kernels).
-        if ((flags & TSX_CRC) && !r.fuse_stages) { tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, c->d_partials, 0); t.crc_launches += 2; }
+        if ((flags & TSX_CRC) && !r.fuse_stages) { tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, dpart, 0); t.crc_launches += 2; }
         HIPCHK(hipEventRecord(e[1], st));
         bool fused = false;
         if (r.comp) {
@@ -674,7 +678,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
             hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, n, (const uint32_t*)dz,
                                (uint64_t)c->mid_stride, r.comp ? 1 : 0, 0, 0, dg, ds);
             uint32_t glen = r.comp ? (uint32_t)tsx_transformed_bound(r.max_len, TSX_COMPRESS) : r.max_len;
-            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, glen, r.comp ? dmid : r.d_src, r.d_dst, c->d_partials, ds, 0);
+            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, glen, r.comp ? dmid : r.d_src, r.d_dst, dpart, ds, 0);
             t.gcm_launches += 2;
         } else {
             uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
@@ -688,19 +692,21 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         if (r.enc) {
             hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, n, (const uint32_t*)dz,
                                (uint64_t)c->mid_stride, 0, 1, r.comp ? 1 : 0, dg, ds);
-            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, r.max_len, r.d_src, r.comp ? dmid : r.d_dst, c->d_partials, ds, 1);
+            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, r.max_len, r.d_src, r.comp ? dmid : r.d_dst, dpart, ds, 1);
             t.gcm_launches += 2;
             zsrc = dmid;
         }
         HIPCHK(hipEventRecord(e[2], st));
         if (r.comp) {
             const uint32_t* skip = nullptr; uint32_t skip_stride = 0;
-            c->last_used_blocks = false;
-            if (c->d_bwork && c->bwork_cap >= tsx_zstd_blockmode_bytes(r.n, r.max_out) && dec_use_blocks(r.n, r.max_out) && sb.n == r.n) {
+            if (c->d_bwork && c->bwork_cap >= tsx_zstd_blockmode_bytes(r.n, r.max_out) && dec_use_blocks(r.n, r.max_out)) {
                 c->last_used_blocks = true;
-                // one workgroup per block; what that form does not take (or gives up on) is decoded by the chunk-serial kernel behind it
-                t.unzstd_launches += tsx_launch_zstd_decompress_blocks(st, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.max_out, r.d_dst, ds, c->d_bwork);
-                skip = tsx_zstd_blockmode_skip(c->d_bwork, &skip_stride);
+                // one workgroup per block; what that form does not take (or gives up on) is decoded by the chunk-serial kernel behind it.
+                // A piece of a batch works in its own part of the workspace (the layout is per chunk: headers, then arenas, of THIS launch).
+                void* const bw = (uint8_t*)c->d_bwork + tsx_zstd_blockmode_bytes(lo, r.max_out);
+                t.unzstd_launches += tsx_launch_zstd_decompress_blocks(st, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.max_out, r.d_dst, ds, bw);
+                skip = tsx_zstd_blockmode_skip(bw, &skip_stride);
+                c->blk_pieces.push_back({lo, n}); c->last_max_out = r.max_out;
             }
             t.unzstd_launches += tsx_launch_zstd_decompress(st, c->dev->d_zc, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.d_dst, ds, dzw, skip, skip_stride);
         } else if (!r.enc) {
@@ -716,7 +722,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     HIPCHK(hipEventRecord(e[3], st));
     if (r.mode == 1 && (flags & TSX_CRC)) {
         // CRC of the restored bytes; upper bound of a restored chunk is its slot capacity
-        tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, c->d_partials, 1);
+        tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, dpart, 1);
         t.crc_launches += 2;
     }
     if (!lean) HIPCHK(hipMemcpyAsync(c->h_descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
@@ -728,6 +734,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
 // Exactly dst_len bytes per chunk: a slot's slack may hold bytes of an earlier batch on this (possibly pooled) context.
 static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, bool* packed_full, hipStream_t out_st) {
     tsx_ctx* c = r.c;
+    size_t run_at = 0, run_len = 0;
     for (uint32_t i = sb.lo; i < sb.lo + sb.n; i++) {
         tsx_chunk_desc& d = r.descs[i];
         if (r.packed) {
@@ -735,13 +742,25 @@ static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, boo
             d.dst_off = *packed_at;
             if (d.status != TSX_OK) { d.dst_len = 0; continue; }
             if (*packed_full || *packed_at + d.dst_len > r.dst_size) { *packed_full = true; d.status = TSX_E_DST_TOO_SMALL; d.dst_len = 0; continue; }
-            if (d.dst_len) HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + *packed_at, c->d_out + slot_off, d.dst_len, hipMemcpyDeviceToHost, out_st));
+            if (d.dst_len) {
+                // packed output lands at any byte of the caller's buffer.  The copy engines move a D2H copy of ODD size to an ODD host
+                // address at 12 GB/s instead of 31 (110 us instead of 42 per 1.3 MB chunk, profiles/r03_copy_engine_probe.txt; every
+                // other combination of size and address is fast): such a copy goes as its 64-byte multiple + the last < 64 bytes.
+                uint8_t* const hp = (uint8_t*)r.dst + *packed_at;
+                const size_t tail = (((uintptr_t)hp & 1) && (d.dst_len & 1) && d.dst_len > 4096) ? (d.dst_len & 63) : 0;
+                HIPCHK(hipMemcpyAsync(hp, c->d_out + slot_off, d.dst_len - tail, hipMemcpyDeviceToHost, out_st));
+                if (tail) HIPCHK(hipMemcpyAsync(hp + (d.dst_len - tail), c->d_out + slot_off + (d.dst_len - tail), tail, hipMemcpyDeviceToHost, out_st));
+            }
             *packed_at += d.dst_len;
         } else {
+            // neighbours that produced back-to-back bytes (restored chunks fill their slots: the usual fetch) travel as ONE copy
             if (d.status != TSX_OK || d.dst_len == 0) continue;
-            HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + d.dst_off, c->d_out + d.dst_off, d.dst_len, hipMemcpyDeviceToHost, out_st));
+            if (run_len && d.dst_off == run_at + run_len) { run_len += d.dst_len; continue; }
+            if (run_len) HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + run_at, c->d_out + run_at, run_len, hipMemcpyDeviceToHost, out_st));
+            run_at = d.dst_off; run_len = d.dst_len;
         }
     }
+    if (run_len) HIPCHK(hipMemcpyAsync((uint8_t*)r.dst + run_at, c->d_out + run_at, run_len, hipMemcpyDeviceToHost, out_st));
     return TSX_OK;
 }
 
@@ -907,7 +926,13 @@ static int run_combined(tsx_run& r) {
         HIPCHK(hipEventRecord(c->ev[2], cb->copy_in));
         if (in_bytes) HIPCHK(hipMemcpyAsync(c->d_in, r.src, in_bytes, hipMemcpyHostToDevice, cb->copy_in));
         HIPCHK(hipEventRecord(c->sub_ev[0][5], cb->copy_in));
-        q.in_ready = c->sub_ev[0][5];
+        // The caller waits for ITS input before it asks for a launch.  Round 3 queued the launch at once, behind a stream wait on the copy:
+        // every caller's gigabyte travels on the one copy-in stream, so with 20-32 callers a launch sat on its lane for the tens to
+        // hundreds of ms its copy stood in that queue - a lane (a hardware queue) held by a kernel that cannot start, while callers whose
+        // input HAD landed waited for a lane.  Now what reaches the combiner is runnable, a lane is only ever occupied by running waves,
+        // and the callers whose copies land while the lanes are busy leave together as one launch (VERDICT r3 #2a: a launch carried
+        // ~1 segment, 8 lanes x 256 chunks left 60 % of the chip's wave slots empty at 32 callers).
+        HIPCHK(hipEventSynchronize(c->sub_ev[0][5]));
     }
     combiner_submit(cb, q);
     if (q.rc != TSX_OK) return q.rc;
@@ -978,13 +1003,20 @@ static int run_batch_inner(tsx_run& r) {
         if (!src_pinned || !dst_pinned) comp_pieces = 1;
     }
     const bool pipelined = r.host && monotonic && !(comp_fwd && (!r.fuse_stages || comp_pieces < 2)) && !getenv("TSX_NO_PIPELINE");
+    // A fetch of 16 .. 256 chunks (a consumer catching up: ChunkCache.java:159-184 with a large prefetch.max.size) decodes in the block
+    // form, whose cost is a ~1.5 ms chain of short kernels + a part proportional to the chunks: cut into up to 8 pieces of >= 8 chunks,
+    // spread over the context's compute streams so that the pieces' chains overlap each other, the later pieces' copy-in and the earlier
+    // pieces' copy-out.  (Round 3 only cut batches of >= 512 chunks: 64 chunks took 7 ms device resident and 17 ms host to host.)
+    c->blk_pieces.clear(); c->last_used_blocks = false;
+    const bool inv_blocks = r.mode == 1 && r.comp && pipelined && n >= 16 && c->d_bwork && dec_use_blocks(n, max_out) && !getenv("TSX_NO_DEC_PIECES");
     if (pipelined) {
         size_t budget = TSX_SUB_BYTES;
         size_t max_subs = TSX_MAX_SUBS;
         if (comp_fwd) { max_subs = comp_pieces; budget = in_bytes / comp_pieces + 1; if (budget < TSX_SUB_BYTES) budget = TSX_SUB_BYTES; }
         if (const char* e = getenv("TSX_SUB_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }     // tests / tuning
         if (in_bytes / budget + 1 > max_subs) budget = in_bytes / max_subs + 1;
-        const uint32_t min_chunks = (r.comp && !comp_fwd) ? 512u : 1u;
+        uint32_t min_chunks = (r.comp && !comp_fwd) ? 512u : 1u;
+        if (inv_blocks) { max_subs = 8; budget = 0; min_chunks = (n + 7) / 8 < 8 ? 8u : (n + 7) / 8; }
         uint32_t lo = 0;
         while (lo < n) {
             uint32_t hi = lo; size_t bytes = 0;
@@ -995,10 +1027,10 @@ static int run_batch_inner(tsx_run& r) {
         }
     } else subs.push_back({0, n, 0, in_bytes});
     const size_t ns = subs.size();
-    const bool multi = comp_fwd && ns > 1;                              // one compute stream per piece
+    const bool multi = (comp_fwd || inv_blocks) && ns > 1;             // pieces side by side: piece k on compute stream k mod TSX_COMP_PIECES
     for (size_t k = 1; k < ns; k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
-    if (multi) for (size_t k = 1; k < ns; k++) if (!c->st_pc[k - 1]) HIPCHK(hipStreamCreateWithFlags(&c->st_pc[k - 1], hipStreamNonBlocking));
-    auto stream_of = [&](size_t k) { return (multi && k > 0) ? c->st_pc[k - 1] : st; };
+    if (multi) for (size_t k = 1; k < ns && k < TSX_COMP_PIECES; k++) if (!c->st_pc[k - 1]) HIPCHK(hipStreamCreateWithFlags(&c->st_pc[k - 1], hipStreamNonBlocking));
+    auto stream_of = [&](size_t k) { return (multi && k % TSX_COMP_PIECES) ? c->st_pc[k % TSX_COMP_PIECES - 1] : st; };
     HIPCHK(hipEventRecord(c->ev[0], st));
     // A compressing batch whose waves run the whole chain needs no kernel besides the compressor's: the key schedule is built on the
     // host, every wave owns its chunk's status.  (Small kernels around a launch wait for a slot on a chip that is full of second-long
@@ -1034,7 +1066,7 @@ static int run_batch_inner(tsx_run& r) {
             HIPCHK(hipEventRecord(e[5], c->st_in));
             HIPCHK(hipStreamWaitEvent(ks, e[5], 0));
         }
-        if (multi && k > 0 && r.enc) HIPCHK(hipStreamWaitEvent(ks, c->ev_key, 0));
+        if (multi && ks != st && r.enc) HIPCHK(hipStreamWaitEvent(ks, c->ev_key, 0));
         return launch_stages(r, sb, e, ks);
     };
     auto collect_piece = [&](size_t k) -> int {
@@ -1193,18 +1225,22 @@ extern "C" int tsx_debug_pool_bwork(int device_index) {
     for (const tsx_ctx* c : g_devs[device_index].idle) if (c->d_bwork) k++;
     return k;
 }
+// test hook: block-form decoder launches of the context's last batch (> 1: the batch was cut into co-resident pieces)
+extern "C" int tsx_debug_blockmode_pieces(tsx_ctx* c) { return c ? (int)c->blk_pieces.size() : TSX_E_INVAL; }
 extern "C" int tsx_debug_blockmode_chunks(tsx_ctx* c, uint32_t n) {
     if (!c) return TSX_E_INVAL;
     if (!c->d_bwork || !c->last_used_blocks) return -1;
     tsx_device_scope keep;
     if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
-    uint32_t stride = 0;
-    const uint32_t* skip = tsx_zstd_blockmode_skip(c->d_bwork, &stride);
     int cnt = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        uint32_t w = 0;
-        if (hipMemcpy(&w, skip + (size_t)i * stride, 4, hipMemcpyDeviceToHost) != hipSuccess) return TSX_E_DEVICE;
-        cnt += w == 1;
+    for (const auto& pc : c->blk_pieces) {                              // every launch of the batch laid its chunks' headers out for itself
+        uint32_t stride = 0;
+        const uint32_t* skip = tsx_zstd_blockmode_skip((const uint8_t*)c->d_bwork + tsx_zstd_blockmode_bytes(pc.first, c->last_max_out), &stride);
+        for (uint32_t i = 0; i < pc.second && pc.first + i < n; i++) {
+            uint32_t w = 0;
+            if (hipMemcpy(&w, skip + (size_t)i * stride, 4, hipMemcpyDeviceToHost) != hipSuccess) return TSX_E_DEVICE;
+            cnt += w == 1;
+        }
     }
     return cnt;
 }

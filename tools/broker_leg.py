@@ -13,8 +13,10 @@ compressor waves it waits for them: standalone, 32 callers moved 11.7 GiB/s with
 (profiles/r03_copy_engine_probe.txt, r03_broker_with_and_without_torch.jsonl).  As a CHILD of bench.py it shares the device with the
 parent's queues and is slower than either, so bench.py calls run() in-process by default (--broker-subprocess for the child).
 
-  broker_leg.py --src S.npy --ivs I.npy --expect L.npy --callers 10,20,32 [--batch 256] [--chunk 4194304] [--window 8] [--lib path]
-prints one JSON line: the list of rows."""
+  broker_leg.py --src S.npy --ivs I.npy [--expect L.npy | --sizes-out L.npy] --callers 10,20,32 [--batch 256] [--chunk 4194304] [--window 8] [--lib path]
+prints one JSON line: the list of rows.  bench.py runs this FIRST, as a child that owns the device alone (before the parent initialises
+HIP), so that the driver's line carries what the product's runtime does; --gen writes the source segments for it (a short-lived helper
+process with torch: the chunks are generated on the device)."""
 import argparse
 import json
 import os
@@ -29,8 +31,9 @@ sys.path.insert(0, ROOT)
 GiB = float(1 << 30)
 
 
-def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_note=""):
-    """hsrc: nseg * B * CH source bytes (registered here), ivs: (nseg * B, 12), expect: dst_len of every chunk from the device-resident run."""
+def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_note="", sizes_out=None):
+    """hsrc: nseg * B * CH source bytes (registered here), ivs: (nseg * B, 12), expect: dst_len of every chunk from the device-resident run
+    (None when this leg runs BEFORE that run: the sizes every caller saw are then handed back through sizes_out for the parent to compare)."""
     nseg = hsrc.size // (B * CH)
     cap = B * (CH // 2 + (64 << 10))                                     # packed output of one segment: 0.33 of the input at r = 0.31, half of it of room
     lock = threading.Lock()
@@ -71,8 +74,14 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
             stop_at[0] = t1 + window
             th = [threading.Thread(target=bworker, args=(t, False)) for t in range(callers)]
             [x.start() for x in th]; [x.join() for x in th]
-            ok = all(bool((dd["status"] == 0).all()) and bool((dd["dst_len"] == expect[(t % nseg) * B:((t % nseg) + 1) * B]).all())
-                     for t, dd in enumerate(des))
+            if expect is None:
+                # no reference sizes yet: every caller of a segment must agree with the first one, and the parent checks those against its own run
+                ok = all(bool((dd["status"] == 0).all()) and bool((dd["dst_len"] == des[t % nseg]["dst_len"]).all()) for t, dd in enumerate(des))
+                if sizes_out is not None and callers >= nseg:
+                    sizes_out[:] = np.concatenate([des[k]["dst_len"] for k in range(nseg)])
+            else:
+                ok = all(bool((dd["status"] == 0).all()) and bool((dd["dst_len"] == expect[(t % nseg) * B:((t % nseg) + 1) * B]).all())
+                         for t, dd in enumerate(des))
             # rate = least-squares slope of completions over time across the middle 60 % of the run (no ramp, no drain; counting the
             # calls that end inside a fixed window would quantise: at 2.5 s per call a caller completes one or two calls in it)
             done_at = np.sort(np.asarray(stamps)) - t1
@@ -84,6 +93,7 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
                          "method": "slope of completions, middle 60 %", "context": "pooled (ctx = NULL), launch combiner", "dst_layout": "packed",
                          "host_memory": "source and outputs registered", "gibs": round(gibs, 4),
                          "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat if x]))) * 1e3, 1),
+                         "whole_window_gibs": round(done * B * CH / GiB / max(float(done_at[-1]), 1e-9), 4),
                          "same_sizes_as_device_run": ok, "torch_in_process": "torch" in sys.modules})
     finally:
         for hb in bufs:
@@ -92,9 +102,28 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
     return rows
 
 
+def gen(path_src, path_ivs, nseg, B, CH, dist):
+    """The leg's source segments, generated on the device exactly as bench.py generates them (segments 0 .. nseg - 1 of rank 0)."""
+    import torch
+    from tsxform import synth
+    dev = torch.device("cuda", 0)
+    out = np.empty(nseg * B * CH, np.uint8)
+    for s_ in range(nseg):
+        for c in range(B):
+            i = s_ * B + c
+            out[i * CH:(i + 1) * CH] = synth.gen_chunk(dist, 1000 + s_, s_, c, CH, device=dev).cpu().numpy()
+    np.save(path_src, out)
+    np.save(path_ivs, np.stack([np.frombuffer(synth.iv_for(s_, c), np.uint8) for s_ in range(nseg) for c in range(B)]))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--gen":
+        gen(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7])
+        return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--src", required=True); ap.add_argument("--ivs", required=True); ap.add_argument("--expect", required=True)
+    ap.add_argument("--src", required=True); ap.add_argument("--ivs", required=True)
+    ap.add_argument("--expect", default="", help="dst_len of every chunk from the device-resident run (omit when this leg runs first: see --sizes-out)")
+    ap.add_argument("--sizes-out", default="", help="write the dst_len every caller agreed on here (.npy), for the parent to compare with its own run")
     ap.add_argument("--callers", default="10,20,32")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--chunk", type=int, default=4 << 20)
@@ -109,8 +138,11 @@ def main():
     N.init(1, [0])
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=args.profile)
-    hsrc = np.load(args.src); ivs = np.load(args.ivs); expect = np.load(args.expect)
-    rows = run(N, nat, params, hsrc, ivs, expect, [int(x) for x in args.callers.split(",")], args.batch, args.chunk, args.window)
+    hsrc = np.load(args.src); ivs = np.load(args.ivs); expect = np.load(args.expect) if args.expect else None
+    sizes = np.zeros(hsrc.size // args.chunk, np.uint32)
+    rows = run(N, nat, params, hsrc, ivs, expect, [int(x) for x in args.callers.split(",")], args.batch, args.chunk, args.window, sizes_out=sizes)
+    if args.sizes_out:
+        np.save(args.sizes_out, sizes)
     print(json.dumps(rows), flush=True)
 
 
