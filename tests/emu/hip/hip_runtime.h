@@ -74,6 +74,7 @@ inline void __syncthreads() { hipemu::block_barrier(); }
 // lane's later loads.  Fibers do not run in lockstep: model the fence as a wave rendezvous.
 inline void __threadfence() { hipemu::wave_barrier(); }
 inline void __threadfence_block() { hipemu::wave_barrier(); }
+inline void __threadfence_system() { hipemu::wave_barrier(); }
 
 // ---- wave collectives -------------------------------------------------------------------------
 template <class T>

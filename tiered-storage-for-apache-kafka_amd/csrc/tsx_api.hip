@@ -6,6 +6,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -100,6 +101,9 @@ struct tsx_ctx {
     uint8_t* h_keyraw = nullptr;                   // pinned 128 bytes: key + aad on their way in (wiped after the batch)
     tsx_gcm_key* h_key = nullptr;                  // pinned: the key schedule built on the host (compressing batches; wiped after the batch)
     tsx_gcm_key* hd_key = nullptr;                 // ... as the device addresses it (every compressor wave takes its own copy, tsx_chain_fuse.key_on_host)
+    uint32_t* d_segdone = nullptr;                 // combined launches: chunks of this context's batch that are done (device counter, self-resetting)
+    uint32_t* h_segflag = nullptr;                 // ... and the word the last of them raises (pinned; hd_segflag = the device's address of it)
+    uint32_t* hd_segflag = nullptr;
     tsx_gcm_chunk* d_gchunks = nullptr;
     int32_t* d_status = nullptr;
     uint32_t* d_zlen = nullptr;
@@ -249,8 +253,9 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     // the key schedule and the raw key never outlive the context in readable form
     if (c->d_key) hipMemset(c->d_key, 0, sizeof(tsx_gcm_key));
     if (c->d_keyraw) hipMemset(c->d_keyraw, 0, 128);
-    void* ptrs[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen, c->d_partials, c->d_key, c->d_keyraw, c->d_in, c->d_out, c->d_mid, c->d_zwork, c->d_bwork};
+    void* ptrs[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen, c->d_partials, c->d_key, c->d_keyraw, c->d_in, c->d_out, c->d_mid, c->d_zwork, c->d_bwork, c->d_segdone};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->h_segflag) hipHostFree(c->h_segflag);
     if (c->h_descs) hipHostFree(c->h_descs);
     if (c->h_keyraw) { memset(c->h_keyraw, 0, 128); hipHostFree(c->h_keyraw); }
     if (c->h_key) { memset(c->h_key, 0, sizeof(tsx_gcm_key)); hipHostFree(c->h_key); }
@@ -363,6 +368,12 @@ static int ctx_init_device_objects(tsx_ctx* c) {
     HIPCHK(hipHostMalloc((void**)&c->h_keyraw, 128, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&c->h_key, sizeof(tsx_gcm_key), hipHostMallocMapped | hipHostMallocPortable));
     HIPCHK(hipHostGetDevicePointer((void**)&c->hd_key, c->h_key, 0));
+    HIPCHK(hipMalloc((void**)&c->d_segdone, 64));
+    HIPCHK(hipMemsetAsync(c->d_segdone, 0, 64, c->st));
+    HIPCHK(hipHostMalloc((void**)&c->h_segflag, 64, hipHostMallocMapped | hipHostMallocPortable));
+    HIPCHK(hipHostGetDevicePointer((void**)&c->hd_segflag, c->h_segflag, 0));
+    *c->h_segflag = 0;
+    HIPCHK(hipStreamSynchronize(c->st));                                // (the counter is zero before a lane of the combiner can touch it)
     return TSX_OK;
 }
 
@@ -829,7 +840,11 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
         sg.src_base = r.d_src; sg.descs = r.enc ? c->hd_descs : c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
         sg.work = (uint8_t*)c->d_zwork;
         sg.fuse.crc = (r.flags & TSX_CRC) ? c->dev->d_crc : nullptr;
-        if (r.enc) { sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->hd_key; sg.fuse.out = r.d_dst; sg.fuse.self_status = 1; sg.fuse.key_on_host = 1; }
+        if (r.enc) {
+            sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->hd_key; sg.fuse.out = r.d_dst; sg.fuse.self_status = 1; sg.fuse.key_on_host = 1;
+            __atomic_store_n(c->h_segflag, 0u, __ATOMIC_RELEASE);
+            sg.done = c->d_segdone; sg.flag = c->hd_segflag;             // this member's caller returns when ITS chunks are done (run_combined)
+        }
         first += n;
     }
     (void)hipGetLastError();                                             // (hipErrorNotReady of the leader's lane queries)
@@ -934,12 +949,36 @@ static int run_combined(tsx_run& r) {
         // ~1 segment, 8 lanes x 256 chunks left 60 % of the chip's wave slots empty at 32 callers).
         HIPCHK(hipEventSynchronize(c->sub_ev[0][5]));
     }
+    const auto t_sub = std::chrono::steady_clock::now();
     combiner_submit(cb, q);
     if (q.rc != TSX_OK) return q.rc;
-    HIPCHK(hipEventSynchronize(c->ev[1]));                              // this batch's descriptors are on the host (its group may still be running for others)
-    memcpy(r.descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc));
     tsx_timing& t = c->timing;
-    t.zstd_ms = ev_ms(c->ev[0], c->ev[1]); t.zstd_launches = 1; t.total_ms = t.zstd_ms;
+    if (r.enc) {
+        // The launch may carry other callers' segments and goes on until the last of THEIR chunks is done; this caller waits for its own:
+        // the wave that finishes this member's last chunk raises the flag (zstd_compress_segments_kernel).  A short sleep between looks -
+        // a chunk takes about a second; the launch's own event is the safety net (a launch that ended, or failed, without raising it).
+        for (uint32_t look = 0;; look++) {
+            if (__atomic_load_n(c->h_segflag, __ATOMIC_ACQUIRE)) break;
+            if ((look & 31) == 31) {
+                const hipError_t e = hipEventQuery(c->ev[1]);
+                if (e == hipSuccess) {
+                    if (__atomic_load_n(c->h_segflag, __ATOMIC_ACQUIRE)) break;
+                    (void)hipMemset(c->d_segdone, 0, 64);                // the count is not to be trusted any more
+                    snprintf(g_last_err, sizeof g_last_err, "combined launch ended without completing a member");
+                    return TSX_E_DEVICE;
+                }
+                if (e != hipErrorNotReady) { (void)hipGetLastError(); tsx_set_err("combined launch", e); return TSX_E_DEVICE; }
+                (void)hipGetLastError();
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(look < 64 ? 20 : 100));
+        }
+        t.zstd_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_sub).count();
+    } else {
+        HIPCHK(hipEventSynchronize(c->ev[1]));                          // this batch's descriptors are on the host (its group may still be running for others)
+        t.zstd_ms = ev_ms(c->ev[0], c->ev[1]);
+    }
+    memcpy(r.descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc));
+    t.zstd_launches = 1; t.total_ms = t.zstd_ms;
     if (r.host) {
         size_t packed_at = 0; bool packed_full = false;
         const tsx_sub sb{0, n, 0, in_bytes};
@@ -947,7 +986,8 @@ static int run_combined(tsx_run& r) {
         HIPCHK(hipEventRecord(c->ev[3], cb->copy_out));
         HIPCHK(hipEventSynchronize(c->ev[3]));
         t.h2d_ms = ev_ms(c->ev[2], c->sub_ev[0][5]);
-        t.total_ms = ev_ms(c->ev[2], c->ev[3]);
+        t.d2h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_sub).count() - t.zstd_ms;
+        t.total_ms = t.h2d_ms + t.zstd_ms + t.d2h_ms;
     }
     return TSX_OK;
 }

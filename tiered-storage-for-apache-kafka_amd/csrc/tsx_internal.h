@@ -74,6 +74,10 @@ struct tsx_zseg {                // one caller's batch inside a combined compres
     uint32_t profile, pad;
     const uint8_t* src_base; tsx_chunk_desc* descs; uint8_t* mid; uint64_t mid_stride; uint32_t* zlen; int32_t* status; uint8_t* work;
     tsx_chain_fuse fuse;
+    // Per-member completion (the front end's launch combiner): a wave that has finished its chunk - frame, GCM tail, descriptor, all
+    // released to system scope - counts itself in *done; the one that completes the member's n resets the counter and raises *flag
+    // (pinned host memory), which is what the member's caller waits for.  A member does not wait for the other members of its launch.
+    uint32_t* done; uint32_t* flag;
 };
 struct tsx_zfirsts { uint32_t first[64]; };   // .first of every segment, passed by value: a wave finds its segment without a memory access
 

@@ -1708,6 +1708,26 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segmen
                                                                                           uint32_t sched ZS_PROF_PARAM) {
     const tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr, 0, 0};
     zstd_compress_body<true>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0u, sched, none, segs, firsts, nsegs ZS_PROF_ARG);
+    // ---- this chunk is done: tell its member's caller when it was the member's last one (tsx_zseg.done / .flag) ----
+    // The kernel goes on for the other members of the launch, so nothing here may rely on the end-of-kernel release: every lane's stores
+    // (ciphertext in device memory, which the caller's copy engine reads next; descriptor in pinned host memory) are complete at the
+    // barrier, lane 0 releases them to system scope (L2 write-back), and only then counts the chunk.
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < 64; i++) if (i < nsegs && firsts.first[i] <= blockIdx.x) k = i;
+    uint32_t* const done = segs[k].done;
+    if (done) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            const uint32_t n = segs[k].n;
+            if (atomicAdd(done, 1u) + 1u == n) {
+                atomicExch(done, 0u);                                    // ready for the context's next batch (ordered before it by the flag)
+                __threadfence_system();
+                atomicExch(segs[k].flag, 1u);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
