@@ -111,8 +111,8 @@ def test_block_form_takes_deep_copy_chains_on_the_device(gpu, oracle):
 
 def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
     """16 threads, context-less 64-chunk compressing batches from / to pinned host buffers: every batch equals the single-threaded
-    result, and the device's launch combiner carried them in fewer launches than batches (callers that arrive while the lanes are busy
-    travel as one zstd_compress_segments_kernel)."""
+    result - each member of a combined launch returns on its own completion flag, raised by its last wave while the launch goes on for the
+    others, and its output is copied out at once: stale ciphertext (a missing release) would show here."""
     import ctypes as C
     import threading
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
@@ -153,4 +153,7 @@ def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
         gpu.host_unregister(h)
     gpu.host_unregister(src)
     assert not errors, errors[:4]
-    assert m1.value - m0.value == T * reps and g1.value - g0.value < T * reps, (g1.value - g0.value, m1.value - m0.value)
+    # every batch travelled through the combiner; HOW MANY shared a launch depends on the lanes the process has (callers ask for a launch
+    # once their input has landed and launch alone while a lane is free - round 4; tests/test_emu_boundary.py pins one lane and asserts
+    # the sharing), so here only: no launch without a member
+    assert m1.value - m0.value == T * reps and 1 <= g1.value - g0.value <= T * reps, (g1.value - g0.value, m1.value - m0.value)

@@ -46,7 +46,8 @@ struct tsx_run;
 // the group that the next free lane launches as ONE kernel (zstd_compress_kernel's segment table: workgroup -> caller's buffers).
 // Group commit: the first waiting caller leads - it queues every member's descriptor upload, key schedule, the one compressor
 // launch, every member's status publication and descriptor download on the lane - the others wait for their own completion event.
-#define TSX_LANES_MAX 8
+#define TSX_LANES_MAX 24
+#define TSX_COPY_STREAMS_MAX 8
 #define TSX_GROUP_MAX_SEGS 64
 #define TSX_GROUP_MAX_CHUNKS 8192
 struct tsx_zreq { tsx_ctx* c; tsx_run* r; hipEvent_t in_ready; int rc; bool done; };
@@ -55,7 +56,12 @@ struct tsx_combiner {
     std::mutex mu; std::condition_variable cv;
     std::vector<tsx_zreq*> pending; bool leader = false;
     tsx_lane lane[TSX_LANES_MAX]; uint32_t nlanes = 0;
-    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    // copy streams of the context-less path, shared by the callers (created before the lanes, so that their event markers get hardware queues
+    // of their own): a call takes one input and one output stream in turn.  One stream each (round 3) serialised 48 callers' copies on one
+    // copy engine queue: an output copy phase of 330 MB took 1.05 s (profiles/r04_broker_phases.txt).
+    hipStream_t copy_in_s[TSX_COPY_STREAMS_MAX] = {nullptr}, copy_out_s[TSX_COPY_STREAMS_MAX] = {nullptr};
+    uint32_t n_in = 1, n_out = 1;
+    std::atomic<uint32_t> rr_in{0}, rr_out{0};
     uint64_t groups = 0, members = 0;                      // launches made, batches they carried (tsx_debug_combiner_stats)
 };
 
@@ -166,8 +172,8 @@ static void device_free_consts(tsx_device& d) {
             if (l.end) hipEventDestroy(l.end);
             if (l.h_segs) hipHostFree(l.h_segs);
         }
-        if (d.comb->copy_in) hipStreamDestroy(d.comb->copy_in);
-        if (d.comb->copy_out) hipStreamDestroy(d.comb->copy_out);
+        for (auto& q : d.comb->copy_in_s) if (q) hipStreamDestroy(q);
+        for (auto& q : d.comb->copy_out_s) if (q) hipStreamDestroy(q);
         d.comb.reset();
     }
     if (d.d_crc) hipFree(d.d_crc);
@@ -791,13 +797,19 @@ static int combiner_get(tsx_device* dev, tsx_combiner** out) {
         if (!cb) return TSX_E_NOMEM;
         // lanes: 3 with the runtime's default of 4 hardware queues (lanes + the two copy streams must not pile up on them); a process that
         // runs with GPU_MAX_HW_QUEUES = q >= 8 gets q / 2 lanes, at most 8 - a caller waits for a free lane 1 / lanes of a kernel's duration
-        // on average, and what waits is not in flight.  TSX_LANES overrides.
+        // on average, and what waits is not in flight.  TSX_LANES overrides (up to 24).  Round 4 swept queues x lanes with 20 / 32 callers
+        // (profiles/r04_broker_lanes_and_queues.txt): 16 x 8 is as good as anything - 12-20 lanes on 16-24 queues measure the same within
+        // the run-to-run spread, 32 queues lose 10-20 %.
         uint32_t nl = 3;
-        if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { const long v = atol(q); if (v >= 8) nl = (uint32_t)(v / 2 > TSX_LANES_MAX ? TSX_LANES_MAX : v / 2); }
+        if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { const long v = atol(q); if (v >= 8) nl = (uint32_t)(v / 2 > 8 ? 8 : v / 2); }
         if (const char* e = getenv("TSX_LANES")) { const long v = atol(e); if (v >= 1 && v <= TSX_LANES_MAX) nl = (uint32_t)v; }
         // the copy streams first: whatever the runtime's stream -> hardware-queue assignment, the short copies and their event markers
         // are not the ones that end up behind a second-long kernel of a lane created later
-        bool ok = hipStreamCreateWithFlags(&cb->copy_in, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&cb->copy_out, hipStreamNonBlocking) == hipSuccess;
+        cb->n_in = 1; cb->n_out = 1;                                    // more streams measured WORSE (2,4: -5 %, 4,8: -30 %: profiles/r04_broker_copy_streams.txt)
+        if (const char* e = getenv("TSX_COPY_STREAMS")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= TSX_COPY_STREAMS_MAX && b >= 1 && b <= TSX_COPY_STREAMS_MAX) { cb->n_in = a; cb->n_out = b; } }
+        bool ok = true;
+        for (uint32_t i = 0; ok && i < cb->n_in; i++) ok = hipStreamCreateWithFlags(&cb->copy_in_s[i], hipStreamNonBlocking) == hipSuccess;
+        for (uint32_t i = 0; ok && i < cb->n_out; i++) ok = hipStreamCreateWithFlags(&cb->copy_out_s[i], hipStreamNonBlocking) == hipSuccess;
         for (uint32_t i = 0; ok && i < nl; i++) {
             tsx_lane& l = cb->lane[i];
             ok = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&l.end, hipEventDisableTiming) == hipSuccess &&
@@ -808,7 +820,8 @@ static int combiner_get(tsx_device* dev, tsx_combiner** out) {
         dev->comb = std::move(cb);
         if (!ok) { (void)hipGetLastError(); tsx_device& d = *dev; std::unique_ptr<tsx_combiner> dead = std::move(d.comb);
                    for (uint32_t i = 0; i < dead->nlanes; i++) { tsx_lane& l = dead->lane[i]; if (l.st) hipStreamDestroy(l.st); if (l.end) hipEventDestroy(l.end); if (l.h_segs) hipHostFree(l.h_segs); }
-                   if (dead->copy_in) hipStreamDestroy(dead->copy_in); if (dead->copy_out) hipStreamDestroy(dead->copy_out);
+                   for (auto& q : dead->copy_in_s) if (q) hipStreamDestroy(q);
+                   for (auto& q : dead->copy_out_s) if (q) hipStreamDestroy(q);
                    return TSX_E_DEVICE; }
     }
     *out = dev->comb.get();
@@ -914,6 +927,12 @@ static void combiner_submit(tsx_combiner* cb, tsx_zreq& q) {
     }
 }
 
+// Where a context-less compressing call spends its time (test / measurement hook, tools/broker_probe.py): nanoseconds summed over calls -
+// waiting for the own input copy, from asking for a launch to the own chunks being done (lane wait + kernel), output copies - and calls.
+static std::atomic<uint64_t> g_phase_ns[4];
+extern "C" void tsx_debug_combined_phases(uint64_t out[4], int reset) {
+    for (int i = 0; i < 4; i++) { out[i] = g_phase_ns[i].load(); if (reset) g_phase_ns[i].store(0); }
+}
 // A ctx-less compressing batch: its buffers live in the pooled context, its work runs on the device's shared streams.
 static int run_combined(tsx_run& r) {
     tsx_ctx* c = r.c;
@@ -929,18 +948,33 @@ static int run_combined(tsx_run& r) {
         out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
     }
     r.max_len = max_len; r.max_out = max_out;
-    rc = reserve_or_drain(c, n, max_len, 0, r.flags, r.host, in_bytes, out_bytes);
+    // Zero-copy output (round 4).  The waves that encrypt a chunk write IV || C || TAG straight into the caller's buffer over PCIe when the
+    // device can address it (memory pinned with tsx_host_register - the JVM's reused direct buffers - or hipHostMalloc): posted writes of
+    // a few ms of a second-long wave, released to system scope before the chunk is counted done.  No device output buffer, no copy-out
+    // phase: with 32-48 callers a segment's 256 output copies stood 0.3-1.0 s in the copy engine's queue behind the other callers'
+    // (profiles/r04_broker_phases.txt) - time in which that caller offered the chip nothing.  Slot layout (TSX_MEM_HOST, what
+    // GpuTransformChunkEnumeration.java:201 issues): nothing is left to do on the host.  Packed layout: the waves fill bound-sized slots
+    // in the caller's buffer when it has room for them and the host packs them down in place; otherwise the copy path below.
+    uint8_t* zc_dst = nullptr;
+    if (r.host && r.enc && !getenv("TSX_NO_ZERO_COPY_OUT") && (!r.packed || r.dst_size >= out_bytes)) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, r.dst, 0) == hipSuccess && dp) zc_dst = (uint8_t*)dp;
+        else (void)hipGetLastError();                                    // pageable memory: not addressable from the device
+    }
+    rc = reserve_or_drain(c, n, max_len, 0, r.flags, r.host, in_bytes, zc_dst ? 0 : out_bytes);
     if (rc) return rc;
     tsx_combiner* cb = nullptr;
     if ((rc = combiner_get(c->dev, &cb))) return rc;
     r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
-    r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
+    r.d_dst = zc_dst ? zc_dst : r.host ? c->d_out : (uint8_t*)r.dst;
     memset(&c->timing, 0, sizeof c->timing);
     tsx_zreq q{c, &r, nullptr, TSX_OK, false};
+    const auto t_in = std::chrono::steady_clock::now();
     if (r.host) {
-        HIPCHK(hipEventRecord(c->ev[2], cb->copy_in));
-        if (in_bytes) HIPCHK(hipMemcpyAsync(c->d_in, r.src, in_bytes, hipMemcpyHostToDevice, cb->copy_in));
-        HIPCHK(hipEventRecord(c->sub_ev[0][5], cb->copy_in));
+        hipStream_t cin = cb->copy_in_s[cb->rr_in.fetch_add(1) % cb->n_in];
+        HIPCHK(hipEventRecord(c->ev[2], cin));
+        if (in_bytes) HIPCHK(hipMemcpyAsync(c->d_in, r.src, in_bytes, hipMemcpyHostToDevice, cin));
+        HIPCHK(hipEventRecord(c->sub_ev[0][5], cin));
         // The caller waits for ITS input before it asks for a launch.  Round 3 queued the launch at once, behind a stream wait on the copy:
         // every caller's gigabyte travels on the one copy-in stream, so with 20-32 callers a launch sat on its lane for the tens to
         // hundreds of ms its copy stood in that queue - a lane (a hardware queue) held by a kernel that cannot start, while callers whose
@@ -979,16 +1013,37 @@ static int run_combined(tsx_run& r) {
     }
     memcpy(r.descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc));
     t.zstd_launches = 1; t.total_ms = t.zstd_ms;
-    if (r.host) {
+    if (zc_dst) {
+        // the bytes are in the caller's buffer already; a packed batch is packed down in place (chunk i's slot starts at or behind its place)
+        if (r.packed) {
+            size_t at = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                tsx_chunk_desc& d = r.descs[i];
+                const size_t slot_off = d.dst_off;
+                d.dst_off = at;
+                if (d.status != TSX_OK) { d.dst_len = 0; continue; }
+                if (d.dst_len && slot_off != at) memmove((uint8_t*)r.dst + at, (const uint8_t*)r.dst + slot_off, d.dst_len);
+                at += d.dst_len;
+            }
+        }
+        t.h2d_ms = ev_ms(c->ev[2], c->sub_ev[0][5]);
+        t.d2h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_sub).count() - t.zstd_ms;
+        t.total_ms = t.h2d_ms + t.zstd_ms + t.d2h_ms;
+    } else if (r.host) {
         size_t packed_at = 0; bool packed_full = false;
         const tsx_sub sb{0, n, 0, in_bytes};
-        if ((rc = copy_back(r, sb, &packed_at, &packed_full, cb->copy_out))) return rc;
-        HIPCHK(hipEventRecord(c->ev[3], cb->copy_out));
+        hipStream_t cout_ = cb->copy_out_s[cb->rr_out.fetch_add(1) % cb->n_out];
+        if ((rc = copy_back(r, sb, &packed_at, &packed_full, cout_))) return rc;
+        HIPCHK(hipEventRecord(c->ev[3], cout_));
         HIPCHK(hipEventSynchronize(c->ev[3]));
         t.h2d_ms = ev_ms(c->ev[2], c->sub_ev[0][5]);
         t.d2h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_sub).count() - t.zstd_ms;
         t.total_ms = t.h2d_ms + t.zstd_ms + t.d2h_ms;
     }
+    g_phase_ns[0] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_sub - t_in).count();
+    g_phase_ns[1] += (uint64_t)(t.zstd_ms * 1e6);
+    g_phase_ns[2] += (uint64_t)(t.d2h_ms * 1e6);
+    g_phase_ns[3] += 1;
     return TSX_OK;
 }
 
@@ -1182,7 +1237,8 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
         // wiped once nothing of this call can still be running
         if (rc != TSX_OK) {
             (void)hipGetLastError();
-            if (c->dev->comb) { (void)hipStreamSynchronize(c->dev->comb->copy_in); (void)hipStreamSynchronize(c->dev->comb->copy_out);
+            if (c->dev->comb) { for (auto& q : c->dev->comb->copy_in_s) if (q) (void)hipStreamSynchronize(q);
+                                for (auto& q : c->dev->comb->copy_out_s) if (q) (void)hipStreamSynchronize(q);
                                 for (uint32_t i = 0; i < c->dev->comb->nlanes; i++) (void)hipStreamSynchronize(c->dev->comb->lane[i].st); }
         }
         if (r.enc) { memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key)); }

@@ -2,8 +2,8 @@
 """The broker-shaped leg of bench.py's `end_to_end` object, runnable in a process of its own WITHOUT torch.
 
 Shape (reference README.md:218-222, RemoteStorageManager.java:400-432: >= 10 RLM upload threads, one segment each): `callers`
-threads, every call ONE B-chunk segment, context-less (pooled contexts, as the JNI shim calls), TSX_MEM_HOST_PACKED from a registered
-source into a registered per-thread output buffer - what GpuTransformChunkEnumeration issues.  The loop is closed: a caller's next
+threads, every call ONE B-chunk segment, context-less (pooled contexts, as the JNI shim calls), TSX_MEM_HOST from a registered
+source into bound-sized slots of a registered per-thread output buffer - what GpuTransformChunkEnumeration issues.  The loop is closed: a caller's next
 call follows its last.
 
 Why it can run in a process of its own: a process has ONE HIP runtime - the first one loaded.  bench.py imports torch, and torch
@@ -35,7 +35,12 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
     """hsrc: nseg * B * CH source bytes (registered here), ivs: (nseg * B, 12), expect: dst_len of every chunk from the device-resident run
     (None when this leg runs BEFORE that run: the sizes every caller saw are then handed back through sizes_out for the parent to compare)."""
     nseg = hsrc.size // (B * CH)
-    cap = B * (CH // 2 + (64 << 10))                                     # packed output of one segment: 0.33 of the input at r = 0.31, half of it of room
+    # Output exactly as GpuTransformChunkEnumeration.java:167-201 lays it out: one bound-sized slot per chunk (align16(bound) + 16 apart)
+    # in the thread's reused, registered direct buffer, TSX_MEM_HOST.  (Until round 4 this leg asked for the packed layout into a smaller
+    # buffer - what the enumeration does NOT issue - and paid 256 copies per segment for it.)
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    slot = (N.transformed_bound(CH, flags) + 15) // 16 * 16 + 16
+    cap = B * slot
     lock = threading.Lock()
     rows = []
     N.host_register(hsrc)
@@ -49,6 +54,7 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
             for t in range(callers):
                 dd = np.zeros(B, nat.DESC_DTYPE)
                 dd["src_off"] = np.arange(B, dtype=np.uint64) * CH; dd["src_len"] = CH
+                dd["dst_off"] = np.arange(B, dtype=np.uint64) * slot; dd["dst_cap"] = N.transformed_bound(CH, flags)
                 dd["iv"] = ivs[(t % nseg) * B:((t % nseg) + 1) * B]
                 des.append(dd)
             lat = [[] for _ in range(callers)]
@@ -58,7 +64,7 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
             def bworker(t, warm):
                 while True:
                     a = time.perf_counter()
-                    N.transform_batch(params, des[t], segs[t], bufs[t], cap, nat.MEM_HOST_PACKED, ctx=None)
+                    N.transform_batch(params, des[t], segs[t], bufs[t], cap, nat.MEM_HOST, ctx=None)
                     b_ = time.perf_counter()
                     if warm:
                         return
@@ -90,7 +96,7 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
             slope = float(np.polyfit(done_at[k0:k1], np.arange(k0, min(k1, done)), 1)[0]) if done >= 4 else done / max(float(done_at[-1]), 1e-9)
             gibs = slope * B * CH / GiB
             rows.append({"callers": callers, "batch_chunks": B, "chunks_offered": callers * B, "calls": done, "seconds": round(float(done_at[-1]), 2),
-                         "method": "slope of completions, middle 60 %", "context": "pooled (ctx = NULL), launch combiner", "dst_layout": "packed",
+                         "method": "slope of completions, middle 60 %", "context": "pooled (ctx = NULL), launch combiner", "dst_layout": "slots (as GpuTransformChunkEnumeration.java:167-201)",
                          "host_memory": "source and outputs registered", "gibs": round(gibs, 4),
                          "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat if x]))) * 1e3, 1),
                          "whole_window_gibs": round(done * B * CH / GiB / max(float(done_at[-1]), 1e-9), 4),

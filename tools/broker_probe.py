@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--src-file", default="", help=".npy of the source chunks: written if missing (needs torch), loaded otherwise - with --mem host the process then "
                     "runs WITHOUT torch, i.e. on the system's HIP runtime as a broker's JVM does (torch bundles its own, older one: profiles/r03_copy_engine_probe.txt)")
     ap.add_argument("--gen-only", action="store_true")
+    ap.add_argument("--layout", default="slots", choices=["slots", "packed"], help="host output layout: bound-sized slots (TSX_MEM_HOST, what "
+                    "GpuTransformChunkEnumeration.java:167-201 issues) or packed (TSX_MEM_HOST_PACKED into a 2 MiB-per-chunk buffer, the round-3 shape)")
     args = ap.parse_args()
     import tsxform
     from tsxform import synth
@@ -80,7 +82,7 @@ def main():
             if args.mem == "device":
                 dsts.append(torch.empty(B * slot, dtype=torch.uint8, device=dev))
             else:
-                h = np.zeros(B * (2 << 20), np.uint8)              # packed output of B chunks: 0.31 x 4 MiB each, 2 MiB of room
+                h = np.zeros(B * (slot if args.layout == "slots" else (2 << 20)), np.uint8)   # (packed: 0.31 x 4 MiB per chunk, 2 MiB of room)
                 N.host_register(h)
                 dsts.append(h)
             ctxs.append(None if args.ctxless else N.ctx_create(0, B, CH))
@@ -89,7 +91,7 @@ def main():
             if args.mem == "device":
                 N.transform_batch(params, descs[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
             else:
-                N.transform_batch(params, descs[t], hsrc, dsts[t], dsts[t].size, nat.MEM_HOST_PACKED, ctx=ctxs[t])
+                N.transform_batch(params, descs[t], hsrc, dsts[t], dsts[t].size, nat.MEM_HOST if args.layout == "slots" else nat.MEM_HOST_PACKED, ctx=ctxs[t])
 
         for t in range(min(T, 4)):                       # workspaces / pools exist before the clock starts
             call(t)
@@ -116,7 +118,15 @@ def main():
         el = time.perf_counter() - t0
         ok = all(bool((d["status"] == 0).all()) for d in descs)
         allat = np.concatenate([np.asarray(x) for x in lat]) if sum(done) else np.zeros(1)
-        print(json.dumps({"tag": args.tag, "torch_in_process": "torch" in sys.modules, "threads": T, "batch_chunks": B, "mem": args.mem, "ctxless": args.ctxless,
+        phases = None
+        if args.ctxless and hasattr(N.lib, "tsx_debug_combined_phases"):
+            import ctypes
+            ph = (ctypes.c_uint64 * 4)(); N.lib.tsx_debug_combined_phases.restype = None
+            N.lib.tsx_debug_combined_phases(ph, 1)
+            if ph[3]:
+                phases = {"calls": int(ph[3]), "input_copy_ms": round(ph[0] / ph[3] / 1e6, 1), "launch_to_own_chunks_done_ms": round(ph[1] / ph[3] / 1e6, 1),
+                          "output_copy_ms": round(ph[2] / ph[3] / 1e6, 1)}
+        print(json.dumps({"tag": args.tag, "phases_mean_per_call": phases, "torch_in_process": "torch" in sys.modules, "threads": T, "batch_chunks": B, "mem": args.mem, "ctxless": args.ctxless, "layout": args.layout if args.mem == "host" else None,
                           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "batches": int(sum(done)), "seconds": round(el, 3),
                           "gibs": round(sum(done) * B * CH / GiB / el, 3), "ms_per_call_median": round(float(np.median(allat)) * 1e3, 1),
                           "ms_per_call_p95": round(float(np.percentile(allat, 95)) * 1e3, 1), "ok": ok}), flush=True)
