@@ -632,7 +632,6 @@ struct tsx_run {                                              // what one batch 
     tsx_ctx* c; const tsx_batch_params* params; tsx_chunk_desc* descs; uint32_t n; const void* src; void* dst; size_t src_size, dst_size;
     int mem_kind, mode; uint32_t flags, max_len, max_out; bool host, packed, enc, comp, fuse_stages, combined;
     const uint8_t* d_src; uint8_t* d_dst;
-    const uint8_t* zc_src = nullptr;                         // combined launches: the caller's host source as the device addresses it (the waves pull it)
 };
 
 static uint32_t zstd_sched_from_env();
@@ -851,8 +850,7 @@ static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_
         tsx_zseg& sg = l.h_segs[k];
         memset(&sg, 0, sizeof sg);
         sg.first = first; sg.n = n; sg.profile = r.params->zstd_profile;
-        sg.src_base = r.zc_src ? r.zc_src : r.d_src; sg.stage_in = r.zc_src ? c->d_in : nullptr;
-        sg.descs = r.enc ? c->hd_descs : c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
+        sg.src_base = r.d_src; sg.descs = r.enc ? c->hd_descs : c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
         sg.work = (uint8_t*)c->d_zwork;
         sg.fuse.crc = (r.flags & TSX_CRC) ? c->dev->d_crc : nullptr;
         if (r.enc) {
@@ -972,16 +970,7 @@ static int run_combined(tsx_run& r) {
     memset(&c->timing, 0, sizeof c->timing);
     tsx_zreq q{c, &r, nullptr, TSX_OK, false};
     const auto t_in = std::chrono::steady_clock::now();
-    // Zero-copy input: when the device can address the caller's source buffer, the launch needs no copy in front of it - every wave pulls
-    // its own chunk into the context's input buffer (zstd_compress_body, stage_in).
-    if (r.host && !getenv("TSX_NO_ZERO_COPY_IN")) {
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, const_cast<void*>(r.src), 0) == hipSuccess && dp) r.zc_src = (const uint8_t*)dp;
-        else (void)hipGetLastError();
-    }
-    if (r.host && r.zc_src) {
-        HIPCHK(hipEventRecord(c->ev[2], c->st_in)); HIPCHK(hipEventRecord(c->sub_ev[0][5], c->st_in));     // (timing events of a phase that does not exist)
-    } else if (r.host) {
+    if (r.host) {
         hipStream_t cin = cb->copy_in_s[cb->rr_in.fetch_add(1) % cb->n_in];
         HIPCHK(hipEventRecord(c->ev[2], cin));
         if (in_bytes) HIPCHK(hipMemcpyAsync(c->d_in, r.src, in_bytes, hipMemcpyHostToDevice, cin));

@@ -78,9 +78,6 @@ struct tsx_zseg {                // one caller's batch inside a combined compres
     // released to system scope - counts itself in *done; the one that completes the member's n resets the counter and raises *flag
     // (pinned host memory), which is what the member's caller waits for.  A member does not wait for the other members of its launch.
     uint32_t* done; uint32_t* flag;
-    // != nullptr: src_base is the caller's HOST buffer as the device addresses it; the wave that owns chunk i first pulls its bytes over
-    // PCIe into stage_in + descs[i].src_off (device memory, the context's input buffer) and works on that copy.
-    uint8_t* stage_in;
 };
 struct tsx_zfirsts { uint32_t first[64]; };   // .first of every segment, passed by value: a wave finds its segment without a memory access
 

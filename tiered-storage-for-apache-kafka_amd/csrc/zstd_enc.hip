@@ -1544,7 +1544,6 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
     const uint8_t* __restrict__ src_base = src_base_; tsx_chunk_desc* __restrict__ descs = descs_; uint8_t* __restrict__ mid = mid_;
     uint64_t mid_stride = mid_stride_; uint32_t* __restrict__ zlen = zlen_; int32_t* __restrict__ status = status_; uint8_t* __restrict__ work = work_;
     uint32_t profile = profile_; tsx_chain_fuse fuse = fuse_;
-    uint8_t* stage_in = nullptr;
     if (SEG) {
         uint32_t k = 0;                                                  // .first values come with the kernel arguments: no memory access to find the segment
 #pragma unroll
@@ -1552,7 +1551,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
         const tsx_zseg sg = segs[k];                                     // (the table itself may sit in pinned host memory: ONE entry is read)
         chunk = blockIdx.x - sg.first;
         src_base = sg.src_base; descs = sg.descs; mid = sg.mid; mid_stride = sg.mid_stride; zlen = sg.zlen; status = sg.status; work = sg.work;
-        profile = sg.profile; fuse = sg.fuse; stage_in = sg.stage_in;
+        profile = sg.profile; fuse = sg.fuse;
     }
 #ifdef TSX_PROF
     if (lane == 0) { for (int i = 0; i < 24; i++) g_prof[i] = 0; g_prof[22] = g_prof[23] = (unsigned long long)clock64(); }
@@ -1560,27 +1559,6 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
 #endif
     const uint8_t* __restrict__ src = src_base + descs[chunk].src_off;
     const uint32_t srcSize = descs[chunk].src_len;
-    if (SEG && stage_in) {
-        // The chunk still lies in the caller's (pinned) host buffer: this wave pulls it into device memory itself - 16 bytes per lane, a
-        // kilobyte per instruction, eight of them in flight - a millisecond or two of its second-long life, and no copy-engine queue in
-        // front of the launch (with 32-48 callers a segment's input copy stood 0.15-0.5 s in that queue: profiles/r04_broker_phases.txt).
-        // Everything after this works on the device copy: the parser re-reads its chunk many times.
-        uint8_t* const dstp = stage_in + descs[chunk].src_off;
-        const uint32_t whole = srcSize & ~15u;
-        uint32_t off = lane * 16;
-        for (; off + 7 * 1024 < whole; off += 8 * 1024) {
-            uint4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const uint4*>(src + off + u * 1024);
-#pragma unroll
-            for (int u = 0; u < 8; u++) *reinterpret_cast<uint4*>(dstp + off + u * 1024) = v[u];
-        }
-        for (; off < whole; off += 1024) *reinterpret_cast<uint4*>(dstp + off) = *reinterpret_cast<const uint4*>(src + off);
-        if (lane < (srcSize & 15u)) dstp[whole + lane] = src[whole + lane];
-        __threadfence_block();
-        __syncthreads();
-        src = dstp;
-    }
     uint8_t* const frame = mid + (uint64_t)chunk * mid_stride;
     uint8_t* const ws = work + (size_t)chunk * ZS_WS_BYTES;
     uint32_t* const hashLong = (uint32_t*)(ws + ZS_WS_HASHLONG);
