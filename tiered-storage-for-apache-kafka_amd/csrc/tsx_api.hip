@@ -1064,10 +1064,17 @@ static int run_batch_inner(tsx_run& r) {
         out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
     }
     r.max_len = max_len; r.max_out = max_out;
-    rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, out_bytes);
+    // zero-copy output, as in run_combined: the compressor waves of a lean batch write into the caller's buffer when the device can address it
+    uint8_t* zc_dst = nullptr;
+    if (r.mode == 0 && r.comp && r.enc && r.fuse_stages && r.host && !getenv("TSX_NO_ZERO_COPY_OUT") && (!r.packed || r.dst_size >= out_bytes)) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, r.dst, 0) == hipSuccess && dp) zc_dst = (uint8_t*)dp;
+        else (void)hipGetLastError();
+    }
+    rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, zc_dst ? 0 : out_bytes);
     if (rc) return rc;
     r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
-    r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
+    r.d_dst = zc_dst ? zc_dst : r.host ? c->d_out : (uint8_t*)r.dst;
     hipStream_t st = c->st;
     memset(&c->timing, 0, sizeof c->timing);
     // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap.  Device-memory batches
@@ -1168,6 +1175,17 @@ static int run_batch_inner(tsx_run& r) {
         const tsx_sub& sb = subs[k];
         HIPCHK(hipEventSynchronize(c->sub_ev[k][4]));                   // descriptors of piece k are on the host
         memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
+        if (zc_dst) {                                                   // the bytes are where they belong; a packed batch is packed down in place
+            if (r.packed) for (uint32_t i = sb.lo; i < sb.lo + sb.n; i++) {
+                tsx_chunk_desc& d = r.descs[i];
+                const size_t slot_off = d.dst_off;
+                d.dst_off = packed_at;
+                if (d.status != TSX_OK) { d.dst_len = 0; continue; }
+                if (d.dst_len && slot_off != packed_at) memmove((uint8_t*)r.dst + packed_at, (const uint8_t*)r.dst + slot_off, d.dst_len);
+                packed_at += d.dst_len;
+            }
+            return TSX_OK;
+        }
         if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, c->st_out);
         return TSX_OK;
     };
