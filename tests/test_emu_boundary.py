@@ -348,3 +348,48 @@ def test_mid_size_fetch_batches_decode_in_co_resident_pieces(emu, oracle, monkey
             assert outs[i] == c.tobytes() == outs1[i], i
             assert d["crc32c"][i] == oracle.crc32c(c.tobytes())
     assert outs[11] == b"" or not any(outs[11])
+
+
+@pytest.mark.parametrize("kind", ["slots", "packed"])
+@pytest.mark.parametrize("ctxless", [True, False])
+def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, monkeypatch):
+    """The compressor waves write into the caller's buffer when the device can address it (always, on the emulator); TSX_NO_ZERO_COPY_OUT=1
+    keeps the device output buffer + copies.  Same bytes, sizes, CRCs and packed offsets either way, with and without a context; what lies
+    between a chunk's last byte and the next slot is untouched; a packed buffer too small for the slots takes the copy path by itself."""
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    sizes = [9000, 0, 131072, 5, 40001, 70000, 1, 20000, 3000]
+    chunks = [synth.gen_chunk("K" if i % 3 else "R", 17, 0, i, s) for i, s in enumerate(sizes)]
+    n = len(chunks)
+    soff, doff, caps, st, dt = pc.layout(sizes, flags, emu)
+    src = np.zeros(st, np.uint8)
+    for c, o_ in zip(chunks, soff):
+        src[o_:o_ + c.size] = c
+    slot = (emu.transformed_bound(max(sizes), flags) + 63) // 64 * 64
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    mem = nat.MEM_HOST if kind == "slots" else nat.MEM_HOST_PACKED
+    ctx = None if ctxless else emu.ctx_create(0, 0, 0)
+    try:
+        res = {}
+        for mode in ("zero_copy", "copies", "small_packed_buffer"):
+            if mode == "small_packed_buffer" and kind != "packed":
+                continue
+            if mode == "copies":
+                monkeypatch.setenv("TSX_NO_ZERO_COPY_OUT", "1")
+            else:
+                monkeypatch.delenv("TSX_NO_ZERO_COPY_OUT", raising=False)
+            size = dt + 64 if kind == "slots" else (n * slot + 64 if mode != "small_packed_buffer" else sum(int(x) for x in caps) // 2)
+            dst = np.full(size, 0xEE, np.uint8)
+            d = pc.make_descs(sizes, soff, doff, caps)
+            emu.transform_batch(p, d, src, dst, dst.size, mem, ctx=ctx)
+            assert (d["status"] == 0).all(), (mode, d["status"])
+            res[mode] = ([dst[int(d["dst_off"][i]):int(d["dst_off"][i]) + int(d["dst_len"][i])].tobytes() for i in range(n)], d.copy())
+            if kind == "slots":
+                assert (dst[doff[0] + int(d["dst_len"][0]):doff[1]] == 0xEE).all(), mode
+        ref, dref = res["copies"]
+        for mode, (got, d) in res.items():
+            assert got == ref and (d["dst_len"] == dref["dst_len"]).all() and (d["crc32c"] == dref["crc32c"]).all() and (d["dst_off"] == dref["dst_off"]).all(), mode
+        for i in (0, 2, 4):
+            assert ref[i] == pc.oracle_transform(oracle, flags, chunks[i], i)
+    finally:
+        if ctx is not None:
+            emu.ctx_destroy(ctx)

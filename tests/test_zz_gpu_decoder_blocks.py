@@ -157,3 +157,66 @@ def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
     # once their input has landed and launch alone while a lane is free - round 4; tests/test_emu_boundary.py pins one lane and asserts
     # the sharing), so here only: no launch without a member
     assert m1.value - m0.value == T * reps and 1 <= g1.value - g0.value <= T * reps, (g1.value - g0.value, m1.value - m0.value)
+
+
+def test_zero_copy_output_into_registered_buffers_on_the_device(gpu, oracle):
+    """Round 4: when the device can address the caller's output buffer (tsx_host_register), the compressor waves write IV || C || TAG
+    straight into it - context-less calls (per-member completion flag, no end-of-kernel release to lean on) and an explicit context, the
+    slot layout GpuTransformChunkEnumeration issues and the packed layout (packed down in place when the buffer has room for the slots).
+    Bytes, sizes, CRCs and packed offsets equal the copy path's and the oracle chain's; a slot that is too small fails its chunk only."""
+    import ctypes as C
+    import threading
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    sizes = [synth.CHUNK, 300000, 0, 131072, 5, synth.CHUNK, 70001, 1 << 20] * 4
+    chunks = [synth.gen_chunk("K" if i % 5 else "R", 91, 0, i, s) for i, s in enumerate(sizes)]
+    n = len(chunks)
+    ref, dref = pc.run_transform(gpu, flags, chunks)                      # pageable numpy buffers: the copy path
+    soff, doff, caps, st, dt = pc.layout(sizes, flags, gpu)
+    src = np.zeros(st, np.uint8)
+    for c, o_ in zip(chunks, soff):
+        src[o_:o_ + c.size] = c
+    gpu.host_register(src)
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    slot = (gpu.transformed_bound(max(sizes), flags) + 63) // 64 * 64
+    errors = []
+
+    def one(kind, ctx, tag):
+        dst = np.full(max(dt, n * slot) + 64, 0xEE, np.uint8)
+        gpu.host_register(dst)
+        try:
+            d = pc.make_descs(sizes, soff, doff, caps)
+            gpu.transform_batch(p, d, src, dst, dst.size, kind, ctx=ctx)
+            got = [dst[int(d["dst_off"][i]):int(d["dst_off"][i]) + int(d["dst_len"][i])].tobytes() for i in range(n)]
+            if got != ref or (d["status"] != 0).any() or (d["crc32c"] != dref["crc32c"]).any():
+                errors.append((tag, "bytes"))
+            if kind == nat.MEM_HOST_PACKED:
+                ends = np.cumsum(d["dst_len"].astype(np.int64))
+                if not (d["dst_off"].astype(np.int64) == ends - d["dst_len"]).all():
+                    errors.append((tag, "packed offsets"))
+            elif not (dst[int(d["dst_off"][2]) + int(d["dst_len"][2]):int(d["dst_off"][3])] == 0xEE).all():
+                errors.append((tag, "bytes written beyond a chunk's dst_len"))
+        except Exception as e:                                          # noqa: BLE001
+            errors.append((tag, repr(e)))
+        finally:
+            gpu.host_unregister(dst)
+
+    ctx = gpu.ctx_create(0, 0, 0)
+    try:
+        for kind, name in ((nat.MEM_HOST, "slots"), (nat.MEM_HOST_PACKED, "packed")):
+            one(kind, None, "ctxless " + name)
+            one(kind, ctx, "ctx " + name)
+        th = [threading.Thread(target=one, args=(nat.MEM_HOST if t % 2 else nat.MEM_HOST_PACKED, None, "thread %d" % t)) for t in range(8)]
+        [x.start() for x in th]; [x.join() for x in th]
+        # one slot too small: that chunk fails, nothing of it is written, its neighbours are whole
+        dst = np.full(dt + 64, 0xEE, np.uint8); gpu.host_register(dst)
+        d = pc.make_descs(sizes, soff, doff, caps); d["dst_cap"][1] = 1000
+        gpu.transform_batch(p, d, src, dst, dst.size, nat.MEM_HOST, ctx=None)
+        assert d["status"][1] == nat.E_DST_TOO_SMALL and d["dst_len"][1] == 0 and (np.delete(d["status"], 1) == 0).all()
+        assert (dst[doff[1]:doff[1] + 1000] == 0xEE).all() and dst[doff[0]:doff[0] + int(d["dst_len"][0])].tobytes() == ref[0]
+        gpu.host_unregister(dst)
+    finally:
+        gpu.ctx_destroy(ctx)
+        gpu.host_unregister(src)
+    assert not errors, errors[:6]
+    for i in (0, 1, 4, 7):
+        assert ref[i] == pc.oracle_transform(oracle, flags, chunks[i], i)
