@@ -45,7 +45,10 @@ extern "C" {
 /* host pointers.  The batch is cut into pieces whose H2D copy, kernels and D2H copy overlap: pieces of >= 64 MiB in order on three
  * streams of the ctx; when compressing, up to 4 co-resident pieces with a compute stream each (a chunk is ~0.6 s of one wave whatever
  * the batch size: piece k starts when its share of the input has landed, its output travels while later pieces run).  Any host memory works - pageable
- * buffers are staged by the HIP runtime; buffers pinned once with tsx_host_register() are copied by DMA without a staging pass. */
+ * buffers are staged by the HIP runtime; buffers pinned once with tsx_host_register() are copied by DMA without a staging pass.
+ * A compressing + encrypting batch whose dst the device can address (tsx_host_register'ed / hipHostMalloc'ed memory) has no output copy
+ * at all: the device writes every chunk's IV || C || TAG straight into [dst_off, dst_off + dst_len) during the call (nothing beyond
+ * dst_len is written; what the buffer holds is defined when the call returns, as for any other kind). */
 #define TSX_MEM_HOST   0
 /* device pointers (same HIP runtime / process): no copies.  The kernels run on the ctx's own streams: work the caller still has
  * queued on other streams for these buffers (the kernel that fills src, a memset of dst) must be complete when the call is made,
@@ -55,7 +58,9 @@ extern "C" {
  * multipart part buffer) exactly as TransformFinisher.java:134-151 (SequenceInputStream over the chunks) hands them to
  * ObjectUploader.upload / S3MultiPartOutputStream.java:89-122, without the bound-sized slot per chunk and the gather copy
  * behind it.  tsx_transform_batch only.  descs[i].dst_off / dst_cap are ignored on entry; on return dst_off is chunk i's
- * offset in dst and dst_len its size; a chunk that no longer fits dst_size gets TSX_E_DST_TOO_SMALL (and so do all after it). */
+ * offset in dst and dst_len its size; a chunk that no longer fits dst_size gets TSX_E_DST_TOO_SMALL (and so do all after it).
+ * The bytes of dst BEHIND the packed chunks are scratch: when dst_size has room for one bound-sized slot per chunk and the device can
+ * address dst, the chunks are written there first and packed down in place (no device output buffer, no copies). */
 #define TSX_MEM_HOST_PACKED 2
 
 /* status / error codes (0 = ok, negative = error) */
