@@ -25,6 +25,16 @@ sys.path.insert(0, ROOT)
 # the legs below are more than 4: the process asks for 16, as INTEGRATION.md tells a broker's launcher to (must be set before the
 # runtime initialises, i.e. before torch is imported; an explicit setting wins).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# torch and the HIP tools want a temporary directory; a box whose /tmp is missing or full (seen once on the GPU pool) must not cost the line
+try:
+    import tempfile
+    tempfile.gettempdir()
+except (OSError, FileNotFoundError):
+    for _d in ("/dev/shm", ROOT):
+        if os.path.isdir(_d) and os.access(_d, os.W_OK):
+            os.environ["TMPDIR"] = _d
+            tempfile.tempdir = None
+            break
 GiB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 
