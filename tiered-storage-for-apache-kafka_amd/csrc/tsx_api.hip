@@ -57,8 +57,9 @@ struct tsx_combiner {
     std::vector<tsx_zreq*> pending; bool leader = false;
     tsx_lane lane[TSX_LANES_MAX]; uint32_t nlanes = 0;
     // copy streams of the context-less path, shared by the callers (created before the lanes, so that their event markers get hardware queues
-    // of their own): a call takes one input and one output stream in turn.  One stream each (round 3) serialised 48 callers' copies on one
-    // copy engine queue: an output copy phase of 330 MB took 1.05 s (profiles/r04_broker_phases.txt).
+    // of their own): a call takes one input and one output stream in turn.  ONE of each by default: with 48 callers an output copy phase of
+    // 330 MB stood 1.05 s in that queue - and more streams made it worse (they collide with the lanes' hardware queues: 2 + 4 streams -5 %,
+    // 4 + 8 -30 %, profiles/r04_broker_shape_experiments.txt); what removed the phase is zero-copy output (run_combined).  TSX_COPY_STREAMS="in,out".
     hipStream_t copy_in_s[TSX_COPY_STREAMS_MAX] = {nullptr}, copy_out_s[TSX_COPY_STREAMS_MAX] = {nullptr};
     uint32_t n_in = 1, n_out = 1;
     std::atomic<uint32_t> rr_in{0}, rr_out{0};
@@ -798,14 +799,14 @@ static int combiner_get(tsx_device* dev, tsx_combiner** out) {
         // lanes: 3 with the runtime's default of 4 hardware queues (lanes + the two copy streams must not pile up on them); a process that
         // runs with GPU_MAX_HW_QUEUES = q >= 8 gets q / 2 lanes, at most 8 - a caller waits for a free lane 1 / lanes of a kernel's duration
         // on average, and what waits is not in flight.  TSX_LANES overrides (up to 24).  Round 4 swept queues x lanes with 20 / 32 callers
-        // (profiles/r04_broker_lanes_and_queues.txt): 16 x 8 is as good as anything - 12-20 lanes on 16-24 queues measure the same within
+        // (profiles/r04_broker_shape_experiments.txt): 16 x 8 is as good as anything - 12-20 lanes on 16-24 queues measure the same within
         // the run-to-run spread, 32 queues lose 10-20 %.
         uint32_t nl = 3;
         if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { const long v = atol(q); if (v >= 8) nl = (uint32_t)(v / 2 > 8 ? 8 : v / 2); }
         if (const char* e = getenv("TSX_LANES")) { const long v = atol(e); if (v >= 1 && v <= TSX_LANES_MAX) nl = (uint32_t)v; }
         // the copy streams first: whatever the runtime's stream -> hardware-queue assignment, the short copies and their event markers
         // are not the ones that end up behind a second-long kernel of a lane created later
-        cb->n_in = 1; cb->n_out = 1;                                    // more streams measured WORSE (2,4: -5 %, 4,8: -30 %: profiles/r04_broker_copy_streams.txt)
+        cb->n_in = 1; cb->n_out = 1;                                    // more streams measured WORSE (see tsx_combiner)
         if (const char* e = getenv("TSX_COPY_STREAMS")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= TSX_COPY_STREAMS_MAX && b >= 1 && b <= TSX_COPY_STREAMS_MAX) { cb->n_in = a; cb->n_out = b; } }
         bool ok = true;
         for (uint32_t i = 0; ok && i < cb->n_in; i++) ok = hipStreamCreateWithFlags(&cb->copy_in_s[i], hipStreamNonBlocking) == hipSuccess;
@@ -952,7 +953,7 @@ static int run_combined(tsx_run& r) {
     // device can address it (memory pinned with tsx_host_register - the JVM's reused direct buffers - or hipHostMalloc): posted writes of
     // a few ms of a second-long wave, released to system scope before the chunk is counted done.  No device output buffer, no copy-out
     // phase: with 32-48 callers a segment's 256 output copies stood 0.3-1.0 s in the copy engine's queue behind the other callers'
-    // (profiles/r04_broker_phases.txt) - time in which that caller offered the chip nothing.  Slot layout (TSX_MEM_HOST, what
+    // (profiles/r04_broker_shape_experiments.txt) - time in which that caller offered the chip nothing.  Slot layout (TSX_MEM_HOST, what
     // GpuTransformChunkEnumeration.java:201 issues): nothing is left to do on the host.  Packed layout: the waves fill bound-sized slots
     // in the caller's buffer when it has room for them and the host packs them down in place; otherwise the copy path below.
     uint8_t* zc_dst = nullptr;
