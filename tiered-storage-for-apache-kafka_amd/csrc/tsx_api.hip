@@ -99,6 +99,7 @@ struct tsx_ctx {
     tsx_device* dev = nullptr;
     hipStream_t st = nullptr;                      // kernels (+ descriptor copies)
     hipStream_t st_in = nullptr, st_out = nullptr; // H2D / D2H of the host-memory staging pipeline
+    hipStream_t st_out2 = nullptr;                 // second D2H stream of a fetch cut into pieces (odd pieces; created on first use)
     hipStream_t st_pc[TSX_COMP_PIECES - 1] = {nullptr}; // compute streams of pieces 1.. of a compressing host batch (created on first use)
     hipEvent_t ev_key = nullptr;                   // key schedule ready (the piece streams wait for it)
     // device workspace (grown on demand)
@@ -271,6 +272,7 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     if (c->st) hipStreamDestroy(c->st);
     if (c->st_in) hipStreamDestroy(c->st_in);
     if (c->st_out) hipStreamDestroy(c->st_out);
+    if (c->st_out2) hipStreamDestroy(c->st_out2);
     for (auto& q : c->st_pc) if (q) hipStreamDestroy(q);
     if (c->ev_key) hipEventDestroy(c->ev_key);
 }
@@ -1172,6 +1174,10 @@ static int run_batch_inner(tsx_run& r) {
         if (multi && ks != st && r.enc) HIPCHK(hipStreamWaitEvent(ks, c->ev_key, 0));
         return launch_stages(r, sb, e, ks);
     };
+    // The restored chunks of a fetch are what crosses PCIe (4 MiB each against 1.3 MB in): one copy stream moves them at ~31 GB/s - 8.7 of a
+    // 64-chunk window's 10.4 ms; the pieces' copies alternate between two streams (TSX_DEC_OUT_STREAMS=1: one).
+    bool out2 = inv_blocks && multi && r.host && !(getenv("TSX_DEC_OUT_STREAMS") && atoi(getenv("TSX_DEC_OUT_STREAMS")) < 2);
+    if (out2 && !c->st_out2 && hipStreamCreateWithFlags(&c->st_out2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->st_out2 = nullptr; out2 = false; }
     auto collect_piece = [&](size_t k) -> int {
         const tsx_sub& sb = subs[k];
         HIPCHK(hipEventSynchronize(c->sub_ev[k][4]));                   // descriptors of piece k are on the host
@@ -1187,7 +1193,7 @@ static int run_batch_inner(tsx_run& r) {
             }
             return TSX_OK;
         }
-        if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, c->st_out);
+        if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, (out2 && (k & 1)) ? c->st_out2 : c->st_out);
         return TSX_OK;
     };
     if (multi) {
@@ -1205,7 +1211,7 @@ static int run_batch_inner(tsx_run& r) {
     if (r.host) HIPCHK(hipEventRecord(c->ev[3], c->st_out));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
-    if (r.host) { HIPCHK(hipStreamSynchronize(c->st_in)); HIPCHK(hipStreamSynchronize(c->st_out)); }
+    if (r.host) { HIPCHK(hipStreamSynchronize(c->st_in)); HIPCHK(hipStreamSynchronize(c->st_out)); if (out2) HIPCHK(hipStreamSynchronize(c->st_out2)); }
     HIPCHK(hipGetLastError());
     tsx_timing& t = c->timing;
     float zmax = 0;
@@ -1276,6 +1282,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
         }
     }
     hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
+    if (c->st_out2) hipStreamSynchronize(c->st_out2);
     for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
     if (rc != TSX_OK) (void)hipGetLastError();
     return rc;
