@@ -1107,6 +1107,11 @@ static int run_batch_inner(tsx_run& r) {
         (void)hipGetLastError();
         if (!src_pinned || !dst_pinned) comp_pieces = 1;
     }
+    // With zero-copy output (round 4) there is no output copy left to overlap, and what the pieces still buy on the input side (~120 ms of
+    // a lone batch's 160 ms copy) they lose in the kernels (four launches of 512 chunks: 770-800 ms against 743) - a lone batch reads 918-935 ms
+    // with pieces; with several callers in flight their 4 x 4 compute streams collide on the hardware queues (14.2 against 16.3 GiB/s at
+    // 4 callers, profiles/r04_bench_default_run_with_zero_copy_row.json): one launch per batch then.
+    if (zc_dst && !getenv("TSX_COMP_PIECES")) comp_pieces = 1;
     const bool pipelined = r.host && monotonic && !(comp_fwd && (!r.fuse_stages || comp_pieces < 2)) && !getenv("TSX_NO_PIPELINE");
     // A fetch of 16 .. 256 chunks (a consumer catching up: ChunkCache.java:159-184 with a large prefetch.max.size) decodes in the block
     // form, whose cost is a ~1.5 ms chain of short kernels + a part proportional to the chunks: cut into up to 8 pieces of >= 8 chunks,
