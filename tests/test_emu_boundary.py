@@ -373,6 +373,7 @@ def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, monke
         for mode in ("zero_copy", "copies", "small_packed_buffer"):
             if mode == "small_packed_buffer" and kind != "packed":
                 continue
+            monkeypatch.setenv("TSX_ZERO_COPY_PACKED", "1")           # (an explicit context packs in place only on request: a whole batch is ~90 ms of memmove)
             if mode == "copies":
                 monkeypatch.setenv("TSX_NO_ZERO_COPY_OUT", "1")
             else:

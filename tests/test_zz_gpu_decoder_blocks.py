@@ -205,6 +205,12 @@ def test_zero_copy_output_into_registered_buffers_on_the_device(gpu, oracle):
         for kind, name in ((nat.MEM_HOST, "slots"), (nat.MEM_HOST_PACKED, "packed")):
             one(kind, None, "ctxless " + name)
             one(kind, ctx, "ctx " + name)
+        import os
+        os.environ["TSX_ZERO_COPY_PACKED"] = "1"                       # an explicit context packs in place only on request (a whole batch is ~90 ms of memmove)
+        try:
+            one(nat.MEM_HOST_PACKED, ctx, "ctx packed in place")
+        finally:
+            os.environ.pop("TSX_ZERO_COPY_PACKED", None)
         th = [threading.Thread(target=one, args=(nat.MEM_HOST if t % 2 else nat.MEM_HOST_PACKED, None, "thread %d" % t)) for t in range(8)]
         [x.start() for x in th]; [x.join() for x in th]
         # one slot too small: that chunk fails, nothing of it is written, its neighbours are whole

@@ -1067,9 +1067,12 @@ static int run_batch_inner(tsx_run& r) {
         out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
     }
     r.max_len = max_len; r.max_out = max_out;
-    // zero-copy output, as in run_combined: the compressor waves of a lean batch write into the caller's buffer when the device can address it
+    // zero-copy output, as in run_combined: the compressor waves of a lean batch write into the caller's buffer when the device can address it.
+    // Slot layout only: packing a whole 2048-chunk batch down in place is ~90 ms of one host thread behind the kernel (1004 against 935 ms
+    // for the lone batch, measured), where the copy path packs piece by piece while later pieces run; TSX_ZERO_COPY_PACKED=1 takes it anyway.
     uint8_t* zc_dst = nullptr;
-    if (r.mode == 0 && r.comp && r.enc && r.fuse_stages && r.host && !getenv("TSX_NO_ZERO_COPY_OUT") && (!r.packed || r.dst_size >= out_bytes)) {
+    if (r.mode == 0 && r.comp && r.enc && r.fuse_stages && r.host && !getenv("TSX_NO_ZERO_COPY_OUT") &&
+        (!r.packed || (r.dst_size >= out_bytes && getenv("TSX_ZERO_COPY_PACKED")))) {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, r.dst, 0) == hipSuccess && dp) zc_dst = (uint8_t*)dp;
         else (void)hipGetLastError();
