@@ -394,3 +394,40 @@ def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, monke
     finally:
         if ctx is not None:
             emu.ctx_destroy(ctx)
+
+
+def test_reserved_cus_for_fetches_change_nothing_but_the_streams(emu):
+    """TSX_FETCH_RESERVED_CUS=n (opt-in; a fetch under full upload load: 3 ms instead of a minute, profiles/r04_mixed_load.txt) gives the
+    compressor's streams - combiner lanes, a context's stream for compressing batches and its pieces - a CU mask; bytes and statuses are
+    the same with and without, context-less and with a context, slot and packed layout, and the fetch side is untouched."""
+    out = _run_py("""
+        import os, numpy as np
+        import tsxform
+        from tests import parity_cases as pc
+        from tests.emu import emu_native
+        from tsxform import synth
+        nat = tsxform._native
+        N = nat.Native(emu_native.build()); N.init()
+        flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+        chunks = [synth.gen_chunk("K", 5, 0, i, 4000 + 1500 * i) for i in range(10)]
+        ctx = N.ctx_create(0, 0, 0)
+        a, da = pc.run_transform(N, flags, chunks)
+        b, db = pc.run_transform(N, flags, chunks, ctx=ctx)
+        c, dc = pc.run_transform(N, flags, chunks, mem="packed")
+        back, d2 = pc.run_detransform(N, flags, a, [int(x.size) for x in chunks], ctx=ctx)
+        assert a == b == c and (da["status"] == 0).all() and back == [x.tobytes() for x in chunks]
+        import hashlib
+        print(hashlib.sha256(b"".join(a)).hexdigest())
+        """, TSX_FETCH_RESERVED_CUS=8, TSX_COMP_PIECES=3, TSX_SUB_BYTES=8192)
+    ref = _run_py("""
+        import hashlib, tsxform
+        from tests import parity_cases as pc
+        from tests.emu import emu_native
+        from tsxform import synth
+        nat = tsxform._native
+        N = nat.Native(emu_native.build()); N.init()
+        chunks = [synth.gen_chunk("K", 5, 0, i, 4000 + 1500 * i) for i in range(10)]
+        a, _ = pc.run_transform(N, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
+        print(hashlib.sha256(b"".join(a)).hexdigest())
+        """)
+    assert out.strip().splitlines()[-1] == ref.strip().splitlines()[-1]

@@ -100,7 +100,9 @@ struct tsx_ctx {
     hipStream_t st = nullptr;                      // kernels (+ descriptor copies)
     hipStream_t st_in = nullptr, st_out = nullptr; // H2D / D2H of the host-memory staging pipeline
     hipStream_t st_out2 = nullptr;                 // second D2H stream of a fetch cut into pieces (odd pieces; created on first use)
-    hipStream_t st_pc[TSX_COMP_PIECES - 1] = {nullptr}; // compute streams of pieces 1.. of a compressing host batch (created on first use)
+    hipStream_t st_pc[TSX_COMP_PIECES - 1] = {nullptr}; // compute streams of pieces 1.. of a host batch cut into co-resident pieces (created on first use)
+    hipStream_t st_fwd = nullptr;                  // compressing batches with CUs reserved for everything else (tsx_compressor_stream): their own stream ...
+    hipStream_t st_pcf[TSX_COMP_PIECES - 1] = {nullptr}; // ... and their pieces' (created on first use)
     hipEvent_t ev_key = nullptr;                   // key schedule ready (the piece streams wait for it)
     // device workspace (grown on demand)
     tsx_chunk_desc* d_descs = nullptr; size_t descs_cap = 0;
@@ -274,6 +276,8 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     if (c->st_out) hipStreamDestroy(c->st_out);
     if (c->st_out2) hipStreamDestroy(c->st_out2);
     for (auto& q : c->st_pc) if (q) hipStreamDestroy(q);
+    for (auto& q : c->st_pcf) if (q) hipStreamDestroy(q);
+    if (c->st_fwd) hipStreamDestroy(c->st_fwd);
     if (c->ev_key) hipEventDestroy(c->ev_key);
 }
 
@@ -287,6 +291,36 @@ extern "C" void tsx_shutdown(void) {
     }
     g_devs.clear();
     g_version.store(kUninitVersion, std::memory_order_release);
+}
+
+// A chip full of compressor waves starves everything else: a freed slot (one wave, 6.7 KB of LDS) is taken at once by the next queued
+// compressor workgroup, while a decoder workgroup (2-8 waves, up to 19.5 KB of LDS) needs several neighbouring slots free at the same
+// time - measured with five callers keeping 10 240 chunks queued: a single-chunk fetch took 64 s instead of 1.6 ms
+// (profiles/r04_mixed_load.txt).  A broker that uploads and serves fetches from the same device can ask for a reservation:
+// TSX_FETCH_RESERVED_CUS=n creates the COMPRESSOR's streams (the combiner's lanes, a context's stream for compressing batches) with a CU
+// mask that leaves n compute units - one per XCD for n = 8: the mask's bit i belongs to XCD i mod 8 - to whatever else runs.  Measured
+// with n = 8: a fetch under full upload load 3.3 ms median (p95 0.8 s; n = 16: 3.4 ms, p95 64 ms) instead of 50-80 s.  The price is not
+// the 3 % of the CUs: kernels on masked queues overlap worse - 14.5-15.2 GiB/s with five batches in flight against 19.4-19.8 (a lone batch:
+// 10.0 against 10.45), whatever GPU_MAX_HW_QUEUES says - so the default is 0, no reservation, and a deployment that serves consumers from
+// tiered storage while it uploads chooses (or gives fetches a device of their own: tsx_set_thread_device).
+static uint32_t reserved_cus() {
+    static const uint32_t v = [] { const char* e = getenv("TSX_FETCH_RESERVED_CUS"); const long x = e ? atol(e) : 0; return (uint32_t)(x < 0 ? 0 : x > 128 ? 128 : x); }();
+    return v;
+}
+static hipError_t tsx_compressor_stream(hipStream_t* out, int hip_device) {
+    const uint32_t r = reserved_cus();
+    hipDeviceProp_t prop;
+    if (r == 0 || hipGetDeviceProperties(&prop, hip_device) != hipSuccess || prop.multiProcessorCount <= (int)r + 8) {
+        (void)hipGetLastError();
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount, words = (cus + 31) / 32;
+    uint32_t mask[64] = {0};
+    for (uint32_t i = 0; i + r < cus && i < 64 * 32; i++) mask[i / 32] |= 1u << (i % 32);      // every CU but the last r of the numbering
+    const hipError_t e = hipExtStreamCreateWithCUMask(out, words, mask);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);        // a runtime without CU masks: no reservation, as before
 }
 
 template <class T>
@@ -815,7 +849,7 @@ static int combiner_get(tsx_device* dev, tsx_combiner** out) {
         for (uint32_t i = 0; ok && i < cb->n_out; i++) ok = hipStreamCreateWithFlags(&cb->copy_out_s[i], hipStreamNonBlocking) == hipSuccess;
         for (uint32_t i = 0; ok && i < nl; i++) {
             tsx_lane& l = cb->lane[i];
-            ok = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&l.end, hipEventDisableTiming) == hipSuccess &&
+            ok = tsx_compressor_stream(&l.st, dev->hip_id) == hipSuccess && hipEventCreateWithFlags(&l.end, hipEventDisableTiming) == hipSuccess &&
                  hipHostMalloc((void**)&l.h_segs, TSX_GROUP_MAX_SEGS * sizeof(tsx_zseg), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
                  hipHostGetDevicePointer((void**)&l.d_segs, l.h_segs, 0) == hipSuccess;
             cb->nlanes = i + 1;
@@ -1082,6 +1116,10 @@ static int run_batch_inner(tsx_run& r) {
     r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
     r.d_dst = zc_dst ? zc_dst : r.host ? c->d_out : (uint8_t*)r.dst;
     hipStream_t st = c->st;
+    if (r.mode == 0 && r.comp && reserved_cus()) {                     // a compressing batch leaves the reserved CUs alone
+        if (!c->st_fwd) HIPCHK(tsx_compressor_stream(&c->st_fwd, c->dev->hip_id));
+        st = c->st_fwd;
+    }
     memset(&c->timing, 0, sizeof c->timing);
     // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap.  Device-memory batches
     // have nothing to overlap.  Two shapes:
@@ -1142,8 +1180,12 @@ static int run_batch_inner(tsx_run& r) {
     const size_t ns = subs.size();
     const bool multi = (comp_fwd || inv_blocks) && ns > 1;             // pieces side by side: piece k on compute stream k mod TSX_COMP_PIECES
     for (size_t k = 1; k < ns; k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
-    if (multi) for (size_t k = 1; k < ns && k < TSX_COMP_PIECES; k++) if (!c->st_pc[k - 1]) HIPCHK(hipStreamCreateWithFlags(&c->st_pc[k - 1], hipStreamNonBlocking));
-    auto stream_of = [&](size_t k) { return (multi && k % TSX_COMP_PIECES) ? c->st_pc[k % TSX_COMP_PIECES - 1] : st; };
+    hipStream_t* const pcs = (comp_fwd && reserved_cus()) ? c->st_pcf : c->st_pc;
+    if (multi) for (size_t k = 1; k < ns && k < TSX_COMP_PIECES; k++) if (!pcs[k - 1]) {
+        if (pcs == c->st_pcf) HIPCHK(tsx_compressor_stream(&pcs[k - 1], c->dev->hip_id));
+        else HIPCHK(hipStreamCreateWithFlags(&pcs[k - 1], hipStreamNonBlocking));
+    }
+    auto stream_of = [&](size_t k) { return (multi && k % TSX_COMP_PIECES) ? pcs[k % TSX_COMP_PIECES - 1] : st; };
     HIPCHK(hipEventRecord(c->ev[0], st));
     // A compressing batch whose waves run the whole chain needs no kernel besides the compressor's: the key schedule is built on the
     // host, every wave owns its chunk's status.  (Small kernels around a launch wait for a slot on a chip that is full of second-long
@@ -1283,6 +1325,8 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     if (r.enc) {
         hipStreamSynchronize(c->st);                                      // (a wave may still be reading the pinned key schedule on an error path)
         for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
+        for (auto& q : c->st_pcf) if (q) hipStreamSynchronize(q);
+        if (c->st_fwd) hipStreamSynchronize(c->st_fwd);
         memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key));
         if (!(mode == 0 && r.comp && r.fuse_stages)) {                    // lean batches uploaded nothing: every wave wiped its own copy of the schedule
             if (getenv("TSX_GCM_SETUP_KERNEL")) hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);      // (the raw key only travels with the setup kernel)
@@ -1292,6 +1336,8 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
     if (c->st_out2) hipStreamSynchronize(c->st_out2);
     for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
+    for (auto& q : c->st_pcf) if (q) hipStreamSynchronize(q);
+    if (c->st_fwd) hipStreamSynchronize(c->st_fwd);
     if (rc != TSX_OK) (void)hipGetLastError();
     return rc;
 }

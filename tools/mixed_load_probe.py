@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""A broker uploads and serves fetches at the same time.  How long does a fetch (tsx_detransform_batch of 1 / 4 chunks, host -> host,
+registered buffers, its own context) take while T caller threads keep the chip full of compressor waves (device-resident 2048-chunk
+batches, as bench.py's timed region)?  One JSON line: latencies on the idle device and under load.
+  python tools/mixed_load_probe.py [--callers 5] [--seconds 12]            (TSX_FETCH_RESERVED_CUS=n in the environment: see tsx_api.hip)"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import torch  # noqa: E402
+import tsxform  # noqa: E402
+from tsxform import synth  # noqa: E402
+
+nat = tsxform._native
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--callers", type=int, default=5)
+    ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    N = nat.Native(); N.init(1, [0])
+    dev = torch.device("cuda", 0)
+    CH, n = synth.CHUNK, 2048
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
+    params = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
+    for i in range(256):
+        src[i * CH:(i + 1) * CH] = synth.gen_chunk("K", 1000, 0, i, CH, device=dev)
+    for i in range(256, n, 256):
+        src[i * CH:(i + 256) * CH] = src[:256 * CH]
+    d = np.zeros(n, nat.DESC_DTYPE); d["src_off"] = np.arange(n, dtype=np.uint64) * CH; d["src_len"] = CH
+    d["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d["dst_cap"] = slot
+    for i in range(n):
+        d["iv"][i] = np.frombuffer(synth.iv_for(0, i % 256), np.uint8)
+    T = args.callers
+    ctxs = [N.ctx_create(0, n, CH) for _ in range(T)]
+    dsts = [torch.empty(n * slot, dtype=torch.uint8, device=dev) for _ in range(T)]
+    ds = [d.copy() for _ in range(T)]
+    for t in range(T):
+        N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+    torch.cuda.synchronize()
+    # the fetch side: 4 transformed chunks in a registered host buffer, restored into a registered host buffer
+    hfr = dsts[0][:4 * slot].cpu().numpy(); hbk = np.zeros(4 * CH, np.uint8)
+    N.host_register(hfr); N.host_register(hbk)
+    fctx = N.ctx_create(0, 4, CH)
+    want = src[:4 * CH].cpu().numpy()
+
+    def fetch(k):
+        e = np.zeros(k, nat.DESC_DTYPE); e["src_off"] = ds[0]["dst_off"][:k]; e["src_len"] = ds[0]["dst_len"][:k]; e["iv"] = ds[0]["iv"][:k]
+        e["dst_off"] = np.arange(k, dtype=np.uint64) * CH; e["dst_cap"] = CH
+        t0 = time.perf_counter()
+        N.detransform_batch(params, e, hfr, hbk, hbk.size, nat.MEM_HOST, ctx=fctx)
+        dt = time.perf_counter() - t0
+        assert (e["status"] == 0).all()
+        return dt
+
+    for k in (1, 4):
+        fetch(k)
+    idle = {k: float(np.median([fetch(k) for _ in range(7)])) * 1e3 for k in (1, 4)}
+    assert np.array_equal(hbk, want)
+    stop = [False]
+    done = [0] * T
+
+    def worker(t):
+        while not stop[0]:
+            N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+            done[t] += 1
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    t0 = time.perf_counter()
+    [x.start() for x in th]
+    time.sleep(2.0)                                                     # the chip is full
+    lat = {1: [], 4: []}
+    while time.perf_counter() - t0 < args.seconds:
+        for k in (1, 4):
+            lat[k].append(fetch(k) * 1e3)
+        time.sleep(0.05)
+    stop[0] = True
+    [x.join() for x in th]
+    el = time.perf_counter() - t0
+    assert np.array_equal(hbk, want)
+    out = {"tag": args.tag, "reserved_cus": os.environ.get("TSX_FETCH_RESERVED_CUS"), "compress_callers": T,
+           "compress_gibs_while_fetching": round(sum(done) * n * CH / float(1 << 30) / el, 3),
+           "fetch_idle_ms": {k: round(v, 3) for k, v in idle.items()}}
+    for k in (1, 4):
+        a = np.asarray(lat[k])
+        out["fetch_%d_under_load_ms" % k] = {"n": int(a.size), "median": round(float(np.median(a)), 2), "p95": round(float(np.percentile(a, 95)), 2), "max": round(float(a.max()), 2)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
