@@ -302,7 +302,8 @@ extern "C" void tsx_shutdown(void) {
 // with n = 8: a fetch under full upload load 3.3 ms median (p95 0.8 s; n = 16: 3.4 ms, p95 64 ms) instead of 50-80 s.  The price is not
 // the 3 % of the CUs: kernels on masked queues overlap worse - 14.5-15.2 GiB/s with five batches in flight against 19.4-19.8 (a lone batch:
 // 10.0 against 10.45), whatever GPU_MAX_HW_QUEUES says - so the default is 0, no reservation, and a deployment that serves consumers from
-// tiered storage while it uploads chooses (or gives fetches a device of their own: tsx_set_thread_device).
+// tiered storage while it uploads chooses (or gives fetches a device of their own: tsx_set_thread_device).  (Queue priority is no remedy:
+// with the fetch context's stream at the highest priority the same fetch still took 40 s - what is missing is room, not turn.)
 static uint32_t reserved_cus() {
     static const uint32_t v = [] { const char* e = getenv("TSX_FETCH_RESERVED_CUS"); const long x = e ? atol(e) : 0; return (uint32_t)(x < 0 ? 0 : x > 128 ? 128 : x); }();
     return v;
