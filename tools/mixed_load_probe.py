@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--callers", type=int, default=5)
     ap.add_argument("--seconds", type=float, default=12.0)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--shape", default="batches", choices=["batches", "broker"],
+                    help="the upload load: `batches` = --callers explicit contexts x 2048-chunk device-resident batches (more chunks queued than the chip has "
+                         "slots); `broker` = --callers context-less calls of ONE 256-chunk segment each, registered host buffers, slot layout (tools/broker_leg.py)")
     args = ap.parse_args()
     N = nat.Native(); N.init(1, [0])
     dev = torch.device("cuda", 0)
@@ -44,11 +47,29 @@ def main():
     for i in range(n):
         d["iv"][i] = np.frombuffer(synth.iv_for(0, i % 256), np.uint8)
     T = args.callers
-    ctxs = [N.ctx_create(0, n, CH) for _ in range(T)]
-    dsts = [torch.empty(n * slot, dtype=torch.uint8, device=dev) for _ in range(T)]
-    ds = [d.copy() for _ in range(T)]
-    for t in range(T):
-        N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+    broker = args.shape == "broker"
+    if not broker:
+        ctxs = [N.ctx_create(0, n, CH) for _ in range(T)]
+        dsts = [torch.empty(n * slot, dtype=torch.uint8, device=dev) for _ in range(T)]
+        ds = [d.copy() for _ in range(T)]
+        for t in range(T):
+            N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+    else:
+        B = 256
+        hslot = (N.transformed_bound(CH, flags) + 15) // 16 * 16 + 16
+        hsrc = src[:B * CH].cpu().numpy(); N.host_register(hsrc)
+        hdsts = []
+        for t in range(T):
+            hb = np.zeros(B * hslot, np.uint8); N.host_register(hb); hdsts.append(hb)
+        ds = []
+        for t in range(T):
+            dd = d[:B].copy(); dd["dst_off"] = np.arange(B, dtype=np.uint64) * hslot; dd["dst_cap"] = N.transformed_bound(CH, flags); ds.append(dd)
+        dsts = [torch.empty(4 * slot, dtype=torch.uint8, device=dev)]
+        d4 = d[:4].copy()
+        c0 = N.ctx_create(0, 4, CH)
+        N.transform_batch(params, d4, src.data_ptr(), dsts[0].data_ptr(), dsts[0].numel(), nat.MEM_DEVICE, ctx=c0)      # the chunks the fetches restore
+        N.ctx_destroy(c0)
+        ds_fetch = d4
     torch.cuda.synchronize()
     # the fetch side: 4 transformed chunks in a registered host buffer, restored into a registered host buffer
     hfr = dsts[0][:4 * slot].cpu().numpy(); hbk = np.zeros(4 * CH, np.uint8)
@@ -56,8 +77,11 @@ def main():
     fctx = N.ctx_create(0, 4, CH)
     want = src[:4 * CH].cpu().numpy()
 
+    if not broker:
+        ds_fetch = ds[0]
+
     def fetch(k):
-        e = np.zeros(k, nat.DESC_DTYPE); e["src_off"] = ds[0]["dst_off"][:k]; e["src_len"] = ds[0]["dst_len"][:k]; e["iv"] = ds[0]["iv"][:k]
+        e = np.zeros(k, nat.DESC_DTYPE); e["src_off"] = ds_fetch["dst_off"][:k]; e["src_len"] = ds_fetch["dst_len"][:k]; e["iv"] = ds_fetch["iv"][:k]
         e["dst_off"] = np.arange(k, dtype=np.uint64) * CH; e["dst_cap"] = CH
         t0 = time.perf_counter()
         N.detransform_batch(params, e, hfr, hbk, hbk.size, nat.MEM_HOST, ctx=fctx)
@@ -74,7 +98,10 @@ def main():
 
     def worker(t):
         while not stop[0]:
-            N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+            if broker:
+                N.transform_batch(params, ds[t], hsrc, hdsts[t], hdsts[t].size, nat.MEM_HOST, ctx=None)
+            else:
+                N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
             done[t] += 1
 
     th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
@@ -91,7 +118,8 @@ def main():
     el = time.perf_counter() - t0
     assert np.array_equal(hbk, want)
     out = {"tag": args.tag, "reserved_cus": os.environ.get("TSX_FETCH_RESERVED_CUS"), "compress_callers": T,
-           "compress_gibs_while_fetching": round(sum(done) * n * CH / float(1 << 30) / el, 3),
+           "upload_shape": args.shape, "chunks_offered": T * (256 if broker else n),
+           "compress_gibs_while_fetching": round(sum(done) * (256 if broker else n) * CH / float(1 << 30) / el, 3),
            "fetch_idle_ms": {k: round(v, 3) for k, v in idle.items()}}
     for k in (1, 4):
         a = np.asarray(lat[k])
