@@ -703,6 +703,13 @@ __global__ __launch_bounds__(ZB_SC_WAVES * LANES) void zb_scatter_kernel(const u
 // (log-like content: every word resolved after 7 jumps = 4 passes, its matches reach ~100 KB back, not to the previous record) while the
 // launcher must queue the passes the WORST case needs (a 4 MiB chain at offset 1 or 2: three guaranteed hops per pass, 15 passes queued): a pass notes whether it left
 // anything unresolved, and the passes behind one that did not return at their first instruction.
+#ifdef HIPEMU
+// Test harness only (tests/test_emu_zstd.py::test_jump_passes_cover_the_worst_store_order): the emulator runs a grid's threads one after
+// the other, so an in-place pass sees every earlier thread's stores - the BEST order for pointer jumping.  With a snapshot every read of
+// a pass sees the words as they were before it - the worst order the device can produce (three hops per pass) - and the pass bound of
+// tsx_launch_zstd_decompress_blocks can be checked against it on the CPU.
+static const uint8_t* g_zb_snap = nullptr;
+#endif
 __global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs, uint8_t* __restrict__ arenas, uint64_t astride, uint32_t lit_cap, uint32_t seq_cap,
                                                       uint32_t round) {
     const uint32_t chunk = blockIdx.y;
@@ -712,22 +719,26 @@ __global__ __launch_bounds__(256) void zb_jump_kernel(uint8_t* __restrict__ hdrs
     const uint32_t n = C->contentSize, p = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (p >= n) return;
     uint32_t* const words = (uint32_t*)(arenas + (size_t)chunk * astride + lit_cap + 12u * (size_t)seq_cap);
+    const uint32_t* rd = words;                                         // what this pass reads (the array itself: the update is in place)
+#ifdef HIPEMU
+    if (g_zb_snap) rd = (const uint32_t*)(g_zb_snap + ((const uint8_t*)words - arenas));
+#endif
     if (p + 4 <= n) {
-        uint4 v = *reinterpret_cast<const uint4*>(words + p);
+        uint4 v = *reinterpret_cast<const uint4*>(rd + p);
         if ((v.x & v.y & v.z & v.w) & ZB_LIT) return;                   // all four resolved already
         // two jumps per pass: a word that is still a position after the first takes its source's word once more (a pass costs one
-        // read and one write of the word array whatever it resolves: log4 instead of log2 passes)
-        uint32_t a = (v.x & ZB_LIT) ? v.x : words[v.x], b_ = (v.y & ZB_LIT) ? v.y : words[v.y], c = (v.z & ZB_LIT) ? v.z : words[v.z], d_ = (v.w & ZB_LIT) ? v.w : words[v.w];
+        // read and one write of the word array whatever it resolves)
+        uint32_t a = (v.x & ZB_LIT) ? v.x : rd[v.x], b_ = (v.y & ZB_LIT) ? v.y : rd[v.y], c = (v.z & ZB_LIT) ? v.z : rd[v.z], d_ = (v.w & ZB_LIT) ? v.w : rd[v.w];
         if (!((a & b_ & c & d_) & ZB_LIT)) {
-            a = (a & ZB_LIT) ? a : words[a]; b_ = (b_ & ZB_LIT) ? b_ : words[b_]; c = (c & ZB_LIT) ? c : words[c]; d_ = (d_ & ZB_LIT) ? d_ : words[d_];
+            a = (a & ZB_LIT) ? a : rd[a]; b_ = (b_ & ZB_LIT) ? b_ : rd[b_]; c = (c & ZB_LIT) ? c : rd[c]; d_ = (d_ & ZB_LIT) ? d_ : rd[d_];
         }
         v.x = a; v.y = b_; v.z = c; v.w = d_;
         *reinterpret_cast<uint4*>(words + p) = v;
         if (!((a & b_ & c & d_) & ZB_LIT) && round < 32) C->live[round] = 1;       // (every writer stores the same value)
     } else {
         for (uint32_t q = p; q < n; q++) {
-            const uint32_t v = words[q];
-            if (!(v & ZB_LIT)) { uint32_t w = words[v]; if (!(w & ZB_LIT)) w = words[w]; words[q] = w; if (!(w & ZB_LIT) && round < 32) C->live[round] = 1; }
+            const uint32_t v = rd[q];
+            if (!(v & ZB_LIT)) { uint32_t w = rd[v]; if (!(w & ZB_LIT)) w = rd[w]; words[q] = w; if (!(w & ZB_LIT) && round < 32) C->live[round] = 1; }
         }
     }
 }
@@ -797,8 +808,21 @@ uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames
     for (uint64_t reach = 1; reach < (uint64_t)max_out; reach *= 3) rounds++;
     static_assert(sizeof(((ZbChunk*)0)->live) / sizeof(((ZbChunk*)0)->live[0]) >= 18, "live[] covers the passes of a 16 MiB chunk");
     const uint32_t tiles = (max_out + 1023) / 1024;                     // 256 threads x 4 words
-    for (uint32_t r = 0; r < rounds; r++)
+#ifdef HIPEMU
+    // test harness: TSX_EMU_JUMP_SNAPSHOT=1 gives every pass the word array as it was before the pass (the worst store order),
+    // TSX_EMU_JUMP_ROUNDS=k queues k passes instead of the bound above (to show what too few do)
+    uint8_t* snap = getenv("TSX_EMU_JUMP_SNAPSHOT") ? (uint8_t*)malloc((size_t)n * astride) : nullptr;
+    if (const char* e = getenv("TSX_EMU_JUMP_ROUNDS")) { const long v = atol(e); if (v >= 1 && v <= 31) rounds = (uint32_t)v; }
+#endif
+    for (uint32_t r = 0; r < rounds; r++) {
+#ifdef HIPEMU
+        if (snap) { memcpy(snap, arenas, (size_t)n * astride); g_zb_snap = snap; }
+#endif
         hipLaunchKernelGGL(zb_jump_kernel, dim3(tiles, n), dim3(256), 0, st, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap, r);
+    }
+#ifdef HIPEMU
+    g_zb_snap = nullptr; free(snap);
+#endif
     hipLaunchKernelGGL(zb_emit_kernel, dim3((max_out + 4095) / 4096, n), dim3(256), 0, st, (const tsx_chunk_desc*)d_descs, dst, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
     return 4 + rounds;
 }
