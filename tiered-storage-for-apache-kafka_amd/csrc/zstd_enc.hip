@@ -1724,7 +1724,13 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segmen
             if (atomicAdd(done, 1u) + 1u == n) {
                 atomicExch(done, 0u);                                    // ready for the context's next batch (ordered before it by the flag)
                 __threadfence_system();
-                atomicExch(segs[k].flag, 1u);
+                // a plain system-scope store, not an atomic read-modify-write: the flag lives in HOST memory, and an atomic there would need
+                // PCIe AtomicOps routed all the way to the root complex - not every server does that
+#ifdef HIPEMU
+                *(volatile uint32_t*)segs[k].flag = 1u;
+#else
+                __hip_atomic_store(segs[k].flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
             }
         }
     }
