@@ -49,6 +49,9 @@ def main():
         import torch                                   # before libtsxform: a process has ONE HIP runtime, the first one loaded (torch bundles its own)
     N = nat.Native()
     N.init(1, [0])
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from numa_bind import bind_to_gpu_numa_node
+    AFFINITY = bind_to_gpu_numa_node(0)                              # before any host buffer is allocated (profiles/r04_broker_numa.txt)
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     slot = (N.transformed_bound(CH, flags) + 63) // 64 * 64
     if hsrc is None:

@@ -18,6 +18,9 @@ from tsxform import synth  # noqa: E402
 
 nat = tsxform._native
 N = nat.Native(); N.init(1, [0])
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from numa_bind import bind_to_gpu_numa_node
+AFFINITY = bind_to_gpu_numa_node(0)                              # before any host buffer is allocated (profiles/r04_broker_numa.txt)
 dev = torch.device("cuda", 0)
 CH = synth.CHUNK
 NMAX = int(sys.argv[1]) if len(sys.argv) > 1 else 256

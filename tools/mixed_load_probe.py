@@ -32,6 +32,9 @@ def main():
                          "slots); `broker` = --callers context-less calls of ONE 256-chunk segment each, registered host buffers, slot layout (tools/broker_leg.py)")
     args = ap.parse_args()
     N = nat.Native(); N.init(1, [0])
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from numa_bind import bind_to_gpu_numa_node
+    AFFINITY = bind_to_gpu_numa_node(0)                              # before any host buffer is allocated (profiles/r04_broker_numa.txt)
     dev = torch.device("cuda", 0)
     CH, n = synth.CHUNK, 2048
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
