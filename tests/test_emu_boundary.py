@@ -431,3 +431,38 @@ def test_reserved_cus_for_fetches_change_nothing_but_the_streams(emu):
         print(hashlib.sha256(b"".join(a)).hexdigest())
         """)
     assert out.strip().splitlines()[-1] == ref.strip().splitlines()[-1]
+
+
+def test_admission_cap_of_the_launch_combiner(emu):
+    """TSX_COMBINER_MAX_CHUNKS=n (opt-in): never more than n compressor chunks launched and not yet done per device - members complete one
+    by one and the next launch waits for room - except a batch that is larger than the cap by itself, which goes alone.  Same bytes."""
+    out = _run_py("""
+        import ctypes, threading, numpy as np
+        import tsxform
+        from tests import parity_cases as pc
+        from tests.emu import emu_native
+        from tsxform import synth
+        nat = tsxform._native
+        N = nat.Native(emu_native.build()); N.init()
+        flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+        small = [synth.gen_chunk("K", 3, 0, i, 3000 + 100 * i) for i in range(4)]
+        big = [synth.gen_chunk("K", 4, 0, i, 2000) for i in range(9)]
+        ref_s, _ = pc.run_transform(N, flags, small)
+        ref_b, _ = pc.run_transform(N, flags, big)
+        errors = []
+        def worker(t):
+            for rep in range(3):
+                chunks, ref = (big, ref_b) if (t == 0 and rep == 1) else (small, ref_s)
+                got, d = pc.run_transform(N, flags, chunks)
+                if got != ref or (d["status"] != 0).any():
+                    errors.append((t, rep))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        [x.start() for x in th]; [x.join() for x in th]
+        assert not errors, errors
+        peak = N.lib.tsx_debug_combiner_inflight_peak
+        peak.restype = ctypes.c_int
+        p = peak(0)
+        assert 4 <= p <= 9, p          # 8 = two small batches; 9 = the big one, alone
+        print("ok", p)
+    """, TSX_COMBINER_MAX_CHUNKS=8, TSX_LANES=3)
+    assert out.strip().splitlines()[-1].startswith("ok")

@@ -64,6 +64,11 @@ struct tsx_combiner {
     uint32_t n_in = 1, n_out = 1;
     std::atomic<uint32_t> rr_in{0}, rr_out{0};
     uint64_t groups = 0, members = 0;                      // launches made, batches they carried (tsx_debug_combiner_stats)
+    // Admission cap (opt-in, TSX_COMBINER_MAX_CHUNKS; 0 = none): compressor chunks launched and not yet done on this device.  With more
+    // chunks launched than the chip has slots (6144) every freed slot is refilled by the hardware at once and anything that is not a
+    // compressor wave starves (mixed load); members are 256 chunks and complete one by one, so holding launches back at ~5600
+    // keeps a few hundred slots turning over in the open.  Prepared in round 4, not yet measured on the device: hence off by default.
+    uint32_t inflight = 0, inflight_peak = 0, cap = 0;
 };
 
 struct tsx_device {
@@ -843,6 +848,7 @@ static int combiner_get(tsx_device* dev, tsx_combiner** out) {
         if (const char* e = getenv("TSX_LANES")) { const long v = atol(e); if (v >= 1 && v <= TSX_LANES_MAX) nl = (uint32_t)v; }
         // the copy streams first: whatever the runtime's stream -> hardware-queue assignment, the short copies and their event markers
         // are not the ones that end up behind a second-long kernel of a lane created later
+        if (const char* e = getenv("TSX_COMBINER_MAX_CHUNKS")) { const long v = atol(e); if (v > 0) cb->cap = (uint32_t)v; }
         cb->n_in = 1; cb->n_out = 1;                                    // more streams measured WORSE (see tsx_combiner)
         if (const char* e = getenv("TSX_COPY_STREAMS")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= TSX_COPY_STREAMS_MAX && b >= 1 && b <= TSX_COPY_STREAMS_MAX) { cb->n_in = a; cb->n_out = b; } }
         bool ok = true;
@@ -944,27 +950,45 @@ static void combiner_submit(tsx_combiner* cb, tsx_zreq& q) {
         // order the members' input copies land in.  Everything onto the first free lane made one launch wait for the LAST member's copy,
         // and its members finish, come back and pile up together for good: 32 callers in step moved 12 GiB/s where 20 moved 17
         // (profiles/r03_bench_default_run_head.json before this).
+        // (admission cap: wait for members to complete - combiner_member_done notifies - while the first waiting batch would exceed it;
+        //  a batch larger than the cap goes alone on an empty device)
+        while (cb->cap && cb->inflight && cb->inflight + cb->pending.front()->r->n > cb->cap) cb->cv.wait_for(lk, std::chrono::microseconds(500));
         const size_t share = (cb->pending.size() + nfree - 1) / nfree;
         std::vector<tsx_zreq*> grp;
         uint32_t chunks = 0;
-        while (!cb->pending.empty() && grp.size() < share && grp.size() < TSX_GROUP_MAX_SEGS && (grp.empty() || chunks + cb->pending.front()->r->n <= TSX_GROUP_MAX_CHUNKS)) {
+        while (!cb->pending.empty() && grp.size() < share && grp.size() < TSX_GROUP_MAX_SEGS && (grp.empty() || chunks + cb->pending.front()->r->n <= TSX_GROUP_MAX_CHUNKS) &&
+               (grp.empty() || !cb->cap || cb->inflight + chunks + cb->pending.front()->r->n <= cb->cap)) {
             grp.push_back(cb->pending.front()); chunks += cb->pending.front()->r->n;
             cb->pending.erase(cb->pending.begin());
         }
         tsx_lane& l = cb->lane[li];
         l.busy = true;
         cb->groups++; cb->members += grp.size();
+        cb->inflight += chunks; if (cb->inflight > cb->inflight_peak) cb->inflight_peak = cb->inflight;
         lk.unlock();
         const int rc = combiner_launch(cb, l, grp);
         if (rc != TSX_OK) { (void)hipGetLastError(); (void)hipStreamSynchronize(l.st); }
         lk.lock();
-        if (rc != TSX_OK) l.busy = false;
+        if (rc != TSX_OK) { l.busy = false; cb->inflight -= chunks; }
         for (tsx_zreq* m : grp) { m->rc = rc; m->done = true; }
         cb->leader = false;
         cb->cv.notify_all();
     }
 }
 
+// A member of a launch is done (or gave up waiting): its chunks leave the admission count.
+static void combiner_member_done(tsx_combiner* cb, uint32_t n) {
+    std::lock_guard<std::mutex> lk(cb->mu);
+    cb->inflight = cb->inflight >= n ? cb->inflight - n : 0;
+    if (cb->cap) cb->cv.notify_all();
+}
+// test hook: the most compressor chunks ever launched and not yet done on a device (admission cap)
+extern "C" int tsx_debug_combiner_inflight_peak(int device_index) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (device_index < 0 || device_index >= (int)g_devs.size() || !g_devs[device_index].comb) return TSX_E_INVAL;
+    std::lock_guard<std::mutex> lk2(g_devs[device_index].comb->mu);
+    return (int)g_devs[device_index].comb->inflight_peak;
+}
 // Where a context-less compressing call spends its time (test / measurement hook, tools/broker_probe.py): nanoseconds summed over calls -
 // waiting for the own input copy, from asking for a launch to the own chunks being done (lane wait + kernel), output copies - and calls.
 static std::atomic<uint64_t> g_phase_ns[4];
@@ -1023,7 +1047,8 @@ static int run_combined(tsx_run& r) {
     }
     const auto t_sub = std::chrono::steady_clock::now();
     combiner_submit(cb, q);
-    if (q.rc != TSX_OK) return q.rc;
+    if (q.rc != TSX_OK) return q.rc;                                    // (the leader has taken the group's chunks out of the admission count)
+    struct member_guard { tsx_combiner* cb; uint32_t n; ~member_guard() { if (cb) combiner_member_done(cb, n); } void release() { combiner_member_done(cb, n); cb = nullptr; } } guard{cb, n};
     tsx_timing& t = c->timing;
     if (r.enc) {
         // The launch may carry other callers' segments and goes on until the last of THEIR chunks is done; this caller waits for its own:
@@ -1049,6 +1074,7 @@ static int run_combined(tsx_run& r) {
         HIPCHK(hipEventSynchronize(c->ev[1]));                          // this batch's descriptors are on the host (its group may still be running for others)
         t.zstd_ms = ev_ms(c->ev[0], c->ev[1]);
     }
+    guard.release();                                                    // this member's chunks are done: the next launch may come
     memcpy(r.descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc));
     t.zstd_launches = 1; t.total_ms = t.zstd_ms;
     if (zc_dst) {
