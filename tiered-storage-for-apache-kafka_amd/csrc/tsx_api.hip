@@ -67,7 +67,8 @@ struct tsx_combiner {
     // Admission cap (opt-in, TSX_COMBINER_MAX_CHUNKS; 0 = none): compressor chunks launched and not yet done on this device.  With more
     // chunks launched than the chip has slots (6144) every freed slot is refilled by the hardware at once and anything that is not a
     // compressor wave starves (mixed load); members are 256 chunks and complete one by one, so holding launches back at ~5600
-    // keeps a few hundred slots turning over in the open.  Prepared in round 4, not yet measured on the device: hence off by default.
+    // keeps a few hundred slots turning over in the open.  One device run (32 callers, cap 5632, profiles/r04_mixed_load.txt): a fetch still
+    // takes 1.8-3.4 s - scattered free slots rarely line up three on one CU - so this is a knob, off by default; TSX_FETCH_RESERVED_CUS is the remedy.
     uint32_t inflight = 0, inflight_peak = 0, cap = 0;
 };
 
