@@ -614,6 +614,22 @@ static void backendTests(bool full) {
             expectThrows<std::runtime_error>([&] { cache.getChunk("k.log", m, 5); }, "Tag mismatch");
             CHECK(cache.getChunk("k.log", m, 6) == plain(6));
         }
+        {   // a load that dies of something that is not a std::exception (the Java twin's OutOfMemoryError / UnsatisfiedLinkError):
+            // every waiter of the window is failed at once - nobody sits out get.timeout.ms - and the ids are loadable again afterwards
+            struct Dying : ObjectFetcher {
+                std::shared_ptr<ObjectFetcher> real; std::atomic<bool> die{true};
+                std::shared_ptr<InputStream> fetch(const std::string& k, BytesRange r) override { if (die) throw 42; return real->fetch(k, r); }
+            };
+            auto dying = std::make_shared<Dying>(); dying->real = fetcher;
+            GpuChunkCache cache(std::make_shared<GpuChunkManager>(be, dying), 3 * cs, (size_t)64 << 20, 10000, 0);
+            const auto t0 = std::chrono::steady_clock::now();
+            bool threw = false;
+            try { cache.getChunk("k.log", m, 2); } catch (...) { threw = true; }
+            CHECK(threw && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5));
+            cache.quiesce();
+            dying->die = false;
+            CHECK(cache.getChunk("k.log", m, 2) == plain(2) && cache.getChunk("k.log", m, 3) == plain(3));       // nothing of the dead load is left in `pending`
+        }
         {   // fetchLogSegment's caller on top: an original-offset range through FetchChunkEnumeration -> GpuChunkCache -> GpuChunkManager
             // gives exactly those bytes, and a reader that closes early has caused nothing beyond its chunk's window to be fetched
             auto cache = std::make_shared<GpuChunkCache>(std::make_shared<GpuChunkManager>(be, fetcher), 2 * cs, (size_t)64 << 20, 10000, 0);

@@ -889,20 +889,37 @@ struct GpuChunkCache::Impl {
         while (bytes > maxBytes && lru.size() > 1) { bytes -= lru.back().second.size(); cached.erase(lru.back().first); lru.pop_back(); st.evictions++; }
     }
     // Runs one batch: one ranged fetch + one device batch; on failure every chunk on its own, so that only the bad one fails.
+    // Whatever happens in here - a manager that throws, returns too few chunks, an allocation that fails while the chunk is cached - no
+    // slot of the batch stays open and no key stays in `pending` (GpuChunkCache.java runBatch / abandon: later getChunk calls for these
+    // ids must start a new load, not wait get.timeout.ms for a task that died).
     void runBatch(const std::shared_ptr<Batch>& b, const SegmentManifest& manifest) {
-        std::vector<Bytes> got;
-        std::exception_ptr batchErr;
-        try { got = mgr->getChunks(b->object, manifest, b->first, b->count); } catch (...) { batchErr = std::current_exception(); }
-        { std::lock_guard<std::mutex> lk(mu); st.fetchCalls++; st.chunksFetched += b->count; }
+        std::vector<char> settled((size_t)b->count, 0);
+        std::exception_ptr fatal;
+        try {
+            std::vector<Bytes> got;
+            std::exception_ptr batchErr;
+            try {
+                got = mgr->getChunks(b->object, manifest, b->first, b->count);
+                if ((int)got.size() != b->count) throw std::runtime_error("getChunks returned " + std::to_string(got.size()) + " chunks for " + std::to_string(b->count));
+            } catch (...) { batchErr = std::current_exception(); }
+            { std::lock_guard<std::mutex> lk(mu); st.fetchCalls++; st.chunksFetched += b->count; }
+            for (int i = 0; i < b->count; i++) {
+                const Key k{b->object, b->first + i};
+                Bytes v;
+                std::exception_ptr err;
+                if (!batchErr) v = std::move(got[(size_t)i]);
+                else if (b->count == 1) err = batchErr;
+                else { try { v = mgr->getChunk(b->object, manifest, b->first + i); } catch (...) { err = std::current_exception(); } }
+                { std::lock_guard<std::mutex> lk(mu); if (!err) insert(k, v); pending.erase(k); }
+                settled[(size_t)i] = 1;
+                if (err) b->slots[(size_t)i]->set_exception(err); else b->slots[(size_t)i]->set_value(std::move(v));
+            }
+        } catch (...) { fatal = std::current_exception(); }
         for (int i = 0; i < b->count; i++) {
-            const Key k{b->object, b->first + i};
-            Bytes v;
-            std::exception_ptr err;
-            if (!batchErr) v = std::move(got[(size_t)i]);
-            else if (b->count == 1) err = batchErr;
-            else { try { v = mgr->getChunk(b->object, manifest, b->first + i); } catch (...) { err = std::current_exception(); } }
-            { std::lock_guard<std::mutex> lk(mu); if (!err) insert(k, v); pending.erase(k); }
-            if (err) b->slots[(size_t)i]->set_exception(err); else b->slots[(size_t)i]->set_value(std::move(v));
+            if (settled[(size_t)i]) continue;
+            { std::lock_guard<std::mutex> lk(mu); pending.erase(Key{b->object, b->first + i}); }
+            try { b->slots[(size_t)i]->set_exception(fatal ? fatal : std::make_exception_ptr(std::runtime_error("chunk load ended without a result"))); }
+            catch (const std::future_error&) {}                          // (the slot was settled by the statement that threw)
         }
     }
 };
