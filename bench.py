@@ -208,6 +208,17 @@ def main():
     else:
         N = nat.Native()
         N.init(1, [local_rank])
+    # host-path legs (end_to_end): this rank's threads and the buffers they first-touch and pin stay on the NUMA node of ITS GPU - the far
+    # socket of a two-socket host costs a third of the rate (profiles/r04_broker_numa.txt).  The timed region is device resident: unaffected.
+    cpu_affinity = "not asked"
+    if not rehearse:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from numa_bind import bind_to_numa_node_of_pci
+            pr = torch.cuda.get_device_properties(local_rank)
+            cpu_affinity = bind_to_numa_node_of_pci(getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception as e:                                           # noqa: BLE001 - a convenience, never a reason to lose the line
+            cpu_affinity = "not bound: %r" % (e,)
     dev = None if rehearse else torch.device("cuda", local_rank)
     MEM = nat.MEM_HOST if rehearse else nat.MEM_DEVICE
 
@@ -784,7 +795,7 @@ def main():
                        "object_gathered_on_rank0_sha": None if not objects else __import__("hashlib").sha256(
                            b"".join((objects[k].cpu().numpy() if hasattr(objects[k], "cpu") else np.asarray(objects[k])).tobytes() for k in sorted(objects))).hexdigest()[:16],
                        "batches_in_flight": T, "gibs_one_batch_at_a_time": None if single is None else round(single, 4),
-                       "hip_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "hip_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "cpu_affinity": cpu_affinity,
                        "process_group": None if not dist_on else {
                            "backend": args.backend + (" (= RCCL)" if args.backend == "nccl" else ""), "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1),
                            "ran": ["barrier", "all_reduce(MAX)"] + (["all_gather(sizes)"] if split else []) + (["p2p slice -> owner"] if split and args.gather_object and (world > 1 or args.backend == "nccl") else [])},

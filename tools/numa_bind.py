@@ -45,3 +45,24 @@ def bind_to_gpu_numa_node(hip_device=0):
         return "bound to %d CPUs of NUMA node %d (the GPU's)" % (len(use), node)
     except (OSError, ValueError, AttributeError) as e:
         return "not bound: %r" % (e,)
+
+
+def bind_to_numa_node_of_pci(domain, bus, device):
+    """The same, for a process that must not touch the HIP runtime by itself (bench.py: torch's bundled runtime is loaded, asking the
+    system's libamdhip64 for the bus id would start a second runtime in the process): the PCI address comes from the caller."""
+    try:
+        path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (int(domain), int(bus), int(device))
+        node = int(open(path).read().strip())
+        if node < 0:
+            return "no NUMA node reported for the GPU"
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        use = cpus & os.sched_getaffinity(0)
+        if not use:
+            return "GPU on NUMA node %d, none of its CPUs allowed here" % node
+        os.sched_setaffinity(0, use)
+        return "bound to %d CPUs of NUMA node %d (the GPU's)" % (len(use), node)
+    except (OSError, ValueError, AttributeError, TypeError) as e:
+        return "not bound: %r" % (e,)
