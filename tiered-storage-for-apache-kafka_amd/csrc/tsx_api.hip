@@ -145,7 +145,7 @@ static std::mutex g_mu;
 static std::vector<tsx_device> g_devs;
 static uint32_t g_rr = 0;
 static thread_local int t_dev_hint = -1;
-static const char kUninitVersion[] = "tsxform 0.3 (gfx950 HIP; uninitialised)";
+static const char kUninitVersion[] = "tsxform 0.4 (gfx950 HIP; uninitialised)";
 static char g_version_buf[2][512];
 static unsigned g_version_gen = 0;
 static std::atomic<const char*> g_version{kUninitVersion};
@@ -253,7 +253,7 @@ extern "C" int tsx_init(int device_count, const int* device_ids) {
     g_devs.swap(devs);
     char* vb = g_version_buf[g_version_gen++ & 1];
     snprintf(vb, sizeof g_version_buf[0],
-             "tsxform 0.3 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; %d device(s): %s)",
+             "tsxform 0.4 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; %d device(s): %s)",
              (int)g_devs.size(), g_devs[0].name);
     g_version.store(vb, std::memory_order_release);
     return (int)g_devs.size();
