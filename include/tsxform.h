@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define TSX_ABI_VERSION 3 /* 2: ctx-less calls spread over all initialised devices; tsx_set_thread_device, tsx_host_register
-                             3: the batch entry points take src_size and reject descriptors that reach beyond it */
+#define TSX_ABI_VERSION 4 /* 2: ctx-less calls spread over all initialised devices; tsx_set_thread_device, tsx_host_register
+                             3: the batch entry points take src_size and reject descriptors that reach beyond it
+                             4: tsx_init_ex / tsx_config, tsx_service_stats, tsx_service_quiesce (the compressor service) */
 
 /* flags: which stages of the chain run.  Replaces the reference's chain construction
  * RemoteStorageManager.transformation(), core/.../RemoteStorageManager.java:434-453
@@ -43,12 +44,13 @@ extern "C" {
 
 /* where src/dst live */
 /* host pointers.  The batch is cut into pieces whose H2D copy, kernels and D2H copy overlap: pieces of >= 64 MiB in order on three
- * streams of the ctx; when compressing, up to 4 co-resident pieces with a compute stream each (a chunk is ~0.6 s of one wave whatever
- * the batch size: piece k starts when its share of the input has landed, its output travels while later pieces run).  Any host memory works - pageable
- * buffers are staged by the HIP runtime; buffers pinned once with tsx_host_register() are copied by DMA without a staging pass.
- * A compressing + encrypting batch whose dst the device can address (tsx_host_register'ed / hipHostMalloc'ed memory) has no output copy
- * at all: the device writes every chunk's IV || C || TAG straight into [dst_off, dst_off + dst_len) during the call (nothing beyond
- * dst_len is written; what the buffer holds is defined when the call returns, as for any other kind). */
+ * streams of the ctx; a compressing batch goes as up to 4 members of the device's compressor service (a chunk is ~1 s of one wave whatever
+ * the batch size: piece k is published when its share of the input has landed, its output travels while later pieces run).  Any host memory
+ * works - pageable buffers are staged by the HIP runtime; buffers pinned once with tsx_host_register() are copied by DMA without a staging pass.
+ * A compressing batch whose WHOLE dst buffer the device can address (inside one tsx_host_register'ed buffer, or one hipHostMalloc'ed
+ * allocation) has no output copy at all: the device writes every chunk's transformed bytes straight into [dst_off, dst_off + dst_len)
+ * during the call (nothing beyond dst_len is written; what the buffer holds is defined when the call returns, as for any other kind).
+ * A dst of which only a part is registered takes the copy path. */
 #define TSX_MEM_HOST   0
 /* device pointers (same HIP runtime / process): no copies.  The kernels run on the ctx's own streams: work the caller still has
  * queued on other streams for these buffers (the kernel that fills src, a memset of dst) must be complete when the call is made,
@@ -122,9 +124,29 @@ typedef struct tsx_timing {
 uint32_t    tsx_abi_version(void);
 const char* tsx_version(void);           /* "tsxform x.y (gfx950; zstd parity target 1.5.7/1.5.6 L3)" */
 const char* tsx_strerror(int code);
-/* device_ids == NULL: use devices 0..device_count-1; device_count <= 0: all visible devices.
+/* device_ids == NULL: use devices 0..device_count-1; device_count <= 0: all visible devices.  An id may be listed more than once
+ * (the same GPU as several logical devices, each with its own pools and compressor service: tests of the multi-device dispatch).
  * Returns the number of devices in use (>0) or TSX_E_DEVICE. */
 int  tsx_init(int device_count, const int* device_ids);
+
+/* What a deployment may want to say about the device-side machinery; TSX_CFG_DEFAULT(64) in a field = the library's default.
+ * The environment of the process, read once inside tsx_init(_ex), overrides both: TSX_FETCH_RESERVED_CUS,
+ * TSX_SERVICE_MAX_LAUNCH_MS, TSX_POOL_IDLE_BYTES.  Nothing on a data path reads the environment. */
+#define TSX_CFG_DEFAULT   0xFFFFFFFFu
+#define TSX_CFG_DEFAULT64 0xFFFFFFFFFFFFFFFFull
+typedef struct tsx_config {
+    uint32_t struct_size;            /* sizeof(tsx_config) as the caller was compiled                                           */
+    uint32_t fetch_reserved_cus;     /* compute units the compressor never occupies, so that a fetch (fetchLogSegment ->
+                                        ChunkCache.java:85-108, get.timeout.ms 10 s) finds room at once while uploads fill the
+                                        chip; spread over the XCDs; default 8 = one per XCD; 0 = no reservation               */
+    uint32_t service_max_launch_ms;  /* one launch of the compressor service kernel stops taking chunks at this age (the next
+                                        launch takes over): bounds how long a device-wide synchronisation made by OTHER code in
+                                        the process (hipFree, hipDeviceSynchronize) can wait under continuous uploads; default
+                                        60000, 0 = no limit                                                                   */
+    uint32_t reserved_;
+    uint64_t pool_idle_bytes;        /* idle pooled workspace kept per device; default 4/9 of its memory                      */
+} tsx_config;
+int  tsx_init_ex(int device_count, const int* device_ids, const tsx_config* cfg);   /* cfg == NULL: tsx_init */
 /* Every tsx_ctx must have been destroyed and no batch may be in flight.  No entry point of this library changes the calling
  * thread's current HIP device: each one that selects a device puts the previous one back before it returns. */
 void tsx_shutdown(void);
@@ -143,6 +165,22 @@ int  tsx_set_thread_device(int device_index);
 /* Pool of the ctx-less calls on one device: idle contexts kept (at most 32, and at most 128 GiB of device workspace between them),
  * contexts out right now, batches served so far. */
 int  tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use, uint64_t* batches);
+
+/* The compressor service of a device (every compressing batch is a member of ONE device-wide queue that persistent waves pull
+ * chunks from; csrc/tsx_internal.h).  Counters since tsx_init; kernel_ms is measured with HIP events on the service's own stream. */
+typedef struct tsx_service_info {
+    uint64_t launches;           /* launches of the service kernel that have been started                                       */
+    uint64_t watchdog_launches;  /* ... of which a waiting caller made because the kernel had ended with work still queued       */
+    uint64_t members, chunks;    /* batches (pieces) published / chunks of completed members                                     */
+    double   kernel_ms;          /* summed duration of the launches that have ENDED                                              */
+    uint32_t running;            /* 1: a launch is out right now                                                                 */
+    uint32_t waves;              /* one-wave workgroups per launch                                                               */
+    uint32_t compute_units, cu_keys_seen, reserved_cus;   /* CUs of the device, distinct CU ids a probe launch met, CUs left alone */
+    uint32_t device_chunks, wave_starts, reserved_exits, skipped_tickets;   /* device-side counters (mod 2^32)                   */
+} tsx_service_info;
+int  tsx_service_stats(int device_index, tsx_service_info* out);
+/* Returns when the device's service kernel has ended (a moment after its last chunk): brackets a measurement. */
+int  tsx_service_quiesce(int device_index);
 
 /* Pin / unpin a host buffer that is reused for TSX_MEM_HOST(_PACKED) batches (hipHostRegister): optional, see TSX_MEM_HOST. */
 int  tsx_host_register(void* p, size_t bytes);

@@ -170,12 +170,21 @@ inline unsigned __byte_perm(unsigned a, unsigned b, unsigned sel) {
 
 // ---- atomics (blocks and fibers never run concurrently) -----------------------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = o - v; return o; }
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// ---- what the compressor service asks the hardware (zstd_enc.hip: svc_now / svc_cu_key) ------------
+// A steady clock in 10 ns units, and the "compute unit" a block runs on: block b of a launch is on CU b mod 4 of the one XCD
+// (hipGetDeviceProperties reports 4 CUs).  hipemu_force_reserved_launches(k): every block of the next k launches reports the
+// LAST CU - the one a reservation of one CU takes - so that a whole launch can be made to leave without doing any work.
+uint64_t hipemu_clock_100mhz();
+uint32_t hipemu_cu_key();
+extern "C" void hipemu_force_reserved_launches(int k);
 
 // ---- host runtime -------------------------------------------------------------------------------
 hipError_t hipGetDeviceCount(int* n);

@@ -133,6 +133,13 @@ static void init_fiber(Fiber& f) {
     f.done = false;
 }
 
+static std::atomic<int> g_force_reserved{0};
+}  // namespace hipemu
+uint64_t hipemu_clock_100mhz() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10; }
+uint32_t hipemu_cu_key() { return hipemu::g_force_reserved.load(std::memory_order_relaxed) > 0 ? 3u : hipemu::g_ctx->bid.x % 4u; }
+extern "C" void hipemu_force_reserved_launches(int k) { hipemu::g_force_reserved = k; }
+namespace hipemu {
+
 // One grid at a time: the scheduler state (and `__shared__` = static storage) is process-wide, while the front end under test is
 // called from several host threads (pooled contexts, device hints).
 static std::mutex g_grid_mu;
@@ -174,6 +181,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& entry) {
                 }
             }
     for (auto& f : blk.fibers) { if (f.stack) g_stack_pool.push_back(f.stack); if (f.tsan) TSAN_FIBER_FREE(f.tsan); }
+    if (g_force_reserved.load(std::memory_order_relaxed) > 0) g_force_reserved--;
     g_blk = saved_blk; g_cur = nullptr; g_ctx = nullptr;
 }
 

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol(product_lib):
     for name in header_functions():
         assert hasattr(lib, name), name
     lib.tsx_abi_version.restype = ctypes.c_uint32
-    assert lib.tsx_abi_version() == 3
+    assert lib.tsx_abi_version() == 4
     lib.tsx_strerror.restype = ctypes.c_char_p
     assert lib.tsx_strerror(-5) == b"Tag mismatch"
     assert b"Invalid decompressed size" in lib.tsx_strerror(-7)

@@ -164,17 +164,14 @@ def test_descriptors_beyond_the_source_buffer_are_rejected(emu):
         emu.transform_batch(p, d, src, dst, dst.size, src_size=32)
 
 
-def test_ctxless_compressing_batches_share_launches(emu, oracle):
-    """Context-less compressing batches do not get streams of their own: callers that arrive while the device's lanes are busy join
-    the group the next free lane launches as ONE kernel (segment table: workgroup -> caller's buffers, key, profile).  12 threads, each
-    with its own key, content and memory kind, 5 batches each: every result equals the single-threaded one, every batch was carried by
-    some launch, and the key material of each member is gone afterwards."""
-    import ctypes as C
+def test_compressing_batches_are_members_of_one_service(emu, oracle):
+    """Every compressing batch of a device - pooled or explicit context, host or device memory, packed or slots - is a member of that
+    device's compressor service: tickets in a ring, persistent waves that pull them (csrc/tsx_internal.h).  12 threads, each with its own
+    key, content and memory kind, 5 batches each: every result equals the single-threaded one, every batch was counted as a member and
+    every chunk as done, waves that found themselves on the reserved compute unit left without work, and a member's key is gone afterwards."""
     import threading
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
-    stats = emu.lib.tsx_debug_combiner_stats
-    stats.restype = C.c_int; stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    g0, m0 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g0), C.byref(m0))
+    s0 = emu.service_stats(0)
     T, reps = 12, 5
     sets = []
     for t in range(T):
@@ -182,8 +179,13 @@ def test_ctxless_compressing_batches_share_launches(emu, oracle):
         key = bytes((b + t) & 0xFF for b in synth.KEY)
         mem = (None, "packed", "device")[t % 3]
         sets.append((chunks, key, mem, pc.run_transform(emu, flags, chunks, key=key, mem=mem)[0]))
-    g1, m1 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g1), C.byref(m1))
-    assert m1.value - m0.value == T and g1.value - g0.value == T        # one caller at a time: one launch per batch
+    s1 = emu.service_stats(0)
+    nchunks = sum(len(x[0]) for x in sets)
+    assert s1["members"] - s0["members"] == T and s1["chunks"] - s0["chunks"] == nchunks == s1["device_chunks"] - s0["device_chunks"]
+    assert s1["launches"] - s0["launches"] == T                        # one caller at a time on the harness: the kernel ends with each batch
+    assert s1["reserved_cus"] == 1 and s1["cu_keys_seen"] == s1["compute_units"] == 4
+    assert s1["reserved_exits"] - s0["reserved_exits"] == T * s1["waves"] // 4       # a quarter of every launch met the reserved CU
+    assert s1["skipped_tickets"] == 0 and s1["watchdog_launches"] == s0["watchdog_launches"]
     errors = []
 
     def worker(t):
@@ -199,10 +201,41 @@ def test_ctxless_compressing_batches_share_launches(emu, oracle):
     th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
     [x.start() for x in th]; [x.join() for x in th]
     assert not errors, errors[:4]
-    g2, m2 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g2), C.byref(m2))
-    assert m2.value - m1.value == T * reps and 1 <= g2.value - g1.value <= T * reps
+    s2 = emu.service_stats(0)
+    assert s2["members"] - s1["members"] == T * reps and s2["chunks"] - s1["chunks"] == nchunks * reps and s2["running"] == 0
     back, d2 = pc.run_detransform(emu, flags, sets[0][3], [int(c.size) for c in sets[0][0]], key=sets[0][1])
     assert (d2["status"] == 0).all() and back == [c.tobytes() for c in sets[0][0]]
+
+
+def test_a_launch_that_met_only_reserved_cus_is_started_again(emu):
+    """HIP promises nothing about where workgroups land: a launch of the service whose every wave found itself on a reserved compute unit
+    (a chip busy elsewhere) ends without having taken a ticket.  The waiting caller's watchdog starts the kernel again; same bytes."""
+    import ctypes
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    chunks = [synth.gen_chunk("K", 3, 0, i, 5000 + 700 * i) for i in range(5)]
+    ref, _ = pc.run_transform(emu, flags, chunks)
+    s0 = emu.service_stats(0)
+    emu.lib.hipemu_force_reserved_launches.argtypes = [ctypes.c_int]; emu.lib.hipemu_force_reserved_launches.restype = None
+    emu.lib.hipemu_force_reserved_launches(2)
+    got, d = pc.run_transform(emu, flags, chunks)
+    s1 = emu.service_stats(0)
+    assert got == ref and (d["status"] == 0).all()
+    assert s1["watchdog_launches"] - s0["watchdog_launches"] == 2 and s1["launches"] - s0["launches"] == 3
+    assert s1["reserved_exits"] - s0["reserved_exits"] == 2 * s1["waves"] + s1["waves"] // 4
+
+
+def test_ticket_counters_wrap(emu):
+    """Tickets are 32-bit counters compared wrap-safely: a device that has compressed 2^32 chunks (ten days at full rate) goes on."""
+    import ctypes
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    chunks = [synth.gen_chunk("K", 8, 0, i, 3000 + 100 * i) for i in range(9)]
+    ref, _ = pc.run_transform(emu, flags, chunks)
+    seed = emu.lib.tsx_debug_service_seed; seed.restype = ctypes.c_int; seed.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    assert seed(0, 0xFFFFFFFF - 3) == 0
+    for _ in range(2):
+        got, d = pc.run_transform(emu, flags, chunks)
+        assert got == ref and (d["status"] == 0).all()
+    assert seed(0, 0) == 0
 
 
 def test_crc_only_batches_publish_their_status(emu):
@@ -214,20 +247,27 @@ def test_crc_only_batches_publish_their_status(emu):
 
 
 @pytest.mark.parametrize("flags", [nat.ENCRYPT | nat.CRC, nat.CRC, 0, nat.COMPRESS | nat.ENCRYPT | nat.CRC, nat.COMPRESS])
-def test_staged_pipeline_equals_single_shot(emu, flags, monkeypatch):
+def test_staged_pipeline_equals_single_shot(emu, flags):
     """TSX_MEM_HOST batches are cut into pieces (copy-in / kernels / copy-out overlapped); forced down to 4 KiB pieces here so that 23
-    chunks make ~20 of them (with compression: 4 co-resident pieces, one compute stream each).  Outputs, descriptors and the inverse
-    must equal the un-pipelined run."""
+    chunks make ~20 of them (with compression: 4 members of the compressor service, each published when its input has landed).  Outputs,
+    descriptors and the inverse must equal the un-pipelined run."""
     chunks = pc.edge_chunks("K", [0, 1, 17, 300, 4096, 5000, 65537, 12, 70001, 33, 2048, 9000, 100, 4097, 1, 31000, 16, 15, 8191, 8192, 8193, 700, 64])
-    monkeypatch.setenv("TSX_NO_PIPELINE", "1")
-    ref, dref = pc.run_transform(emu, flags, chunks)
-    refp, dpk = pc.run_transform(emu, flags, chunks, mem="packed")
-    monkeypatch.delenv("TSX_NO_PIPELINE")
-    monkeypatch.setenv("TSX_SUB_BYTES", "4096")
-    monkeypatch.setenv("TSX_COMP_PIECES", "4")                       # (co-resident pieces are on only with >= 8 hardware queues, or by this switch)
-    monkeypatch.setenv("TSX_NO_COMBINE", "1")                        # ... and belong to the context's own path, not the launch combiner's
-    got, dgot = pc.run_transform(emu, flags, chunks)
-    gotp, dgp = pc.run_transform(emu, flags, chunks, mem="packed")
+    with emu.configured(no_pipeline=1):
+        ref, dref = pc.run_transform(emu, flags, chunks)
+        refp, dpk = pc.run_transform(emu, flags, chunks, mem="packed")
+    ctx = emu.ctx_create(0, 0, 0)
+    try:
+        with emu.configured(sub_bytes=4096, comp_pieces=4):
+            got, dgot = pc.run_transform(emu, flags, chunks)
+            gotp, dgp = pc.run_transform(emu, flags, chunks, mem="packed")
+            gotc, dgc = pc.run_transform(emu, flags, chunks, ctx=ctx)
+            if flags & nat.COMPRESS:
+                import ctypes
+                lm = emu.lib.tsx_debug_last_members; lm.restype = ctypes.c_int; lm.argtypes = [ctypes.c_void_p]
+                assert lm(ctx) == 4
+    finally:
+        emu.ctx_destroy(ctx)
+    assert gotc == ref and (dgc["dst_len"] == dref["dst_len"]).all() and (dgc["status"] == dref["status"]).all()
     assert got == ref and gotp == refp == ref
     for f in ("dst_len", "crc32c", "status"):
         assert (dgot[f] == dref[f]).all() and (dgp[f] == dpk[f]).all(), f
@@ -320,7 +360,7 @@ def test_idle_contexts_do_not_all_keep_a_block_form_workspace(emu):
     assert out.strip().endswith("ok")
 
 
-def test_mid_size_fetch_batches_decode_in_co_resident_pieces(emu, oracle, monkeypatch):
+def test_mid_size_fetch_batches_decode_in_co_resident_pieces(emu, oracle):
     """a host-memory inverse batch of 16 .. 256 chunks is cut into up to 8 pieces on the context's compute streams (copy-in
     of piece k + 1, block-form decode of piece k, copy-out of piece k - 1 overlap).  40 chunks of mixed sizes incl. an empty one and a
     forged one: same bytes and statuses as the uncut batch, every good chunk decoded by the block form, CRCs of the restored bytes right."""
@@ -336,9 +376,9 @@ def test_mid_size_fetch_batches_decode_in_co_resident_pieces(emu, oracle, monkey
         import ctypes
         pieces = emu.lib.tsx_debug_blockmode_pieces; pieces.restype = ctypes.c_int; pieces.argtypes = [ctypes.c_void_p]
         assert pieces(ctx) == 5, pieces(ctx)                            # 40 chunks: pieces of 8
-        monkeypatch.setenv("TSX_NO_DEC_PIECES", "1")
-        outs1, d1 = pc.run_detransform(emu, flags, blobs, sizes, ctx=ctx)
-        assert pc.blockmode_chunks(emu, ctx, len(blobs)) == taken and pieces(ctx) == 1
+        with emu.configured(no_dec_pieces=1):
+            outs1, d1 = pc.run_detransform(emu, flags, blobs, sizes, ctx=ctx)
+            assert pc.blockmode_chunks(emu, ctx, len(blobs)) == taken and pieces(ctx) == 1
     finally:
         emu.ctx_destroy(ctx)
     assert list(d["status"]) == list(d1["status"]) and d["status"][11] == nat.E_TAG_MISMATCH and (np.delete(d["status"], 11) == 0).all()
@@ -352,11 +392,13 @@ def test_mid_size_fetch_batches_decode_in_co_resident_pieces(emu, oracle, monkey
 
 @pytest.mark.parametrize("kind", ["slots", "packed"])
 @pytest.mark.parametrize("ctxless", [True, False])
-def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, monkeypatch):
-    """The compressor waves write into the caller's buffer when the device can address it (always, on the emulator); TSX_NO_ZERO_COPY_OUT=1
-    keeps the device output buffer + copies.  Same bytes, sizes, CRCs and packed offsets either way, with and without a context; what lies
-    between a chunk's last byte and the next slot is untouched; a packed buffer too small for the slots takes the copy path by itself."""
-    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+@pytest.mark.parametrize("flags", [nat.COMPRESS | nat.ENCRYPT | nat.CRC, nat.COMPRESS | nat.CRC])
+def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, flags):
+    """The compressor waves write into the caller's buffer when the device can address ALL of it (a buffer pinned with tsx_host_register);
+    the test hook no_zero_copy_out keeps the device output buffer + copies.  Same bytes, sizes, CRCs and packed offsets either way, with and
+    without a context, with and without encryption; what lies between a chunk's last byte and the next slot is untouched; a packed buffer
+    too small for the slots, an unregistered buffer and one of which only the first half is registered take the copy path by themselves."""
+    import ctypes
     sizes = [9000, 0, 131072, 5, 40001, 70000, 1, 20000, 3000]
     chunks = [synth.gen_chunk("K" if i % 3 else "R", 17, 0, i, s) for i, s in enumerate(sizes)]
     n = len(chunks)
@@ -367,21 +409,32 @@ def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, monke
     slot = (emu.transformed_bound(max(sizes), flags) + 63) // 64 * 64
     p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
     mem = nat.MEM_HOST if kind == "slots" else nat.MEM_HOST_PACKED
-    ctx = None if ctxless else emu.ctx_create(0, 0, 0)
+    ctx = emu.ctx_create(0, 0, 0)                                       # (the pooled path is reached with ctx=None; this one is asked about afterwards)
+    zc = emu.lib.tsx_debug_last_zero_copy; zc.restype = ctypes.c_int; zc.argtypes = [ctypes.c_void_p]
     try:
         res = {}
-        for mode in ("zero_copy", "copies", "small_packed_buffer"):
+        for mode in ("zero_copy", "copies", "unregistered", "half_registered", "small_packed_buffer"):
             if mode == "small_packed_buffer" and kind != "packed":
                 continue
-            monkeypatch.setenv("TSX_ZERO_COPY_PACKED", "1")           # (an explicit context packs in place only on request: a whole batch is ~90 ms of memmove)
-            if mode == "copies":
-                monkeypatch.setenv("TSX_NO_ZERO_COPY_OUT", "1")
-            else:
-                monkeypatch.delenv("TSX_NO_ZERO_COPY_OUT", raising=False)
             size = dt + 64 if kind == "slots" else (n * slot + 64 if mode != "small_packed_buffer" else sum(int(x) for x in caps) // 2)
             dst = np.full(size, 0xEE, np.uint8)
-            d = pc.make_descs(sizes, soff, doff, caps)
-            emu.transform_batch(p, d, src, dst, dst.size, mem, ctx=ctx)
+            reg = None
+            if mode in ("zero_copy", "copies", "small_packed_buffer"):
+                reg = dst
+            elif mode == "half_registered":
+                reg = dst[:size // 2]
+            if reg is not None:
+                emu.host_register(reg)
+            try:
+                d = pc.make_descs(sizes, soff, doff, caps)
+                # (an explicit context packs in place only on request: a whole batch is ~90 ms of memmove)
+                with emu.configured(zero_copy_packed=1, no_zero_copy_out=1 if mode == "copies" else 0):
+                    emu.transform_batch(p, d, src, dst, dst.size, mem, ctx=None if ctxless else ctx)
+                    if not ctxless:
+                        assert zc(ctx) == (1 if mode == "zero_copy" else 0), mode
+            finally:
+                if reg is not None:
+                    emu.host_unregister(reg)
             assert (d["status"] == 0).all(), (mode, d["status"])
             res[mode] = ([dst[int(d["dst_off"][i]):int(d["dst_off"][i]) + int(d["dst_len"][i])].tobytes() for i in range(n)], d.copy())
             if kind == "slots":
@@ -392,22 +445,21 @@ def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, monke
         for i in (0, 2, 4):
             assert ref[i] == pc.oracle_transform(oracle, flags, chunks[i], i)
     finally:
-        if ctx is not None:
-            emu.ctx_destroy(ctx)
+        emu.ctx_destroy(ctx)
 
 
-def test_reserved_cus_for_fetches_change_nothing_but_the_streams(emu):
-    """TSX_FETCH_RESERVED_CUS=n (opt-in; a fetch under full upload load: 3 ms instead of a minute, profiles/r04_mixed_load.txt) gives the
-    compressor's streams - combiner lanes, a context's stream for compressing batches and its pieces - a CU mask; bytes and statuses are
-    the same with and without, context-less and with a context, slot and packed layout, and the fetch side is untouched."""
-    out = _run_py("""
-        import os, numpy as np
+def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
+    """tsx_config.fetch_reserved_cus (default 8: one compute unit per XCD that the compressor never occupies - a fetch under full upload load
+    finds room at once) decides which waves of the service leave at once; bytes and statuses are the same with a reservation,
+    without one, and with the environment's override, context-less and with a context, slot and packed layout; the fetch side is untouched."""
+    code = """
+        import os, hashlib, numpy as np
         import tsxform
         from tests import parity_cases as pc
         from tests.emu import emu_native
         from tsxform import synth
         nat = tsxform._native
-        N = nat.Native(emu_native.build()); N.init()
+        N = nat.Native(emu_native.build()); N.init(%s)
         flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
         chunks = [synth.gen_chunk("K", 5, 0, i, 4000 + 1500 * i) for i in range(10)]
         ctx = N.ctx_create(0, 0, 0)
@@ -416,53 +468,11 @@ def test_reserved_cus_for_fetches_change_nothing_but_the_streams(emu):
         c, dc = pc.run_transform(N, flags, chunks, mem="packed")
         back, d2 = pc.run_detransform(N, flags, a, [int(x.size) for x in chunks], ctx=ctx)
         assert a == b == c and (da["status"] == 0).all() and back == [x.tobytes() for x in chunks]
-        import hashlib
-        print(hashlib.sha256(b"".join(a)).hexdigest())
-        """, TSX_FETCH_RESERVED_CUS=8, TSX_COMP_PIECES=3, TSX_SUB_BYTES=8192)
-    ref = _run_py("""
-        import hashlib, tsxform
-        from tests import parity_cases as pc
-        from tests.emu import emu_native
-        from tsxform import synth
-        nat = tsxform._native
-        N = nat.Native(emu_native.build()); N.init()
-        chunks = [synth.gen_chunk("K", 5, 0, i, 4000 + 1500 * i) for i in range(10)]
-        a, _ = pc.run_transform(N, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
-        print(hashlib.sha256(b"".join(a)).hexdigest())
-        """)
-    assert out.strip().splitlines()[-1] == ref.strip().splitlines()[-1]
-
-
-def test_admission_cap_of_the_launch_combiner(emu):
-    """TSX_COMBINER_MAX_CHUNKS=n (opt-in): never more than n compressor chunks launched and not yet done per device - members complete one
-    by one and the next launch waits for room - except a batch that is larger than the cap by itself, which goes alone.  Same bytes."""
-    out = _run_py("""
-        import ctypes, threading, numpy as np
-        import tsxform
-        from tests import parity_cases as pc
-        from tests.emu import emu_native
-        from tsxform import synth
-        nat = tsxform._native
-        N = nat.Native(emu_native.build()); N.init()
-        flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
-        small = [synth.gen_chunk("K", 3, 0, i, 3000 + 100 * i) for i in range(4)]
-        big = [synth.gen_chunk("K", 4, 0, i, 2000) for i in range(9)]
-        ref_s, _ = pc.run_transform(N, flags, small)
-        ref_b, _ = pc.run_transform(N, flags, big)
-        errors = []
-        def worker(t):
-            for rep in range(3):
-                chunks, ref = (big, ref_b) if (t == 0 and rep == 1) else (small, ref_s)
-                got, d = pc.run_transform(N, flags, chunks)
-                if got != ref or (d["status"] != 0).any():
-                    errors.append((t, rep))
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
-        [x.start() for x in th]; [x.join() for x in th]
-        assert not errors, errors
-        peak = N.lib.tsx_debug_combiner_inflight_peak
-        peak.restype = ctypes.c_int
-        p = peak(0)
-        assert 4 <= p <= 9, p          # 8 = two small batches; 9 = the big one, alone
-        print("ok", p)
-    """, TSX_COMBINER_MAX_CHUNKS=8, TSX_LANES=3)
-    assert out.strip().splitlines()[-1].startswith("ok")
+        s = N.service_stats(0)
+        print(hashlib.sha256(b"".join(a)).hexdigest(), s["reserved_cus"], s["reserved_exits"] > 0)
+        """
+    with_default = _run_py(code % "").strip().splitlines()[-1].split()
+    without = _run_py(code % "fetch_reserved_cus=0").strip().splitlines()[-1].split()
+    by_env = _run_py(code % "fetch_reserved_cus=0", TSX_FETCH_RESERVED_CUS=1).strip().splitlines()[-1].split()
+    assert with_default[0] == without[0] == by_env[0]
+    assert with_default[1:] == ["1", "True"] and without[1:] == ["0", "False"] and by_env[1:] == ["1", "True"]      # (the harness has 4 CUs: at most one is reserved)

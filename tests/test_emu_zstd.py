@@ -49,13 +49,15 @@ def test_compressor_is_byte_identical_to_libzstd(emu, oracle):
 
 
 @pytest.mark.parametrize("sched", ["1,1", "2,16", "7,59", "59,59"])
-def test_speculation_schedule_never_changes_the_bytes(emu, oracle, sched, monkeypatch):
-    """How many positions a step of the parser evaluates speculatively (default 4 after a match, then 32, then 59; TSX_ZSTD_SCHED=k0,k1
-    overrides it for measurements) decides what a search run costs, never what it finds: identical frames, identical to libzstd."""
+def test_speculation_schedule_never_changes_the_bytes(emu, oracle, sched):
+    """How many positions a step of the parser evaluates speculatively (default 4 after a match, then 32, then 59; TSX_ZSTD_SCHED=k0,k1 at
+    tsx_init - here the configuration hook - overrides it for measurements) decides what a search run costs, never what it finds:
+    identical frames, identical to libzstd."""
     _need157(oracle)
-    monkeypatch.setenv("TSX_ZSTD_SCHED", sched)
+    k0, k1 = (int(x) for x in sched.split(","))
     names = ["K70000", "K200000", "mixKR", "farmatch", "jumps", "period7", "lowent"]
-    outs, d = pc.run_transform(emu, nat.COMPRESS, [CASES[n] for n in names])
+    with emu.configured(zstd_sched=k0 | k1 << 8):
+        outs, d = pc.run_transform(emu, nat.COMPRESS, [CASES[n] for n in names])
     for i, n in enumerate(names):
         assert outs[i] == oracle.zstd_compress_chunk(CASES[n].tobytes()), (n, sched)
 
@@ -103,14 +105,15 @@ def test_profile_1_5_6_is_pinned_to_the_real_library_wherever_the_splitter_is_id
 
 
 @pytest.mark.parametrize("gcm", ["in_compressor_wave", "separate_kernels"])
-def test_full_chain_vs_oracle(emu, oracle, gcm, monkeypatch):
+def test_full_chain_vs_oracle(emu, oracle, gcm):
     """With compression, each compressor wave also checksums its source chunk (crc32c_wave) and encrypts its own frame
-    (gcm_encrypt_wave); TSX_STAGES_SEPARATE=1 keeps one launch per stage.  Both must give the oracle's bytes and CRCs."""
+    (gcm_encrypt_wave); the test hook stages_separate keeps one launch per stage.  Both must give the oracle's bytes and CRCs."""
     _need157(oracle)
-    if gcm == "separate_kernels":
-        monkeypatch.setenv("TSX_STAGES_SEPARATE", "1")
-    else:
-        monkeypatch.delenv("TSX_STAGES_SEPARATE", raising=False)
+    with emu.configured(stages_separate=1 if gcm == "separate_kernels" else 0):
+        _full_chain_vs_oracle(emu, oracle)
+
+
+def _full_chain_vs_oracle(emu, oracle):
     chunks = [CASES[n] for n in ("K70000", "R50000", "K1000", "empty", "one")]
     pc.check_transform_vs_oracle(emu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
     pc.check_roundtrip(emu, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
@@ -169,9 +172,9 @@ def test_both_decoder_forms_agree(emu, oracle, monkeypatch):
         outs, d = pc.run_detransform(emu, nat.COMPRESS, blobs, sizes, ctx=ctx)
         taken = pc.blockmode_chunks(emu, ctx, len(blobs))
         assert pc.blockmode_chunks(emu, ctx, good) == good, "an undamaged frame fell back to the chunk-serial decoder"
-        monkeypatch.setenv("TSX_DEC_BLOCK_CHUNKS", "0")
-        outs0, d0 = pc.run_detransform(emu, nat.COMPRESS, blobs, sizes, ctx=ctx)
-        assert pc.blockmode_chunks(emu, ctx, len(blobs)) == -1
+        with emu.configured(dec_block_chunks=0):
+            outs0, d0 = pc.run_detransform(emu, nat.COMPRESS, blobs, sizes, ctx=ctx)
+            assert pc.blockmode_chunks(emu, ctx, len(blobs)) == -1
     finally:
         emu.ctx_destroy(ctx)
     assert list(d["status"]) == list(d0["status"]) and (d["status"][:good] == 0).all()

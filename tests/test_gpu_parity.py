@@ -164,15 +164,16 @@ def test_zstd_profile_1_5_6_whole_case_set_and_fuzz(gpu, oracle):
 
 
 @pytest.mark.parametrize("gcm", ["in_compressor_wave", "separate_kernels"])
-def test_zstd_full_size_chunks_and_full_chain(gpu, oracle, gcm, monkeypatch):
-    """With compression each compressor wave also checksums its chunk and encrypts its frame, unless TSX_STAGES_SEPARATE=1
-    (one launch per stage)."""
+def test_zstd_full_size_chunks_and_full_chain(gpu, oracle, gcm):
+    """With compression each compressor wave also checksums its chunk and encrypts its frame, unless the test hook stages_separate
+    asks for one launch per stage."""
     if not oracle.zstd_version().startswith("1.5.7"):
         pytest.skip("libzstd 1.5.7 not available")
-    if gcm == "separate_kernels":
-        monkeypatch.setenv("TSX_STAGES_SEPARATE", "1")
-    else:
-        monkeypatch.delenv("TSX_STAGES_SEPARATE", raising=False)
+    with gpu.configured(stages_separate=1 if gcm == "separate_kernels" else 0):
+        _zstd_full_size_chunks_and_full_chain(gpu, oracle)
+
+
+def _zstd_full_size_chunks_and_full_chain(gpu, oracle):
     small = [synth.gen_chunk("K", 7, 1, i, s) for i, s in enumerate([0, 1, 15, 16, 17, 1000, 65536, 70001, 300007])]
     pc.check_transform_vs_oracle(gpu, oracle, nat.COMPRESS | nat.ENCRYPT | nat.CRC, small)
     outs, d = pc.run_transform(gpu, nat.COMPRESS | nat.ENCRYPT, [synth.gen_chunk("R", 7, 1, 0, 50000), small[5]], dst_caps=[50000, None])
@@ -328,13 +329,17 @@ def test_forged_chunk_is_scrubbed_from_a_device_slot(gpu):
 
 
 @pytest.mark.parametrize("flags", [nat.ENCRYPT | nat.CRC, nat.COMPRESS | nat.ENCRYPT | nat.CRC])
-def test_staged_host_pipeline_on_the_device(gpu, oracle, flags, monkeypatch):
-    """Host-memory batches in pieces (three streams) = one shot = the oracle; pageable and registered buffers; packed output."""
+def test_staged_host_pipeline_on_the_device(gpu, oracle, flags):
+    """Host-memory batches in pieces (three streams; members of the compressor service) = one shot = the oracle; pageable and registered
+    buffers; packed output."""
     chunks = [synth.gen_chunk("K", 11, 0, i, s) for i, s in enumerate([CHUNK, 1 << 20, 70001, 0, 17, CHUNK - 5, 300000, 1 << 16, 4096, 2 << 20, 12345, 1 << 20])]
-    monkeypatch.setenv("TSX_NO_PIPELINE", "1")
-    ref, dref = pc.run_transform(gpu, flags, chunks)
-    monkeypatch.delenv("TSX_NO_PIPELINE")
-    monkeypatch.setenv("TSX_SUB_BYTES", str(3 << 20))
+    with gpu.configured(no_pipeline=1):
+        ref, dref = pc.run_transform(gpu, flags, chunks)
+    with gpu.configured(sub_bytes=3 << 20):
+        _staged_host_pipeline(gpu, oracle, flags, chunks, ref, dref)
+
+
+def _staged_host_pipeline(gpu, oracle, flags, chunks, ref, dref):
     got, dgot = pc.check_transform_vs_oracle(gpu, oracle, flags, chunks)
     gotp, dpk = pc.run_transform(gpu, flags, chunks, mem="packed")
     assert got == ref == gotp and (dgot["crc32c"] == dref["crc32c"]).all() and (dpk["dst_len"] == dref["dst_len"]).all()
@@ -356,7 +361,7 @@ def test_staged_host_pipeline_on_the_device(gpu, oracle, flags, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", ["K6", "K10", "mixed6", "mixed10", "sparse64", "K64"])
-def test_chunks_beyond_4_MiB(gpu, oracle, kind, monkeypatch):
+def test_chunks_beyond_4_MiB(gpu, oracle, kind):
     """chunk.size above 4 MiB - up to a whole segment as ONE chunk (RemoteStorageManagerConfig.java:122-130, chunk.size = 0 in
     BaseTransformChunkEnumeration.java:85-89; the reference's integration matrix has a 10 MiB segment as one chunk): the full chain
     equals libzstd 1.5.7 + OpenSSL for both Zstd profiles (wherever 1.5.7's pre-splitter is idle), decodes back, and the host-memory
@@ -370,8 +375,8 @@ def test_chunks_beyond_4_MiB(gpu, oracle, kind, monkeypatch):
     back, d2 = pc.run_detransform(gpu, flags, outs, [int(x.size), int(small.size)])
     assert (d2["status"] == 0).all() and back[0] == x.tobytes() and back[1] == small.tobytes() and d2["crc32c"][0] == d["crc32c"][0]
     pinned, differ = pc.check_profile_1_5_6(gpu, oracle, {kind: x})
-    monkeypatch.setenv("TSX_SUB_BYTES", str(3 << 20))                  # pieces smaller than the chunk: one chunk never straddles two
-    outs2, _ = pc.run_transform(gpu, flags, [x, small], mem="packed")
+    with gpu.configured(sub_bytes=3 << 20):                           # pieces smaller than the chunk: one chunk never straddles two
+        outs2, _ = pc.run_transform(gpu, flags, [x, small], mem="packed")
     assert outs2 == outs
     dev, _ = pc.run_transform(gpu, flags, [x, small], mem="device")
     assert dev == outs
@@ -431,7 +436,7 @@ def test_concurrent_ctxless_host_batches(gpu, oracle):
     """The JVM case in small: 8 threads, no context of their own (ctx == NULL -> pooled contexts), host buffers, full chain and
     encrypt-only batches interleaved, the staged pipeline cut into small pieces - every result equals the single-threaded one."""
     import threading
-    os.environ["TSX_SUB_BYTES"] = str(2 << 20)
+    old_sub = gpu.debug_config("sub_bytes", 2 << 20)
     try:
         sets = {}
         for flags in (nat.ENCRYPT | nat.CRC, nat.COMPRESS | nat.ENCRYPT | nat.CRC):
@@ -460,4 +465,4 @@ def test_concurrent_ctxless_host_batches(gpu, oracle):
         s = gpu.pool_stats(0)
         assert s["in_use"] == 0 and 1 <= s["idle"] <= 32
     finally:
-        os.environ.pop("TSX_SUB_BYTES", None)
+        gpu.debug_config("sub_bytes", old_sub)

@@ -68,10 +68,9 @@ def test_both_decoder_forms_agree_on_the_device(gpu, oracle, monkeypatch):
         from tests import zstd_inspect as zi
         fits = sum(1 for b in blobs[:good] if len(zi.parse_frame(b, decode=False)[1]) <= 264)
         assert fits >= good - 2 and pc.blockmode_chunks(gpu, ctx, good) == fits
-        monkeypatch.setenv("TSX_DEC_BLOCK_CHUNKS", "0")
-        outs0, d0 = pc.run_detransform(gpu, nat.COMPRESS, blobs, sizes, ctx=ctx)
-        assert pc.blockmode_chunks(gpu, ctx, len(blobs)) == -1
-        monkeypatch.delenv("TSX_DEC_BLOCK_CHUNKS")
+        with gpu.configured(dec_block_chunks=0):
+            outs0, d0 = pc.run_detransform(gpu, nat.COMPRESS, blobs, sizes, ctx=ctx)
+            assert pc.blockmode_chunks(gpu, ctx, len(blobs)) == -1
         # above the threshold the batch takes the chunk form by itself
         many = [blobs[3]] * 300
         outs2, d2 = pc.run_detransform(gpu, nat.COMPRESS, many, [sizes[3]] * 300, ctx=ctx)
@@ -205,12 +204,8 @@ def test_zero_copy_output_into_registered_buffers_on_the_device(gpu, oracle):
         for kind, name in ((nat.MEM_HOST, "slots"), (nat.MEM_HOST_PACKED, "packed")):
             one(kind, None, "ctxless " + name)
             one(kind, ctx, "ctx " + name)
-        import os
-        os.environ["TSX_ZERO_COPY_PACKED"] = "1"                       # an explicit context packs in place only on request (a whole batch is ~90 ms of memmove)
-        try:
+        with gpu.configured(zero_copy_packed=1):                      # an explicit context packs in place only on request (a whole batch is ~90 ms of memmove)
             one(nat.MEM_HOST_PACKED, ctx, "ctx packed in place")
-        finally:
-            os.environ.pop("TSX_ZERO_COPY_PACKED", None)
         th = [threading.Thread(target=one, args=(nat.MEM_HOST if t % 2 else nat.MEM_HOST_PACKED, None, "thread %d" % t)) for t in range(8)]
         [x.start() for x in th]; [x.join() for x in th]
         # one slot too small: that chunk fails, nothing of it is written, its neighbours are whole

@@ -17,7 +17,7 @@ MEM_HOST, MEM_DEVICE, MEM_HOST_PACKED = 0, 1, 2
 OK, E_INVAL, E_DEVICE, E_NOMEM, E_DST_TOO_SMALL, E_TAG_MISMATCH, E_BAD_FRAME, E_BAD_SIZE, E_SHORT_CHUNK, E_UNSUPPORTED = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 ZSTD_PROFILE_1_5_6, ZSTD_PROFILE_1_5_7 = 0, 1
-ABI_VERSION = 3          # TSX_ABI_VERSION of include/tsxform.h these prototypes were written against
+ABI_VERSION = 4          # TSX_ABI_VERSION of include/tsxform.h these prototypes were written against
 
 
 class ChunkDesc(C.Structure):
@@ -37,6 +37,20 @@ class Timing(C.Structure):
                 ("unzstd_launches", C.c_uint32)]
 
 
+class Config(C.Structure):
+    """tsx_config of include/tsxform.h; fields left at CFG_DEFAULT take the library's default."""
+    _fields_ = [("struct_size", C.c_uint32), ("fetch_reserved_cus", C.c_uint32), ("service_max_launch_ms", C.c_uint32), ("reserved_", C.c_uint32),
+                ("pool_idle_bytes", C.c_uint64)]
+
+
+class ServiceInfo(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("watchdog_launches", C.c_uint64), ("members", C.c_uint64), ("chunks", C.c_uint64),
+                ("kernel_ms", C.c_double), ("running", C.c_uint32), ("waves", C.c_uint32), ("compute_units", C.c_uint32),
+                ("cu_keys_seen", C.c_uint32), ("reserved_cus", C.c_uint32), ("device_chunks", C.c_uint32), ("wave_starts", C.c_uint32),
+                ("reserved_exits", C.c_uint32), ("skipped_tickets", C.c_uint32)]
+
+
+CFG_DEFAULT, CFG_DEFAULT64 = 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF
 DESC_DTYPE = np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("src_len", "<u4"), ("dst_cap", "<u4"), ("dst_len", "<u4"),
                        ("crc32c", "<u4"), ("status", "<i4"), ("iv", "u1", (12,))])
 assert DESC_DTYPE.itemsize == C.sizeof(ChunkDesc) == 48
@@ -44,7 +58,8 @@ assert DESC_DTYPE.itemsize == C.sizeof(ChunkDesc) == 48
 EXPORTS = ["tsx_abi_version", "tsx_version", "tsx_strerror", "tsx_init", "tsx_shutdown", "tsx_device_count",
            "tsx_ctx_create", "tsx_ctx_destroy", "tsx_ctx_timing", "tsx_transformed_bound", "tsx_transform_batch",
            "tsx_detransform_batch", "tsx_crc32c_batch", "tsx_device_malloc", "tsx_device_free", "tsx_memcpy_h2d",
-           "tsx_memcpy_d2h", "tsx_ctx_device", "tsx_set_thread_device", "tsx_pool_stats", "tsx_host_register", "tsx_host_unregister"]
+           "tsx_memcpy_d2h", "tsx_ctx_device", "tsx_set_thread_device", "tsx_pool_stats", "tsx_host_register", "tsx_host_unregister",
+           "tsx_init_ex", "tsx_service_stats", "tsx_service_quiesce"]
 
 
 class TsxError(RuntimeError):
@@ -71,6 +86,10 @@ class Native:
         L.tsx_version.restype = C.c_char_p
         L.tsx_strerror.restype = C.c_char_p; L.tsx_strerror.argtypes = [C.c_int]
         L.tsx_init.restype = C.c_int; L.tsx_init.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.tsx_init_ex.restype = C.c_int; L.tsx_init_ex.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(Config)]
+        L.tsx_service_stats.restype = C.c_int; L.tsx_service_stats.argtypes = [C.c_int, C.POINTER(ServiceInfo)]
+        L.tsx_service_quiesce.restype = C.c_int; L.tsx_service_quiesce.argtypes = [C.c_int]
+        L.tsx_debug_config.restype = C.c_longlong; L.tsx_debug_config.argtypes = [C.c_char_p, C.c_longlong]      # test hook, not in the header
         L.tsx_shutdown.restype = None
         L.tsx_device_count.restype = C.c_int
         L.tsx_ctx_create.restype = C.c_int; L.tsx_ctx_create.argtypes = [C.c_int, u32, u32, C.POINTER(vp)]
@@ -101,11 +120,48 @@ class Native:
             raise TsxError(rc, self.lib.tsx_strerror(rc).decode())
         return rc
 
-    def init(self, device_count=0, device_ids=None):
+    def init(self, device_count=0, device_ids=None, fetch_reserved_cus=None, service_max_launch_ms=None, pool_idle_bytes=None):
         ids = (C.c_int * len(device_ids))(*device_ids) if device_ids else None
-        n = self.check(self.lib.tsx_init(device_count, ids))
+        if fetch_reserved_cus is None and service_max_launch_ms is None and pool_idle_bytes is None:
+            n = self.check(self.lib.tsx_init(device_count, ids))
+        else:
+            cfg = Config(C.sizeof(Config), CFG_DEFAULT if fetch_reserved_cus is None else fetch_reserved_cus,
+                         CFG_DEFAULT if service_max_launch_ms is None else service_max_launch_ms, 0,
+                         CFG_DEFAULT64 if pool_idle_bytes is None else pool_idle_bytes)
+            n = self.check(self.lib.tsx_init_ex(device_count, ids, C.byref(cfg)))
         self._inited = True
         return n
+
+    def service_stats(self, device_index=0):
+        """Counters of the device's compressor service (tsx_service_info) as a dict."""
+        s = ServiceInfo()
+        self.check(self.lib.tsx_service_stats(device_index, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in ServiceInfo._fields_}
+
+    def service_quiesce(self, device_index=0):
+        self.check(self.lib.tsx_service_quiesce(device_index))
+
+    def debug_config(self, key, value):
+        """Test / measurement hook: set one configuration field of the loaded library, return the previous value."""
+        old = self.lib.tsx_debug_config(key.encode(), int(value))
+        if old == E_INVAL and key not in ("pool_idle_bytes",):
+            raise KeyError(key)
+        return old
+
+    def configured(self, **kv):
+        """Context manager: configuration fields set for the duration of a with-block (tests)."""
+        nat = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = {k: nat.debug_config(k, v) for k, v in kv.items()}
+                return nat
+
+            def __exit__(self_, *a):
+                for k, v in self_.old.items():
+                    nat.debug_config(k, v)
+                return False
+        return _Scope()
 
     def version(self):
         return self.lib.tsx_version().decode()

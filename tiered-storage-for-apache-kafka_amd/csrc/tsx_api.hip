@@ -1,8 +1,9 @@
-// C-ABI front end of libtsxform: device/context management and the batch pipelines.
+// C-ABI front end of libtsxform: device/context management, the compressor service's host side and the batch pipelines.
 // See include/tsxform.h for the contract and the reference call sites each entry point replaces.
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -17,10 +18,57 @@
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { tsx_set_err(#x, e_); return TSX_E_DEVICE; } } while (0)
 
+// ---- configuration -----------------------------------------------------------------------------------------------------------------
+// Read ONCE, in tsx_init: tsx_init_ex's tsx_config first, then the environment of the process for the few settings a deployment may
+// want to change without touching code (INTEGRATION.md 5 lists them).  No entry point on a data path reads the environment.  The
+// fields under "test hooks" have no environment variable: tests and measurement tools set them through tsx_debug_config().
+struct tsx_cfg {
+    uint32_t reserved_cus = 8;            // compute units the compressor service leaves to everything else (one per XCD); TSX_FETCH_RESERVED_CUS
+    uint32_t svc_max_launch_ms = 60000;   // age limit of one launch of the service kernel (0 = none); TSX_SERVICE_MAX_LAUNCH_MS
+    uint32_t svc_idle_exit_us = 300;      // the service kernel ends when it has had nothing to do for this long
+    long long pool_idle_bytes = -1;       // idle pooled workspace kept per device (-1: 4/9 of its memory); TSX_POOL_IDLE_BYTES
+    uint32_t zstd_sched = 0;              // parser speculation schedule k0 | k1 << 8 (0 = the kernel's default; same bytes); TSX_ZSTD_SCHED
+    bool debug = false;                   // TSX_DEBUG: HIP failures go to stderr as they happen
+    bool allow_any_arch = false;          // TSX_ALLOW_ANY_ARCH: the CPU test harness
+    // ---- test hooks (tsx_debug_config) ----
+    uint32_t dec_block_chunks = 256;      // largest detransform batch that takes the block-parallel decoder form (0 = never)
+    uint32_t comp_pieces = 4;             // members a compressing host-memory batch is cut into (input copy of piece k + 1 overlaps piece k's waves)
+    long long sub_bytes = 0;              // input bytes per piece of the staging pipeline (0 = TSX_SUB_BYTES)
+    bool stages_separate = false;         // one launch per stage instead of the whole chain in the compressor wave
+    bool no_pipeline = false;             // host-memory batches in one piece
+    bool no_zero_copy_out = false;        // never let the waves write into the caller's buffer
+    bool zero_copy_packed = false;        // explicit contexts: packed output in place too
+    bool gcm_setup_kernel = false;        // key schedule by gcm_setup_kernel instead of on the host
+    bool no_dec_pieces = false;           // block-form fetches in one piece
+};
+static tsx_cfg g_cfg;
+
 static thread_local char g_last_err[256];
 static void tsx_set_err(const char* what, hipError_t e) {
     snprintf(g_last_err, sizeof g_last_err, "%s failed: %s", what, hipGetErrorString(e));
-    if (getenv("TSX_DEBUG")) fprintf(stderr, "[tsxform] %s\n", g_last_err);
+    if (g_cfg.debug) fprintf(stderr, "[tsxform] %s\n", g_last_err);
+}
+
+static void cfg_from_env(tsx_cfg& c) {
+    if (const char* e = getenv("TSX_FETCH_RESERVED_CUS")) { const long v = atol(e); c.reserved_cus = (uint32_t)(v < 0 ? 0 : v > 128 ? 128 : v); }
+    if (const char* e = getenv("TSX_SERVICE_MAX_LAUNCH_MS")) { const long v = atol(e); if (v >= 0) c.svc_max_launch_ms = (uint32_t)v; }
+    if (const char* e = getenv("TSX_POOL_IDLE_BYTES")) { const long long v = atoll(e); if (v >= 0) c.pool_idle_bytes = v; }
+    if (const char* e = getenv("TSX_ZSTD_SCHED")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) c.zstd_sched = a | b << 8; }
+    c.debug = getenv("TSX_DEBUG") != nullptr;
+    c.allow_any_arch = getenv("TSX_ALLOW_ANY_ARCH") != nullptr;
+}
+
+// Test / measurement hook (not part of the ABI in include/tsxform.h): set one configuration field, return its previous value
+// (TSX_E_INVAL: no such field).  Takes effect for calls made afterwards; reserved_cus only for a tsx_init made afterwards.
+extern "C" long long tsx_debug_config(const char* key, long long value) {
+    if (!key) return TSX_E_INVAL;
+#define CFG_FIELD(name, T) if (!strcmp(key, #name)) { const long long old = (long long)g_cfg.name; g_cfg.name = (T)value; return old; }
+    CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
+    CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
+    CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool)
+#undef CFG_FIELD
+    return TSX_E_INVAL;
 }
 
 // Every entry point that selects a device puts the calling thread's current device back on the way out: the caller may share
@@ -35,41 +83,34 @@ struct tsx_device_scope {
 
 struct tsx_ctx;
 struct tsx_run;
+struct tsx_device;
 
-// ---- launch combiner (ctx-less compressing batches) ----------------------------------------------------------------------------
-// The HIP runtime multiplexes a process's streams onto a handful of hardware queues (4 unless GPU_MAX_HW_QUEUES says otherwise),
-// and two streams that share one run their kernels one after the other.  A broker drives the forward chain from >= 10 threads, one
-// 256-chunk segment each (reference README.md:218-222): with a stream per caller, measured on MI355X, 10-24 callers moved 5.5-5.9
-// GiB/s where three 2048-chunk batches move 19 - four kernels at a time, 1024 chunks on a chip that holds 6144 - and the copy
-// streams' event markers sat behind other callers' second-long kernels.  So ctx-less compressing batches do not get streams of
-// their own: per device there are TSX_LANES compute streams and two copy streams, and whoever arrives while all lanes are busy joins
-// the group that the next free lane launches as ONE kernel (zstd_compress_kernel's segment table: workgroup -> caller's buffers).
-// Group commit: the first waiting caller leads - it queues every member's descriptor upload, key schedule, the one compressor
-// launch, every member's status publication and descriptor download on the lane - the others wait for their own completion event.
-#define TSX_LANES_MAX 24
-#define TSX_COPY_STREAMS_MAX 8
-#define TSX_GROUP_MAX_SEGS 64
-#define TSX_GROUP_MAX_CHUNKS 8192
-struct tsx_zreq { tsx_ctx* c; tsx_run* r; hipEvent_t in_ready; int rc; bool done; };
-struct tsx_lane { hipStream_t st = nullptr; hipEvent_t end = nullptr; bool busy = false; tsx_zseg* h_segs = nullptr; tsx_zseg* d_segs = nullptr; /* pinned segment table: host view, device alias */ };
-struct tsx_combiner {
+// ---- the compressor service, host side (device side: zstd_enc.hip, zstd_service_kernel; layout: tsx_internal.h) -----------------------
+// Rounds 2-4 launched one compressor kernel per batch (or per group of callers: the "launch combiner") and let the hardware's
+// dispatcher hand workgroups to freed wave slots.  Two things followed from a launch being the unit of work: the chip ran in
+// generations (a batch's stragglers held its hardware queue while slots sat empty; 18.0 GiB/s in a timed region against 18.7-20.4
+// continuously fed), and everything that is not a compressor wave starved - a freed 6.7 KB slot is refilled by the dispatcher before a
+// decoder workgroup finds three neighbouring ones: a fetch under upload load took 1-65 s (profiles/r04_mixed_load.txt).  Now a
+// compressing batch is a MEMBER of its device's queue: tickets in pinned memory, persistent waves that pull them, per-member completion
+// flags.  One kernel, on one stream that carries nothing else; it is (re)started by whoever publishes work and finds it gone, and by
+// the waiting callers' watchdog (a launch that ended - idle, age limit, every wave on a reserved CU - with tickets still unserved).
+struct tsx_svc_member { uint64_t id; uint32_t first, n; uint16_t slot; bool done; };
+struct tsx_service {
     std::mutex mu; std::condition_variable cv;
-    std::vector<tsx_zreq*> pending; bool leader = false;
-    tsx_lane lane[TSX_LANES_MAX]; uint32_t nlanes = 0;
-    // copy streams of the context-less path, shared by the callers (created before the lanes, so that their event markers get hardware queues
-    // of their own): a call takes one input and one output stream in turn.  ONE of each by default: with 48 callers an output copy phase of
-    // 330 MB stood 1.05 s in that queue - and more streams made it worse (they collide with the lanes' hardware queues: 2 + 4 streams -5 %,
-    // 4 + 8 -30 %, profiles/r04_broker_shape_experiments.txt); what removed the phase is zero-copy output (run_combined).  TSX_COPY_STREAMS="in,out".
-    hipStream_t copy_in_s[TSX_COPY_STREAMS_MAX] = {nullptr}, copy_out_s[TSX_COPY_STREAMS_MAX] = {nullptr};
-    uint32_t n_in = 1, n_out = 1;
-    std::atomic<uint32_t> rr_in{0}, rr_out{0};
-    uint64_t groups = 0, members = 0;                      // launches made, batches they carried (tsx_debug_combiner_stats)
-    // Admission cap (opt-in, TSX_COMBINER_MAX_CHUNKS; 0 = none): compressor chunks launched and not yet done on this device.  With more
-    // chunks launched than the chip has slots (6144) every freed slot is refilled by the hardware at once and anything that is not a
-    // compressor wave starves (mixed load); members are 256 chunks and complete one by one, so holding launches back at ~5600
-    // keeps a few hundred slots turning over in the open.  One device run (32 callers, cap 5632, profiles/r04_mixed_load.txt): a fetch still
-    // takes 1.8-3.4 s - scattered free slots rarely line up three on one CU - so this is a knob, off by default; TSX_FETCH_RESERVED_CUS is the remedy.
-    uint32_t inflight = 0, inflight_peak = 0, cap = 0;
+    tsx_svc_host* h = nullptr; tsx_svc_host* hd = nullptr;          // the queue in pinned host memory: host view, device alias
+    tsx_svc_dev* d = nullptr;
+    uint32_t* h_zero = nullptr;                                      // pinned zero word (resets of device words travel as copies, not kernels)
+    hipStream_t st = nullptr; hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool launched = false;                                           // a launch is out whose end this side has not seen yet
+    bool stop_dirty = false;                                         // the device's stop word must be cleared in front of the next launch
+    uint32_t paused = 0;                                             // > 0: no launches (memory management in progress)
+    uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0;
+    uint32_t published = 0;
+    uint64_t next_id = 1;
+    std::deque<tsx_svc_member> out;                                  // members published and not yet retired, oldest first
+    std::vector<uint16_t> free_slots; uint16_t slot_gen[TSX_SVC_MEMBERS] = {0};
+    uint64_t launches = 0, watchdog_launches = 0, members = 0, chunks = 0; double kernel_ms = 0;
+    std::vector<void*> deferred_dev, deferred_host;                  // frees that wait for the kernel to be gone (svc_free_*)
 };
 
 struct tsx_device {
@@ -86,7 +127,11 @@ struct tsx_device {
     std::vector<tsx_ctx*> idle;
     size_t idle_bytes = 0;
     size_t idle_cap = 0;                                     // most idle workspace kept (init_devices: a fraction of THIS device's memory)
-    std::unique_ptr<tsx_combiner> comb;                      // created with the first ctx-less compressing batch
+    std::vector<std::pair<void*, size_t>> spare_bwork;       // block-form decoder workspaces that left their context (pool_release), for the next one
+    std::unique_ptr<tsx_service> svc;
+    // copy streams of the context-less compressing calls, shared by the callers: ONE of each.  With a stream per caller a segment's copies
+    // stood behind other callers' in the engines' queues anyway, and more streams measured worse (profiles/r04_broker_shape_experiments.txt).
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
     uint32_t in_use = 0;
     uint64_t batches = 0;
 };
@@ -95,10 +140,10 @@ struct tsx_device {
 #define TSX_SUB_BYTES ((size_t)64 << 20) /* input bytes per sub-batch: >= 1000 workgroups of the GCM / CRC kernels */
 #define TSX_POOL_MAX_IDLE 32            /* idle pooled contexts kept per device (a broker: >= 10 RLM threads + read-ahead helpers + the fetch pool) ... */
 // ... as long as their workspaces together stay under tsx_device.idle_cap = 4/9 of the device's memory (128 of the MI355X's 288 GB; a smaller
-// device or several processes per GPU get their share: TSX_POOL_IDLE_BYTES overrides); the rest are destroyed on release, and an
+// device or several processes per GPU get their share: tsx_config.pool_idle_bytes); the rest are destroyed on release, and an
 // allocation that fails drains the idle pool and is tried again (reserve_or_drain) - cached memory is never the reason for TSX_E_NOMEM.
 #define TSX_POOL_MAX_IDLE_BWORK 4       /* idle contexts that keep their block-form decoder workspace (37 MiB per 4 MiB chunk: 9.4 GiB for a segment) */
-#define TSX_COMP_PIECES 4               /* pieces of a host-memory batch on the compress path: one compute stream each (they must co-reside) */
+#define TSX_COMP_PIECES_MAX 8           /* members of one compressing host-memory batch (a completion counter + flag each) */
 
 struct tsx_ctx {
     int dev_index = 0;
@@ -106,19 +151,17 @@ struct tsx_ctx {
     hipStream_t st = nullptr;                      // kernels (+ descriptor copies)
     hipStream_t st_in = nullptr, st_out = nullptr; // H2D / D2H of the host-memory staging pipeline
     hipStream_t st_out2 = nullptr;                 // second D2H stream of a fetch cut into pieces (odd pieces; created on first use)
-    hipStream_t st_pc[TSX_COMP_PIECES - 1] = {nullptr}; // compute streams of pieces 1.. of a host batch cut into co-resident pieces (created on first use)
-    hipStream_t st_fwd = nullptr;                  // compressing batches with CUs reserved for everything else (tsx_compressor_stream): their own stream ...
-    hipStream_t st_pcf[TSX_COMP_PIECES - 1] = {nullptr}; // ... and their pieces' (created on first use)
+    hipStream_t st_pc[3] = {nullptr};              // compute streams of pieces 1.. of a block-form fetch cut into pieces (created on first use)
     hipEvent_t ev_key = nullptr;                   // key schedule ready (the piece streams wait for it)
     // device workspace (grown on demand)
     tsx_chunk_desc* d_descs = nullptr; size_t descs_cap = 0;
     tsx_chunk_desc* h_descs = nullptr;             // pinned mirror of the descriptors: no pageable copy ever sits in a stream
-    tsx_chunk_desc* hd_descs = nullptr;            // ... as the device addresses it: lean compressing batches read and write it in place
+    tsx_chunk_desc* hd_descs = nullptr;            // ... as the device addresses it: compressor waves read and write it in place
     uint8_t* h_keyraw = nullptr;                   // pinned 128 bytes: key + aad on their way in (wiped after the batch)
-    tsx_gcm_key* h_key = nullptr;                  // pinned: the key schedule built on the host (compressing batches; wiped after the batch)
+    tsx_gcm_key* h_key = nullptr;                  // pinned: the key schedule built on the host (wiped after the batch)
     tsx_gcm_key* hd_key = nullptr;                 // ... as the device addresses it (every compressor wave takes its own copy, tsx_chain_fuse.key_on_host)
-    uint32_t* d_segdone = nullptr;                 // combined launches: chunks of this context's batch that are done (device counter, self-resetting)
-    uint32_t* h_segflag = nullptr;                 // ... and the word the last of them raises (pinned; hd_segflag = the device's address of it)
+    uint32_t* d_segdone = nullptr;                 // per member of this context's batch: chunks that are done (device counters, self-resetting)
+    uint32_t* h_segflag = nullptr;                 // ... and the words the last of them raise (pinned; hd_segflag = the device's address)
     uint32_t* hd_segflag = nullptr;
     tsx_gcm_chunk* d_gchunks = nullptr;
     int32_t* d_status = nullptr;
@@ -139,16 +182,21 @@ struct tsx_ctx {
     tsx_timing timing{};
     bool pooled = false;
     bool last_used_blocks = false;                 // the last batch ran the block-parallel frame decoder (test hook)
+    uint32_t last_members = 0;                     // members the last compressing batch went as (test hook)
+    bool last_zero_copy = false;                   // ... and whether its waves wrote into the caller's buffer (test hook)
 };
 
 static std::mutex g_mu;
 static std::vector<tsx_device> g_devs;
 static uint32_t g_rr = 0;
 static thread_local int t_dev_hint = -1;
-static const char kUninitVersion[] = "tsxform 0.4 (gfx950 HIP; uninitialised)";
+static const char kUninitVersion[] = "tsxform 0.5 (gfx950 HIP; uninitialised)";
 static char g_version_buf[2][512];
 static unsigned g_version_gen = 0;
 static std::atomic<const char*> g_version{kUninitVersion};
+// buffers pinned through tsx_host_register: the only host ranges the device is KNOWN to address end to end (zero-copy output)
+static std::mutex g_reg_mu;
+static std::vector<std::pair<uintptr_t, size_t>> g_registered;
 
 extern "C" uint32_t tsx_abi_version(void) { return TSX_ABI_VERSION; }
 
@@ -172,25 +220,172 @@ extern "C" const char* tsx_strerror(int code) {
     }
 }
 
+// ---- service: lifetime ------------------------------------------------------------------------------------------------------------------
+// Is the service kernel of this device still out?  (mu held.)  When its end is seen for the first time, its duration joins the statistics
+// and what waited for it to be gone is freed: hipFree / hipHostFree wait for EVERY stream of the device, i.e. for a kernel that lives
+// as long as uploads go on - nothing in this library frees device or pinned memory while that kernel may be running (svc_free_*).
+static bool svc_running_locked(tsx_service& s) {
+    if (!s.launched) return false;
+    const hipError_t e = hipEventQuery(s.ev_end);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return true; }
+    (void)hipGetLastError();
+    float ms = 0;
+    if (e == hipSuccess && hipEventElapsedTime(&ms, s.ev_begin, s.ev_end) == hipSuccess) s.kernel_ms += ms;
+    (void)hipGetLastError();
+    s.launched = false;
+    for (void* p : s.deferred_dev) (void)hipFree(p);
+    for (void* p : s.deferred_host) (void)hipHostFree(p);
+    s.deferred_dev.clear(); s.deferred_host.clear();
+    return false;
+}
+
+// Start the service kernel (mu held, kernel known to be gone, device current).
+static int svc_launch_locked(tsx_service& s) {
+    if (s.paused) return TSX_OK;                                        // whoever paused the service starts it again (svc_resume)
+    if (s.stop_dirty) {
+        HIPCHK(hipMemcpyAsync(&s.d->stop, s.h_zero, 4, hipMemcpyHostToDevice, s.st));
+        s.stop_dirty = false;
+    }
+    tsx_svc_launch a{};
+    a.sched = g_cfg.zstd_sched;
+#ifdef HIPEMU
+    a.poll_ticks = 0; a.idle_exit_ticks = 0;                             // blocks run one after the other: nobody to wait for
+#else
+    a.poll_ticks = 500;                                                  // one look at the host's word per 5 us, device-wide
+    a.idle_exit_ticks = g_cfg.svc_idle_exit_us * 100u;
+#endif
+    const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
+    a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
+    HIPCHK(hipEventRecord(s.ev_begin, s.st));
+    (void)hipGetLastError();
+    tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);
+    if (hipGetLastError() != hipSuccess) { snprintf(g_last_err, sizeof g_last_err, "launch of the compressor service kernel failed"); return TSX_E_DEVICE; }
+    HIPCHK(hipEventRecord(s.ev_end, s.st));
+    s.launched = true; s.launches++;
+    return TSX_OK;
+}
+
+static void svc_destroy(tsx_device& d) {
+    if (!d.svc) return;
+    tsx_service& s = *d.svc;
+    if (s.h) __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
+    if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
+    for (void* p : s.deferred_dev) (void)hipFree(p);
+    for (void* p : s.deferred_host) (void)hipHostFree(p);
+    if (s.ev_begin) (void)hipEventDestroy(s.ev_begin);
+    if (s.ev_end) (void)hipEventDestroy(s.ev_end);
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.h_zero) (void)hipHostFree(s.h_zero);
+    if (s.d) (void)hipFree(s.d);
+    d.svc.reset();
+}
+
+// The queue, the device words and - from a probe launch that covers the chip - the CU keys that exist and the ones the compressor leaves alone.
+static int svc_create(tsx_device& d, int cus) {
+    std::unique_ptr<tsx_service> sp(new (std::nothrow) tsx_service);
+    if (!sp) return TSX_E_NOMEM;
+    d.svc = std::move(sp);
+    tsx_service& s = *d.svc;
+    HIPCHK(hipHostMalloc((void**)&s.h, sizeof(tsx_svc_host), hipHostMallocMapped | hipHostMallocPortable));
+    memset(s.h, 0, sizeof(tsx_svc_host));
+    HIPCHK(hipHostGetDevicePointer((void**)&s.hd, s.h, 0));
+    HIPCHK(hipHostMalloc((void**)&s.h_zero, 64, hipHostMallocDefault));
+    memset(s.h_zero, 0, 64);
+    HIPCHK(hipMalloc((void**)&s.d, sizeof(tsx_svc_dev)));
+    HIPCHK(hipMemset(s.d, 0, sizeof(tsx_svc_dev)));
+    HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&s.ev_begin));
+    HIPCHK(hipEventCreate(&s.ev_end));
+    for (uint32_t i = TSX_SVC_MEMBERS; i-- > 0;) s.free_slots.push_back((uint16_t)i);
+    // which compute units are there?  (HIP promises nothing about placement: a launch of three 48 KiB workgroups per CU that stay ~30 us each
+    // has to spread over all of them; twice, in case the first one met a chip that was busy)
+    std::vector<uint32_t> seen(128, 0);
+    for (int pass = 0; pass < 2; pass++) {
+        (void)hipGetLastError();
+        tsx_launch_cu_probe(s.st, s.d, (uint32_t)cus * 3u * 2u);
+        HIPCHK(hipStreamSynchronize(s.st));
+        HIPCHK(hipMemcpy(seen.data(), s.d->seen, 512, hipMemcpyDeviceToHost));
+        uint32_t k = 0; for (uint32_t w : seen) k += (uint32_t)__builtin_popcount(w);
+        s.cu_keys = k;
+        if ((int)k >= cus) break;
+    }
+    s.cus = (uint32_t)cus;
+    // the reservation: the highest keys of every XCD, as evenly as the number asked for divides (8 = one per XCD on an MI355X).  Never more
+    // than a quarter of the chip, and nothing at all when the probe did not find one key per CU (a key that stood for two CUs would take both).
+    std::vector<uint32_t> res(128, 0);
+    uint32_t want = g_cfg.reserved_cus;
+    if (want > s.cus / 4) want = s.cus / 4;
+    if (s.cu_keys != s.cus) {
+        if (g_cfg.debug || want) fprintf(stderr, "[tsxform] device %d: %u CU keys seen for %u compute units - no CU reservation\n", d.hip_id, s.cu_keys, s.cus);
+        want = 0;
+    }
+    uint32_t xccs = 0; for (uint32_t x = 0; x < 16; x++) { bool any = false; for (uint32_t w = 0; w < 8; w++) any |= seen[x * 8 + w] != 0; xccs += any; }
+    uint32_t taken = 0;
+    for (uint32_t round = 0; taken < want && round < 256; round++)      // round r takes the r-th highest key of every XCD that has one
+        for (uint32_t x = 0; x < 16 && taken < want; x++) {
+            uint32_t nth = 0;
+            for (int k = 255; k >= 0; k--) {
+                const uint32_t key = x << 8 | (uint32_t)k;
+                if (!((seen[key >> 5] >> (key & 31)) & 1)) continue;
+                if (nth++ == round) { res[key >> 5] |= 1u << (key & 31); taken++; break; }
+            }
+        }
+    (void)xccs;
+    s.cus_reserved = taken;
+    HIPCHK(hipMemcpy(s.d->reserved, res.data(), 512, hipMemcpyHostToDevice));
+    s.grid = s.cus * 24u;                                               // 24 one-wave workgroups fill a CU's LDS: the launch covers the chip once
+    return TSX_OK;
+}
+
+// Frees that must not wait for the service kernel: freed at once when it is known to be gone (mu held meanwhile: no launch can begin),
+// otherwise when its end is seen (svc_running_locked) or at shutdown.
+static void svc_free_dev(tsx_device* dev, void* p) {
+    if (!p) return;
+    if (!dev->svc) { (void)hipFree(p); return; }
+    std::lock_guard<std::mutex> lk(dev->svc->mu);
+    if (svc_running_locked(*dev->svc)) dev->svc->deferred_dev.push_back(p); else (void)hipFree(p);
+}
+static void svc_free_host(tsx_device* dev, void* p) {
+    if (!p) return;
+    if (!dev->svc) { (void)hipHostFree(p); return; }
+    std::lock_guard<std::mutex> lk(dev->svc->mu);
+    if (svc_running_locked(*dev->svc)) dev->svc->deferred_host.push_back(p); else (void)hipHostFree(p);
+}
+
+// Memory management that needs the memory BACK (an allocation has failed): no launches until svc_resume, the running kernel is told to
+// stop (its waves leave after their current chunk, <= ~1.3 s), deferred frees happen.  Members that wait meanwhile just wait.
+static void svc_pause(tsx_device* dev) {
+    if (!dev->svc) return;
+    tsx_service& s = *dev->svc;
+    std::unique_lock<std::mutex> lk(s.mu);
+    s.paused++;
+    __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
+    s.stop_dirty = true;
+    while (svc_running_locked(s)) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(200)); lk.lock(); }
+}
+static void svc_resume(tsx_device* dev) {
+    if (!dev->svc) return;
+    tsx_service& s = *dev->svc;
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (s.paused && --s.paused == 0) {
+        __atomic_store_n(&s.h->stop, 0u, __ATOMIC_RELEASE);
+        if (!s.out.empty() && !svc_running_locked(s)) (void)svc_launch_locked(s);     // (a failure shows up in the waiting members' watchdog)
+    }
+}
+
 static void device_free_consts(tsx_device& d) {
     if (d.hip_id < 0) return;
     hipSetDevice(d.hip_id);
-    if (d.comb) {
-        for (uint32_t i = 0; i < d.comb->nlanes; i++) {
-            tsx_lane& l = d.comb->lane[i];
-            if (l.st) { hipStreamSynchronize(l.st); hipStreamDestroy(l.st); }
-            if (l.end) hipEventDestroy(l.end);
-            if (l.h_segs) hipHostFree(l.h_segs);
-        }
-        for (auto& q : d.comb->copy_in_s) if (q) hipStreamDestroy(q);
-        for (auto& q : d.comb->copy_out_s) if (q) hipStreamDestroy(q);
-        d.comb.reset();
-    }
+    svc_destroy(d);
+    for (auto& b : d.spare_bwork) (void)hipFree(b.first);
+    d.spare_bwork.clear();
+    if (d.copy_in) hipStreamDestroy(d.copy_in);
+    if (d.copy_out) hipStreamDestroy(d.copy_out);
     if (d.d_crc) hipFree(d.d_crc);
     if (d.d_aes) hipFree(d.d_aes);
     if (d.d_zc) hipFree(d.d_zc);
     if (d.h_zeros) hipHostFree(d.h_zeros);
-    d.d_crc = nullptr; d.d_aes = nullptr; d.d_zc = nullptr; d.h_zeros = nullptr;
+    d.d_crc = nullptr; d.d_aes = nullptr; d.d_zc = nullptr; d.h_zeros = nullptr; d.copy_in = nullptr; d.copy_out = nullptr;
 }
 
 static int init_devices(std::vector<tsx_device>& devs, int want, const int* device_ids, const tsx_crc_tables* hc, const tsx_aes_tables* ha,
@@ -203,7 +398,7 @@ static int init_devices(std::vector<tsx_device>& devs, int want, const int* devi
         HIPCHK(hipGetDeviceProperties(&prop, d.hip_id));
         snprintf(d.name, sizeof d.name, "%s", prop.name);
         snprintf(d.arch, sizeof d.arch, "%s", prop.gcnArchName);
-        if (strncmp(d.arch, "gfx950", 6) != 0 && !getenv("TSX_ALLOW_ANY_ARCH")) {
+        if (strncmp(d.arch, "gfx950", 6) != 0 && !g_cfg.allow_any_arch) {
             snprintf(g_last_err, sizeof g_last_err, "device %d is %s, this library is built for gfx950 only", d.hip_id, d.arch);
             return TSX_E_DEVICE;
         }
@@ -211,7 +406,7 @@ static int init_devices(std::vector<tsx_device>& devs, int want, const int* devi
         {   size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) { (void)hipGetLastError(); total_b = prop.totalGlobalMem; }
             d.idle_cap = total_b / 9 * 4;
-            if (const char* e = getenv("TSX_POOL_IDLE_BYTES")) { const long long v = atoll(e); if (v >= 0) d.idle_cap = (size_t)v; }
+            if (g_cfg.pool_idle_bytes >= 0) d.idle_cap = (size_t)g_cfg.pool_idle_bytes;
         }
         HIPCHK(hipMalloc((void**)&d.d_crc, sizeof(tsx_crc_tables)));
         HIPCHK(hipMalloc((void**)&d.d_aes, sizeof(tsx_aes_tables)));
@@ -221,21 +416,38 @@ static int init_devices(std::vector<tsx_device>& devs, int want, const int* devi
         HIPCHK(hipMemcpy(d.d_crc, hc, sizeof(tsx_crc_tables), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.d_aes, ha, sizeof(tsx_aes_tables), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.d_zc, hz, tsx_zstd_consts_bytes(), hipMemcpyHostToDevice));
+        // the copy streams first, then the service's stream: whatever the runtime's stream -> hardware-queue assignment, the short copies and
+        // their event markers are not the ones that end up behind the long-lived kernel
+        HIPCHK(hipStreamCreateWithFlags(&d.copy_in, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&d.copy_out, hipStreamNonBlocking));
+        const int rc = svc_create(d, prop.multiProcessorCount);
+        if (rc) return rc;
     }
     return TSX_OK;
 }
 
-extern "C" int tsx_init(int device_count, const int* device_ids) {
+extern "C" int tsx_init_ex(int device_count, const int* device_ids, const tsx_config* cfg) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_devs.empty()) return (int)g_devs.size();
     tsx_device_scope keep;
+    {   // what the process has (defaults, or what tsx_debug_config set), then the caller's structure, then the environment - a deployment's last word
+        tsx_cfg c = g_cfg;
+        if (cfg && cfg->struct_size >= sizeof(tsx_config)) {
+            if (cfg->fetch_reserved_cus != TSX_CFG_DEFAULT) c.reserved_cus = cfg->fetch_reserved_cus > 128 ? 128 : cfg->fetch_reserved_cus;
+            if (cfg->service_max_launch_ms != TSX_CFG_DEFAULT) c.svc_max_launch_ms = cfg->service_max_launch_ms;
+            if (cfg->pool_idle_bytes != TSX_CFG_DEFAULT64) c.pool_idle_bytes = (long long)cfg->pool_idle_bytes;
+        } else if (cfg) return TSX_E_INVAL;
+        cfg_from_env(c);
+        g_cfg = c;
+    }
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
         snprintf(g_last_err, sizeof g_last_err, "no HIP device visible");
         return TSX_E_DEVICE;
     }
     int want = device_count <= 0 ? visible : device_count;
-    if (want > visible) return TSX_E_INVAL;
+    if (device_ids) { for (int i = 0; i < want; i++) if (device_ids[i] < 0 || device_ids[i] >= visible) return TSX_E_INVAL; }
+    else if (want > visible) return TSX_E_INVAL;
     tsx_crc_tables* hc = new (std::nothrow) tsx_crc_tables;
     tsx_aes_tables* ha = new (std::nothrow) tsx_aes_tables;
     tsx_zstd_consts* hz = (tsx_zstd_consts*)malloc(tsx_zstd_consts_bytes());
@@ -253,11 +465,14 @@ extern "C" int tsx_init(int device_count, const int* device_ids) {
     g_devs.swap(devs);
     char* vb = g_version_buf[g_version_gen++ & 1];
     snprintf(vb, sizeof g_version_buf[0],
-             "tsxform 0.4 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; %d device(s): %s)",
-             (int)g_devs.size(), g_devs[0].name);
+             "tsxform 0.5 (gfx950 HIP; CRC32C, AES-256-GCM, Zstd level-3 frames; zstd parity target libzstd 1.5.7 / 1.5.6 profile; %d device(s): %s; "
+             "compressor service: %u waves, %u of %u CUs reserved for fetches)",
+             (int)g_devs.size(), g_devs[0].name, g_devs[0].svc->grid, g_devs[0].svc->cus_reserved, g_devs[0].svc->cus);
     g_version.store(vb, std::memory_order_release);
     return (int)g_devs.size();
 }
+
+extern "C" int tsx_init(int device_count, const int* device_ids) { return tsx_init_ex(device_count, device_ids, nullptr); }
 
 extern "C" int tsx_device_count(void) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -266,15 +481,16 @@ extern "C" int tsx_device_count(void) {
 
 static void ctx_free_device_mem(tsx_ctx* c) {
     hipSetDevice(c->dev->hip_id);
-    // the key schedule and the raw key never outlive the context in readable form
-    if (c->d_key) hipMemset(c->d_key, 0, sizeof(tsx_gcm_key));
-    if (c->d_keyraw) hipMemset(c->d_keyraw, 0, 128);
+    // the key schedule and the raw key never outlive the context in readable form (copies of zeros, not kernels)
+    if (c->st && c->d_key) { hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st); }
+    if (c->st && c->d_keyraw) { hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st); }
+    if (c->st) hipStreamSynchronize(c->st);
     void* ptrs[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen, c->d_partials, c->d_key, c->d_keyraw, c->d_in, c->d_out, c->d_mid, c->d_zwork, c->d_bwork, c->d_segdone};
-    for (void* p : ptrs) if (p) hipFree(p);
-    if (c->h_segflag) hipHostFree(c->h_segflag);
-    if (c->h_descs) hipHostFree(c->h_descs);
-    if (c->h_keyraw) { memset(c->h_keyraw, 0, 128); hipHostFree(c->h_keyraw); }
-    if (c->h_key) { memset(c->h_key, 0, sizeof(tsx_gcm_key)); hipHostFree(c->h_key); }
+    for (void* p : ptrs) svc_free_dev(c->dev, p);
+    svc_free_host(c->dev, c->h_segflag);
+    svc_free_host(c->dev, c->h_descs);
+    if (c->h_keyraw) { memset(c->h_keyraw, 0, 128); svc_free_host(c->dev, c->h_keyraw); }
+    if (c->h_key) { memset(c->h_key, 0, sizeof(tsx_gcm_key)); svc_free_host(c->dev, c->h_key); }
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     for (auto& row : c->sub_ev) for (auto& e : row) if (e) hipEventDestroy(e);
     if (c->st) hipStreamDestroy(c->st);
@@ -282,8 +498,6 @@ static void ctx_free_device_mem(tsx_ctx* c) {
     if (c->st_out) hipStreamDestroy(c->st_out);
     if (c->st_out2) hipStreamDestroy(c->st_out2);
     for (auto& q : c->st_pc) if (q) hipStreamDestroy(q);
-    for (auto& q : c->st_pcf) if (q) hipStreamDestroy(q);
-    if (c->st_fwd) hipStreamDestroy(c->st_fwd);
     if (c->ev_key) hipEventDestroy(c->ev_key);
 }
 
@@ -296,44 +510,14 @@ extern "C" void tsx_shutdown(void) {
         device_free_consts(d);
     }
     g_devs.clear();
+    { std::lock_guard<std::mutex> lr(g_reg_mu); g_registered.clear(); }
     g_version.store(kUninitVersion, std::memory_order_release);
 }
 
-// A chip full of compressor waves starves everything else: a freed slot (one wave, 6.7 KB of LDS) is taken at once by the next queued
-// compressor workgroup, while a decoder workgroup (2-8 waves, up to 19.5 KB of LDS) needs several neighbouring slots free at the same
-// time - measured with five callers keeping 10 240 chunks queued: a single-chunk fetch took 64 s instead of 1.6 ms
-// (profiles/r04_mixed_load.txt).  A broker that uploads and serves fetches from the same device can ask for a reservation:
-// TSX_FETCH_RESERVED_CUS=n creates the COMPRESSOR's streams (the combiner's lanes, a context's stream for compressing batches) with a CU
-// mask that leaves n compute units - one per XCD for n = 8: the mask's bit i belongs to XCD i mod 8 - to whatever else runs.  Measured
-// with n = 8: a fetch under full upload load 3.3 ms median (p95 0.8 s; n = 16: 3.4 ms, p95 64 ms) instead of 50-80 s.  The price is not
-// the 3 % of the CUs: kernels on masked queues overlap worse - 14.5-15.2 GiB/s with five batches in flight against 19.4-19.8 (a lone batch:
-// 10.0 against 10.45), whatever GPU_MAX_HW_QUEUES says - so the default is 0, no reservation, and a deployment that serves consumers from
-// tiered storage while it uploads chooses (or gives fetches a device of their own: tsx_set_thread_device).  (Queue priority is no remedy:
-// with the fetch context's stream at the highest priority the same fetch still took 40 s - what is missing is room, not turn.)
-static uint32_t reserved_cus() {
-    static const uint32_t v = [] { const char* e = getenv("TSX_FETCH_RESERVED_CUS"); const long x = e ? atol(e) : 0; return (uint32_t)(x < 0 ? 0 : x > 128 ? 128 : x); }();
-    return v;
-}
-static hipError_t tsx_compressor_stream(hipStream_t* out, int hip_device) {
-    const uint32_t r = reserved_cus();
-    hipDeviceProp_t prop;
-    if (r == 0 || hipGetDeviceProperties(&prop, hip_device) != hipSuccess || prop.multiProcessorCount <= (int)r + 8) {
-        (void)hipGetLastError();
-        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-    }
-    const uint32_t cus = (uint32_t)prop.multiProcessorCount, words = (cus + 31) / 32;
-    uint32_t mask[64] = {0};
-    for (uint32_t i = 0; i + r < cus && i < 64 * 32; i++) mask[i / 32] |= 1u << (i % 32);      // every CU but the last r of the numbering
-    const hipError_t e = hipExtStreamCreateWithCUMask(out, words, mask);
-    if (e == hipSuccess) return e;
-    (void)hipGetLastError();
-    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);        // a runtime without CU masks: no reservation, as before
-}
-
 template <class T>
-static int grow(T** p, size_t* cap, size_t need) {
+static int grow(tsx_device* dev, T** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return TSX_OK;
-    if (*p) { if (hipFree(*p) != hipSuccess) return TSX_E_DEVICE; *p = nullptr; *cap = 0; }
+    if (*p) { svc_free_dev(dev, *p); *p = nullptr; *cap = 0; }
     size_t want = need + need / 8 + 256;
     hipError_t e = hipMalloc((void**)p, want * sizeof(T));
     if (e != hipSuccess) { tsx_set_err("hipMalloc(workspace)", e); return TSX_E_NOMEM; }
@@ -342,21 +526,17 @@ static int grow(T** p, size_t* cap, size_t need) {
 }
 
 // Small detransform batches (a fetch: one chunk, a prefetch window) decode one workgroup per BLOCK instead of per chunk: the
-// chunk-serial decoder needs 25-50 ms for a chunk however idle the chip is.  TSX_DEC_BLOCK_CHUNKS: largest batch that takes this
-// form (default 256, 0 = never).
-static uint32_t dec_block_chunks() {
-    if (const char* e = getenv("TSX_DEC_BLOCK_CHUNKS")) { const long v = atol(e); return v < 0 ? 0u : (uint32_t)v; }
-    return 256u;                                            // measured: 27.6 ms at 256 chunks against the chunk form's 33, profiles/r03_dec_latency_block_form.jsonl
-}
-static bool dec_use_blocks(uint32_t n, uint32_t max_out) { return n <= dec_block_chunks() && tsx_zstd_blockmode_takes(max_out); }
+// chunk-serial decoder needs 25-50 ms for a chunk however idle the chip is.  Up to 256 chunks (measured: 27.6 ms at 256 chunks against
+// the chunk form's 33, profiles/r03_dec_latency_block_form.jsonl); the test hook dec_block_chunks moves the limit (0 = never).
+static bool dec_use_blocks(uint32_t n, uint32_t max_out) { return n <= g_cfg.dec_block_chunks && tsx_zstd_blockmode_takes(max_out); }
 
 // max_out: largest output slot of the batch (detransform: the CRC of the restored bytes runs over dst_cap-sized slots)
 static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_out, uint32_t flags, bool host_mem, size_t in_bytes, size_t out_bytes) {
     HIPCHK(hipSetDevice(c->dev->hip_id));
     if (n > c->descs_cap || !c->d_descs) {
         void* olds[] = {c->d_descs, c->d_gchunks, c->d_status, c->d_zlen};
-        for (void* p : olds) if (p) hipFree(p);
-        if (c->h_descs) hipHostFree(c->h_descs);
+        for (void* p : olds) svc_free_dev(c->dev, p);
+        svc_free_host(c->dev, c->h_descs);
         c->d_descs = nullptr; c->d_gchunks = nullptr; c->d_status = nullptr; c->d_zlen = nullptr; c->h_descs = nullptr; c->hd_descs = nullptr;
         c->descs_cap = 0;                                    // a failure below leaves a context that reallocates, not one with holes
         size_t cap = (size_t)n + n / 4 + 16;
@@ -374,25 +554,37 @@ static int ctx_reserve(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_ou
     size_t subs = (bound + TSX_GCM_SUB_BYTES - 1) / TSX_GCM_SUB_BYTES + 1;
     size_t crc_subs = ((size_t)(max_out > max_len ? max_out : max_len) + TSX_CRC_SUB_BYTES - 1) / TSX_CRC_SUB_BYTES + 1;
     size_t per_chunk = subs * 4 > crc_subs ? subs * 4 : crc_subs;
-    int rc = grow(&c->d_partials, &c->partials_cap, (size_t)n * per_chunk);
+    int rc = grow(c->dev, &c->d_partials, &c->partials_cap, (size_t)n * per_chunk);
     if (rc) return rc;
     c->partials_per_chunk = per_chunk;
     if (host_mem) {
-        if ((rc = grow(&c->d_in, &c->in_cap, in_bytes + 64))) return rc;
-        if ((rc = grow(&c->d_out, &c->out_cap, out_bytes + 64))) return rc;
+        if ((rc = grow(c->dev, &c->d_in, &c->in_cap, in_bytes + 64))) return rc;
+        if ((rc = grow(c->dev, &c->d_out, &c->out_cap, out_bytes + 64))) return rc;
     }
     if (flags & TSX_COMPRESS) {
         size_t stride = (tsx_transformed_bound(max_len, TSX_COMPRESS) + 63) & ~(size_t)63;
-        if ((rc = grow(&c->d_mid, &c->mid_cap, stride * n))) return rc;
+        if ((rc = grow(c->dev, &c->d_mid, &c->mid_cap, stride * n))) return rc;
         c->mid_stride = stride;
         size_t zw = tsx_zstd_workspace_bytes(n, max_len);
         uint8_t* zp = (uint8_t*)c->d_zwork;
-        rc = grow(&zp, &c->zwork_cap, zw);
+        rc = grow(c->dev, &zp, &c->zwork_cap, zw);
         c->d_zwork = zp;                                     // also when grow failed: it has freed the old block
         if (rc) return rc;
         if (max_out && dec_use_blocks(n, max_out)) {         // inverse chain, small batch
+            const size_t need = tsx_zstd_blockmode_bytes(n, max_out);
+            if (!c->d_bwork || c->bwork_cap < need) {
+                // a workspace another context left behind (pool_release) before a fresh allocation
+                std::lock_guard<std::mutex> lk(g_mu);
+                auto& sp = c->dev->spare_bwork;
+                for (size_t k = 0; k < sp.size(); k++) if (sp[k].second >= need) {
+                    if (c->d_bwork) sp.push_back({c->d_bwork, c->bwork_cap});
+                    c->d_bwork = sp[k].first; c->bwork_cap = sp[k].second;
+                    sp.erase(sp.begin() + (long)k);
+                    break;
+                }
+            }
             uint8_t* bp = (uint8_t*)c->d_bwork;
-            rc = grow(&bp, &c->bwork_cap, tsx_zstd_blockmode_bytes(n, max_out));
+            rc = grow(c->dev, &bp, &c->bwork_cap, need);
             c->d_bwork = bp;
             if (rc) { c->d_bwork = nullptr; c->bwork_cap = 0; (void)hipGetLastError(); }   // no room for the fast path: the chunk form decodes the batch
         }
@@ -410,20 +602,20 @@ static int ctx_init_device_objects(tsx_ctx* c) {
     for (auto& e : c->sub_ev[0]) HIPCHK(hipEventCreate(&e));      // the other rows are created by the first pipelined batch
     HIPCHK(hipMalloc((void**)&c->d_key, sizeof(tsx_gcm_key)));
     HIPCHK(hipMalloc((void**)&c->d_keyraw, 128));
-    // the raw-key buffer is only written with TSX_GCM_SETUP_KERNEL: what tsx_debug_key_residue reads must never be an allocator's leftovers.
-    // On the context's OWN stream: it is non-blocking, a memset on the null stream could land behind the first batch's key copy
-    // (seen on the device: the first batch of a fresh pooled context encrypted with a zeroed schedule).
-    HIPCHK(hipMemsetAsync(c->d_key, 0, sizeof(tsx_gcm_key), c->st));
-    HIPCHK(hipMemsetAsync(c->d_keyraw, 0, 128, c->st));
+    HIPCHK(hipMalloc((void**)&c->d_segdone, 64));
+    // Nothing an allocator left behind: what tsx_debug_key_residue reads, and the completion counters, start from zero.  Copies of pinned
+    // zeros on the context's OWN stream - it is non-blocking (a memset on the null stream could land behind the first batch's key copy: seen
+    // on the device), and a memset would be a kernel, which waits for a wave slot on a chip full of compressor waves.
+    HIPCHK(hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->d_segdone, c->dev->h_zeros, 64, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipHostMalloc((void**)&c->h_keyraw, 128, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&c->h_key, sizeof(tsx_gcm_key), hipHostMallocMapped | hipHostMallocPortable));
     HIPCHK(hipHostGetDevicePointer((void**)&c->hd_key, c->h_key, 0));
-    HIPCHK(hipMalloc((void**)&c->d_segdone, 64));
-    HIPCHK(hipMemsetAsync(c->d_segdone, 0, 64, c->st));
     HIPCHK(hipHostMalloc((void**)&c->h_segflag, 64, hipHostMallocMapped | hipHostMallocPortable));
     HIPCHK(hipHostGetDevicePointer((void**)&c->hd_segflag, c->h_segflag, 0));
-    *c->h_segflag = 0;
-    HIPCHK(hipStreamSynchronize(c->st));                                // (the counter is zero before a lane of the combiner can touch it)
+    memset(c->h_segflag, 0, 64);
+    HIPCHK(hipStreamSynchronize(c->st));                                // (the counters are zero before a wave of the service can touch them)
     return TSX_OK;
 }
 
@@ -511,16 +703,22 @@ static tsx_ctx* pool_acquire(int* rc) {
     c->pooled = true;
     return c;
 }
-// Idle pooled contexts of device di give their memory back (an allocation has just failed: what is cached must not be the reason).
+// Idle pooled contexts of a device give their memory back (an allocation has just failed: what is cached must not be the reason).  The
+// service is paused meanwhile: a free only happens with its kernel gone.
 static bool pool_drain(tsx_device* dev) {
     std::vector<tsx_ctx*> dead;
+    std::vector<std::pair<void*, size_t>> spare;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         dead.swap(dev->idle); dev->idle_bytes = 0;
+        spare.swap(dev->spare_bwork);
     }
-    if (dead.empty()) return false;
+    if (dead.empty() && spare.empty()) return false;
     tsx_device_scope keep;
+    svc_pause(dev);
     for (tsx_ctx* c : dead) { ctx_free_device_mem(c); delete c; }
+    for (auto& b : spare) { hipSetDevice(dev->hip_id); (void)hipFree(b.first); }
+    svc_resume(dev);
     return true;
 }
 static int reserve_or_drain(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t max_out, uint32_t flags, bool host_mem, size_t in_bytes, size_t out_bytes) {
@@ -531,26 +729,31 @@ static int reserve_or_drain(tsx_ctx* c, uint32_t n, uint32_t max_len, uint32_t m
     return ctx_reserve(c, n, max_len, max_out, flags, host_mem, in_bytes, out_bytes);
 }
 static void pool_release(tsx_ctx* c) {
+    void* surplus = nullptr;
+    tsx_device* const dev = c->dev;
     {
         std::unique_lock<std::mutex> lk(g_mu);
         tsx_device& d = *c->dev;
         d.in_use--;
         if (c->d_bwork) {
             // the fetch side's ForkJoinPool issues from dozens of threads (ChunkCache.java:140): without a bound every idle context would
-            // park a block-form workspace; beyond a few the next small fetch on such a context re-allocates it (~1 ms) instead
+            // park a block-form workspace.  Beyond a few, the workspace leaves its context for the device's spare list - the next small fetch
+            // on a context without one takes it from there (ctx_reserve).  Never a hipFree here: that call waits for every stream of the
+            // device, i.e. for second-long compressor waves, on the path of a fetch.
             uint32_t with = 0;
             for (const tsx_ctx* o : d.idle) if (o->d_bwork) with++;
             if (with >= TSX_POOL_MAX_IDLE_BWORK) {
-                lk.unlock();
-                { tsx_device_scope keep; hipSetDevice(d.hip_id); hipFree(c->d_bwork); }
+                if (d.spare_bwork.size() < TSX_POOL_MAX_IDLE_BWORK) d.spare_bwork.push_back({c->d_bwork, c->bwork_cap});
+                else surplus = c->d_bwork;                               // freed when the service kernel is gone (svc_free_dev), not here
                 c->d_bwork = nullptr; c->bwork_cap = 0;
-                lk.lock();
             }
         }
         const size_t b = ctx_workspace_bytes(c);
-        if (d.idle.size() < TSX_POOL_MAX_IDLE && (d.idle.empty() || d.idle_bytes + b <= d.idle_cap)) { d.idle.push_back(c); d.idle_bytes += b; return; }
+        if (d.idle.size() < TSX_POOL_MAX_IDLE && (d.idle.empty() || d.idle_bytes + b <= d.idle_cap)) { d.idle.push_back(c); d.idle_bytes += b; c = nullptr; }
     }
     tsx_device_scope keep;
+    if (surplus) { hipSetDevice(dev->hip_id); svc_free_dev(dev, surplus); }
+    if (!c) return;
     ctx_free_device_mem(c);                                            // a burst of callers does not pin its workspaces forever
     delete c;
 }
@@ -674,16 +877,323 @@ struct tsx_sub { uint32_t lo, n; size_t in_lo, in_hi; };     // chunks [lo, lo +
 
 struct tsx_run {                                              // what one batch needs everywhere below
     tsx_ctx* c; const tsx_batch_params* params; tsx_chunk_desc* descs; uint32_t n; const void* src; void* dst; size_t src_size, dst_size;
-    int mem_kind, mode; uint32_t flags, max_len, max_out; bool host, packed, enc, comp, fuse_stages, combined;
+    int mem_kind, mode; uint32_t flags, max_len, max_out; bool host, packed, enc, comp, fuse_stages, pooled;
     const uint8_t* d_src; uint8_t* d_dst;
 };
 
-static uint32_t zstd_sched_from_env();
-// Enqueues the kernels of chunks [lo, lo + n) on compute stream st; e[0..3] are recorded at the stage boundaries.
+// ---- service: members ---------------------------------------------------------------------------------------------------------------
+// Publish one member: `proto` names its buffers (n, done and flag included); its n chunks become the next n tickets.  Returns the member's
+// id (for svc_retire) through *id.  Blocks while the ticket ring or the member slots are full (members retire one by one).
+static int svc_submit(tsx_device* dev, const tsx_zseg& proto, uint64_t* id) {
+    tsx_service& s = *dev->svc;
+    const uint32_t n = proto.n;
+    if (!n || n > TSX_SVC_MEMBER_MAX) return TSX_E_INVAL;
+    std::unique_lock<std::mutex> lk(s.mu);
+    // room: a ticket record is reused TSX_SVC_TICKETS tickets later - by then every member up to it must be gone
+    while (s.free_slots.empty() || (!s.out.empty() && (uint32_t)(s.published + n - s.out.front().first) > TSX_SVC_TICKETS))
+        s.cv.wait_for(lk, std::chrono::milliseconds(1));
+    const uint16_t slot = s.free_slots.back(); s.free_slots.pop_back();
+    const uint16_t gen = ++s.slot_gen[slot];
+    tsx_zseg e = proto;
+    e.gen = gen; e.pad = 0;
+    s.h->member[slot] = e;
+    const uint32_t first = s.published;
+    for (uint32_t i = 0; i < n; i++) { tsx_svc_ticket& t = s.h->ticket[(first + i) & (TSX_SVC_TICKETS - 1)]; t.member_gen = (uint32_t)gen << 16 | slot; t.chunk = i; }
+    s.published = first + n;
+    __atomic_store_n(&s.h->published, s.published, __ATOMIC_RELEASE);   // the waves' poll picks it up (a few microseconds)
+    *id = s.next_id++;
+    s.out.push_back({*id, first, n, slot, false});
+    s.members++;
+    if (!svc_running_locked(s)) return svc_launch_locked(s);           // (on failure the caller abandons the member: svc_retire)
+    return TSX_OK;
+}
+
+// The member is over - completed, or abandoned (`abandon`: its tickets, should a later launch ever reach them, name a stale generation).
+static void svc_retire(tsx_device* dev, uint64_t id, bool abandon) {
+    tsx_service& s = *dev->svc;
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (auto& m : s.out) if (m.id == id) {
+        m.done = true;
+        if (abandon) { s.slot_gen[m.slot]++; __atomic_store_n(&s.h->member[m.slot].gen, (uint32_t)s.slot_gen[m.slot], __ATOMIC_RELEASE); }
+        else s.chunks += m.n;
+        break;
+    }
+    while (!s.out.empty() && s.out.front().done) { s.free_slots.push_back(s.out.front().slot); s.out.pop_front(); }
+    s.cv.notify_all();
+}
+
+// Wait for a member's flag.  A chunk takes about a second: short sleeps only while the member is young (tests, tiny chunks), a
+// millisecond between looks afterwards - dozens of callers must not burn the cores next to the GPU's NUMA node.  Every look that follows
+// a real sleep is also the service's watchdog: a kernel that has ended with this member unfinished is started again.
+static int svc_wait(tsx_device* dev, uint32_t* h_flag) {
+    tsx_service& s = *dev->svc;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t failures = 0;
+    for (uint32_t look = 0;; look++) {
+        if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE)) return TSX_OK;
+        const auto age = std::chrono::steady_clock::now() - t0;
+        const bool young = age < std::chrono::milliseconds(2);
+        if (!young || (look & 7) == 7) {
+            std::lock_guard<std::mutex> lk(s.mu);
+            if (!s.paused && !svc_running_locked(s)) {
+                if (__atomic_load_n(h_flag, __ATOMIC_ACQUIRE)) return TSX_OK;
+                s.watchdog_launches++;
+                if (svc_launch_locked(s) != TSX_OK && ++failures >= 3) return TSX_E_DEVICE;
+            }
+        }
+        std::this_thread::sleep_for(young ? std::chrono::microseconds(20) : age < std::chrono::milliseconds(50) ? std::chrono::microseconds(250) : std::chrono::microseconds(1000));
+    }
+}
+
+// Returns when the device's service kernel has ended (its waves leave a moment after the last chunk): measurement tools bracket a timed
+// region with it so that the region's chunks and the kernel launches that did them can be set against each other (tsx_service_stats).
+extern "C" int tsx_service_quiesce(int device_index) {
+    tsx_device* dev;
+    { std::lock_guard<std::mutex> lk(g_mu); if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL; dev = &g_devs[device_index]; }
+    tsx_service& s = *dev->svc;
+    for (;;) {
+        { std::lock_guard<std::mutex> lk(s.mu); if (!svc_running_locked(s)) return TSX_OK; }
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
+
+extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
+    if (!out) return TSX_E_INVAL;
+    tsx_device* dev;
+    { std::lock_guard<std::mutex> lk(g_mu); if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL; dev = &g_devs[device_index]; }
+    tsx_service& s = *dev->svc;
+    tsx_device_scope keep;
+    if (hipSetDevice(dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
+    std::lock_guard<std::mutex> lk(s.mu);
+    const bool running = svc_running_locked(s);
+    memset(out, 0, sizeof *out);
+    out->launches = s.launches; out->watchdog_launches = s.watchdog_launches; out->members = s.members; out->chunks = s.chunks;
+    out->kernel_ms = s.kernel_ms; out->running = running ? 1u : 0u;
+    out->waves = s.grid; out->compute_units = s.cus; out->cu_keys_seen = s.cu_keys; out->reserved_cus = s.cus_reserved;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (hipMemcpy(w, &s.d->stat_chunks, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
+        out->device_chunks = w[0]; out->wave_starts = w[1]; out->reserved_exits = w[2]; out->skipped_tickets = w[3];
+    } else (void)hipGetLastError();
+    return TSX_OK;
+}
+
+// Test hook (not part of the ABI): put the device's ticket counters at `published` (an idle service only) - the wrap-around of the 32-bit
+// counters is ten days of full-rate compression away otherwise.
+extern "C" int tsx_debug_service_seed(int device_index, uint32_t published) {
+    tsx_device* dev;
+    { std::lock_guard<std::mutex> lk(g_mu); if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL; dev = &g_devs[device_index]; }
+    tsx_service& s = *dev->svc;
+    tsx_device_scope keep;
+    if (hipSetDevice(dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (svc_running_locked(s) || !s.out.empty()) return TSX_E_INVAL;
+    const uint32_t w[2] = {published, published};
+    if (hipMemcpy(&s.d->next, w, 8, hipMemcpyHostToDevice) != hipSuccess) return TSX_E_DEVICE;      // next, pub
+    s.published = published;
+    __atomic_store_n(&s.h->published, published, __ATOMIC_RELEASE);
+    return TSX_OK;
+}
+
+// Can the device address ALL of [p, p + bytes)?  Zero-copy output lets the compressor waves write there; a buffer of which only a
+// prefix is registered, or that spans two registrations, would fault the process (the broker's JVM) at the first byte behind the
+// mapping.  Known extents only: a range inside ONE tsx_host_register'ed buffer, or inside one allocation the runtime reports
+// (hipHostMalloc'ed memory); anything else takes the copy path.
+static uint8_t* device_alias_of_range(void* p, size_t bytes) {
+    if (!p || !bytes) return nullptr;
+    bool inside = false;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (const auto& r : g_registered) if ((uintptr_t)p >= r.first && (uintptr_t)p - r.first <= r.second && bytes <= r.second - ((uintptr_t)p - r.first)) { inside = true; break; }
+    }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || !dp) { (void)hipGetLastError(); return nullptr; }      // pageable memory
+    if (inside) return (uint8_t*)dp;
+#ifndef HIPEMU
+    void* base = nullptr; size_t size = 0;
+    if (hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)dp) == hipSuccess && base && (uintptr_t)dp >= (uintptr_t)base &&
+        bytes <= size - ((uintptr_t)dp - (uintptr_t)base)) return (uint8_t*)dp;
+    (void)hipGetLastError();
+#endif
+    return nullptr;
+}
+
+static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, bool* packed_full, hipStream_t out_st);
+
+// ---- the compressing forward chain: members of the device's service ---------------------------------------------------------------------
+// Any compressing batch - explicit context or pooled, device or host memory - takes this way.  The batch is cut into at most comp_pieces
+// members when its input comes from host memory (piece k + 1's input copy overlaps piece k's waves; a member is published when ITS input
+// has landed: what is in the queue is runnable), otherwise it is one member (several beyond TSX_SVC_MEMBER_MAX chunks).  The waves run the
+// whole chain of a chunk and own its descriptor in the context's pinned mirror: nothing but tickets goes to the device - no descriptor
+// upload, no status kernels, no key upload (a small copy or kernel queued next to second-long waves waits for them: measured in rounds 3-4).
+static int run_compress(tsx_run& r) {
+    tsx_ctx* c = r.c;
+    tsx_device* dev = c->dev;
+    const uint32_t n = r.n;
+    uint32_t max_len, max_out; size_t in_bytes; bool monotonic;
+    int rc = validate(r.descs, n, r.src_size, r.dst_size, !r.packed, &max_len, &max_out, &in_bytes, &monotonic);
+    if (rc) return rc;
+    size_t out_bytes = r.dst_size;
+    if (r.packed) {
+        // the waves still write one bound-sized slot per chunk; only the bytes produced end up, back to back, in the caller's buffer
+        const size_t slot = (tsx_transformed_bound(max_len, r.flags) + 63) & ~(size_t)63;
+        if (slot >= ((size_t)1 << 32)) return TSX_E_INVAL;
+        for (uint32_t i = 0; i < n; i++) { r.descs[i].dst_off = (uint64_t)i * slot; r.descs[i].dst_cap = (uint32_t)slot; }
+        out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
+    }
+    r.max_len = max_len; r.max_out = max_out;
+    // Zero-copy output (round 4).  The wave that finishes a chunk writes its bytes straight into the caller's buffer over PCIe when the device
+    // can address ALL of it (device_alias_of_range): posted writes of a few ms of a second-long wave, released to system scope before the
+    // chunk is counted done.  No device output buffer, no copy-out phase: with 32-48 callers a segment's 256 output copies stood 0.3-1.0 s
+    // in the copy engine's queue behind the other callers' (profiles/r04_broker_shape_experiments.txt).  Slot layout (TSX_MEM_HOST, what
+    // GpuTransformChunkEnumeration.java issues): nothing is left to do on the host.  Packed layout: pooled contexts (256-chunk segments) let
+    // the waves fill bound-sized slots in the caller's buffer when it has room for them and pack them down in place; an explicit context's
+    // 2048-chunk batch would spend ~90 ms of one host thread on that behind the kernel - it keeps the copy path, which packs piece by piece
+    // while later pieces run (test hook zero_copy_packed takes it anyway).
+    uint8_t* zc_dst = nullptr;
+    if (r.host && r.fuse_stages && !g_cfg.no_zero_copy_out && (!r.packed || (r.dst_size >= out_bytes && (r.pooled || g_cfg.zero_copy_packed))))
+        zc_dst = device_alias_of_range(r.dst, r.packed ? out_bytes : r.dst_size);
+    rc = reserve_or_drain(c, n, max_len, 0, r.flags, r.host, in_bytes, zc_dst ? 0 : out_bytes);
+    if (rc) return rc;
+    r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
+    r.d_dst = zc_dst ? zc_dst : r.host ? c->d_out : (uint8_t*)r.dst;
+    memset(&c->timing, 0, sizeof c->timing);
+    tsx_timing& t = c->timing;
+    c->last_zero_copy = zc_dst != nullptr;
+    // ---- the pieces ----
+    std::vector<tsx_sub> subs;
+    {
+        uint32_t pieces = 1;
+        if (r.host && monotonic && !g_cfg.no_pipeline) { pieces = g_cfg.comp_pieces < 1 ? 1 : g_cfg.comp_pieces > TSX_COMP_PIECES_MAX ? TSX_COMP_PIECES_MAX : g_cfg.comp_pieces; if (n < 8 * pieces && !g_cfg.sub_bytes) pieces = n >= 16 ? 2 : 1; }
+        uint32_t per = (n + pieces - 1) / pieces;
+        if (per > TSX_SVC_MEMBER_MAX) per = TSX_SVC_MEMBER_MAX;
+        if ((n + per - 1) / per > TSX_COMP_PIECES_MAX) return TSX_E_INVAL;                // (> 131072 chunks in one call)
+        for (uint32_t lo = 0; lo < n; lo += per) {
+            const uint32_t cnt = n - lo < per ? n - lo : per;
+            size_t a = r.descs[lo].src_off, b = a;
+            if (monotonic) b = (size_t)(r.descs[lo + cnt - 1].src_off + r.descs[lo + cnt - 1].src_len);
+            else { a = 0; b = in_bytes; }
+            subs.push_back({lo, cnt, a, b});
+        }
+    }
+    const size_t ns = subs.size();
+    c->last_members = (uint32_t)ns;
+    for (size_t k = 1; k < ns; k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
+    // ---- descriptors and key schedule, where the waves read and write them: the context's pinned memory ----
+    memcpy(c->h_descs, r.descs, (size_t)n * sizeof(tsx_chunk_desc));
+    const bool self_status = r.fuse_stages;
+    if (self_status) for (uint32_t i = 0; i < n; i++) { c->h_descs[i].status = TSX_E_DEVICE; c->h_descs[i].dst_len = 0; }   // the waves own them from here: a
+                                                                        // stale TSX_OK the caller handed in must not survive a chunk that never ran
+    if (r.enc && r.fuse_stages) tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
+    hipStream_t cin = r.pooled ? dev->copy_in : c->st_in, cout_ = r.pooled ? dev->copy_out : c->st_out;
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!self_status) {
+        // test hook stages_separate: CRC, compressor, GCM (or the copy into the slots) as separate launches around the service's members
+        HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, c->st));
+        hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, c->st, c->d_status, n);
+    }
+    // ---- input copies, all queued at once; every piece is published when its own bytes are on the device ----
+    if (r.host) {
+        HIPCHK(hipEventRecord(c->ev[2], cin));
+        for (size_t k = 0; k < ns; k++) {
+            const tsx_sub& sb = subs[k];
+            if ((k == 0 || monotonic) && sb.in_hi > sb.in_lo) HIPCHK(hipMemcpyAsync(c->d_in + sb.in_lo, (const uint8_t*)r.src + sb.in_lo, sb.in_hi - sb.in_lo, hipMemcpyHostToDevice, cin));
+            HIPCHK(hipEventRecord(c->sub_ev[k][5], cin));
+        }
+    }
+    uint64_t ids[TSX_COMP_PIECES_MAX] = {0};
+    size_t submitted = 0;
+    auto abandon_all = [&](int code) {
+        // nothing of this call may still be running when it returns with an error: members that were published are taken back (their
+        // tickets become stale) only once the service kernel is gone
+        if (submitted) { svc_pause(dev); for (size_t k = 0; k < submitted; k++) svc_retire(dev, ids[k], true); svc_resume(dev);
+                         (void)hipMemcpy(c->d_segdone, dev->h_zeros, 64, hipMemcpyHostToDevice); memset(c->h_segflag, 0, 64); }
+        (void)hipGetLastError();
+        if (r.host) { (void)hipStreamSynchronize(cin); (void)hipStreamSynchronize(cout_); }
+        return code;
+    };
+    for (size_t k = 0; k < ns; k++) {
+        const tsx_sub& sb = subs[k];
+        if (r.host && hipEventSynchronize(c->sub_ev[k][5]) != hipSuccess) return abandon_all(TSX_E_DEVICE);
+        if (k == 0) t.h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        if (!self_status) {
+            if ((r.flags & TSX_CRC)) { tsx_launch_crc32c(c->st, dev->d_crc, r.d_src, c->d_descs + sb.lo, sb.n, r.max_len, c->d_partials + (size_t)sb.lo * c->partials_per_chunk, 0); t.crc_launches += 2; }
+            if (hipStreamSynchronize(c->st) != hipSuccess) return abandon_all(TSX_E_DEVICE);
+        }
+        tsx_zseg m; memset(&m, 0, sizeof m);
+        m.n = sb.n; m.profile = r.params->zstd_profile;
+        m.src_base = r.d_src; m.descs = (self_status ? c->hd_descs : c->d_descs) + sb.lo; m.mid = c->d_mid + (size_t)sb.lo * c->mid_stride; m.mid_stride = c->mid_stride;
+        m.zlen = c->d_zlen + sb.lo; m.status = c->d_status + sb.lo; m.work = (uint8_t*)c->d_zwork + (size_t)sb.lo * tsx_zstd_workspace_bytes(1, 0);
+        if (self_status) {
+            m.fuse.crc = (r.flags & TSX_CRC) ? dev->d_crc : nullptr;
+            m.fuse.out = r.d_dst; m.fuse.self_status = 1;
+            if (r.enc) { m.fuse.aes = dev->d_aes; m.fuse.key = c->hd_key; m.fuse.key_on_host = 1; }
+        }
+        __atomic_store_n(&c->h_segflag[k], 0u, __ATOMIC_RELEASE);
+        m.done = c->d_segdone + k; m.flag = c->hd_segflag + k;
+        rc = svc_submit(dev, m, &ids[k]);
+        if (rc == TSX_E_INVAL) return abandon_all(rc);
+        submitted = k + 1;
+        if (rc) return abandon_all(rc);
+    }
+    // ---- completions, in order; a piece's bytes travel back (or are packed down) while the later pieces still run ----
+    size_t packed_at = 0; bool packed_full = false;
+    const auto t_pub = std::chrono::steady_clock::now();
+    for (size_t k = 0; k < ns; k++) {
+        const tsx_sub& sb = subs[k];
+        if ((rc = svc_wait(dev, &c->h_segflag[k]))) return abandon_all(rc);
+        svc_retire(dev, ids[k], false);
+        ids[k] = 0;
+        if (k + 1 == ns) t.zstd_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_pub).count();
+        if (!self_status) {
+            // stages_separate: the frames are in the staging buffer; GCM (or the copy into the slots) and the status publication follow
+            tsx_chunk_desc* dd = c->d_descs + sb.lo; int32_t* ds = c->d_status + sb.lo; uint32_t* dz = c->d_zlen + sb.lo;
+            uint8_t* dmid = c->d_mid + (size_t)sb.lo * c->mid_stride;
+            if (r.enc) {
+                if (k == 0) {
+                    tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
+                    HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st));
+                }
+                hipLaunchKernelGGL(plan_gcm_kernel, dim3((sb.n + 255) / 256), dim3(256), 0, c->st, dd, sb.n, (const uint32_t*)dz, (uint64_t)c->mid_stride, 1, 0, 0, c->d_gchunks + sb.lo, ds);
+                tsx_launch_gcm(c->st, dev->d_aes, c->d_key, c->d_gchunks + sb.lo, sb.n, (uint32_t)tsx_transformed_bound(r.max_len, TSX_COMPRESS), dmid, r.d_dst,
+                               c->d_partials + (size_t)sb.lo * c->partials_per_chunk, ds, 0);
+                t.gcm_launches += 2;
+            } else {
+                const uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
+                hipLaunchKernelGGL(copy_chunks_kernel, dim3(sb.n * bpc), dim3(256), 0, c->st, dd, (const uint32_t*)dz, (uint64_t)c->mid_stride, 1, (const uint8_t*)dmid, r.d_dst, ds, bpc);
+            }
+            hipLaunchKernelGGL(publish_status_kernel, dim3((sb.n + 255) / 256), dim3(256), 0, c->st, dd, (const int32_t*)ds, sb.n);
+            HIPCHK(hipMemcpyAsync(c->h_descs + sb.lo, dd, (size_t)sb.n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, c->st));
+            if (hipStreamSynchronize(c->st) != hipSuccess) return abandon_all(TSX_E_DEVICE);
+        }
+        memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
+        if (zc_dst) {                                                   // the bytes are where they belong; a packed batch is packed down in place
+            if (r.packed) for (uint32_t i = sb.lo; i < sb.lo + sb.n; i++) {
+                tsx_chunk_desc& d = r.descs[i];
+                const size_t slot_off = d.dst_off;
+                d.dst_off = packed_at;
+                if (d.status != TSX_OK) { d.dst_len = 0; continue; }
+                if (d.dst_len && slot_off != packed_at) memmove((uint8_t*)r.dst + packed_at, (const uint8_t*)r.dst + slot_off, d.dst_len);
+                packed_at += d.dst_len;
+            }
+        } else if (r.host) {
+            if ((rc = copy_back(r, sb, &packed_at, &packed_full, cout_))) return abandon_all(rc);
+        }
+    }
+    const auto t_done = std::chrono::steady_clock::now();
+    if (r.host && !zc_dst) { HIPCHK(hipEventRecord(c->ev[3], cout_)); HIPCHK(hipEventSynchronize(c->ev[3])); }
+    t.zstd_launches = (uint32_t)ns;
+    t.d2h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_done).count();
+    t.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (!r.host) { t.h2d_ms = 0; t.d2h_ms = 0; }
+    return TSX_OK;
+}
+
+// ---- everything else: forward chain without compression, the inverse chain, CRC only ---------------------------------------------------
+// Enqueues the kernels of chunks [lo, lo + n) on compute stream st; e[0..4] are recorded at the stage boundaries.
 static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st) {
     tsx_ctx* c = r.c;
     const uint32_t n = sb.n, lo = sb.lo, flags = r.flags;
-    tsx_chunk_desc* dd = c->d_descs + lo;                              // (lean batches: the pinned host mirror instead, below)
+    tsx_chunk_desc* dd = c->d_descs + lo;
     int32_t* ds = c->d_status + lo;
     uint32_t* dz = c->d_zlen + lo;
     tsx_gcm_chunk* dg = c->d_gchunks + lo;
@@ -693,20 +1203,8 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     uint32_t* const dpart = c->d_partials + (size_t)lo * c->partials_per_chunk;     // this piece's slice of the CRC / GHASH partial sums
     tsx_timing& t = c->timing;
     memcpy(c->h_descs + lo, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc));
-    // lean: the compressor waves own and publish their chunks' statuses and work on the descriptors and the key schedule where they
-    // are - in the context's pinned host memory.  Nothing but the launch goes into the stream: a small copy queued while the copy
-    // engines move other callers' gigabytes waits for them (measured: +550 ms per 256-chunk call with 10 callers), a small kernel
-    // waits for a slot on a chip full of compressor waves.
-    const bool lean = r.mode == 0 && r.comp && r.enc && r.fuse_stages;
-    if (lean) {
-        dd = c->hd_descs + lo;
-        // the waves are the only writers of status / dst_len here and no init or publish kernel runs: what the caller handed in (often a
-        // stale TSX_OK) must not survive a launch that never ran
-        for (uint32_t i = lo; i < lo + n; i++) { c->h_descs[i].status = TSX_E_DEVICE; c->h_descs[i].dst_len = 0; }
-    } else {
-        HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
-    }
+    HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
     HIPCHK(hipEventRecord(e[0], st));
     if (r.mode == 2) {
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, dpart, 0);
@@ -714,39 +1212,20 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         t.crc_launches += 2;
         hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);      // a reused descriptor must not keep an old status
     } else if (r.mode == 0) {
-        // With compression the whole chain of a chunk runs in the wave that compresses it: CRC32C of the source chunk first, GCM over
-        // the finished frame last - one launch per batch.  The batch CRC / GCM kernels want 20 / 40 KiB of LDS per workgroup and, on
-        // a chip filled by the compressor waves of the batches in flight, sat hundreds of ms in the queue for a few ms of work.
-        // TSX_STAGES_SEPARATE=1 keeps one launch per stage (A/B measurements, tests of the stand-alone kernels).
-        if ((flags & TSX_CRC) && !r.fuse_stages) { tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, dpart, 0); t.crc_launches += 2; }
+        // forward chain WITHOUT compression (producers compress: RemoteStorageManager.java:381-398 leaves Zstd out): CRC32C of the chunk,
+        // then AES-256-GCM (or the plain copy) as batch kernels - milliseconds of work, no residency to protect
+        if (flags & TSX_CRC) { tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, dpart, 0); t.crc_launches += 2; }
         HIPCHK(hipEventRecord(e[1], st));
-        bool fused = false;
-        if (r.comp) {
-            fused = r.enc && r.fuse_stages;
-            tsx_chain_fuse fuse{nullptr, nullptr, nullptr, nullptr, 0, 0};
-            if (r.fuse_stages && (flags & TSX_CRC)) fuse.crc = c->dev->d_crc;
-            if (fused) { fuse.aes = c->dev->d_aes; fuse.key = c->hd_key; fuse.out = r.d_dst; fuse.self_status = 1; fuse.key_on_host = 1; }
-            const uint32_t sched = zstd_sched_from_env();
-            (void)hipGetLastError();
-            t.zstd_launches += tsx_launch_zstd_compress(st, c->dev->d_zc, r.d_src, dd, n, r.max_len, dmid, c->mid_stride, dz, ds, dzw,
-                                                       r.params->zstd_profile, sched, fuse);
-            // hipLaunchKernelGGL reports through the last-error slot only; a lean batch has nothing behind the launch that would notice
-            if (hipGetLastError() != hipSuccess) return TSX_E_DEVICE;
-        }
         HIPCHK(hipEventRecord(e[2], st));
-        if (fused) {
-        } else if (r.enc) {
-            hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, n, (const uint32_t*)dz,
-                               (uint64_t)c->mid_stride, r.comp ? 1 : 0, 0, 0, dg, ds);
-            uint32_t glen = r.comp ? (uint32_t)tsx_transformed_bound(r.max_len, TSX_COMPRESS) : r.max_len;
-            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, glen, r.comp ? dmid : r.d_src, r.d_dst, dpart, ds, 0);
+        if (r.enc) {
+            hipLaunchKernelGGL(plan_gcm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, n, (const uint32_t*)dz, (uint64_t)c->mid_stride, 0, 0, 0, dg, ds);
+            tsx_launch_gcm(st, c->dev->d_aes, c->d_key, dg, n, r.max_len, r.d_src, r.d_dst, dpart, ds, 0);
             t.gcm_launches += 2;
         } else {
             uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
-            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz,
-                               (uint64_t)c->mid_stride, r.comp ? 1 : 0, r.comp ? (const uint8_t*)dmid : r.d_src, r.d_dst, ds, bpc);
+            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz, (uint64_t)c->mid_stride, 0, r.d_src, r.d_dst, ds, bpc);
         }
-        if (!lean) hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
     } else {
         HIPCHK(hipEventRecord(e[1], st));
         const uint8_t* zsrc = r.d_src;    // where the Zstd frames live when there is no encryption
@@ -786,12 +1265,12 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, dpart, 1);
         t.crc_launches += 2;
     }
-    if (!lean) HIPCHK(hipMemcpyAsync(c->h_descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(e[4], st));                                   // the caller's descriptors are filled in when this event has passed
     return TSX_OK;
 }
 
-// The bytes chunks [lo, lo + n) produced travel back on st_out (host-memory batches; their descriptors are on the host already).
+// The bytes chunks [lo, lo + n) produced travel back on out_st (host-memory batches; their descriptors are on the host already).
 // Exactly dst_len bytes per chunk: a slot's slack may hold bytes of an earlier batch on this (possibly pooled) context.
 static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, bool* packed_full, hipStream_t out_st) {
     tsx_ctx* c = r.c;
@@ -825,293 +1304,6 @@ static int copy_back(const tsx_run& r, const tsx_sub& sb, size_t* packed_at, boo
     return TSX_OK;
 }
 
-static uint32_t zstd_sched_from_env() {
-    uint32_t sched = 0;                                              // the kernel's default speculation schedule
-    if (const char* e = getenv("TSX_ZSTD_SCHED")) {                  // "k0,k1": explicit schedule (measurements; same bytes)
-        unsigned a = 0, b = 0;
-        if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) sched = a | b << 8;
-    }
-    return sched;
-}
-
-static int combiner_get(tsx_device* dev, tsx_combiner** out) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!dev->comb) {
-        std::unique_ptr<tsx_combiner> cb(new (std::nothrow) tsx_combiner);
-        if (!cb) return TSX_E_NOMEM;
-        // lanes: 3 with the runtime's default of 4 hardware queues (lanes + the two copy streams must not pile up on them); a process that
-        // runs with GPU_MAX_HW_QUEUES = q >= 8 gets q / 2 lanes, at most 8 - a caller waits for a free lane 1 / lanes of a kernel's duration
-        // on average, and what waits is not in flight.  TSX_LANES overrides (up to 24).  Round 4 swept queues x lanes with 20 / 32 callers
-        // (profiles/r04_broker_shape_experiments.txt): 16 x 8 is as good as anything - 12-20 lanes on 16-24 queues measure the same within
-        // the run-to-run spread, 32 queues lose 10-20 %.
-        uint32_t nl = 3;
-        if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { const long v = atol(q); if (v >= 8) nl = (uint32_t)(v / 2 > 8 ? 8 : v / 2); }
-        if (const char* e = getenv("TSX_LANES")) { const long v = atol(e); if (v >= 1 && v <= TSX_LANES_MAX) nl = (uint32_t)v; }
-        // the copy streams first: whatever the runtime's stream -> hardware-queue assignment, the short copies and their event markers
-        // are not the ones that end up behind a second-long kernel of a lane created later
-        if (const char* e = getenv("TSX_COMBINER_MAX_CHUNKS")) { const long v = atol(e); if (v > 0) cb->cap = (uint32_t)v; }
-        cb->n_in = 1; cb->n_out = 1;                                    // more streams measured WORSE (see tsx_combiner)
-        if (const char* e = getenv("TSX_COPY_STREAMS")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= TSX_COPY_STREAMS_MAX && b >= 1 && b <= TSX_COPY_STREAMS_MAX) { cb->n_in = a; cb->n_out = b; } }
-        bool ok = true;
-        for (uint32_t i = 0; ok && i < cb->n_in; i++) ok = hipStreamCreateWithFlags(&cb->copy_in_s[i], hipStreamNonBlocking) == hipSuccess;
-        for (uint32_t i = 0; ok && i < cb->n_out; i++) ok = hipStreamCreateWithFlags(&cb->copy_out_s[i], hipStreamNonBlocking) == hipSuccess;
-        for (uint32_t i = 0; ok && i < nl; i++) {
-            tsx_lane& l = cb->lane[i];
-            ok = tsx_compressor_stream(&l.st, dev->hip_id) == hipSuccess && hipEventCreateWithFlags(&l.end, hipEventDisableTiming) == hipSuccess &&
-                 hipHostMalloc((void**)&l.h_segs, TSX_GROUP_MAX_SEGS * sizeof(tsx_zseg), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess &&
-                 hipHostGetDevicePointer((void**)&l.d_segs, l.h_segs, 0) == hipSuccess;
-            cb->nlanes = i + 1;
-        }
-        dev->comb = std::move(cb);
-        if (!ok) { (void)hipGetLastError(); tsx_device& d = *dev; std::unique_ptr<tsx_combiner> dead = std::move(d.comb);
-                   for (uint32_t i = 0; i < dead->nlanes; i++) { tsx_lane& l = dead->lane[i]; if (l.st) hipStreamDestroy(l.st); if (l.end) hipEventDestroy(l.end); if (l.h_segs) hipHostFree(l.h_segs); }
-                   for (auto& q : dead->copy_in_s) if (q) hipStreamDestroy(q);
-                   for (auto& q : dead->copy_out_s) if (q) hipStreamDestroy(q);
-                   return TSX_E_DEVICE; }
-    }
-    *out = dev->comb.get();
-    return TSX_OK;
-}
-
-// The leader's part, outside the lock: everything the members of one group need on lane `l`, in stream order.
-static int combiner_launch(tsx_combiner* cb, tsx_lane& l, const std::vector<tsx_zreq*>& grp) {
-    hipStream_t ls = l.st;
-    uint32_t first = 0;
-    for (size_t k = 0; k < grp.size(); k++) {
-        tsx_zreq* q = grp[k]; tsx_ctx* c = q->c; const tsx_run& r = *q->r;
-        const uint32_t n = r.n;
-        if (q->in_ready) HIPCHK(hipStreamWaitEvent(ls, q->in_ready, 0));
-        HIPCHK(hipEventRecord(c->ev[0], ls));
-        memcpy(c->h_descs, r.descs, (size_t)n * sizeof(tsx_chunk_desc));
-        // with encryption the launch is the group's ONLY operation on the lane: descriptors and key schedules stay in the members' pinned
-        // memory (the waves read and write them in place), statuses are owned by the waves
-        if (r.enc) {
-            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
-            for (uint32_t i = 0; i < n; i++) { c->h_descs[i].status = TSX_E_DEVICE; c->h_descs[i].dst_len = 0; }      // the waves own them from here
-        } else {
-            HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, ls));
-            hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_status, n);
-        }
-        tsx_zseg& sg = l.h_segs[k];
-        memset(&sg, 0, sizeof sg);
-        sg.first = first; sg.n = n; sg.profile = r.params->zstd_profile;
-        sg.src_base = r.d_src; sg.descs = r.enc ? c->hd_descs : c->d_descs; sg.mid = c->d_mid; sg.mid_stride = c->mid_stride; sg.zlen = c->d_zlen; sg.status = c->d_status;
-        sg.work = (uint8_t*)c->d_zwork;
-        sg.fuse.crc = (r.flags & TSX_CRC) ? c->dev->d_crc : nullptr;
-        if (r.enc) {
-            sg.fuse.aes = c->dev->d_aes; sg.fuse.key = c->hd_key; sg.fuse.out = r.d_dst; sg.fuse.self_status = 1; sg.fuse.key_on_host = 1;
-            __atomic_store_n(c->h_segflag, 0u, __ATOMIC_RELEASE);
-            sg.done = c->d_segdone; sg.flag = c->hd_segflag;             // this member's caller returns when ITS chunks are done (run_combined)
-        }
-        first += n;
-    }
-    (void)hipGetLastError();                                             // (hipErrorNotReady of the leader's lane queries)
-    tsx_launch_zstd_compress_segments(ls, l.d_segs, l.h_segs, (uint32_t)grp.size(), first, zstd_sched_from_env());
-    if (hipGetLastError() != hipSuccess) return TSX_E_DEVICE;           // every member gets the rc (combiner_submit)
-    for (tsx_zreq* q : grp) {
-        tsx_ctx* c = q->c; const tsx_run& r = *q->r;
-        const uint32_t n = r.n;
-        if (!r.enc) {                                                    // compression only: the frames go from the staging buffer to the caller's slots
-            const uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
-            hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, ls, c->d_descs, (const uint32_t*)c->d_zlen, (uint64_t)c->mid_stride, 1,
-                               (const uint8_t*)c->d_mid, r.d_dst, c->d_status, bpc);
-            hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, ls, c->d_descs, (const int32_t*)c->d_status, n);
-            HIPCHK(hipMemcpyAsync(c->h_descs, c->d_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, ls));
-        }
-        HIPCHK(hipEventRecord(c->ev[1], ls));
-    }
-    HIPCHK(hipEventRecord(l.end, ls));
-    (void)cb;
-    return TSX_OK;
-}
-
-// Hand one batch to the device's combiner and return when its group has been queued (q.done); the caller then waits for its own event.
-static void combiner_submit(tsx_combiner* cb, tsx_zreq& q) {
-    std::unique_lock<std::mutex> lk(cb->mu);
-    cb->pending.push_back(&q);
-    cb->cv.notify_all();
-    while (!q.done) {
-        if (cb->leader) { cb->cv.wait(lk); continue; }
-        cb->leader = true;
-        // ---- lead: wait for a free lane (requests keep arriving meanwhile and join the group), take a group, queue it ----
-        int li = -1;
-        uint32_t nfree = 0;
-        for (;;) {
-            nfree = 0;
-            for (uint32_t i = 0; i < cb->nlanes; i++) {
-                tsx_lane& l = cb->lane[i];
-                if (l.busy && hipEventQuery(l.end) != hipErrorNotReady) l.busy = false;     // done - or failed: the launch on it will say so
-                if (!l.busy) { if (li < 0) li = (int)i; nfree++; }
-            }
-            if (li >= 0) break;
-            (void)hipGetLastError();                                     // hipErrorNotReady of the queries
-            cb->cv.wait_for(lk, std::chrono::microseconds(200));
-        }
-        // What waits is shared out over the lanes that are free NOW (the next leader takes the next lane), in arrival order - which is the
-        // order the members' input copies land in.  Everything onto the first free lane made one launch wait for the LAST member's copy,
-        // and its members finish, come back and pile up together for good: 32 callers in step moved 12 GiB/s where 20 moved 17
-        // (profiles/r03_bench_default_run_head.json before this).
-        // (admission cap: wait for members to complete - combiner_member_done notifies - while the first waiting batch would exceed it;
-        //  a batch larger than the cap goes alone on an empty device)
-        while (cb->cap && cb->inflight && cb->inflight + cb->pending.front()->r->n > cb->cap) cb->cv.wait_for(lk, std::chrono::microseconds(500));
-        const size_t share = (cb->pending.size() + nfree - 1) / nfree;
-        std::vector<tsx_zreq*> grp;
-        uint32_t chunks = 0;
-        while (!cb->pending.empty() && grp.size() < share && grp.size() < TSX_GROUP_MAX_SEGS && (grp.empty() || chunks + cb->pending.front()->r->n <= TSX_GROUP_MAX_CHUNKS) &&
-               (grp.empty() || !cb->cap || cb->inflight + chunks + cb->pending.front()->r->n <= cb->cap)) {
-            grp.push_back(cb->pending.front()); chunks += cb->pending.front()->r->n;
-            cb->pending.erase(cb->pending.begin());
-        }
-        tsx_lane& l = cb->lane[li];
-        l.busy = true;
-        cb->groups++; cb->members += grp.size();
-        cb->inflight += chunks; if (cb->inflight > cb->inflight_peak) cb->inflight_peak = cb->inflight;
-        lk.unlock();
-        const int rc = combiner_launch(cb, l, grp);
-        if (rc != TSX_OK) { (void)hipGetLastError(); (void)hipStreamSynchronize(l.st); }
-        lk.lock();
-        if (rc != TSX_OK) { l.busy = false; cb->inflight -= chunks; }
-        for (tsx_zreq* m : grp) { m->rc = rc; m->done = true; }
-        cb->leader = false;
-        cb->cv.notify_all();
-    }
-}
-
-// A member of a launch is done (or gave up waiting): its chunks leave the admission count.
-static void combiner_member_done(tsx_combiner* cb, uint32_t n) {
-    std::lock_guard<std::mutex> lk(cb->mu);
-    cb->inflight = cb->inflight >= n ? cb->inflight - n : 0;
-    if (cb->cap) cb->cv.notify_all();
-}
-// test hook: the most compressor chunks ever launched and not yet done on a device (admission cap)
-extern "C" int tsx_debug_combiner_inflight_peak(int device_index) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (device_index < 0 || device_index >= (int)g_devs.size() || !g_devs[device_index].comb) return TSX_E_INVAL;
-    std::lock_guard<std::mutex> lk2(g_devs[device_index].comb->mu);
-    return (int)g_devs[device_index].comb->inflight_peak;
-}
-// Where a context-less compressing call spends its time (test / measurement hook, tools/broker_probe.py): nanoseconds summed over calls -
-// waiting for the own input copy, from asking for a launch to the own chunks being done (lane wait + kernel), output copies - and calls.
-static std::atomic<uint64_t> g_phase_ns[4];
-extern "C" void tsx_debug_combined_phases(uint64_t out[4], int reset) {
-    for (int i = 0; i < 4; i++) { out[i] = g_phase_ns[i].load(); if (reset) g_phase_ns[i].store(0); }
-}
-// A ctx-less compressing batch: its buffers live in the pooled context, its work runs on the device's shared streams.
-static int run_combined(tsx_run& r) {
-    tsx_ctx* c = r.c;
-    const uint32_t n = r.n;
-    uint32_t max_len, max_out; size_t in_bytes; bool monotonic;
-    int rc = validate(r.descs, n, r.src_size, r.dst_size, !r.packed, &max_len, &max_out, &in_bytes, &monotonic);
-    if (rc) return rc;
-    size_t out_bytes = r.dst_size;
-    if (r.packed) {
-        const size_t slot = (tsx_transformed_bound(max_len, r.flags) + 63) & ~(size_t)63;
-        if (slot >= ((size_t)1 << 32)) return TSX_E_INVAL;
-        for (uint32_t i = 0; i < n; i++) { r.descs[i].dst_off = (uint64_t)i * slot; r.descs[i].dst_cap = (uint32_t)slot; }
-        out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
-    }
-    r.max_len = max_len; r.max_out = max_out;
-    // Zero-copy output (round 4).  The waves that encrypt a chunk write IV || C || TAG straight into the caller's buffer over PCIe when the
-    // device can address it (memory pinned with tsx_host_register - the JVM's reused direct buffers - or hipHostMalloc): posted writes of
-    // a few ms of a second-long wave, released to system scope before the chunk is counted done.  No device output buffer, no copy-out
-    // phase: with 32-48 callers a segment's 256 output copies stood 0.3-1.0 s in the copy engine's queue behind the other callers'
-    // (profiles/r04_broker_shape_experiments.txt) - time in which that caller offered the chip nothing.  Slot layout (TSX_MEM_HOST, what
-    // GpuTransformChunkEnumeration.java:201 issues): nothing is left to do on the host.  Packed layout: the waves fill bound-sized slots
-    // in the caller's buffer when it has room for them and the host packs them down in place; otherwise the copy path below.
-    uint8_t* zc_dst = nullptr;
-    if (r.host && r.enc && !getenv("TSX_NO_ZERO_COPY_OUT") && (!r.packed || r.dst_size >= out_bytes)) {
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, r.dst, 0) == hipSuccess && dp) zc_dst = (uint8_t*)dp;
-        else (void)hipGetLastError();                                    // pageable memory: not addressable from the device
-    }
-    rc = reserve_or_drain(c, n, max_len, 0, r.flags, r.host, in_bytes, zc_dst ? 0 : out_bytes);
-    if (rc) return rc;
-    tsx_combiner* cb = nullptr;
-    if ((rc = combiner_get(c->dev, &cb))) return rc;
-    r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
-    r.d_dst = zc_dst ? zc_dst : r.host ? c->d_out : (uint8_t*)r.dst;
-    memset(&c->timing, 0, sizeof c->timing);
-    tsx_zreq q{c, &r, nullptr, TSX_OK, false};
-    const auto t_in = std::chrono::steady_clock::now();
-    if (r.host) {
-        hipStream_t cin = cb->copy_in_s[cb->rr_in.fetch_add(1) % cb->n_in];
-        HIPCHK(hipEventRecord(c->ev[2], cin));
-        if (in_bytes) HIPCHK(hipMemcpyAsync(c->d_in, r.src, in_bytes, hipMemcpyHostToDevice, cin));
-        HIPCHK(hipEventRecord(c->sub_ev[0][5], cin));
-        // The caller waits for ITS input before it asks for a launch.  Round 3 queued the launch at once, behind a stream wait on the copy:
-        // every caller's gigabyte travels on the one copy-in stream, so with 20-32 callers a launch sat on its lane for the tens to
-        // hundreds of ms its copy stood in that queue - a lane (a hardware queue) held by a kernel that cannot start, while callers whose
-        // input HAD landed waited for a lane.  Now what reaches the combiner is runnable, a lane is only ever occupied by running waves,
-        // and the callers whose copies land while the lanes are busy leave together as one launch (VERDICT r3 #2a: a launch carried
-        // ~1 segment, 8 lanes x 256 chunks left 60 % of the chip's wave slots empty at 32 callers).
-        HIPCHK(hipEventSynchronize(c->sub_ev[0][5]));
-    }
-    const auto t_sub = std::chrono::steady_clock::now();
-    combiner_submit(cb, q);
-    if (q.rc != TSX_OK) return q.rc;                                    // (the leader has taken the group's chunks out of the admission count)
-    struct member_guard { tsx_combiner* cb; uint32_t n; ~member_guard() { if (cb) combiner_member_done(cb, n); } void release() { combiner_member_done(cb, n); cb = nullptr; } } guard{cb, n};
-    tsx_timing& t = c->timing;
-    if (r.enc) {
-        // The launch may carry other callers' segments and goes on until the last of THEIR chunks is done; this caller waits for its own:
-        // the wave that finishes this member's last chunk raises the flag (zstd_compress_segments_kernel).  A short sleep between looks -
-        // a chunk takes about a second; the launch's own event is the safety net (a launch that ended, or failed, without raising it).
-        for (uint32_t look = 0;; look++) {
-            if (__atomic_load_n(c->h_segflag, __ATOMIC_ACQUIRE)) break;
-            if ((look & 31) == 31) {
-                const hipError_t e = hipEventQuery(c->ev[1]);
-                if (e == hipSuccess) {
-                    if (__atomic_load_n(c->h_segflag, __ATOMIC_ACQUIRE)) break;
-                    (void)hipMemset(c->d_segdone, 0, 64);                // the count is not to be trusted any more
-                    snprintf(g_last_err, sizeof g_last_err, "combined launch ended without completing a member");
-                    return TSX_E_DEVICE;
-                }
-                if (e != hipErrorNotReady) { (void)hipGetLastError(); tsx_set_err("combined launch", e); return TSX_E_DEVICE; }
-                (void)hipGetLastError();
-            }
-            std::this_thread::sleep_for(std::chrono::microseconds(look < 64 ? 20 : 100));
-        }
-        t.zstd_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_sub).count();
-    } else {
-        HIPCHK(hipEventSynchronize(c->ev[1]));                          // this batch's descriptors are on the host (its group may still be running for others)
-        t.zstd_ms = ev_ms(c->ev[0], c->ev[1]);
-    }
-    guard.release();                                                    // this member's chunks are done: the next launch may come
-    memcpy(r.descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc));
-    t.zstd_launches = 1; t.total_ms = t.zstd_ms;
-    if (zc_dst) {
-        // the bytes are in the caller's buffer already; a packed batch is packed down in place (chunk i's slot starts at or behind its place)
-        if (r.packed) {
-            size_t at = 0;
-            for (uint32_t i = 0; i < n; i++) {
-                tsx_chunk_desc& d = r.descs[i];
-                const size_t slot_off = d.dst_off;
-                d.dst_off = at;
-                if (d.status != TSX_OK) { d.dst_len = 0; continue; }
-                if (d.dst_len && slot_off != at) memmove((uint8_t*)r.dst + at, (const uint8_t*)r.dst + slot_off, d.dst_len);
-                at += d.dst_len;
-            }
-        }
-        t.h2d_ms = ev_ms(c->ev[2], c->sub_ev[0][5]);
-        t.d2h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_sub).count() - t.zstd_ms;
-        t.total_ms = t.h2d_ms + t.zstd_ms + t.d2h_ms;
-    } else if (r.host) {
-        size_t packed_at = 0; bool packed_full = false;
-        const tsx_sub sb{0, n, 0, in_bytes};
-        hipStream_t cout_ = cb->copy_out_s[cb->rr_out.fetch_add(1) % cb->n_out];
-        if ((rc = copy_back(r, sb, &packed_at, &packed_full, cout_))) return rc;
-        HIPCHK(hipEventRecord(c->ev[3], cout_));
-        HIPCHK(hipEventSynchronize(c->ev[3]));
-        t.h2d_ms = ev_ms(c->ev[2], c->sub_ev[0][5]);
-        t.d2h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_sub).count() - t.zstd_ms;
-        t.total_ms = t.h2d_ms + t.zstd_ms + t.d2h_ms;
-    }
-    g_phase_ns[0] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_sub - t_in).count();
-    g_phase_ns[1] += (uint64_t)(t.zstd_ms * 1e6);
-    g_phase_ns[2] += (uint64_t)(t.d2h_ms * 1e6);
-    g_phase_ns[3] += 1;
-    return TSX_OK;
-}
-
 static int run_batch_inner(tsx_run& r) {
     tsx_ctx* c = r.c;
     const uint32_t n = r.n;
@@ -1129,72 +1321,28 @@ static int run_batch_inner(tsx_run& r) {
         out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
     }
     r.max_len = max_len; r.max_out = max_out;
-    // zero-copy output, as in run_combined: the compressor waves of a lean batch write into the caller's buffer when the device can address it.
-    // Slot layout only: packing a whole 2048-chunk batch down in place is ~90 ms of one host thread behind the kernel (1004 against 935 ms
-    // for the lone batch, measured), where the copy path packs piece by piece while later pieces run; TSX_ZERO_COPY_PACKED=1 takes it anyway.
-    uint8_t* zc_dst = nullptr;
-    if (r.mode == 0 && r.comp && r.enc && r.fuse_stages && r.host && !getenv("TSX_NO_ZERO_COPY_OUT") &&
-        (!r.packed || (r.dst_size >= out_bytes && getenv("TSX_ZERO_COPY_PACKED")))) {
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, r.dst, 0) == hipSuccess && dp) zc_dst = (uint8_t*)dp;
-        else (void)hipGetLastError();
-    }
-    rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, zc_dst ? 0 : out_bytes);
+    rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, out_bytes);
     if (rc) return rc;
     r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
-    r.d_dst = zc_dst ? zc_dst : r.host ? c->d_out : (uint8_t*)r.dst;
+    r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
     hipStream_t st = c->st;
-    if (r.mode == 0 && r.comp && reserved_cus()) {                     // a compressing batch leaves the reserved CUs alone
-        if (!c->st_fwd) HIPCHK(tsx_compressor_stream(&c->st_fwd, c->dev->hip_id));
-        st = c->st_fwd;
-    }
     memset(&c->timing, 0, sizeof c->timing);
-    // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap.  Device-memory batches
-    // have nothing to overlap.  Two shapes:
-    //  * short kernels (no compression, or the inverse chain): many pieces of >= 64 MiB in order on ONE compute stream, three streams
-    //    in all (the frame decoder is bound by per-chunk latency - ~30 ms however few chunks a launch has: its pieces are >= 512 chunks);
-    //  * the compressing chain: every chunk is ~0.6 s of one wave whatever the batch size, so the pieces must CO-RESIDE - at most
-    //    TSX_COMP_PIECES of them, each on its own compute stream, all copies and launches queued before the host waits for anything.
-    //    Piece k's waves start when its share of the input has landed instead of when the whole batch has, and its output travels
-    //    back while the later pieces still run; what stays serial is the input copy of the whole batch + one piece's kernel + one
-    //    piece's output copy.
+    // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap (device-memory batches have
+    // nothing to overlap): pieces of >= 64 MiB in order on ONE compute stream, three streams in all (the chunk-serial frame decoder is bound
+    // by per-chunk latency - ~30 ms however few chunks a launch has: its pieces are >= 512 chunks).
     std::vector<tsx_sub> subs;
-    const bool comp_fwd = r.mode == 0 && r.comp;
-    // Co-resident pieces need a hardware queue per compute stream: with the runtime's default of 4 queues for ALL streams of the process
-    // the pieces' kernels and the copy streams' event markers end up behind one another (measured: 945 -> 1300-2400 ms per 2048-chunk
-    // batch).  So only when the process runs with GPU_MAX_HW_QUEUES >= 8, or TSX_COMP_PIECES says so.
-    uint32_t comp_pieces = 1;
-    if (const char* e = getenv("TSX_COMP_PIECES")) { const long v = atol(e); if (v >= 1 && v <= TSX_COMP_PIECES) comp_pieces = (uint32_t)v; }
-    else if (const char* q = getenv("GPU_MAX_HW_QUEUES")) { if (atol(q) >= 8) comp_pieces = TSX_COMP_PIECES; }
-    if (comp_fwd && comp_pieces > 1 && r.host && !getenv("TSX_COMP_PIECES")) {
-        // ... and only from / to pinned memory: a pageable copy is staged by the runtime with a copy kernel, and a copy kernel queued while
-        // the chip is full of second-long compressor waves waits for them (measured: 2.4 s per 2048-chunk batch instead of 0.95)
-        hipPointerAttribute_t a;
-        // (the runtime answers for pageable memory too - hipMemoryTypeUnregistered - instead of failing)
-        const bool src_pinned = hipPointerGetAttributes(&a, r.src) == hipSuccess && a.type == hipMemoryTypeHost;
-        const bool dst_pinned = hipPointerGetAttributes(&a, r.dst) == hipSuccess && a.type == hipMemoryTypeHost;
-        (void)hipGetLastError();
-        if (!src_pinned || !dst_pinned) comp_pieces = 1;
-    }
-    // With zero-copy output (round 4) there is no output copy left to overlap, and what the pieces still buy on the input side (~120 ms of
-    // a lone batch's 160 ms copy) they lose in the kernels (four launches of 512 chunks: 770-800 ms against 743) - a lone batch reads 918-935 ms
-    // with pieces; with several callers in flight their 4 x 4 compute streams collide on the hardware queues (14.2 against 16.3 GiB/s at
-    // 4 callers, profiles/r04_bench_default_run_with_zero_copy_row.json): one launch per batch then.
-    if (zc_dst && !getenv("TSX_COMP_PIECES")) comp_pieces = 1;
-    const bool pipelined = r.host && monotonic && !(comp_fwd && (!r.fuse_stages || comp_pieces < 2)) && !getenv("TSX_NO_PIPELINE");
+    const bool pipelined = r.host && monotonic && !g_cfg.no_pipeline;
     // A fetch of 16 .. 256 chunks (a consumer catching up: ChunkCache.java:159-184 with a large prefetch.max.size) decodes in the block
     // form, whose cost is a ~1.5 ms chain of short kernels + a part proportional to the chunks: cut into up to 8 pieces of >= 8 chunks,
     // spread over the context's compute streams so that the pieces' chains overlap each other, the later pieces' copy-in and the earlier
     // pieces' copy-out.  (Round 3 only cut batches of >= 512 chunks: 64 chunks took 7 ms device resident and 17 ms host to host.)
     c->blk_pieces.clear(); c->last_used_blocks = false;
-    const bool inv_blocks = r.mode == 1 && r.comp && pipelined && n >= 16 && c->d_bwork && dec_use_blocks(n, max_out) && !getenv("TSX_NO_DEC_PIECES");
+    const bool inv_blocks = r.mode == 1 && r.comp && pipelined && n >= 16 && c->d_bwork && dec_use_blocks(n, max_out) && !g_cfg.no_dec_pieces;
     if (pipelined) {
-        size_t budget = TSX_SUB_BYTES;
+        size_t budget = g_cfg.sub_bytes > 0 ? (size_t)g_cfg.sub_bytes : TSX_SUB_BYTES;
         size_t max_subs = TSX_MAX_SUBS;
-        if (comp_fwd) { max_subs = comp_pieces; budget = in_bytes / comp_pieces + 1; if (budget < TSX_SUB_BYTES) budget = TSX_SUB_BYTES; }
-        if (const char* e = getenv("TSX_SUB_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }     // tests / tuning
         if (in_bytes / budget + 1 > max_subs) budget = in_bytes / max_subs + 1;
-        uint32_t min_chunks = (r.comp && !comp_fwd) ? 512u : 1u;
+        uint32_t min_chunks = r.comp ? 512u : 1u;
         if (inv_blocks) { max_subs = 8; budget = 0; min_chunks = (n + 7) / 8 < 8 ? 8u : (n + 7) / 8; }
         uint32_t lo = 0;
         while (lo < n) {
@@ -1206,36 +1354,29 @@ static int run_batch_inner(tsx_run& r) {
         }
     } else subs.push_back({0, n, 0, in_bytes});
     const size_t ns = subs.size();
-    const bool multi = (comp_fwd || inv_blocks) && ns > 1;             // pieces side by side: piece k on compute stream k mod TSX_COMP_PIECES
+    const bool multi = inv_blocks && ns > 1;                            // pieces side by side: piece k on compute stream k mod 4
     for (size_t k = 1; k < ns; k++) for (auto& e : c->sub_ev[k]) if (!e) HIPCHK(hipEventCreate(&e));
-    hipStream_t* const pcs = (comp_fwd && reserved_cus()) ? c->st_pcf : c->st_pc;
-    if (multi) for (size_t k = 1; k < ns && k < TSX_COMP_PIECES; k++) if (!pcs[k - 1]) {
-        if (pcs == c->st_pcf) HIPCHK(tsx_compressor_stream(&pcs[k - 1], c->dev->hip_id));
-        else HIPCHK(hipStreamCreateWithFlags(&pcs[k - 1], hipStreamNonBlocking));
-    }
-    auto stream_of = [&](size_t k) { return (multi && k % TSX_COMP_PIECES) ? pcs[k % TSX_COMP_PIECES - 1] : st; };
+    if (multi) for (size_t k = 1; k < ns && k < 4; k++) if (!c->st_pc[k - 1]) HIPCHK(hipStreamCreateWithFlags(&c->st_pc[k - 1], hipStreamNonBlocking));
+    auto stream_of = [&](size_t k) { return (multi && k % 4) ? c->st_pc[k % 4 - 1] : st; };
     HIPCHK(hipEventRecord(c->ev[0], st));
-    // A compressing batch whose waves run the whole chain needs no kernel besides the compressor's: the key schedule is built on the
-    // host, every wave owns its chunk's status.  (Small kernels around a launch wait for a slot on a chip that is full of second-long
-    // compressor waves: gcm_setup's workgroup wants 11 KiB of LDS where 3 KiB per CU are free.)
-    const bool lean = comp_fwd && r.enc && r.fuse_stages;
+    bool keyraw_written = false;
     if (r.enc) {
-        // The key schedule is built on the host for every encrypting / decrypting batch (~10 us with the host's carry-less multiplier).
-        // Lean batches leave it in pinned memory (the waves fetch it); the batch GCM kernels - decryption on the fetch path, encryption
-        // without compression - get it as ONE 21 KB copy in front of them instead of a raw-key copy + gcm_setup_kernel: that kernel was 0.17
-        // of a single-chunk fetch's 1.7 ms and, on a busy device, one more small kernel waiting for a slot behind compressor waves
-        // (VERDICT r3 #6).  TSX_GCM_SETUP_KERNEL=1 keeps the kernel (its tests; both produce the same schedule).
-        static const bool setup_kernel = getenv("TSX_GCM_SETUP_KERNEL") != nullptr;
-        if (lean || !setup_kernel) {
+        // The key schedule is built on the host (~10 us with the host's carry-less multiplier) and travels as ONE 21 KB copy in front of the
+        // batch's GCM kernels instead of a raw-key copy + gcm_setup_kernel: that kernel was 0.17 of a single-chunk fetch's 1.7 ms and, on a
+        // busy device, one more small kernel waiting for a slot.  Test hook gcm_setup_kernel keeps the kernel (both
+        // produce the same schedule).
+        if (!g_cfg.gcm_setup_kernel) {
             tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
-            if (!lean) HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, st));
         } else {
             memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
             HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, st));
+            keyraw_written = true;
             tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
         }
         if (multi) HIPCHK(hipEventRecord(c->ev_key, st));
     }
+    (void)keyraw_written;                                               // (run_batch wipes both device copies whatever was written)
     if (r.host) HIPCHK(hipEventRecord(c->ev[2], c->st_in));
     size_t packed_at = 0; bool packed_full = false;
     auto enqueue_piece = [&](size_t k) -> int {
@@ -1253,24 +1394,13 @@ static int run_batch_inner(tsx_run& r) {
         return launch_stages(r, sb, e, ks);
     };
     // The restored chunks of a fetch are what crosses PCIe (4 MiB each against 1.3 MB in): one copy stream moves them at ~31 GB/s - 8.7 of a
-    // 64-chunk window's 10.4 ms; the pieces' copies alternate between two streams (TSX_DEC_OUT_STREAMS=1: one).
-    bool out2 = inv_blocks && multi && r.host && !(getenv("TSX_DEC_OUT_STREAMS") && atoi(getenv("TSX_DEC_OUT_STREAMS")) < 2);
+    // 64-chunk window's 10.4 ms; the pieces' copies alternate between two streams.
+    bool out2 = inv_blocks && multi && r.host;
     if (out2 && !c->st_out2 && hipStreamCreateWithFlags(&c->st_out2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->st_out2 = nullptr; out2 = false; }
     auto collect_piece = [&](size_t k) -> int {
         const tsx_sub& sb = subs[k];
         HIPCHK(hipEventSynchronize(c->sub_ev[k][4]));                   // descriptors of piece k are on the host
         memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
-        if (zc_dst) {                                                   // the bytes are where they belong; a packed batch is packed down in place
-            if (r.packed) for (uint32_t i = sb.lo; i < sb.lo + sb.n; i++) {
-                tsx_chunk_desc& d = r.descs[i];
-                const size_t slot_off = d.dst_off;
-                d.dst_off = packed_at;
-                if (d.status != TSX_OK) { d.dst_len = 0; continue; }
-                if (d.dst_len && slot_off != packed_at) memmove((uint8_t*)r.dst + packed_at, (const uint8_t*)r.dst + slot_off, d.dst_len);
-                packed_at += d.dst_len;
-            }
-            return TSX_OK;
-        }
         if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, (out2 && (k & 1)) ? c->st_out2 : c->st_out);
         return TSX_OK;
     };
@@ -1292,15 +1422,13 @@ static int run_batch_inner(tsx_run& r) {
     if (r.host) { HIPCHK(hipStreamSynchronize(c->st_in)); HIPCHK(hipStreamSynchronize(c->st_out)); if (out2) HIPCHK(hipStreamSynchronize(c->st_out2)); }
     HIPCHK(hipGetLastError());
     tsx_timing& t = c->timing;
-    float zmax = 0;
     for (size_t k = 0; k < ns; k++) {
         hipEvent_t* e = c->sub_ev[k];
         const float a = ev_ms(e[0], e[1]), b = ev_ms(e[1], e[2]), d = ev_ms(e[2], e[3]), f = ev_ms(e[3], e[4]);
         if (r.mode == 2) t.crc_ms += a;
-        else if (r.mode == 0) { t.crc_ms += (r.flags & TSX_CRC) ? a : 0; if (multi) { if (b > zmax) zmax = b; } else t.zstd_ms += r.comp ? b : 0; t.gcm_ms += d; }
+        else if (r.mode == 0) { t.crc_ms += (r.flags & TSX_CRC) ? a : 0; t.gcm_ms += d; }
         else { t.gcm_ms += r.enc ? b : 0; t.unzstd_ms += d; t.crc_ms += (r.flags & TSX_CRC) ? f : 0; }
     }
-    if (multi) t.zstd_ms = zmax;                                        // co-resident pieces: the longest launch, not their sum
     t.total_ms = ev_ms(c->ev[0], c->ev[1]);
     if (r.host) {
         // with pieces in flight the copies overlap the kernels: h2d_ms / d2h_ms are the spans of the copy streams, not additive
@@ -1313,7 +1441,7 @@ static int run_batch_inner(tsx_run& r) {
 }
 
 static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc* descs, uint32_t n, const void* src, size_t src_size, void* dst,
-                     size_t dst_size, int mem_kind, int mode /*0 transform, 1 detransform, 2 crc only*/, bool combined = false) {
+                     size_t dst_size, int mem_kind, int mode /*0 transform, 1 detransform, 2 crc only*/, bool pooled = false) {
     if (!descs || (n && !src) || (mode != 2 && (!params || (n && !dst)))) return TSX_E_INVAL;
     if (mem_kind != TSX_MEM_HOST && mem_kind != TSX_MEM_DEVICE && mem_kind != TSX_MEM_HOST_PACKED) return TSX_E_INVAL;
     const bool packed = mem_kind == TSX_MEM_HOST_PACKED;
@@ -1330,42 +1458,31 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     if (hipSetDevice(c->dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
     tsx_run r{};
     r.c = c; r.params = params; r.descs = descs; r.n = n; r.src = src; r.dst = dst; r.src_size = src_size; r.dst_size = dst_size; r.mem_kind = mem_kind; r.mode = mode;
-    r.flags = flags; r.host = mem_kind != TSX_MEM_DEVICE; r.packed = packed;
+    r.flags = flags; r.host = mem_kind != TSX_MEM_DEVICE; r.packed = packed; r.pooled = pooled;
     r.enc = mode != 2 && (flags & TSX_ENCRYPT); r.comp = mode != 2 && (flags & TSX_COMPRESS);
-    r.fuse_stages = r.comp && !getenv("TSX_STAGES_SEPARATE");
-    r.combined = combined && mode == 0 && r.comp && r.fuse_stages && !getenv("TSX_NO_COMBINE");
-    const int rc = r.combined ? run_combined(r) : run_batch_inner(r);
-    if (r.combined) {
-        // nothing of the key was uploaded (every wave took and wiped its own copy of the schedule); what is left is the pinned original -
-        // wiped once nothing of this call can still be running
-        if (rc != TSX_OK) {
-            (void)hipGetLastError();
-            if (c->dev->comb) { for (auto& q : c->dev->comb->copy_in_s) if (q) (void)hipStreamSynchronize(q);
-                                for (auto& q : c->dev->comb->copy_out_s) if (q) (void)hipStreamSynchronize(q);
-                                for (uint32_t i = 0; i < c->dev->comb->nlanes; i++) (void)hipStreamSynchronize(c->dev->comb->lane[i].st); }
-        }
-        if (r.enc) { memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key)); }
-        return rc;
-    }
+    r.fuse_stages = r.comp && !g_cfg.stages_separate;
+    const bool service = mode == 0 && r.comp;
+    const int rc = service ? run_compress(r) : run_batch_inner(r);
     // Whatever happened: nothing of this call is still in flight when it returns (the copies reference the caller's buffers), and
     // the data key does not stay behind in a context that may serve another segment next (the native side zeroises its
     // copy; the round keys and H powers are as good as the key).
+    if (service && r.fuse_stages) {
+        // nothing of the key was uploaded (every wave took and wiped its own copy of the schedule); what is left is the pinned original,
+        // and run_compress returns only when none of the batch's members can still be running
+        if (r.enc) { memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key)); }
+        if (rc != TSX_OK) (void)hipGetLastError();
+        return rc;
+    }
     if (r.enc) {
-        hipStreamSynchronize(c->st);                                      // (a wave may still be reading the pinned key schedule on an error path)
+        hipStreamSynchronize(c->st);
         for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
-        for (auto& q : c->st_pcf) if (q) hipStreamSynchronize(q);
-        if (c->st_fwd) hipStreamSynchronize(c->st_fwd);
         memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key));
-        if (!(mode == 0 && r.comp && r.fuse_stages)) {                    // lean batches uploaded nothing: every wave wiped its own copy of the schedule
-            if (getenv("TSX_GCM_SETUP_KERNEL")) hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);      // (the raw key only travels with the setup kernel)
-            hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st);                           // wiped by copies, not kernels
-        }
+        hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);                  // wiped by copies, not kernels; both, whichever
+        hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st);   // of them this batch wrote
     }
     hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
     if (c->st_out2) hipStreamSynchronize(c->st_out2);
     for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
-    for (auto& q : c->st_pcf) if (q) hipStreamSynchronize(q);
-    if (c->st_fwd) hipStreamSynchronize(c->st_fwd);
     if (rc != TSX_OK) (void)hipGetLastError();
     return rc;
 }
@@ -1406,18 +1523,13 @@ extern "C" int tsx_debug_key_residue(tsx_ctx* c) {
     if (hipMemcpy(h.data() + sizeof(tsx_gcm_key), c->d_keyraw, 128, hipMemcpyDeviceToHost) != hipSuccess) return TSX_E_DEVICE;
     int acc = 0;
     for (uint8_t b : h) acc |= b;
+    for (size_t i = 0; i < sizeof(tsx_gcm_key); i++) acc |= ((const uint8_t*)c->h_key)[i];
     return acc;
 }
 
-// Test hook (not part of the ABI): launches the device's combiner has made and the batches they carried.
-extern "C" int tsx_debug_combiner_stats(int device_index, uint64_t* groups, uint64_t* members) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL;
-    tsx_combiner* cb = g_devs[device_index].comb.get();
-    if (groups) *groups = cb ? cb->groups : 0;
-    if (members) *members = cb ? cb->members : 0;
-    return TSX_OK;
-}
+// Test hooks (not part of the ABI): members the context's last compressing batch went as; whether its waves wrote into the caller's buffer.
+extern "C" int tsx_debug_last_members(tsx_ctx* c) { return c ? (int)c->last_members : TSX_E_INVAL; }
+extern "C" int tsx_debug_last_zero_copy(tsx_ctx* c) { return c ? (int)c->last_zero_copy : TSX_E_INVAL; }
 
 // Test hook (not part of the ABI): how many of the first n chunks of the context's LAST detransform batch were decoded by the
 // block-parallel form (the rest went through the chunk-serial kernel); -1 when that batch did not use the form at all.
@@ -1450,26 +1562,34 @@ extern "C" int tsx_debug_blockmode_chunks(tsx_ctx* c, uint32_t n) {
 }
 
 // Pins a caller buffer that will be used for TSX_MEM_HOST / TSX_MEM_HOST_PACKED batches again and again (the JVM side registers its
-// per-thread direct ByteBuffers once): copies from / to it go by DMA and overlap fully instead of being staged by the runtime.
+// per-thread direct ByteBuffers once): copies from / to it go by DMA and overlap fully instead of being staged by the runtime, and
+// compressing batches write their output straight into it (zero-copy output: the registered extent is what the device may touch).
 // Portable: the pinning holds for every device of the node, whichever one the pool picks for a batch.
 extern "C" int tsx_host_register(void* p, size_t bytes) {
     if (!p || !bytes) return TSX_E_INVAL;
     { std::lock_guard<std::mutex> lk(g_mu); if (g_devs.empty()) return TSX_E_DEVICE; }
     hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
     if (e != hipSuccess) { tsx_set_err("hipHostRegister", e); (void)hipGetLastError(); return TSX_E_DEVICE; }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_registered.push_back({(uintptr_t)p, bytes});
     return TSX_OK;
 }
 extern "C" int tsx_host_unregister(void* p) {
     if (!p) return TSX_E_INVAL;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (size_t i = 0; i < g_registered.size(); i++) if (g_registered[i].first == (uintptr_t)p) { g_registered.erase(g_registered.begin() + (long)i); break; }
+    }
     hipError_t e = hipHostUnregister(p);
     if (e != hipSuccess) { tsx_set_err("hipHostUnregister", e); (void)hipGetLastError(); return TSX_E_DEVICE; }
     return TSX_OK;
 }
 
 // ---- device memory helpers -------------------------------------------------------------------------
-static int set_dev(int device_index) {
+static int set_dev(int device_index, tsx_device** dev = nullptr) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL;
+    if (dev) *dev = &g_devs[device_index];
     return hipSetDevice(g_devs[device_index].hip_id) == hipSuccess ? TSX_OK : TSX_E_DEVICE;
 }
 extern "C" int tsx_device_malloc(int device_index, size_t bytes, void** out) {
@@ -1480,8 +1600,10 @@ extern "C" int tsx_device_malloc(int device_index, size_t bytes, void** out) {
 }
 extern "C" int tsx_device_free(int device_index, void* p) {
     tsx_device_scope keep;
-    int rc = set_dev(device_index); if (rc) return rc;
-    return hipFree(p) == hipSuccess ? TSX_OK : TSX_E_DEVICE;
+    tsx_device* dev = nullptr;
+    int rc = set_dev(device_index, &dev); if (rc) return rc;
+    svc_free_dev(dev, p);                                               // (given back when the compressor service's kernel is gone: a free waits for every stream)
+    return TSX_OK;
 }
 extern "C" int tsx_memcpy_h2d(int device_index, void* d, const void* s, size_t bytes) {
     tsx_device_scope keep;

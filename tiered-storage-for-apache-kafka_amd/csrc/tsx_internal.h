@@ -69,17 +69,59 @@ struct tsx_chain_fuse {          // stages the compressor wave of chunk i runs i
                                  // before the GCM tail and wipes that copy afterwards (no upload, no device-side wipe: nothing but the launch)
 };
 
-struct tsx_zseg {                // one caller's batch inside a combined compressor launch (zstd_compress_kernel, tsx_api.hip's combiner)
-    uint32_t first, n;           // workgroups [first, first + n) of the launch work on this batch's chunks 0 .. n - 1
-    uint32_t profile, pad;
+struct tsx_zseg {                // one caller's batch ("member") in the device's compressor service queue (zstd_service_kernel, tsx_api.hip)
+    uint32_t n, profile;         // chunks 0 .. n - 1 of the batch; TSX_ZSTD_PROFILE_*
+    uint32_t gen, pad;           // generation of this member slot: a ticket that names an older generation is skipped (abandoned member)
     const uint8_t* src_base; tsx_chunk_desc* descs; uint8_t* mid; uint64_t mid_stride; uint32_t* zlen; int32_t* status; uint8_t* work;
     tsx_chain_fuse fuse;
-    // Per-member completion (the front end's launch combiner): a wave that has finished its chunk - frame, GCM tail, descriptor, all
-    // released to system scope - counts itself in *done; the one that completes the member's n resets the counter and raises *flag
-    // (pinned host memory), which is what the member's caller waits for.  A member does not wait for the other members of its launch.
+    // Per-member completion: a wave that has finished its chunk - frame, GCM tail, descriptor, all released to system scope - counts
+    // itself in *done (device memory); the one that completes the member's n resets the counter and raises *flag (pinned host memory),
+    // which is what the member's caller waits for.  A member does not wait for any other member.
     uint32_t* done; uint32_t* flag;
 };
-struct tsx_zfirsts { uint32_t first[64]; };   // .first of every segment, passed by value: a wave finds its segment without a memory access
+
+// ---- the compressor service: one device-wide work queue, persistent waves --------------------------------------------------------
+// Every compressing batch of a device - whichever thread or context it comes from - is a MEMBER of that device's queue: the host
+// appends one ticket per chunk (ticket -> member slot + chunk index) to a ring in pinned host memory and publishes the new end of the
+// ring; the waves of zstd_service_kernel take tickets one by one (a device-side counter), compress (+ checksum + encrypt) the chunk and
+// come back for the next.  One kernel per device is alive while there is work (it ends when the queue has been dry and no wave busy for
+// a moment; the host starts the next one with the next member), so nothing about hardware queues, launch order or batch boundaries
+// decides when a chunk starts: a freed wave takes the next chunk of whatever member is next.
+// Software CU reservation (mixed load): a wave that finds itself on a RESERVED compute unit (s_getreg HW_ID / XCC_ID against a bitmap the
+// host built from a probe launch at tsx_init) leaves before it takes a ticket.  Compressor waves hold every other wave slot and LDS
+// byte of the chip for as long as uploads go on - the reserved CUs are where a fetch's decoder kernels (2-8 waves, up to 19.5 KB of LDS
+// per workgroup) find room at once (ChunkCache.java:85-108 waits get.timeout.ms for them).
+#define TSX_SVC_MEMBERS 512u          /* member slots */
+#define TSX_SVC_TICKETS 65536u        /* ticket ring (power of two): chunks published and not yet completed never exceed it */
+#define TSX_SVC_MEMBER_MAX 16384u     /* chunks per member (a larger batch goes as several members) */
+struct tsx_svc_ticket { uint32_t member_gen; uint32_t chunk; };   // member slot in the low 16 bits, the slot's generation (16 bits) above
+struct tsx_svc_host {                // pinned host memory, written by the host, read by the device (through its device alias)
+    uint32_t published;              // tickets [.., published) are valid; release-stored after their records and member entries
+    uint32_t stop;                   // != 0: waves leave after their current chunk (shutdown / pause for memory management)
+    uint32_t pad_[14];
+    tsx_zseg member[TSX_SVC_MEMBERS];
+    tsx_svc_ticket ticket[TSX_SVC_TICKETS];
+};
+struct tsx_svc_dev {                 // device memory: the waves' shared state
+    uint32_t next;                   // next ticket to hand out (wrap-safe comparisons against pub)
+    uint32_t pub;                    // device mirror of tsx_svc_host.published (an elected idle wave refreshes it)
+    uint32_t busy;                   // waves that hold a ticket
+    uint32_t poll_stamp;             // low 32 bits of the 100 MHz clock at the last host poll
+    uint32_t stop;                   // mirror of tsx_svc_host.stop
+    uint32_t gen_start_lo, gen_start_hi, gen_started;   // clock at the first wave of this launch (generation age)
+    uint32_t stat_chunks, stat_wave_starts, stat_reserved_exits, stat_skipped;
+    uint32_t pad_[4];
+    uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
+    uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
+};
+struct tsx_svc_launch {              // kernel arguments that shape a launch
+    uint32_t sched;                  // parser speculation schedule (0 = default)
+    uint32_t poll_ticks;             // 100 MHz ticks between two host polls (device-wide)
+    uint32_t idle_exit_ticks;        // a wave leaves when the queue has been dry and no wave busy for this long
+    uint32_t max_age_ticks_lo, max_age_ticks_hi;   // != 0: waves stop taking tickets when the launch is older (the host starts the next one)
+};
+void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, uint32_t grid, tsx_svc_launch a);
+void tsx_launch_cu_probe(hipStream_t st, tsx_svc_dev* d, uint32_t grid);
 
 struct tsx_gcm_chunk {           // per-chunk work item (device)
     uint64_t in_off;             // plaintext (encrypt) / IV||C||TAG (decrypt) offset within `in`

@@ -1493,10 +1493,23 @@ __device__ static bool wave_is_rle(const uint8_t* __restrict__ p, uint32_t n, ui
 __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ descs, uint32_t chunk, const uint8_t* frame, uint32_t flen,
                                     uint32_t* __restrict__ zlen, int32_t* __restrict__ status, const tsx_chain_fuse fuse, uint8_t* keyLocal, EncLds& L, uint32_t lane) {
     if (lane == 0) zlen[chunk] = flen;
-    if (!fuse.key) return;
+    if (!fuse.key && !fuse.out) return;                                 // the frame stays in the staging buffer (stages as separate launches)
     __threadfence_block();
     __syncthreads();
     const uint64_t dstOff = descs[chunk].dst_off;
+    if (!fuse.key) {
+        // compression without encryption: the frame goes to the caller's slot as it is (16 bytes per lane: slots are 16-byte aligned)
+        if (flen > descs[chunk].dst_cap) {
+            if (lane == 0) { status[chunk] = TSX_E_DST_TOO_SMALL; descs[chunk].dst_len = 0; if (fuse.self_status) descs[chunk].status = TSX_E_DST_TOO_SMALL; }
+            return;
+        }
+        uint8_t* const o = fuse.out + dstOff;
+        const uint32_t q = flen >> 4;
+        for (uint32_t i = lane; i < q; i += LANES) reinterpret_cast<uint4*>(o)[i] = reinterpret_cast<const uint4*>(frame)[i];
+        for (uint32_t i = (q << 4) + lane; i < flen; i += LANES) o[i] = frame[i];
+        if (lane == 0) { descs[chunk].dst_len = flen; if (fuse.self_status) descs[chunk].status = TSX_OK; }
+        return;
+    }
     if ((uint64_t)flen + 28 > descs[chunk].dst_cap) {
         if (lane == 0) { status[chunk] = TSX_E_DST_TOO_SMALL; descs[chunk].dst_len = 0; if (fuse.self_status) descs[chunk].status = TSX_E_DST_TOO_SMALL; }
         return;
@@ -1524,35 +1537,17 @@ __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ des
     if (lane == 0) { descs[chunk].dst_len = flen + 28; if (fuse.self_status) descs[chunk].status = TSX_OK; }
 }
 
-static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
-// SEG = false: one batch, the kernel arguments themselves (the body is exactly the single-batch kernel: the segment lookup folds away
-// and the arguments stay reloadable kernel arguments instead of live registers).  SEG = true: one launch carries the batches of
-// several callers (tsx_api.hip, the launch combiner): workgroup b belongs to the segment whose range holds b and works on that
-// caller's buffers, key and profile.
-template <bool SEG>
-__device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restrict__ src_base_, tsx_chunk_desc* __restrict__ descs_,
-                                                              uint8_t* __restrict__ mid_, uint64_t mid_stride_, uint32_t* __restrict__ zlen_,
-                                                              int32_t* __restrict__ status_, uint8_t* __restrict__ work_, uint32_t profile_, uint32_t sched,
-                                                              const tsx_chain_fuse fuse_, const tsx_zseg* __restrict__ segs, const tsx_zfirsts& firsts, uint32_t nsegs
+// One chunk, start to finish, in the calling wave: CRC32C head, frame, GCM tail (or the copy into the caller's slot), descriptor.
+// Every argument is the same in all lanes (the service kernel hands them over in SGPRs).
+__device__ __forceinline__ static void zstd_compress_chunk(EncLds& L, const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
+                                                           uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
+                                                           int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
+                                                           const tsx_chain_fuse fuse, const uint32_t chunk
 #ifdef TSX_PROF
-                                                              , unsigned long long* __restrict__ prof_out
+                                                           , unsigned long long* __restrict__ prof_out
 #endif
-                                                              ) {
-    __shared__ EncLds L;
+                                                           ) {
     const uint32_t lane = threadIdx.x;
-    uint32_t chunk = blockIdx.x;
-    const uint8_t* __restrict__ src_base = src_base_; tsx_chunk_desc* __restrict__ descs = descs_; uint8_t* __restrict__ mid = mid_;
-    uint64_t mid_stride = mid_stride_; uint32_t* __restrict__ zlen = zlen_; int32_t* __restrict__ status = status_; uint8_t* __restrict__ work = work_;
-    uint32_t profile = profile_; tsx_chain_fuse fuse = fuse_;
-    if (SEG) {
-        uint32_t k = 0;                                                  // .first values come with the kernel arguments: no memory access to find the segment
-#pragma unroll
-        for (uint32_t i = 1; i < 64; i++) if (i < nsegs && firsts.first[i] <= blockIdx.x) k = i;
-        const tsx_zseg sg = segs[k];                                     // (the table itself may sit in pinned host memory: ONE entry is read)
-        chunk = blockIdx.x - sg.first;
-        src_base = sg.src_base; descs = sg.descs; mid = sg.mid; mid_stride = sg.mid_stride; zlen = sg.zlen; status = sg.status; work = sg.work;
-        profile = sg.profile; fuse = sg.fuse;
-    }
 #ifdef TSX_PROF
     if (lane == 0) { for (int i = 0; i < 24; i++) g_prof[i] = 0; g_prof[22] = g_prof[23] = (unsigned long long)clock64(); }
     __syncthreads();
@@ -1572,7 +1567,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
         const uint32_t crc = crc32c_wave(fuse.crc, src, srcSize, L.crcTab, lane);
         if (lane == 0) descs[chunk].crc32c = crc;
     }
-    if (fuse.self_status) { if (lane == 0) status[chunk] = TSX_OK; }    // (only with fuse.key: finish_frame publishes)
+    if (fuse.self_status) { if (lane == 0) status[chunk] = TSX_OK; }    // (finish_frame publishes the chunk's final status in its descriptor)
     else if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } return; }
 
     const zs_cparams cp = zs_level3_cparams(srcSize);
@@ -1690,6 +1685,7 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
 #endif
 }
 
+
 #ifdef TSX_PROF
 #define ZS_PROF_PARAM , unsigned long long* __restrict__ prof_out
 #define ZS_PROF_ARG , prof_out
@@ -1697,43 +1693,154 @@ __device__ __forceinline__ static void zstd_compress_body(const uint8_t* __restr
 #define ZS_PROF_PARAM
 #define ZS_PROF_ARG
 #endif
-__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_kernel(const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
-                                                              uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
-                                                              int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
-                                                              const tsx_chain_fuse fuse ZS_PROF_PARAM) {
-    const tsx_zfirsts nofirsts{};
-    zstd_compress_body<false>(src_base, descs, mid, mid_stride, zlen, status, work, profile, sched, fuse, nullptr, nofirsts, 0u ZS_PROF_ARG);
+
+// ---------------------------------------------------------------------------------------------------
+// the compressor service (tsx_internal.h: tsx_svc_host / tsx_svc_dev): persistent waves, one device-wide ticket queue
+// ---------------------------------------------------------------------------------------------------
+// Words the host (or another wave) rewrites while this kernel lives are never read through a cache: member slots and ticket
+// records are reused, and a persistent wave gets no kernel-boundary invalidate.
+#ifdef HIPEMU
+#define SVC_LD_SYS(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define SVC_LD_DEV(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define SVC_ST_DEV(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define SVC_ST_SYS(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+__device__ static inline uint64_t svc_now() { return hipemu_clock_100mhz(); }
+__device__ static inline uint32_t svc_cu_key() { return hipemu_cu_key(); }
+__device__ static inline void svc_nap(uint32_t) {}
+__device__ static inline void svc_acquire_chunk() {}
+__device__ static inline void svc_release_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }   // (the harness's __threadfence_system is a wave rendezvous: lane 0 is alone here)
+#else
+#define SVC_LD_SYS(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define SVC_LD_DEV(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SVC_ST_DEV(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SVC_ST_SYS(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM)
+__device__ static inline uint64_t svc_now() { return wall_clock64(); }                       // 100 MHz, the same on every CU
+// Which compute unit is this wave on?  HW_ID[15:8] = CU_ID | SH_ID | SE_ID, XCC_ID[3:0] = the XCD: a 12-bit key, unique per CU
+// (tsx_launch_cu_probe counts the keys of a launch that covers the chip; the front end checks the count against the CU count).
+__device__ static inline uint32_t svc_cu_key() {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);              // hwreg(HW_REG_HW_ID, 0, 32)
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);             // hwreg(HW_REG_XCC_ID, 0, 4)
+    return ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
 }
-__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_compress_segments_kernel(const tsx_zseg* __restrict__ segs, const tsx_zfirsts firsts, uint32_t nsegs,
-                                                                                          uint32_t sched ZS_PROF_PARAM) {
-    const tsx_chain_fuse none{nullptr, nullptr, nullptr, nullptr, 0, 0};
-    zstd_compress_body<true>(nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0u, sched, none, segs, firsts, nsegs ZS_PROF_ARG);
-    // ---- this chunk is done: tell its member's caller when it was the member's last one (tsx_zseg.done / .flag) ----
-    // The kernel goes on for the other members of the launch, so nothing here may rely on the end-of-kernel release: every lane's stores
-    // (ciphertext in device memory, which the caller's copy engine reads next; descriptor in pinned host memory) are complete at the
-    // barrier, lane 0 releases them to system scope (L2 write-back), and only then counts the chunk.
-    uint32_t k = 0;
-#pragma unroll
-    for (uint32_t i = 1; i < 64; i++) if (i < nsegs && firsts.first[i] <= blockIdx.x) k = i;
-    uint32_t* const done = segs[k].done;
-    if (done) {
+__device__ static inline void svc_nap(uint32_t n) { for (uint32_t i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127); }     // ~3.5 us each
+// What this wave reads next (a source chunk the copy engine has just written, descriptors the host has just rewritten) must not come
+// from this CU's vector L1 or the scalar cache: both survive from the wave's previous chunk.
+__device__ static inline void svc_acquire_chunk() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ static inline void svc_release_system() { __threadfence_system(); }
+#endif
+static_assert(sizeof(tsx_zseg) == 128 && offsetof(tsx_zseg, src_base) == 16 && offsetof(tsx_zseg, fuse) == 72 && offsetof(tsx_zseg, done) == 112,
+              "zstd_service_kernel reads a member entry as 16 eight-byte words, one per lane");
+static_assert(sizeof(tsx_chain_fuse) == 40 && offsetof(tsx_chain_fuse, self_status) == 32, "layout of the fuse words");
+
+__device__ static inline uint64_t svc_word(uint64_t w, int k) {            // word k of the member entry (lane k holds it), in every lane
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, k), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), k);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Lane 0 of an idle wave: the next ticket (1), or leave (2).  A wave leaves when the device is told to stop, when its launch has
+// reached its age limit, or when the queue has been dry AND no wave has held a ticket for idle_exit_ticks - as long as anyone is
+// still compressing, the idle waves stay (napping): the next member finds the whole supply of waves, not the stragglers' kernel.
+__device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a, const uint64_t t_start, uint32_t* ticket) {
+    const uint64_t max_age = ((uint64_t)a.max_age_ticks_hi << 32) | a.max_age_ticks_lo;
+    uint64_t quiet_since = 0;
+    uint32_t nap = 1;
+    for (;;) {
+        const uint64_t now = svc_now();
+        if (SVC_LD_DEV(&D->stop)) return 2;
+        if (max_age && now - t_start > max_age) return 2;
+        const uint32_t nx = SVC_LD_DEV(&D->next), pb = SVC_LD_DEV(&D->pub);
+        if ((int32_t)(pb - nx) > 0) {
+            atomicAdd(&D->busy, 1u);                                     // before the ticket is taken: busy >= waves that hold one
+            if (atomicCAS(&D->next, nx, nx + 1u) == nx) { *ticket = nx; return 1; }
+            atomicSub(&D->busy, 1u);
+            continue;
+        }
+        // dry, as far as the mirror knows: one wave per poll_ticks asks the host
+        const uint32_t ps = SVC_LD_DEV(&D->poll_stamp);
+        if ((uint32_t)now - ps >= a.poll_ticks && atomicCAS(&D->poll_stamp, ps, (uint32_t)now) == ps) {
+            const uint32_t p = SVC_LD_SYS(&H->published);
+            if (SVC_LD_SYS(&H->stop)) SVC_ST_DEV(&D->stop, 1u);
+            uint32_t old = SVC_LD_DEV(&D->pub);
+            while ((int32_t)(p - old) > 0) { const uint32_t prev = atomicCAS(&D->pub, old, p); if (prev == old) break; old = prev; }
+            if ((int32_t)(p - nx) > 0) continue;
+        }
+        if (SVC_LD_DEV(&D->busy) != 0 || quiet_since == 0) quiet_since = now;
+        if (now - quiet_since >= a.idle_exit_ticks && SVC_LD_DEV(&D->busy) == 0) return 2;
+        svc_nap(nap);
+        if (nap < 64) nap *= 2;
+    }
+}
+
+static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
+__global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a ZS_PROF_PARAM) {
+    __shared__ EncLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t key = UNI(svc_cu_key());
+    if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h)
+        if (lane == 0) atomicAdd(&D->stat_reserved_exits, 1u);
+        return;
+    }
+    if (lane == 0) atomicAdd(&D->stat_wave_starts, 1u);
+    const uint64_t t_start = svc_now();
+    for (;;) {
+        uint32_t got = 0, ticket = 0;
+        if (lane == 0) got = svc_take(H, D, a, t_start, &ticket);
+        got = UNI(got); ticket = UNI(ticket);
+        if (got != 1) break;
+        svc_acquire_chunk();
+        // the ticket's record and its member's entry, straight from host memory
+        uint32_t mg = 0, chunk = 0;
+        if (lane == 0) { const tsx_svc_ticket* t = &H->ticket[ticket & (TSX_SVC_TICKETS - 1)]; mg = SVC_LD_SYS(&t->member_gen); chunk = SVC_LD_SYS(&t->chunk); }
+        mg = UNI(mg); chunk = UNI(chunk);
+        const uint32_t slot = mg & 0xFFFFu;
+        uint64_t w = 0;
+        if (lane < 16 && slot < TSX_SVC_MEMBERS) w = SVC_LD_SYS(reinterpret_cast<const uint64_t*>(&H->member[slot]) + lane);
+        const uint64_t w0 = svc_word(w, 0), w1 = svc_word(w, 1);
+        const uint32_t n = (uint32_t)w0, profile = (uint32_t)(w0 >> 32), gen = (uint32_t)w1;
+        if (slot >= TSX_SVC_MEMBERS || (gen & 0xFFFFu) != (mg >> 16) || chunk >= n) {          // an abandoned member's ticket
+            if (lane == 0) { atomicAdd(&D->stat_skipped, 1u); atomicSub(&D->busy, 1u); }
+            continue;
+        }
+        tsx_chain_fuse fuse;
+        fuse.crc = (const tsx_crc_tables*)svc_word(w, 9); fuse.aes = (const tsx_aes_tables*)svc_word(w, 10);
+        fuse.key = (const tsx_gcm_key*)svc_word(w, 11); fuse.out = (uint8_t*)svc_word(w, 12);
+        { const uint64_t f = svc_word(w, 13); fuse.self_status = (uint32_t)f; fuse.key_on_host = (uint32_t)(f >> 32); }
+        uint32_t* const done = (uint32_t*)svc_word(w, 14); uint32_t* const flag = (uint32_t*)svc_word(w, 15);
+        zstd_compress_chunk(L, (const uint8_t*)svc_word(w, 2), (tsx_chunk_desc*)svc_word(w, 3), (uint8_t*)svc_word(w, 4), svc_word(w, 5),
+                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk ZS_PROF_ARG);
+        // ---- this chunk is done: tell its member's caller when it was the member's last one ----
+        // The kernel goes on, so nothing here may rely on an end-of-kernel release: every lane's stores (ciphertext in device memory, which
+        // the caller's copy engine reads next, or in the caller's registered buffer; descriptor in pinned host memory) are complete at the
+        // barrier, lane 0 releases them to system scope, and only then counts the chunk.
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence_system();
-            const uint32_t n = segs[k].n;
+        if (lane == 0) {
+            svc_release_system();
+            atomicAdd(&D->stat_chunks, 1u);
             if (atomicAdd(done, 1u) + 1u == n) {
-                atomicExch(done, 0u);                                    // ready for the context's next batch (ordered before it by the flag)
-                __threadfence_system();
+                atomicExch(done, 0u);                                    // ready for the context's next member (ordered before it by the flag)
+                svc_release_system();
                 // a plain system-scope store, not an atomic read-modify-write: the flag lives in HOST memory, and an atomic there would need
                 // PCIe AtomicOps routed all the way to the root complex - not every server does that
-#ifdef HIPEMU
-                *(volatile uint32_t*)segs[k].flag = 1u;
-#else
-                __hip_atomic_store(segs[k].flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
+                SVC_ST_SYS(flag, 1u);
             }
+            atomicSub(&D->busy, 1u);
         }
+        __syncthreads();
     }
+}
+
+// A launch that covers the chip (48 KiB of LDS per one-wave workgroup: three per CU) and notes every CU key it meets.
+__global__ __launch_bounds__(LANES) void cu_probe_kernel(tsx_svc_dev* D) {
+    __shared__ uint32_t big[12288];
+    big[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    const uint32_t key = UNI(svc_cu_key());
+    if (threadIdx.x == 0) atomicOr(&D->seen[key >> 5], 1u << (key & 31));
+    const uint64_t t0 = svc_now();
+    while (svc_now() - t0 < 3000u && big[(threadIdx.x * 7u) & 63u] != 0xFFFFFFFFu) svc_nap(1);   // ~30 us: later workgroups must go elsewhere
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1743,28 +1850,14 @@ size_t tsx_zstd_consts_bytes(void) { return sizeof(tsx_zstd_consts); }
 void tsx_zstd_build_consts(tsx_zstd_consts* h) { h->abi = 1; h->pad[0] = h->pad[1] = h->pad[2] = 0; }
 size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t /*max_len*/) { return (size_t)n * ZS_WS_BYTES; }
 
-// Several callers' batches in one launch: d_segs[0 .. nsegs) (device memory, ascending .first, segment k = workgroups [first, first + n)).
-uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, const tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched) {
-    if (!total_chunks || !nsegs || nsegs > 64) return 0;
-    tsx_zfirsts f{};
-    for (uint32_t k = 0; k < nsegs; k++) f.first[k] = h_segs[k].first;
-    hipLaunchKernelGGL(zstd_compress_segments_kernel, dim3(total_chunks), dim3(LANES), 0, st, d_segs, f, nsegs, sched
+void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, uint32_t grid, tsx_svc_launch a) {
+    if (!grid) return;
+    hipLaunchKernelGGL(zstd_service_kernel, dim3(grid), dim3(LANES), 0, st, hd, d, a
 #ifdef TSX_PROF
                        , g_prof_out
 #endif
                        );
-    return 1;
 }
-
-uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* src, tsx_chunk_desc* d_descs, uint32_t n,
-                                  uint32_t /*max_len*/, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status, void* d_work,
-                                  uint32_t profile, uint32_t sched, tsx_chain_fuse fuse) {
-    if (!n) return 0;
-    hipLaunchKernelGGL(zstd_compress_kernel, dim3(n), dim3(LANES), 0, st, src, d_descs, mid, (uint64_t)mid_stride, d_zlen, d_status,
-                       (uint8_t*)d_work, profile, sched, fuse
-#ifdef TSX_PROF
-                       , g_prof_out
-#endif
-                       );
-    return 1;
+void tsx_launch_cu_probe(hipStream_t st, tsx_svc_dev* d, uint32_t grid) {
+    if (grid) hipLaunchKernelGGL(cu_probe_kernel, dim3(grid), dim3(LANES), 0, st, d);
 }

@@ -7,18 +7,12 @@ size_t tsx_zstd_consts_bytes(void);
 void tsx_zstd_build_consts(tsx_zstd_consts* host_out);
 // Device workspace needed for a batch of n chunks of at most max_len bytes (compress or decompress).
 size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t max_len);
-// One Zstd frame per chunk (CompressionChunkEnumeration.java:50-63): chunk i = src + descs[i].src_off,
-// frame i written at mid + i * mid_stride, its size to zlen[i].  With fuse.crc set the wave first
-// stores the CRC32C of its source chunk in descs[i].crc32c; with fuse.key set, the wave that wrote frame i also encrypts it
-// (EncryptionChunkEnumeration.java:66-84) to fuse.out + descs[i].dst_off and sets descs[i].dst_len (0 and
-// TSX_E_DST_TOO_SMALL in d_status when the slot is too small).  Returns the number of kernel launches.
-uint32_t tsx_launch_zstd_compress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* src, tsx_chunk_desc* d_descs,
-                                  uint32_t n, uint32_t max_len, uint8_t* mid, size_t mid_stride, uint32_t* d_zlen, int32_t* d_status,
-                                  void* d_work, uint32_t profile, uint32_t sched /* 0 lean, 1 wide speculation: zstd_enc.hip */, tsx_chain_fuse fuse);
-// Several callers' batches in ONE launch (the front end's launch combiner): segment k of the table covers workgroups [first, first + n)
-// and names that caller's buffers, key and profile.  d_segs: the table as the DEVICE reads it (device memory, or the device alias of
-// pinned host memory - a wave reads one entry); h_segs: the same table as the host reads it (its .first values travel as kernel arguments).
-uint32_t tsx_launch_zstd_compress_segments(hipStream_t st, const tsx_zseg* d_segs, const tsx_zseg* h_segs, uint32_t nsegs, uint32_t total_chunks, uint32_t sched);
+// One Zstd frame per chunk (CompressionChunkEnumeration.java:50-63) is the work of the device's compressor service
+// (tsx_internal.h: tsx_zseg, tsx_launch_zstd_service): chunk i of a member = src_base + descs[i].src_off, frame i written at
+// mid + i * mid_stride, its size to zlen[i].  With fuse.crc set the wave first stores the CRC32C of its source chunk in
+// descs[i].crc32c; with fuse.key set, the wave that wrote frame i also encrypts it (EncryptionChunkEnumeration.java:66-84) to
+// fuse.out + descs[i].dst_off and sets descs[i].dst_len (0 and TSX_E_DST_TOO_SMALL when the slot is too small); with fuse.out but
+// no key the frame itself goes to the slot.
 // Inverse (DecompressionChunkEnumeration.java:39-46): frame i at (from_mid ? frames + i*mid_stride :
 // frames + descs[i].src_off), length descs[i].src_len - (from_mid ? 28 : 0); output to dst + descs[i].dst_off,
 // descs[i].dst_len set; status TSX_E_BAD_SIZE / TSX_E_BAD_FRAME / TSX_E_DST_TOO_SMALL on failure.
