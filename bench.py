@@ -77,6 +77,11 @@ def parse():
                          "size all-gather and a point-to-point loop-back) even with ONE rank: RCCL on a single GPU (tests/test_gpu_parity.py)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process group of the N > 1 barrier / max-over-ranks (gloo: CPU rehearsal)")
     ap.add_argument("--no-inverse", action="store_true", help="skip the detransform (fetch side) measurement after the timed region")
+    ap.add_argument("--no-mixed-load", action="store_true", help="skip the mixed-load leg (fetch latency while the timed region's callers keep the chip full)")
+    ap.add_argument("--mixed-load-seconds", type=float, default=8.0)
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[1] / configs[2] legs (CRC32C only; AES-256-GCM + CRC32C on one 1 GiB segment)")
+    ap.add_argument("--settle-seconds", type=float, default=10.0,
+                    help="idle time between the broker-shaped children (which saturate the chip for ~100 s) and this process's own measurement")
     return ap.parse_args()
 
 
@@ -180,6 +185,7 @@ def main():
     if (rank == 0 and world == 1 and not args.rehearse and args.workload in ("auto", "full") and not args.no_broker and not args.no_end_to_end
             and not args.broker_inprocess and args.inflight > 1 and args.steps > 1 and not args.split_segments):
         broker_first = broker_leg_first(args)
+        time.sleep(max(0.0, args.settle_seconds))                        # the children kept the chip saturated: let it idle before the timed region
     import torch  # before libtsxform: one shared HIP runtime
     import torch.distributed as dist
     rehearse = args.rehearse
@@ -338,6 +344,11 @@ def main():
                 stage["crc"] += tm.crc_ms; stage["zstd"] += tm.zstd_ms; stage["gcm"] += tm.gcm_ms
                 launches["crc"] += 1; launches["zstd"] += 1; launches["gcm"] += 1
 
+    # the compressor service's kernel of the warm-up is gone before the clock starts: the launches counted below are the timed region's
+    svc0 = None
+    if flags & nat.COMPRESS:
+        N.service_quiesce(0)
+        svc0 = N.service_stats(0)
     t0 = time.perf_counter()
     if T == 1:
         worker(0)
@@ -347,6 +358,12 @@ def main():
         [x.join() for x in th]
     fence()
     elapsed = time.perf_counter() - t0
+    svc = None
+    if svc0 is not None:
+        N.service_quiesce(0)
+        svc1 = N.service_stats(0)
+        svc = {k: svc1[k] - svc0[k] for k in ("launches", "watchdog_launches", "members", "chunks", "kernel_ms", "device_chunks", "wave_starts", "reserved_exits")}
+        svc.update({k: svc1[k] for k in ("waves", "compute_units", "cu_keys_seen", "reserved_cus")})
     for t in range(1, T):
         assert (ds[t]["status"] == 0).all() and (ds[t]["dst_len"] == d["dst_len"]).all() and (ds[t]["crc32c"] == d["crc32c"]).all()
     # for the record (outside the timed region): the same batch strictly one at a time
@@ -401,6 +418,61 @@ def main():
         for c in xctx:
             N.ctx_destroy(c)
         del xdst, sdst
+    # ---- mixed load (outside the timed region): what a consumer's fetch costs while uploads keep the chip full -----------------------
+    # A broker tiers and serves from the same GPU: fetchLogSegment -> ChunkCache.java:85-108 waits get.timeout.ms (10 s) for a chunk.  The
+    # timed region's callers go on submitting their batches (more chunks queued than the chip holds) while this thread restores 1 and 4
+    # chunks host -> host through a context of its own.  The compressor service leaves `reserved_cus` compute units alone for exactly this.
+    mixed = None
+    if rank == 0 and world == 1 and workload == "full" and T > 1 and not split and not args.no_mixed_load and not rehearse and n >= 4:
+        try:
+            hfr = dst[:4 * slot].cpu().numpy(); hbk = np.zeros(4 * CH, np.uint8)
+            N.host_register(hfr); N.host_register(hbk)
+            fctx = N.ctx_create(0, 4, CH)
+            want4 = src[:4 * CH].cpu().numpy()
+
+            def fetch(k):
+                e_ = np.zeros(k, nat.DESC_DTYPE); e_["src_off"] = d["dst_off"][:k]; e_["src_len"] = d["dst_len"][:k]; e_["iv"] = d["iv"][:k]
+                e_["dst_off"] = np.arange(k, dtype=np.uint64) * CH; e_["dst_cap"] = CH
+                t1 = time.perf_counter()
+                N.detransform_batch(params, e_, hfr, hbk, hbk.size, nat.MEM_HOST, ctx=fctx)
+                dt_ = time.perf_counter() - t1
+                assert (e_["status"] == 0).all()
+                return dt_ * 1e3
+
+            for k_ in (1, 4):
+                fetch(k_)
+            idle_ms = {k_: round(float(np.median([fetch(k_) for _ in range(7)])), 3) for k_ in (1, 4)}
+            stop = [False]
+            done = [0] * T
+
+            def loader(t):
+                while not stop[0]:
+                    step(t)
+                    done[t] += 1
+
+            th = [threading.Thread(target=loader, args=(t,)) for t in range(T)]
+            tm0 = time.perf_counter()
+            [x.start() for x in th]
+            time.sleep(2.0)                                              # the chip is full
+            lat = {1: [], 4: []}
+            while time.perf_counter() - tm0 < 2.0 + args.mixed_load_seconds:
+                for k_ in (1, 4):
+                    lat[k_].append(fetch(k_))
+                time.sleep(0.03)
+            stop[0] = True
+            [x.join() for x in th]
+            el_ = time.perf_counter() - tm0
+            exact = bool(np.array_equal(hbk, want4))
+            N.host_unregister(hfr); N.host_unregister(hbk); N.ctx_destroy(fctx)
+            mixed = {"metric": "latency of a fetch (tsx_detransform_batch of 1 / 4 chunks, host -> host, own context) while %d callers keep %d compressor chunks queued" % (T, T * n),
+                     "reserved_cus": None if svc is None else svc["reserved_cus"], "compress_callers": T, "chunks_offered": T * n,
+                     "compress_gibs_while_fetching": round(sum(done) * float(n) * CH / GiB / el_, 3),
+                     "fetch_idle_ms": {str(k_): v for k_, v in idle_ms.items()}, "restored_bytes_exact": exact, "unit": "ms"}
+            for k_ in (1, 4):
+                a_ = np.asarray(lat[k_])
+                mixed["fetch_%d_under_load_ms" % k_] = {"n": int(a_.size), "p50": round(float(np.median(a_)), 2), "p95": round(float(np.percentile(a_, 95)), 2), "max": round(float(a_.max()), 2)}
+        except (nat.TsxError, AssertionError) as ex:                     # reported, never fatal for the line
+            mixed = {"error": repr(ex)[:300]}
     # the timed region's extra callers are done: their workspaces (12.7 GiB each) and output buffers (8.5 GiB each) go back before the
     # legs below allocate their own (pooled contexts of the broker leg, host staging buffers)
     for c_ in ctxs[1:]:
@@ -523,6 +595,16 @@ def main():
         # the whole chain of a chunk runs in its compressor wave (CRC head, GCM tail): N bytes read, the transformed chunk
         # (frame, + IV and tag when encrypting) written
         alg = n * (CH + mean_out)
+    launches_meta = None
+    if dom == "zstd" and svc is not None and svc["launches"] > 0 and svc["kernel_ms"] > 0:
+        # the compressor is ONE persistent kernel per device (csrc/tsx_internal.h): a launch does as many chunks as were queued while it
+        # lived.  Per launch: the timed region's chunks / its launches, against the launches' average duration - HIP events on the service's
+        # own stream, read through tsx_service_stats (the same launches rocprofv3 --kernel-trace sees as zstd_service_kernel).
+        cpl = float(svc["chunks"]) / svc["launches"]
+        ms = svc["kernel_ms"] / svc["launches"]
+        alg = cpl * (CH + mean_out)
+        launches_meta = {"launches_in_timed_region": int(svc["launches"]), "chunks_per_launch": round(cpl, 1), "started_by_watchdog": int(svc["watchdog_launches"]),
+                         "waves_per_launch": int(svc["waves"]), "reserved_cus": int(svc["reserved_cus"]), "compute_units": int(svc["compute_units"]), "cu_keys_seen": int(svc["cu_keys_seen"])}
     achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_zstd.sh -> profiles/pmc_traffic.json:
     # FETCH_SIZE + WRITE_SIZE of the same kernel build and workload); null when no such measurement is recorded
@@ -531,24 +613,29 @@ def main():
     rec, fresh = pmc_record("%s/%s/%d" % (workload, args.dist, n))
     if rec and fresh:
         traffic = rec["hbm_bytes_per_launch"]
+        scale = 1.0
+        if dom == "zstd" and launches_meta is not None and rec.get("chunks"):
+            scale = launches_meta["chunks_per_launch"] / float(rec["chunks"])      # the PMC pass was one launch of rec["chunks"] chunks
+            traffic = int(traffic * scale)
         if dom == "zstd" and "tcc_ea_rdreq" in rec:
             # The resource that actually binds the hash-table parser: 64-B lines moved between L2 and memory at random addresses (one
             # per 4-byte table probe / insertion).  Requests per launch from the committed PMC passes (TCC_EA0_RDREQ + WRREQ), rate over
             # the whole timed region (all launches, as they overlapped).  The ceiling is what the chip sustains for the same mix with
             # waves that do nothing else (tools/ubench/mix.hip): 36-46 G lines/s by box and run - a band, so this is a diagnosis,
             # not a roofline; the roofline above is the contract's (HBM streaming peak).
-            req = float(rec["tcc_ea_rdreq"] + rec["tcc_ea_wrreq"])
-            rate = req * args.steps / elapsed / 1e9
+            req = float(rec["tcc_ea_rdreq"] + rec["tcc_ea_wrreq"]) * scale
+            rate = req * (svc["launches"] if launches_meta is not None else args.steps) / elapsed / 1e9
             binding = {"resource": "random 64-B line accesses L2<->HBM (table probes + insertions)", "requests_per_launch": int(req),
                        "requests_per_sequence": rec.get("requests_per_sequence"),
                        "achieved": round(rate, 2), "peak_band": [36.0, 46.0], "unit": "G lines/s", "frac_band": [round(rate / 46.0, 3), round(rate / 36.0, 3)],
                        "peak_source": "profiles/r02_ubench_mix_same_box_as_pmc.txt, r02_ubench_mix4_placement.txt (waves that do nothing else, 58/42 read / write-back mix)"}
-    roofline = {"bound": "hbm", "kernel": {"crc": "crc32c_partial_kernel", "gcm": "gcm_ctr_ghash_kernel", "zstd": "zstd_compress_kernel"}[dom],
+    roofline = {"bound": "hbm", "kernel": {"crc": "crc32c_partial_kernel", "gcm": "gcm_ctr_ghash_kernel", "zstd": "zstd_service_kernel"}[dom],
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "traffic_source": None if not rec else (rec.get("source") if fresh else "STALE: %s was measured on another build of the kernel - rerun tools/pmc_zstd.sh + tools/pmc_traffic.py" % rec.get("source")),
                 "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
-                "launches_in_flight": T, "achieved_aggregate": round(achieved * T, 2),
+                "launches_in_flight": 1 if launches_meta is not None else T, "achieved_aggregate": round(achieved * (1 if launches_meta is not None else T), 2),
+                "service": launches_meta, "callers": T,
                 "stage_ms_per_step": {k: round(v / args.steps, 4) for k, v in stage.items()}, "binding_resource": binding}
 
     # ---- CPU baseline: the oracle port (libzstd + OpenSSL GCM + CRC32C) on 1, 10 and all usable host cores, bounded samples ---------
@@ -774,6 +861,73 @@ def main():
                "value": max([r["gibs"] for r in rows] + [c_["gibs"] for c_ in (conc or [])] + [b_["gibs"] for b_ in (broker or []) if "gibs" in b_]) if rows else None, "unit": "GiB/s"}
         del hsrc, hdst
 
+    # ---- BASELINE configs[1] and configs[2] on one 1 GiB segment (never `value`): CRC32C only; AES-256-GCM + CRC32C - what a broker runs
+    # whenever the producers compress (RemoteStorageManager.java:381-398 leaves Zstd out then, EncryptionChunkEnumeration.java:66-84) ----
+    configs = None
+    if rank == 0 and world == 1 and workload == "full" and not rehearse and not args.no_configs and n >= 256:
+        configs = {}
+        m = 256
+        from oracle import oracle as o
+        for name, fl in (("crc", nat.CRC), ("gcm_crc", nat.ENCRYPT | nat.CRC)):
+            try:
+                sl = (N.transformed_bound(CH, fl) + 63) // 64 * 64
+                dd = d[:m].copy(); dd["dst_off"] = np.arange(m, dtype=np.uint64) * sl; dd["dst_cap"] = sl; dd["status"] = 0; dd["dst_len"] = 0
+                outb = Mem.empty(m * sl if name != "crc" else 64)
+                pr = nat.Native.make_params(fl, synth.KEY, synth.AAD)
+
+                def run_dev():
+                    if name == "crc":
+                        N.crc32c_batch(dd, Mem.ptr(src), MEM, ctx=ctx)
+                    else:
+                        N.transform_batch(pr, dd, Mem.ptr(src), Mem.ptr(outb), outb.numel(), MEM, ctx=ctx)
+
+                run_dev(); fence()
+                reps = 10
+                kms = 0.0
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    run_dev()
+                    tm_ = N.ctx_timing(ctx)
+                    kms += tm_.crc_ms if name == "crc" else tm_.gcm_ms
+                fence()
+                dt_ = (time.perf_counter() - t1) / reps
+                kms /= reps
+                okc = bool((dd["status"] == 0).all() and (dd["crc32c"] == d["crc32c"][:m]).all())
+                for i in (0, m - 1):                                      # two chunks against the oracle chain (OpenSSL GCM, CRC32C)
+                    chunk = Mem.host(src, i * CH, (i + 1) * CH)
+                    okc = okc and int(dd["crc32c"][i]) == o.crc32c(chunk)
+                    if name != "crc":
+                        exp, _ = o.transform_chunk(o.ENCRYPT | o.OPENSSL, synth.KEY, synth.AAD, dd["iv"][i].tobytes(), chunk.tobytes())
+                        okc = okc and Mem.host(outb, i * sl, i * sl + int(dd["dst_len"][i])).tobytes() == exp
+                alg_ = m * (CH + 4.0) if name == "crc" else m * (2.0 * CH + 28.0)
+                ach_ = alg_ / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+                rec_, fresh_ = pmc_record("%s/%s/%d" % (name, args.dist, m))
+                # host -> host, registered buffers (what the JNI shim hands over)
+                hs_ = src[:m * CH].cpu().numpy(); hd_ = np.zeros(m * sl if name != "crc" else 64, np.uint8)
+                N.host_register(hs_); N.host_register(hd_)
+                best = None
+                for _ in range(3):
+                    de_ = dd.copy()
+                    t1 = time.perf_counter()
+                    if name == "crc":
+                        N.crc32c_batch(de_, hs_, nat.MEM_HOST, ctx=ctx)
+                    else:
+                        N.transform_batch(pr, de_, hs_, hd_, hd_.size, nat.MEM_HOST, ctx=ctx)
+                    el_ = time.perf_counter() - t1
+                    best = el_ if best is None else min(best, el_)
+                okh = bool((de_["status"] == 0).all() and (de_["crc32c"] == d["crc32c"][:m]).all())
+                N.host_unregister(hs_); N.host_unregister(hd_)
+                configs[name] = {"workload": "1 GiB segment, 256 x 4 MiB chunks, %s (BASELINE configs[%d])" % ("CRC32C only" if name == "crc" else "AES-256-GCM + CRC32C", 1 if name == "crc" else 2),
+                                 "device_resident_gibs": round(m * float(CH) / GiB / dt_, 3), "ms_per_batch": round(dt_ * 1e3, 3),
+                                 "host_to_host_gibs": round(m * float(CH) / GiB / best, 3), "exact_vs_oracle": bool(okc and okh),
+                                 "roofline": {"bound": "hbm", "kernel": "crc32c_partial_kernel" if name == "crc" else "gcm_ctr_ghash_kernel", "achieved": round(ach_, 2), "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": round(ach_ / HBM_PEAK_GBS, 5), "ms_per_launch": round(kms, 4), "algorithmic_bytes_per_launch": int(alg_),
+                                              "traffic": rec_["hbm_bytes_per_launch"] if rec_ and fresh_ else None,
+                                              "traffic_source": None if not rec_ else (rec_.get("source") if fresh_ else "STALE: measured on another build of the kernel")}}
+                del outb, hs_, hd_
+            except (nat.TsxError, AssertionError) as ex:                 # reported, never fatal for the line
+                configs[name] = {"error": repr(ex)[:300]}
+
     if rank == 0:
         line = {
             "metric": "GiB/s segment chunk transform (Zstd+AES+CRC), 4MiB chunks",
@@ -800,7 +954,7 @@ def main():
                            "backend": args.backend + (" (= RCCL)" if args.backend == "nccl" else ""), "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1),
                            "ran": ["barrier", "all_reduce(MAX)"] + (["all_gather(sizes)"] if split else []) + (["p2p slice -> owner"] if split and args.gather_object and (world > 1 or args.backend == "nccl") else [])},
                        "verified_chunks_vs_oracle": verified},
-            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "end_to_end": e2e, "detransform": inverse,
+            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "mixed_load": mixed, "configs": configs, "end_to_end": e2e, "detransform": inverse,
         }
         print(json.dumps(line))
     for c in ctxs:

@@ -108,15 +108,13 @@ def test_block_form_takes_deep_copy_chains_on_the_device(gpu, oracle):
         gpu.ctx_destroy(ctx)
 
 
-def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
+def test_ctxless_compressing_callers_are_members_of_the_service_on_the_device(gpu, oracle):
     """16 threads, context-less 64-chunk compressing batches from / to pinned host buffers: every batch equals the single-threaded
-    result - each member of a combined launch returns on its own completion flag, raised by its last wave while the launch goes on for the
-    others, and its output is copied out at once: stale ciphertext (a missing release) would show here."""
-    import ctypes as C
+    result - each member of the compressor service returns on its own completion flag, raised by its last wave while the persistent kernel
+    goes on for the others (and re-reads descriptors, keys and source bytes that the host and the copy engine have rewritten since the
+    wave's previous chunk): stale ciphertext, a stale descriptor or a stale source line (a missing release / acquire) would show here."""
     import threading
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
-    stats = gpu.lib.tsx_debug_combiner_stats
-    stats.restype = C.c_int; stats.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     T, reps, B = 16, 3, 64
     CH = 1 << 20
     chunks = [synth.gen_chunk("K", 77, 0, i, CH) for i in range(B)]
@@ -130,7 +128,7 @@ def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
     dsts = [np.zeros(B * (CH + 4096), np.uint8) for _ in range(T)]
     for h in dsts:
         gpu.host_register(h)
-    g0, m0 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g0), C.byref(m0))
+    s0 = gpu.service_stats(0)
     errors = []
     p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
 
@@ -147,15 +145,16 @@ def test_ctxless_compressing_callers_share_launches_on_the_device(gpu, oracle):
 
     th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
     [x.start() for x in th]; [x.join() for x in th]
-    g1, m1 = C.c_uint64(), C.c_uint64(); stats(0, C.byref(g1), C.byref(m1))
+    gpu.service_quiesce(0)
+    s1 = gpu.service_stats(0)
     for h in dsts:
         gpu.host_unregister(h)
     gpu.host_unregister(src)
     assert not errors, errors[:4]
-    # every batch travelled through the combiner; HOW MANY shared a launch depends on the lanes the process has (callers ask for a launch
-    # once their input has landed and launch alone while a lane is free - round 4; tests/test_emu_boundary.py pins one lane and asserts
-    # the sharing), so here only: no launch without a member
-    assert m1.value - m0.value == T * reps and 1 <= g1.value - g0.value <= T * reps, (g1.value - g0.value, m1.value - m0.value)
+    # every batch went through the queue (a 64-chunk host batch is cut into 4 members: piece k + 1's input copy overlaps piece k's waves),
+    # every chunk was counted on the device, and far fewer kernels were launched than batches: the waves stay while there is work
+    assert s1["members"] - s0["members"] == 4 * T * reps and s1["chunks"] - s0["chunks"] == T * reps * B == s1["device_chunks"] - s0["device_chunks"], (s0, s1)
+    assert 1 <= s1["launches"] - s0["launches"] <= T * reps and s1["skipped_tickets"] == 0, (s0, s1)
 
 
 def test_zero_copy_output_into_registered_buffers_on_the_device(gpu, oracle):

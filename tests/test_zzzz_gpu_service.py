@@ -1,0 +1,171 @@
+"""The compressor service on the device (csrc/tsx_internal.h, zstd_service_kernel): what the CU probe of tsx_init found, the software CU
+reservation doing its job - a fetch stays fast while uploads keep the chip full (ChunkCache.java:85-108 waits get.timeout.ms, 10 s by
+default: CacheConfig.java:135-142; SURVEY 8b "bounded latency") - and the one-JVM-many-GPUs dispatch on the real HIP runtime, with the
+same physical GPU initialised as two logical devices (a broker drives every GPU of the node from one process)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import tsxform
+from tests import parity_cases as pc
+from tsxform import synth
+
+pytestmark = pytest.mark.gpu
+nat = tsxform._native
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHUNK = synth.CHUNK
+
+
+def test_cu_probe_found_every_compute_unit_and_the_reservation_holds(gpu):
+    """HW_ID[15:8] + XCC_ID is a key per compute unit: the probe launch of tsx_init met exactly as many keys as the device has CUs, 8 of
+    them (one per XCD) are left to everything but the compressor, and a launch of the service starts 24 waves on each of the others."""
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    s0 = gpu.service_stats(0)
+    assert s0["compute_units"] == 256 and s0["cu_keys_seen"] == 256, s0
+    assert s0["reserved_cus"] == 8 and s0["waves"] == 256 * 24, s0
+    gpu.service_quiesce(0)
+    s0 = gpu.service_stats(0)
+    chunks = [synth.gen_chunk("K", 3, 0, i, 100000) for i in range(32)]
+    pc.run_transform(gpu, flags, chunks, mem="device")
+    gpu.service_quiesce(0)
+    s1 = gpu.service_stats(0)
+    launches = s1["launches"] - s0["launches"]
+    assert launches >= 1 and s1["device_chunks"] - s0["device_chunks"] == 32
+    # on an idle chip a launch covers it once - 24 workgroups per CU, those that land on the 8 reserved CUs leave at once (and make room
+    # there for a few more of the launch, which leave as well): nearly all of the other 248 CUs' 5952 slots get their wave
+    starts, exits = s1["wave_starts"] - s0["wave_starts"], s1["reserved_exits"] - s0["reserved_exits"]
+    print("service launches %d: %d waves stayed, %d left a reserved CU" % (launches, starts, exits))
+    assert starts + exits == launches * 256 * 24, (s0, s1)
+    assert exits >= launches * 8 * 24 * 0.5 and starts >= launches * 248 * 24 * 0.8, (s0, s1)
+
+
+@pytest.mark.timeout(600)
+def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
+    """Four callers keep 4 x 2048 four-MiB chunks queued at the compressor (more than the chip holds) while this thread restores one chunk
+    host -> host, again and again: median <= 5 ms, 95th percentile <= 50 ms, never more than a second (round 4, no reservation: 50-80 s;
+    profiles/r04_mixed_load.txt), and the restored bytes are right."""
+    import torch
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    dev = torch.device("cuda", 0)
+    n, T = 2048, 4
+    slot = (gpu.transformed_bound(CHUNK, flags) + 63) // 64 * 64
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    src = torch.empty(n * CHUNK, dtype=torch.uint8, device=dev)
+    for i in range(64):
+        src[i * CHUNK:(i + 1) * CHUNK] = synth.gen_chunk("K", 1000, 0, i, CHUNK, device=dev)
+    for i in range(64, n, 64):
+        src[i * CHUNK:(i + 64) * CHUNK] = src[:64 * CHUNK]
+    d = np.zeros(n, nat.DESC_DTYPE); d["src_off"] = np.arange(n, dtype=np.uint64) * CHUNK; d["src_len"] = CHUNK
+    d["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d["dst_cap"] = slot
+    for i in range(n):
+        d["iv"][i] = np.frombuffer(synth.iv_for(0, i % 64), np.uint8)
+    ctxs = [gpu.ctx_create(0, n, CHUNK) for _ in range(T)]
+    dsts = [torch.empty(n * slot, dtype=torch.uint8, device=dev) for _ in range(T)]
+    ds = [d.copy() for _ in range(T)]
+    gpu.transform_batch(p, ds[0], src.data_ptr(), dsts[0].data_ptr(), dsts[0].numel(), nat.MEM_DEVICE, ctx=ctxs[0])
+    torch.cuda.synchronize()
+    hfr = dsts[0][:slot].cpu().numpy(); hbk = np.zeros(CHUNK, np.uint8)
+    gpu.host_register(hfr); gpu.host_register(hbk)
+    fctx = gpu.ctx_create(0, 4, CHUNK)
+    want = src[:CHUNK].cpu().numpy()
+
+    def fetch():
+        e = np.zeros(1, nat.DESC_DTYPE); e["src_off"] = 0; e["src_len"] = ds[0]["dst_len"][:1]; e["iv"] = ds[0]["iv"][:1]; e["dst_off"] = 0; e["dst_cap"] = CHUNK
+        t0 = time.perf_counter()
+        gpu.detransform_batch(p, e, hfr, hbk, hbk.size, nat.MEM_HOST, ctx=fctx)
+        dt = time.perf_counter() - t0
+        assert e["status"][0] == 0
+        return dt * 1e3
+
+    for _ in range(3):
+        fetch()
+    stop = [False]
+    errors = []
+
+    def loader(t):
+        try:
+            while not stop[0]:
+                gpu.transform_batch(p, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
+        except Exception as e:                                          # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=loader, args=(t,)) for t in range(T)]
+    [x.start() for x in th]
+    try:
+        time.sleep(2.5)                                                 # the chip is full
+        lat = []
+        t_end = time.perf_counter() + 8.0
+        while time.perf_counter() < t_end:
+            lat.append(fetch())
+            time.sleep(0.02)
+    finally:
+        stop[0] = True
+        [x.join() for x in th]
+    a = np.asarray(lat)
+    print("fetch under load: n=%d p50=%.2f ms p95=%.2f ms max=%.2f ms" % (a.size, np.median(a), np.percentile(a, 95), a.max()))
+    ok_bytes = np.array_equal(hbk, want)
+    gpu.host_unregister(hfr); gpu.host_unregister(hbk)
+    gpu.ctx_destroy(fctx)
+    for c in ctxs:
+        gpu.ctx_destroy(c)
+    assert not errors, errors[:3]
+    assert ok_bytes
+    assert all((x["status"] == 0).all() for x in ds)
+    assert np.median(a) <= 5.0 and np.percentile(a, 95) <= 50.0 and a.max() <= 1000.0, (float(np.median(a)), float(np.percentile(a, 95)), float(a.max()))
+
+
+@pytest.mark.timeout(600)
+def test_two_logical_devices_on_one_gpu():
+    """tsx_init(2, {0, 0}): the same physical GPU twice - per-device pools, per-device constants and compressor services, the least-loaded
+    pick and tsx_set_thread_device on the real HIP runtime (the emulator's HIPEMU_DEVICES=2 is all that ran it before).  16 threads,
+    context-less batches with and without a device hint: both devices serve batches, every result equals the single-device one, shutdown is clean."""
+    code = """
+        import threading, hashlib, json, numpy as np
+        import torch
+        import tsxform
+        from tests import parity_cases as pc
+        from tsxform import synth
+        nat = tsxform._native
+        N = nat.Native()
+        assert N.init(2, [0, 0]) == 2
+        flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+        chunks = [synth.gen_chunk("K", 5, 0, i, 300000 + 4096 * i) for i in range(24)]
+        ref, dref = pc.run_transform(N, flags, chunks)
+        errors = []
+        def worker(t):
+            try:
+                N.set_thread_device(-1 if t % 4 == 0 else t % 2)
+                for rep in range(3):
+                    fl = flags if (t + rep) % 3 else (nat.ENCRYPT | nat.CRC)
+                    outs, d = pc.run_transform(N, fl, chunks, mem="packed" if rep % 2 else None)
+                    if fl == flags and (outs != ref or (d["status"] != 0).any()):
+                        errors.append((t, rep, "transform"))
+                    back, d2 = pc.run_detransform(N, fl, outs, [int(c.size) for c in chunks])
+                    if back != [c.tobytes() for c in chunks] or (d2["status"] != 0).any():
+                        errors.append((t, rep, "detransform"))
+            except Exception as e:
+                errors.append((t, repr(e)))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+        [x.start() for x in th]; [x.join() for x in th]
+        assert not errors, errors[:4]
+        s = [N.pool_stats(i) for i in (0, 1)]
+        v = [N.service_stats(i) for i in (0, 1)]
+        assert all(x["in_use"] == 0 and x["batches"] > 0 for x in s), s
+        assert all(x["chunks"] > 0 and x["cu_keys_seen"] == x["compute_units"] for x in v), v
+        c1 = N.ctx_create(1, 0, 0); assert N.ctx_device(c1) == 1
+        got, _ = pc.run_transform(N, flags, chunks, ctx=c1); assert got == ref
+        N.ctx_destroy(c1)
+        N.shutdown()
+        assert N.lib.tsx_device_count() == 0
+        print("ok", json.dumps({"batches": [x["batches"] for x in s], "chunks": [x["chunks"] for x in v]}))
+    """
+    r = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], cwd=ROOT, capture_output=True, text=True, timeout=550)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+    print(r.stdout.strip().splitlines()[-1])

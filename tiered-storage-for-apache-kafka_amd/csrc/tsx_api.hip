@@ -94,7 +94,7 @@ struct tsx_device;
 // compressing batch is a MEMBER of its device's queue: tickets in pinned memory, persistent waves that pull them, per-member completion
 // flags.  One kernel, on one stream that carries nothing else; it is (re)started by whoever publishes work and finds it gone, and by
 // the waiting callers' watchdog (a launch that ended - idle, age limit, every wave on a reserved CU - with tickets still unserved).
-struct tsx_svc_member { uint64_t id; uint32_t first, n; uint16_t slot; bool done; };
+struct tsx_svc_member { uint64_t id; uint32_t first, n; uint16_t slot; bool done; const uint32_t* h_flag; };
 struct tsx_service {
     std::mutex mu; std::condition_variable cv;
     tsx_svc_host* h = nullptr; tsx_svc_host* hd = nullptr;          // the queue in pinned host memory: host view, device alias
@@ -884,14 +884,20 @@ struct tsx_run {                                              // what one batch 
 // ---- service: members ---------------------------------------------------------------------------------------------------------------
 // Publish one member: `proto` names its buffers (n, done and flag included); its n chunks become the next n tickets.  Returns the member's
 // id (for svc_retire) through *id.  Blocks while the ticket ring or the member slots are full (members retire one by one).
-static int svc_submit(tsx_device* dev, const tsx_zseg& proto, uint64_t* id) {
+static int svc_submit(tsx_device* dev, const tsx_zseg& proto, const uint32_t* h_flag, uint64_t* id) {
     tsx_service& s = *dev->svc;
     const uint32_t n = proto.n;
     if (!n || n > TSX_SVC_MEMBER_MAX) return TSX_E_INVAL;
     std::unique_lock<std::mutex> lk(s.mu);
-    // room: a ticket record is reused TSX_SVC_TICKETS tickets later - by then every member up to it must be gone
-    while (s.free_slots.empty() || (!s.out.empty() && (uint32_t)(s.published + n - s.out.front().first) > TSX_SVC_TICKETS))
+    // room: a ticket record is reused TSX_SVC_TICKETS tickets later - by then every member up to it must be complete ON THE DEVICE (its flag
+    // raised; whether its caller has come back for it yet does not matter: a caller that publishes its pieces one after the other must
+    // never wait here for a piece of its own that only it can retire)
+    for (;;) {
+        uint32_t oldest = s.published; bool any = false;
+        for (const auto& m : s.out) if (!m.done && !__atomic_load_n(m.h_flag, __ATOMIC_ACQUIRE)) { oldest = m.first; any = true; break; }
+        if (!s.free_slots.empty() && (!any || (uint32_t)(s.published + n - oldest) <= TSX_SVC_TICKETS)) break;
         s.cv.wait_for(lk, std::chrono::milliseconds(1));
+    }
     const uint16_t slot = s.free_slots.back(); s.free_slots.pop_back();
     const uint16_t gen = ++s.slot_gen[slot];
     tsx_zseg e = proto;
@@ -902,7 +908,7 @@ static int svc_submit(tsx_device* dev, const tsx_zseg& proto, uint64_t* id) {
     s.published = first + n;
     __atomic_store_n(&s.h->published, s.published, __ATOMIC_RELEASE);   // the waves' poll picks it up (a few microseconds)
     *id = s.next_id++;
-    s.out.push_back({*id, first, n, slot, false});
+    s.out.push_back({*id, first, n, slot, false, h_flag});
     s.members++;
     if (!svc_running_locked(s)) return svc_launch_locked(s);           // (on failure the caller abandons the member: svc_retire)
     return TSX_OK;
@@ -1130,7 +1136,7 @@ static int run_compress(tsx_run& r) {
         }
         __atomic_store_n(&c->h_segflag[k], 0u, __ATOMIC_RELEASE);
         m.done = c->d_segdone + k; m.flag = c->hd_segflag + k;
-        rc = svc_submit(dev, m, &ids[k]);
+        rc = svc_submit(dev, m, &c->h_segflag[k], &ids[k]);
         if (rc == TSX_E_INVAL) return abandon_all(rc);
         submitted = k + 1;
         if (rc) return abandon_all(rc);

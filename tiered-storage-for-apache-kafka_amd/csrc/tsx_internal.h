@@ -91,7 +91,7 @@ struct tsx_zseg {                // one caller's batch ("member") in the device'
 // host built from a probe launch at tsx_init) leaves before it takes a ticket.  Compressor waves hold every other wave slot and LDS
 // byte of the chip for as long as uploads go on - the reserved CUs are where a fetch's decoder kernels (2-8 waves, up to 19.5 KB of LDS
 // per workgroup) find room at once (ChunkCache.java:85-108 waits get.timeout.ms for them).
-#define TSX_SVC_MEMBERS 512u          /* member slots */
+#define TSX_SVC_MEMBERS 2048u         /* member slots (a caller holds up to 8 until it has collected its pieces) */
 #define TSX_SVC_TICKETS 65536u        /* ticket ring (power of two): chunks published and not yet completed never exceed it */
 #define TSX_SVC_MEMBER_MAX 16384u     /* chunks per member (a larger batch goes as several members) */
 struct tsx_svc_ticket { uint32_t member_gen; uint32_t chunk; };   // member slot in the low 16 bits, the slot's generation (16 bits) above

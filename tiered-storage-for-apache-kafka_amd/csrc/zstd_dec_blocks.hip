@@ -821,7 +821,7 @@ uint32_t tsx_launch_zstd_decompress_blocks(hipStream_t st, const uint8_t* frames
         hipLaunchKernelGGL(zb_jump_kernel, dim3(tiles, n), dim3(256), 0, st, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap, r);
     }
 #ifdef HIPEMU
-    g_zb_snap = nullptr; free(snap);
+    if (snap) { g_zb_snap = nullptr; free(snap); }                     // (snapshot mode is a single-threaded test: callers without it never touch the word)
 #endif
     hipLaunchKernelGGL(zb_emit_kernel, dim3((max_out + 4095) / 4096, n), dim3(256), 0, st, (const tsx_chunk_desc*)d_descs, dst, hdrs, arenas, (uint64_t)astride, lit_cap, seq_cap);
     return 4 + rounds;

@@ -96,7 +96,9 @@ def run(N, nat, params, hsrc, ivs, expect, callers_list, B, CH, window, profile_
             slope = float(np.polyfit(done_at[k0:k1], np.arange(k0, min(k1, done)), 1)[0]) if done >= 4 else done / max(float(done_at[-1]), 1e-9)
             gibs = slope * B * CH / GiB
             rows.append({"callers": callers, "batch_chunks": B, "chunks_offered": callers * B, "calls": done, "seconds": round(float(done_at[-1]), 2),
-                         "method": "slope of completions, middle 60 %", "context": "pooled (ctx = NULL), launch combiner", "dst_layout": "slots (as GpuTransformChunkEnumeration.java:167-201)",
+                         "models": {10: "10 RLM upload threads, no read-ahead", 20: "10 RLM upload threads + one batch of read-ahead each (gpu.read.ahead, the default)",
+                                    32: "16 RLM upload threads + read-ahead"}.get(callers, "%d callers" % callers),
+                         "method": "slope of completions, middle 60 %", "context": "pooled (ctx = NULL), members of the device's compressor service", "dst_layout": "slots (as GpuTransformChunkEnumeration.java:167-201)",
                          "host_memory": "source and outputs registered", "gibs": round(gibs, 4),
                          "ms_per_call_median": round(float(np.median(np.concatenate([np.asarray(x) for x in lat if x]))) * 1e3, 1),
                          "whole_window_gibs": round(done * B * CH / GiB / max(float(done_at[-1]), 1e-9), 4),

@@ -150,6 +150,28 @@ PY
           TSX_ZSTD_SCHED=$m timeout 400 python bench.py --steps 40 --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained --no-verify 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['config']['gibs_one_batch_at_a_time'])"
         done
       done | tee $O/sched_ab.txt ;;
+    probe)
+      # what tsx_init found: CU keys of the probe launch, reserved CUs, waves per launch of the compressor service
+      timeout 300 python -c "
+import torch, tsxform, json
+N = tsxform.get(); print(N.version()); print(json.dumps(N.service_stats(0)))" 2>&1 | grep -v amdgpu.ids | tee $O/probe.txt ;;
+    benchq)
+      # the timed region + sustained + mixed-load legs only (no CPU baseline, no host-path legs, no broker children)
+      timeout 600 python bench.py ${arg:+--steps $arg} --no-cpu-baseline --no-end-to-end --no-inverse --no-configs > $O/bench_quick.json 2> $O/bench_quick.err
+      python - <<PY
+import json
+try:
+    j = json.loads(open("$O/bench_quick.json").read().strip().splitlines()[-1])
+    print("value", j["value"], "ms/step", j["ms_per_step"], "one at a time", j["config"]["gibs_one_batch_at_a_time"]); print("roofline", json.dumps(j["roofline"])[:900])
+    print("sustained", json.dumps(j["sustained"])[:400]); print("mixed_load", json.dumps(j["mixed_load"]))
+except Exception as e: print("benchq failed", e); print(open("$O/bench_quick.err").read()[-1500:])
+PY
+      ;;
+    mixed)
+      # fetch latency under upload load, tools/mixed_load_probe.py: arg = "shape,callers[,reserved]" ... (default: both shapes, library default)
+      for cfg in ${arg:-"batches,5 broker,32"}; do set -- ${cfg//,/ }
+        timeout 300 python tools/mixed_load_probe.py --shape $1 --callers $2 ${3:+--reserved-cus $3} --seconds 10 --tag "$cfg" 2>> $O/mixed.err | tee -a $O/mixed.jsonl
+      done ;;
     *) echo "unknown section $name" ;;
   esac
 done

@@ -2,7 +2,7 @@
 """A broker uploads and serves fetches at the same time.  How long does a fetch (tsx_detransform_batch of 1 / 4 chunks, host -> host,
 registered buffers, its own context) take while T caller threads keep the chip full of compressor waves (device-resident 2048-chunk
 batches, as bench.py's timed region)?  One JSON line: latencies on the idle device and under load.
-  python tools/mixed_load_probe.py [--callers 5] [--seconds 12]            (TSX_FETCH_RESERVED_CUS=n in the environment: see tsx_api.hip)"""
+  python tools/mixed_load_probe.py [--callers 5] [--seconds 12] [--reserved-cus n]     (n: tsx_config.fetch_reserved_cus; default: the library's)"""
 import argparse
 import json
 import os
@@ -30,8 +30,9 @@ def main():
     ap.add_argument("--shape", default="batches", choices=["batches", "broker"],
                     help="the upload load: `batches` = --callers explicit contexts x 2048-chunk device-resident batches (more chunks queued than the chip has "
                          "slots); `broker` = --callers context-less calls of ONE 256-chunk segment each, registered host buffers, slot layout (tools/broker_leg.py)")
+    ap.add_argument("--reserved-cus", type=int, default=-1, help="tsx_config.fetch_reserved_cus (-1: the library's default)")
     args = ap.parse_args()
-    N = nat.Native(); N.init(1, [0])
+    N = nat.Native(); N.init(1, [0], fetch_reserved_cus=None if args.reserved_cus < 0 else args.reserved_cus)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from numa_bind import bind_to_gpu_numa_node
     AFFINITY = bind_to_gpu_numa_node(0)                              # before any host buffer is allocated (profiles/r04_broker_numa.txt)
@@ -120,7 +121,9 @@ def main():
     [x.join() for x in th]
     el = time.perf_counter() - t0
     assert np.array_equal(hbk, want)
-    out = {"tag": args.tag, "reserved_cus": os.environ.get("TSX_FETCH_RESERVED_CUS"), "compress_callers": T,
+    st = N.service_stats(0)
+    out = {"tag": args.tag, "reserved_cus": st["reserved_cus"], "cu_keys_seen": st["cu_keys_seen"], "service_launches": st["launches"], "watchdog_launches": st["watchdog_launches"],
+           "compress_callers": T,
            "upload_shape": args.shape, "chunks_offered": T * (256 if broker else n),
            "compress_gibs_while_fetching": round(sum(done) * (256 if broker else n) * CH / float(1 << 30) / el, 3),
            "fetch_idle_ms": {k: round(v, 3) for k, v in idle.items()}}
