@@ -103,6 +103,34 @@ def test_product_never_touches_the_oracle_or_the_emulator():
     assert "zstd" not in linked and "crypto" not in linked and "oracle" not in linked
 
 
+def test_no_kernel_on_the_fetch_path_uses_scratch(product_lib):
+    """A queue's first dispatch that needs scratch makes the runtime (re)size that queue's scratch, and while the compressor service's
+    long-lived kernel holds its own the request waits for that kernel to END: the first fetch after uploads began took 18.6 s on the device
+    (every later one 4 ms).  So only two kernels of the library may have a private segment at all - the compressor itself and the batch
+    build of the chunk-serial decoder, which is never launched while the service is alive (tsx_api.hip launch_stages).  Read from the
+    compiler's resource report of the build that produced libtsxform.so (csrc/Makefile)."""
+    obj = os.path.join(PKG, "csrc", "_obj")
+    reports = [f for f in os.listdir(obj) if f.endswith(".usage.txt")] if os.path.isdir(obj) else []
+    if len(reports) < 6:
+        pytest.skip("no resource reports next to the library (not built by csrc/Makefile in this tree)")
+    usage = {}
+    for f in reports:
+        name = None
+        for line in open(os.path.join(obj, f), errors="ignore"):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and name:
+                usage[name] = int(m.group(1))
+    kernels = {k: v for k, v in usage.items() if "kernel" in k}
+    assert len(kernels) >= 18, sorted(kernels)
+    with_scratch = sorted(k for k, v in kernels.items() if v)
+    assert all(("zstd_service_kernel" in k) or ("22zstd_decompress_kernel" in k) for k in with_scratch), with_scratch
+    for must in ("zstd_decompress_fallback_kernel", "zb_index_kernel", "zb_decode_kernel", "gcm_ctr_ghash_kernel", "crc32c_partial_kernel"):
+        assert any(must in k and v == 0 for k, v in kernels.items()), must
+
+
 def test_java_binding_agrees_with_the_header_and_the_shim():
     """The Java side cannot be compiled in this image (no JDK): what can be checked is that TsxNative.java's constants are the
     C header's, and that every `native` method has its JNI entry point in java/jni/tsx_jni.c with the same number of arguments

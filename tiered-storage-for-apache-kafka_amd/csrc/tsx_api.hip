@@ -1254,7 +1254,11 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
                 skip = tsx_zstd_blockmode_skip(bw, &skip_stride);
                 c->blk_pieces.push_back({lo, n}); c->last_max_out = r.max_out;
             }
-            t.unzstd_launches += tsx_launch_zstd_decompress(st, c->dev->d_zc, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.d_dst, ds, dzw, skip, skip_stride);
+            // (a batch decode next to running uploads takes the scratch-free build of the chunk-serial kernel: a dispatch that needs scratch
+            //  waits for the compressor service's kernel - and its scratch - to go away)
+            bool busy_service = false;
+            if (!skip) { std::lock_guard<std::mutex> lk(c->dev->svc->mu); busy_service = svc_running_locked(*c->dev->svc) || !c->dev->svc->out.empty(); }
+            t.unzstd_launches += tsx_launch_zstd_decompress(st, c->dev->d_zc, zsrc, r.enc ? 1 : 0, (uint64_t)c->mid_stride, dd, n, r.d_dst, ds, dzw, skip, skip_stride, busy_service);
         } else if (!r.enc) {
             uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
             hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz, (uint64_t)0, 0, r.d_src, r.d_dst, ds, bpc);

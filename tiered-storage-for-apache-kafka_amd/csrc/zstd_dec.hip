@@ -30,15 +30,14 @@ extern "C" void tsx_debug_set_dprof(void* dev_ptr) { g_dprof_out = (unsigned lon
 #define FAIL(code) do { err = (code); goto done; } while (0)                 /* both waves, before the block loop */
 #define RFAIL(code) do { myErr = (code); goto block_end; } while (0)        /* one wave, inside its role */
 
-__global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6))) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
-                                                                tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
-                                                                int32_t* __restrict__ status, uint8_t* __restrict__ work,
-                                                                const uint32_t* __restrict__ skip, uint32_t skip_stride
+__device__ __forceinline__ static void zstd_decompress_body(DecLds& L, const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                            tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
+                                                            int32_t* __restrict__ status, uint8_t* __restrict__ work,
+                                                            const uint32_t* __restrict__ skip, uint32_t skip_stride
 #ifdef TSX_PROF2
-                                                                , unsigned long long* __restrict__ dprof
+                                                            , unsigned long long* __restrict__ dprof
 #endif
-                                                                ) {
-    __shared__ DecLds L;
+                                                            ) {
     const uint32_t lane = threadIdx.x & (LANES - 1), role = DUNI(threadIdx.x >> 6), chunk = blockIdx.x;   // wave 0: sequence streams, wave 1: literals, wave 2: execution
     if (status[chunk] != TSX_OK) return;
     if (skip && skip[(size_t)chunk * skip_stride] == 1) return;       // decoded by the block-parallel form (zstd_dec_blocks.hip)
@@ -572,11 +571,43 @@ done:
     }
 }
 
+#ifdef TSX_PROF2
+#define ZD_PROF_PARAM , unsigned long long* __restrict__ dprof
+#define ZD_PROF_ARG , dprof
+#else
+#define ZD_PROF_PARAM
+#define ZD_PROF_ARG
+#endif
+// Two builds of the same body.  The batch decoder is shaped for residency: 6 waves per SIMD (80 VGPRs, a few spilled to scratch).  The one
+// that runs BEHIND the block-parallel form of a fetch (skip list: it only decodes what that form handed back) must not touch scratch at
+// all: a queue's first scratch-using dispatch makes the runtime (re)size that queue's scratch, and while the compressor service's
+// long-lived kernel holds its own (large) scratch that request waits for the kernel to end - measured: the first fetch after uploads
+// began took 18.6 s, every later one 4 ms (gpurun r05a).  No fetch-path kernel uses scratch (tests/test_boundary.py checks the code object).
+__global__ __launch_bounds__(3 * LANES) __attribute__((amdgpu_waves_per_eu(6, 6))) void zstd_decompress_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                                tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
+                                                                int32_t* __restrict__ status, uint8_t* __restrict__ work,
+                                                                const uint32_t* __restrict__ skip, uint32_t skip_stride ZD_PROF_PARAM) {
+    __shared__ DecLds L;
+    zstd_decompress_body(L, frames, from_mid, mid_stride, descs, dst_base, status, work, skip, skip_stride ZD_PROF_ARG);
+}
+__global__ __launch_bounds__(3 * LANES) void zstd_decompress_fallback_kernel(const uint8_t* __restrict__ frames, int from_mid, uint64_t mid_stride,
+                                                                tsx_chunk_desc* __restrict__ descs, uint8_t* __restrict__ dst_base,
+                                                                int32_t* __restrict__ status, uint8_t* __restrict__ work,
+                                                                const uint32_t* __restrict__ skip, uint32_t skip_stride ZD_PROF_PARAM) {
+    __shared__ DecLds L;
+    zstd_decompress_body(L, frames, from_mid, mid_stride, descs, dst_base, status, work, skip, skip_stride ZD_PROF_ARG);
+}
+
 uint32_t tsx_launch_zstd_decompress(hipStream_t st, const tsx_zstd_consts* /*d_zc*/, const uint8_t* frames, int from_mid, uint64_t mid_stride,
                                     tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work,
-                                    const uint32_t* skip, uint32_t skip_stride) {
+                                    const uint32_t* skip, uint32_t skip_stride, bool no_scratch) {
     if (!n) return 0;
-    hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(3 * LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work, skip, skip_stride
+    if (skip || no_scratch) hipLaunchKernelGGL(zstd_decompress_fallback_kernel, dim3(n), dim3(3 * LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work, skip, skip_stride
+#ifdef TSX_PROF2
+                       , g_dprof_out
+#endif
+                       );
+    else hipLaunchKernelGGL(zstd_decompress_kernel, dim3(n), dim3(3 * LANES), 0, st, frames, from_mid, mid_stride, d_descs, dst, d_status, (uint8_t*)d_work, skip, skip_stride
 #ifdef TSX_PROF2
                        , g_dprof_out
 #endif

@@ -176,15 +176,18 @@ __global__ __launch_bounds__(LANES) void zb_index_kernel(const uint8_t* __restri
                             uint32_t t = q + 1;
                             if (modes & 3) bad = true;
                             B.modes = (uint8_t)modes;
-                            for (int k = 0; k < 3 && !bad; k++) {
+                            // (unrolled: B stays in registers - a dynamic index into B.tOff would put the whole struct into scratch, and no
+                            //  kernel on the fetch path may use scratch: see zstd_dec.hip, zstd_decompress_fallback_kernel)
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                if (bad) continue;
                                 const uint32_t mode = (modes >> (6 - 2 * k)) & 3;
                                 const uint32_t maxSymK = k == 0 ? 35 : k == 1 ? 31 : 52, maxLogK = k == 0 ? 9 : k == 1 ? 8 : 9;
                                 B.tOff[k] = t;
                                 if (mode == 1) { if (t >= B.bsize) bad = true; t++; }
                                 else if (mode == 2) {
-                                    if (t >= B.bsize) { bad = true; break; }
-                                    short norm[64]; uint32_t ms = maxSymK, tl = 0;
-                                    const uint32_t used = fse_readNCount(norm, &ms, &tl, blk + t, B.bsize - t, maxLogK);
+                                    if (t >= B.bsize) { bad = true; continue; }
+                                    const uint32_t used = fse_skipNCount(maxSymK, blk + t, B.bsize - t, maxLogK);
                                     if (!used) bad = true;
                                     t += used;
                                 }

@@ -160,7 +160,9 @@ __device__ __forceinline__ void seq_chain_step(const SeqD* __restrict__ tbl, uin
 
 // ---- FSE table description + decoding table (lane 0) ---------------------------------------------------------
 // returns bytes consumed, 0 on error
-__device__ static uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint32_t* tableLogPtr, const uint8_t* src, uint32_t n, uint32_t maxLogAllowed) {
+// (STORE = false walks the description without keeping the counts: how long it is, and whether it is well formed)
+template <bool STORE>
+__device__ static uint32_t fse_walkNCount(short* norm, uint32_t* maxSymPtr, uint32_t* tableLogPtr, const uint8_t* src, uint32_t n, uint32_t maxLogAllowed) {
     if (n < 1) return 0;
     // bounded forward bit reader over at most n bytes
     uint64_t bitpos = 0;
@@ -178,7 +180,7 @@ __device__ static uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint
         if (prev0) {
             for (;;) {
                 const uint32_t r = NC_PEEK(2); bitpos += 2;
-                for (uint32_t k = 0; k < r; k++) { if (sym > maxSym) return 0; norm[sym++] = 0; }
+                for (uint32_t k = 0; k < r; k++) { if (sym > maxSym) return 0; if (STORE) norm[sym] = 0; sym++; }
                 if (r != 3) break;
                 if ((bitpos >> 3) > n + 4) return 0;
             }
@@ -193,7 +195,8 @@ __device__ static uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint
         count--;
         remaining -= count < 0 ? -count : count;
         if (sym > maxSym) return 0;
-        norm[sym++] = (short)count;
+        if (STORE) norm[sym] = (short)count;
+        sym++;
         prev0 = count == 0;
         while (remaining < threshold) { nbBits--; threshold >>= 1; }
         if ((bitpos >> 3) > n + 4) return 0;
@@ -204,6 +207,13 @@ __device__ static uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint
     if (used > n) return 0;
     *maxSymPtr = sym - 1; *tableLogPtr = tableLog;
     return used;
+}
+__device__ static inline uint32_t fse_readNCount(short* norm, uint32_t* maxSymPtr, uint32_t* tableLogPtr, const uint8_t* src, uint32_t n, uint32_t maxLogAllowed) {
+    return fse_walkNCount<true>(norm, maxSymPtr, tableLogPtr, src, n, maxLogAllowed);
+}
+__device__ static inline uint32_t fse_skipNCount(uint32_t maxSym, const uint8_t* src, uint32_t n, uint32_t maxLogAllowed) {
+    uint32_t ms = maxSym, tl = 0;
+    return fse_walkNCount<false>(nullptr, &ms, &tl, src, n, maxLogAllowed);
 }
 
 template <class E, class Fill>

@@ -17,9 +17,11 @@ size_t tsx_zstd_workspace_bytes(uint32_t n, uint32_t max_len);
 // frames + descs[i].src_off), length descs[i].src_len - (from_mid ? 28 : 0); output to dst + descs[i].dst_off,
 // descs[i].dst_len set; status TSX_E_BAD_SIZE / TSX_E_BAD_FRAME / TSX_E_DST_TOO_SMALL on failure.
 // skip (may be NULL): chunk i is left alone when skip[i * skip_stride] == 1 - it was decoded by the block-parallel form below.
+// no_scratch (or a skip list): the build of the kernel that keeps everything in registers (4 waves per SIMD instead of 6) - the only one that
+// may be launched while the compressor service's kernel is alive (zstd_dec.hip).
 uint32_t tsx_launch_zstd_decompress(hipStream_t st, const tsx_zstd_consts* d_zc, const uint8_t* frames, int from_mid, uint64_t mid_stride,
                                     tsx_chunk_desc* d_descs, uint32_t n, uint8_t* dst, int32_t* d_status, void* d_work,
-                                    const uint32_t* skip, uint32_t skip_stride);
+                                    const uint32_t* skip, uint32_t skip_stride, bool no_scratch);
 // The same, one workgroup per BLOCK (zstd_dec_blocks.hip): for small batches, where a chunk's 32 blocks one after the other are all
 // latency.  A fast path with a fallback: chunks it does not take (or gives up on) keep their skip word at 0 and must be decoded by
 // tsx_launch_zstd_decompress behind it, with tsx_zstd_blockmode_skip() as the skip list.  bwork: tsx_zstd_blockmode_bytes(n, max_out).
