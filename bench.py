@@ -445,10 +445,14 @@ def main():
             stop = [False]
             done = [0] * T
 
+            mstamps = []
+
             def loader(t):
                 while not stop[0]:
                     step(t)
                     done[t] += 1
+                    with lock:
+                        mstamps.append(time.perf_counter())
 
             th = [threading.Thread(target=loader, args=(t,)) for t in range(T)]
             tm0 = time.perf_counter()
@@ -467,7 +471,14 @@ def main():
             mixed = {"metric": "latency of a fetch (tsx_detransform_batch of 1 / 4 chunks, host -> host, own context) while %d callers keep %d compressor chunks queued" % (T, T * n),
                      "reserved_cus": None if svc is None else svc["reserved_cus"], "compress_callers": T, "chunks_offered": T * n,
                      "compress_gibs_while_fetching": round(sum(done) * float(n) * CH / GiB / el_, 3),
+                     "compress_gibs_while_fetching_note": "whole window incl. the callers' ramp and drain; `_slope` = least-squares slope of batch completions over the middle 60 %, as `sustained`",
                      "fetch_idle_ms": {str(k_): v for k_, v in idle_ms.items()}, "restored_bytes_exact": exact, "unit": "ms"}
+            da_ = np.sort(np.asarray(mstamps)) - tm0
+            if da_.size >= 8:
+                q0, q1 = int(da_.size * 0.2), int(da_.size * 0.8)
+                mixed["compress_gibs_while_fetching_slope"] = round(float(np.polyfit(da_[q0:q1], np.arange(q0, q1), 1)[0]) * float(n) * CH / GiB, 3)
+                if sustained:
+                    mixed["frac_of_sustained"] = round(mixed["compress_gibs_while_fetching_slope"] / sustained["value"], 3)
             for k_ in (1, 4):
                 a_ = np.asarray(lat[k_])
                 mixed["fetch_%d_under_load_ms" % k_] = {"n": int(a_.size), "p50": round(float(np.median(a_)), 2), "p95": round(float(np.percentile(a_, 95)), 2), "max": round(float(a_.max()), 2)}

@@ -40,6 +40,8 @@ struct tsx_cfg {
     bool zero_copy_packed = false;        // explicit contexts: packed output in place too
     bool gcm_setup_kernel = false;        // key schedule by gcm_setup_kernel instead of on the host
     bool no_dec_pieces = false;           // block-form fetches in one piece
+    bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
+    bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
 };
 static tsx_cfg g_cfg;
 
@@ -66,7 +68,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(trace, bool)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -293,7 +295,19 @@ static int svc_create(tsx_device& d, int cus) {
     memset(s.h_zero, 0, 64);
     HIPCHK(hipMalloc((void**)&s.d, sizeof(tsx_svc_dev)));
     HIPCHK(hipMemset(s.d, 0, sizeof(tsx_svc_dev)));
-    HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+    // The service's stream gets the LOWEST stream priority of the device.  Two reasons: the runtime keeps a pool of hardware queues per
+    // priority and multiplexes a process's streams onto them - a stream that shared the service's hardware queue would sit behind a kernel
+    // that lives as long as uploads go on, and nothing else in this library (or, normally, in the process) creates low-priority streams;
+    // and between a compressor wave and a fetch's workgroup that could both be placed, the fetch's goes first.
+    {
+        int least = 0, greatest = 0;
+        if (g_cfg.svc_normal_priority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
+            hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();
+            s.st = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        }
+    }
     HIPCHK(hipEventCreate(&s.ev_begin));
     HIPCHK(hipEventCreate(&s.ev_end));
     for (uint32_t i = TSX_SVC_MEMBERS; i-- > 0;) s.free_slots.push_back((uint16_t)i);
@@ -871,6 +885,13 @@ static int validate(const tsx_chunk_desc* descs, uint32_t n, size_t src_size, si
     return TSX_OK;
 }
 
+// test hook `trace`: where a batch spends its time, as seen from the calling thread (microseconds since the first mark of the call)
+struct tsx_trace {
+    std::chrono::steady_clock::time_point t0; bool on;
+    tsx_trace() : t0(std::chrono::steady_clock::now()), on(g_cfg.trace) {}
+    void mark(const char* what) const { if (on) fprintf(stderr, "[tsx trace %p] %9.0f us  %s\n", (const void*)this, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what); }
+};
+
 static float ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; hipEventElapsedTime(&ms, a, b); return ms; }
 
 struct tsx_sub { uint32_t lo, n; size_t in_lo, in_hi; };     // chunks [lo, lo + n), their input bytes [in_lo, in_hi) of src
@@ -1331,8 +1352,10 @@ static int run_batch_inner(tsx_run& r) {
         out_bytes = (size_t)n * slot; max_out = (uint32_t)slot;
     }
     r.max_len = max_len; r.max_out = max_out;
+    const tsx_trace tr;
     rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, out_bytes);
     if (rc) return rc;
+    tr.mark("workspace reserved");
     r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
     r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
     hipStream_t st = c->st;
@@ -1423,13 +1446,17 @@ static int run_batch_inner(tsx_run& r) {
         // (they say how many bytes each chunk produced) and queues its copy-out
         for (size_t k = 0; k <= ns; k++) {
             if (k < ns && (rc = enqueue_piece(k))) return rc;
+            if (k < ns) tr.mark("piece enqueued (copy-in + kernels)");
             if (k > 0 && (rc = collect_piece(k - 1))) return rc;
+            if (k > 0) tr.mark("piece collected (descriptors back, copy-out queued)");
         }
     }
     if (r.host) HIPCHK(hipEventRecord(c->ev[3], c->st_out));
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
+    tr.mark("compute stream idle");
     if (r.host) { HIPCHK(hipStreamSynchronize(c->st_in)); HIPCHK(hipStreamSynchronize(c->st_out)); if (out2) HIPCHK(hipStreamSynchronize(c->st_out2)); }
+    tr.mark("copy streams idle");
     HIPCHK(hipGetLastError());
     tsx_timing& t = c->timing;
     for (size_t k = 0; k < ns; k++) {

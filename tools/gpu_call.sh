@@ -170,7 +170,8 @@ PY
     mixed)
       # fetch latency under upload load, tools/mixed_load_probe.py: arg = "shape,callers[,reserved]" ... (default: both shapes, library default)
       for cfg in ${arg:-"batches,5 broker,32"}; do set -- ${cfg//,/ }
-        timeout 300 python tools/mixed_load_probe.py --shape $1 --callers $2 ${3:+--reserved-cus $3} --seconds 10 --tag "$cfg" 2>> $O/mixed.err | tee -a $O/mixed.jsonl
+        nf=""; [ "$4" = "nofetch" ] && nf="--no-fetch"
+        timeout 300 python tools/mixed_load_probe.py --shape $1 --callers $2 ${3:+--reserved-cus $3} $nf --seconds ${MIXED_SECONDS:-12} --tag "$cfg" 2>> $O/mixed.err | tee -a $O/mixed.jsonl
       done ;;
     *) echo "unknown section $name" ;;
   esac

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--shape", default="batches", choices=["batches", "broker"],
                     help="the upload load: `batches` = --callers explicit contexts x 2048-chunk device-resident batches (more chunks queued than the chip has "
                          "slots); `broker` = --callers context-less calls of ONE 256-chunk segment each, registered host buffers, slot layout (tools/broker_leg.py)")
+    ap.add_argument("--no-fetch", action="store_true", help="the same upload load without any fetch: the rate the fetches (and the reservation) are set against")
     ap.add_argument("--reserved-cus", type=int, default=-1, help="tsx_config.fetch_reserved_cus (-1: the library's default)")
     args = ap.parse_args()
     N = nat.Native(); N.init(1, [0], fetch_reserved_cus=None if args.reserved_cus < 0 else args.reserved_cus)
@@ -99,6 +100,8 @@ def main():
     assert np.array_equal(hbk, want)
     stop = [False]
     done = [0] * T
+    stamps = []
+    slock = threading.Lock()
 
     def worker(t):
         while not stop[0]:
@@ -107,6 +110,8 @@ def main():
             else:
                 N.transform_batch(params, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t])
             done[t] += 1
+            with slock:
+                stamps.append(time.perf_counter())
 
     th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
     t0 = time.perf_counter()
@@ -114,6 +119,9 @@ def main():
     time.sleep(2.0)                                                     # the chip is full
     lat = {1: [], 4: []}
     while time.perf_counter() - t0 < args.seconds:
+        if args.no_fetch:
+            time.sleep(0.2)
+            continue
         for k in (1, 4):
             lat[k].append(fetch(k) * 1e3)
         time.sleep(0.05)
@@ -125,9 +133,13 @@ def main():
     out = {"tag": args.tag, "reserved_cus": st["reserved_cus"], "cu_keys_seen": st["cu_keys_seen"], "service_launches": st["launches"], "watchdog_launches": st["watchdog_launches"],
            "compress_callers": T,
            "upload_shape": args.shape, "chunks_offered": T * (256 if broker else n),
-           "compress_gibs_while_fetching": round(sum(done) * (256 if broker else n) * CH / float(1 << 30) / el, 3),
+           "compress_gibs_while_fetching": round(sum(done) * (256 if broker else n) * CH / float(1 << 30) / el, 3), "fetching": not args.no_fetch,
            "fetch_idle_ms": {k: round(v, 3) for k, v in idle.items()}}
-    for k in (1, 4):
+    da = np.sort(np.asarray(stamps)) - t0
+    if da.size >= 8:                                                  # rate without ramp and drain: slope of completions over the middle 60 %
+        k0, k1 = int(da.size * 0.2), int(da.size * 0.8)
+        out["compress_gibs_slope"] = round(float(np.polyfit(da[k0:k1], np.arange(k0, k1), 1)[0]) * (256 if broker else n) * CH / float(1 << 30), 3)
+    for k in (() if args.no_fetch else (1, 4)):
         a = np.asarray(lat[k])
         out["fetch_%d_under_load_ms" % k] = {"n": int(a.size), "median": round(float(np.median(a)), 2), "p95": round(float(np.percentile(a, 95)), 2), "max": round(float(a.max()), 2)}
     print(json.dumps(out), flush=True)
