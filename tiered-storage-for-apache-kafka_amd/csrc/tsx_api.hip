@@ -102,7 +102,8 @@ struct tsx_service {
     tsx_svc_host* h = nullptr; tsx_svc_host* hd = nullptr;          // the queue in pinned host memory: host view, device alias
     tsx_svc_dev* d = nullptr;
     uint32_t* h_zero = nullptr;                                      // pinned zero word (resets of device words travel as copies, not kernels)
-    hipStream_t st = nullptr; hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    hipStream_t st = nullptr;                                        // the service kernel's stream: launches only - no events, no copies while it runs
+    uint32_t launch_id = 0;                                          // id of the last launch made
     bool launched = false;                                           // a launch is out whose end this side has not seen yet
     bool stop_dirty = false;                                         // the device's stop word must be cleared in front of the next launch
     uint32_t paused = 0;                                             // > 0: no launches (memory management in progress)
@@ -228,12 +229,9 @@ extern "C" const char* tsx_strerror(int code) {
 // as long as uploads go on - nothing in this library frees device or pinned memory while that kernel may be running (svc_free_*).
 static bool svc_running_locked(tsx_service& s) {
     if (!s.launched) return false;
-    const hipError_t e = hipEventQuery(s.ev_end);
-    if (e == hipErrorNotReady) { (void)hipGetLastError(); return true; }
-    (void)hipGetLastError();
-    float ms = 0;
-    if (e == hipSuccess && hipEventElapsedTime(&ms, s.ev_begin, s.ev_end) == hipSuccess) s.kernel_ms += ms;
-    (void)hipGetLastError();
+    // the launch's last wave says so itself (tsx_svc_host.ended_launch): nothing is queued behind the kernel that could be asked
+    if (__atomic_load_n(&s.h->ended_launch, __ATOMIC_ACQUIRE) != s.launch_id) return true;
+    s.kernel_ms += (double)(s.h->t_last - s.h->t_first) / 1e5;           // 100 MHz ticks
     s.launched = false;
     for (void* p : s.deferred_dev) (void)hipFree(p);
     for (void* p : s.deferred_host) (void)hipHostFree(p);
@@ -258,11 +256,11 @@ static int svc_launch_locked(tsx_service& s) {
 #endif
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
-    HIPCHK(hipEventRecord(s.ev_begin, s.st));
+    a.launch_id = s.launch_id + 1;
     (void)hipGetLastError();
     tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_last_err, sizeof g_last_err, "launch of the compressor service kernel failed"); return TSX_E_DEVICE; }
-    HIPCHK(hipEventRecord(s.ev_end, s.st));
+    s.launch_id = a.launch_id;
     s.launched = true; s.launches++;
     return TSX_OK;
 }
@@ -274,8 +272,6 @@ static void svc_destroy(tsx_device& d) {
     if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
     for (void* p : s.deferred_dev) (void)hipFree(p);
     for (void* p : s.deferred_host) (void)hipHostFree(p);
-    if (s.ev_begin) (void)hipEventDestroy(s.ev_begin);
-    if (s.ev_end) (void)hipEventDestroy(s.ev_end);
     if (s.h) (void)hipHostFree(s.h);
     if (s.h_zero) (void)hipHostFree(s.h_zero);
     if (s.d) (void)hipFree(s.d);
@@ -308,8 +304,6 @@ static int svc_create(tsx_device& d, int cus) {
             HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
         }
     }
-    HIPCHK(hipEventCreate(&s.ev_begin));
-    HIPCHK(hipEventCreate(&s.ev_end));
     for (uint32_t i = TSX_SVC_MEMBERS; i-- > 0;) s.free_slots.push_back((uint16_t)i);
     // which compute units are there?  (HIP promises nothing about placement: a launch of three 48 KiB workgroups per CU that stay ~30 us each
     // has to spread over all of them; twice, in case the first one met a chip that was busy)
@@ -1432,6 +1426,11 @@ static int run_batch_inner(tsx_run& r) {
     if (out2 && !c->st_out2 && hipStreamCreateWithFlags(&c->st_out2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->st_out2 = nullptr; out2 = false; }
     auto collect_piece = [&](size_t k) -> int {
         const tsx_sub& sb = subs[k];
+        if (tr.on) {                                                    // (test hook: which stage a waiting batch is waiting in)
+            static const char* const names[6] = {"descriptors up + status init", "stage 1", "stage 2", "stage 3", "descriptors down", "copy-in landed"};
+            if (r.host) { (void)hipEventSynchronize(c->sub_ev[k][5]); tr.mark(names[5]); }
+            for (int q = 0; q < 5; q++) { (void)hipEventSynchronize(c->sub_ev[k][q]); tr.mark(names[q]); }
+        }
         HIPCHK(hipEventSynchronize(c->sub_ev[k][4]));                   // descriptors of piece k are on the host
         memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
         if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, (out2 && (k & 1)) ? c->st_out2 : c->st_out);

@@ -95,10 +95,18 @@ struct tsx_zseg {                // one caller's batch ("member") in the device'
 #define TSX_SVC_TICKETS 65536u        /* ticket ring (power of two): chunks published and not yet completed never exceed it */
 #define TSX_SVC_MEMBER_MAX 16384u     /* chunks per member (a larger batch goes as several members) */
 struct tsx_svc_ticket { uint32_t member_gen; uint32_t chunk; };   // member slot in the low 16 bits, the slot's generation (16 bits) above
-struct tsx_svc_host {                // pinned host memory, written by the host, read by the device (through its device alias)
+struct tsx_svc_host {                // pinned host memory, written by the host, read by the device (through its device alias) ...
     uint32_t published;              // tickets [.., published) are valid; release-stored after their records and member entries
     uint32_t stop;                   // != 0: waves leave after their current chunk (shutdown / pause for memory management)
     uint32_t pad_[14];
+    // ... except this line, which the LAST wave of a launch writes: the launch is over.  The service's stream carries no HIP event: a marker
+    // queued behind the kernel is a barrier packet that waits, at the head of its hardware queue, for as long as the kernel lives - and
+    // while it waited, the first command of every stream whose hardware queue shares that queue's pipe did not start either (measured:
+    // the first fetch after uploads began returned when the service kernel ended; profiles/r05_mixed_probe_trace_first_fetch_blocked.txt).
+    uint32_t ended_launch;           // id of the last launch that has ended (release-stored after the two stamps)
+    uint32_t ended_pad_;
+    uint64_t t_first, t_last;        // 100 MHz clock at the launch's first wave start / last wave exit
+    uint32_t pad2_[10];
     tsx_zseg member[TSX_SVC_MEMBERS];
     tsx_svc_ticket ticket[TSX_SVC_TICKETS];
 };
@@ -110,11 +118,13 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
     uint32_t stop;                   // mirror of tsx_svc_host.stop
     uint32_t gen_start_lo, gen_start_hi, gen_started;   // clock at the first wave of this launch (generation age)
     uint32_t stat_chunks, stat_wave_starts, stat_reserved_exits, stat_skipped;
-    uint32_t pad_[4];
+    uint32_t entered, exited;        // waves of the current launch that have started / left (the last one to leave reports the launch's end)
+    uint32_t t_first_lo, t_first_hi; // clock at the first wave's start
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
 };
 struct tsx_svc_launch {              // kernel arguments that shape a launch
+    uint32_t launch_id;              // what the last wave writes to tsx_svc_host.ended_launch
     uint32_t sched;                  // parser speculation schedule (0 = default)
     uint32_t poll_ticks;             // 100 MHz ticks between two host polls (device-wide)
     uint32_t idle_exit_ticks;        // a wave leaves when the queue has been dry and no wave busy for this long

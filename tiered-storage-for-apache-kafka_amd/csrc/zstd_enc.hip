@@ -1775,16 +1775,33 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
 }
 
 static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
+// A wave leaves: the last one of the launch tells the host (pinned memory) that the launch is over, and when it began and ended.
+__device__ ZS_NOINLINE static void svc_wave_exit(tsx_svc_host* H, tsx_svc_dev* D, uint32_t launch_id) {
+    if (atomicAdd(&D->exited, 1u) + 1u != gridDim.x) return;
+    const uint64_t now = svc_now();
+    const uint64_t first = ((uint64_t)SVC_LD_DEV(&D->t_first_hi) << 32) | SVC_LD_DEV(&D->t_first_lo);
+    SVC_ST_DEV(&D->entered, 0u); SVC_ST_DEV(&D->exited, 0u);            // the next launch counts from zero (it is only started once this one is seen ended)
+#ifdef HIPEMU
+    H->t_first = first; H->t_last = now;
+#else
+    __hip_atomic_store(&H->t_first, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&H->t_last, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+    svc_release_system();
+    SVC_ST_SYS(&H->ended_launch, launch_id);
+}
+
 __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a ZS_PROF_PARAM) {
     __shared__ EncLds L;
     const uint32_t lane = threadIdx.x;
+    const uint64_t t_start = svc_now();
+    if (lane == 0 && atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
     const uint32_t key = UNI(svc_cu_key());
     if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h)
-        if (lane == 0) atomicAdd(&D->stat_reserved_exits, 1u);
+        if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }
         return;
     }
     if (lane == 0) atomicAdd(&D->stat_wave_starts, 1u);
-    const uint64_t t_start = svc_now();
     for (;;) {
         uint32_t got = 0, ticket = 0;
         if (lane == 0) got = svc_take(H, D, a, t_start, &ticket);
@@ -1830,6 +1847,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         }
         __syncthreads();
     }
+    if (lane == 0) svc_wave_exit(H, D, a.launch_id);
 }
 
 // A launch that covers the chip (48 KiB of LDS per one-wave workgroup: three per CU) and notes every CU key it meets.

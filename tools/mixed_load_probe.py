@@ -30,10 +30,12 @@ def main():
     ap.add_argument("--shape", default="batches", choices=["batches", "broker"],
                     help="the upload load: `batches` = --callers explicit contexts x 2048-chunk device-resident batches (more chunks queued than the chip has "
                          "slots); `broker` = --callers context-less calls of ONE 256-chunk segment each, registered host buffers, slot layout (tools/broker_leg.py)")
+    ap.add_argument("--trace", action="store_true", help="the library's phase trace (stderr) for the fetches under load")
+    ap.add_argument("--max-launch-ms", type=int, default=-1)
     ap.add_argument("--no-fetch", action="store_true", help="the same upload load without any fetch: the rate the fetches (and the reservation) are set against")
     ap.add_argument("--reserved-cus", type=int, default=-1, help="tsx_config.fetch_reserved_cus (-1: the library's default)")
     args = ap.parse_args()
-    N = nat.Native(); N.init(1, [0], fetch_reserved_cus=None if args.reserved_cus < 0 else args.reserved_cus)
+    N = nat.Native(); N.init(1, [0], fetch_reserved_cus=None if args.reserved_cus < 0 else args.reserved_cus, service_max_launch_ms=None if args.max_launch_ms < 0 else args.max_launch_ms)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from numa_bind import bind_to_gpu_numa_node
     AFFINITY = bind_to_gpu_numa_node(0)                              # before any host buffer is allocated (profiles/r04_broker_numa.txt)
@@ -117,6 +119,8 @@ def main():
     t0 = time.perf_counter()
     [x.start() for x in th]
     time.sleep(2.0)                                                     # the chip is full
+    if args.trace:
+        N.debug_config("trace", 1)
     lat = {1: [], 4: []}
     while time.perf_counter() - t0 < args.seconds:
         if args.no_fetch:
