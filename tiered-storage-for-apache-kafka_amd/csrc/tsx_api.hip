@@ -40,6 +40,7 @@ struct tsx_cfg {
     bool zero_copy_packed = false;        // explicit contexts: packed output in place too
     bool gcm_setup_kernel = false;        // key schedule by gcm_setup_kernel instead of on the host
     bool no_dec_pieces = false;           // block-form fetches in one piece
+    bool svc_no_primer = false;           // cold starts of the service kernel without the dry launch in front (measurements)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
 };
@@ -68,7 +69,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(trace, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_no_primer, bool) CFG_FIELD(trace, bool)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -256,8 +257,17 @@ static int svc_launch_locked(tsx_service& s) {
 #endif
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
-    a.launch_id = s.launch_id + 1;
     (void)hipGetLastError();
+    if (!g_cfg.svc_no_primer) {
+        // A primer in front of every start: the same kernel, every wave leaving at once (microseconds).  Measured on the device (gpurun r05k,
+        // profiles/r05_cold_start_of_the_service.txt): while a service launch that began on a device that had been IDLE was alive - up to its
+        // age limit - the first command other streams issued did not start; a launch that follows another one within a millisecond (the
+        // watchdog's relaunch) never had that effect.  With the primer every real launch is one of the second kind.
+        tsx_svc_launch p = a;
+        p.dry = 1; p.launch_id = ++s.launch_id;
+        tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, p);
+    }
+    a.launch_id = s.launch_id + 1;
     tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_last_err, sizeof g_last_err, "launch of the compressor service kernel failed"); return TSX_E_DEVICE; }
     s.launch_id = a.launch_id;

@@ -125,6 +125,7 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
 };
 struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t launch_id;              // what the last wave writes to tsx_svc_host.ended_launch
+    uint32_t dry;                    // != 0: a primer - every wave leaves at once (tsx_api.hip, svc_launch_locked)
     uint32_t sched;                  // parser speculation schedule (0 = default)
     uint32_t poll_ticks;             // 100 MHz ticks between two host polls (device-wide)
     uint32_t idle_exit_ticks;        // a wave leaves when the queue has been dry and no wave busy for this long

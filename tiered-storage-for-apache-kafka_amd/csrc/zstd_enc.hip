@@ -1796,6 +1796,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     const uint32_t lane = threadIdx.x;
     const uint64_t t_start = svc_now();
     if (lane == 0 && atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
+    if (a.dry) { if (lane == 0) svc_wave_exit(H, D, a.launch_id); return; }
     const uint32_t key = UNI(svc_cu_key());
     if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h)
         if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }

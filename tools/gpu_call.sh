@@ -173,6 +173,14 @@ PY
         nf=""; [ "$4" = "nofetch" ] && nf="--no-fetch"
         timeout 300 python tools/mixed_load_probe.py --shape $1 --callers $2 ${3:+--reserved-cus $3} $nf --seconds ${MIXED_SECONDS:-12} --tag "$cfg" 2>> $O/mixed.err | tee -a $O/mixed.jsonl
       done ;;
+    mixednt)
+      # fetch latency under upload load in a process WITHOUT torch (the system's HIP runtime): arg = "shape,callers[,reserved[,nofetch]]" ...
+      export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/mixednt.err
+      for cfg in ${arg:-"broker,32 batches,5"}; do set -- ${cfg//,/ }
+        nf=""; [ "$4" = "nofetch" ] && nf="--no-fetch"
+        timeout 300 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape $1 --callers $2 ${3:+--reserved-cus $3} $nf --seconds ${MIXED_SECONDS:-12} ${MIXED_MAX_LAUNCH_MS:+--max-launch-ms $MIXED_MAX_LAUNCH_MS} --tag "$cfg" 2>> $O/mixednt.err | tee -a $O/mixednt.jsonl
+      done ;;
     *) echo "unknown section $name" ;;
   esac
 done
