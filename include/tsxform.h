@@ -177,6 +177,7 @@ typedef struct tsx_service_info {
     uint32_t waves;              /* one-wave workgroups per launch                                                               */
     uint32_t compute_units, cu_keys_seen, reserved_cus;   /* CUs of the device, distinct CU ids a probe launch met, CUs left alone */
     uint32_t device_chunks, wave_starts, reserved_exits, skipped_tickets;   /* device-side counters (mod 2^32)                   */
+    uint32_t live_waves, live_waves_max;   /* waves of the service resident right now / the most ever                              */
 } tsx_service_info;
 int  tsx_service_stats(int device_index, tsx_service_info* out);
 /* Returns when the device's service kernel has ended (a moment after its last chunk): brackets a measurement. */

@@ -1,5 +1,6 @@
 // C-ABI front end of libtsxform: device/context management, the compressor service's host side and the batch pipelines.
 // See include/tsxform.h for the contract and the reference call sites each entry point replaces.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -40,6 +41,7 @@ struct tsx_cfg {
     bool zero_copy_packed = false;        // explicit contexts: packed output in place too
     bool gcm_setup_kernel = false;        // key schedule by gcm_setup_kernel instead of on the host
     bool no_dec_pieces = false;           // block-form fetches in one piece
+    bool svc_cu_mask = false;             // the reservation as a CU mask on the service's stream instead of waves that leave (measurements)
     bool svc_no_primer = false;           // cold starts of the service kernel without the dry launch in front (measurements)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
@@ -69,7 +71,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_no_primer, bool) CFG_FIELD(trace, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_no_primer, bool) CFG_FIELD(svc_cu_mask, bool) CFG_FIELD(trace, bool)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -305,7 +307,14 @@ static int svc_create(tsx_device& d, int cus) {
     // priority and multiplexes a process's streams onto them - a stream that shared the service's hardware queue would sit behind a kernel
     // that lives as long as uploads go on, and nothing else in this library (or, normally, in the process) creates low-priority streams;
     // and between a compressor wave and a fetch's workgroup that could both be placed, the fetch's goes first.
-    {
+    if (g_cfg.svc_cu_mask && g_cfg.reserved_cus && cus > 16) {
+        // measurement variant: the hardware keeps the service off the last `reserved` CUs of the numbering (bit i of the mask belongs to XCD i mod 8)
+        const uint32_t r = g_cfg.reserved_cus > (uint32_t)cus / 4 ? (uint32_t)cus / 4 : g_cfg.reserved_cus, words = ((uint32_t)cus + 31) / 32;
+        uint32_t mask[64] = {0};
+        for (uint32_t i = 0; i + r < (uint32_t)cus && i < 64 * 32; i++) mask[i / 32] |= 1u << (i % 32);
+        if (hipExtStreamCreateWithCUMask(&s.st, words, mask) != hipSuccess) { (void)hipGetLastError(); s.st = nullptr; }
+    }
+    if (!s.st) {
         int least = 0, greatest = 0;
         if (g_cfg.svc_normal_priority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
             hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, least) != hipSuccess) {
@@ -349,9 +358,10 @@ static int svc_create(tsx_device& d, int cus) {
             }
         }
     (void)xccs;
+    if (g_cfg.svc_cu_mask && g_cfg.reserved_cus && cus > 16) { std::fill(res.begin(), res.end(), 0u); }      // (the mask does it)
     s.cus_reserved = taken;
     HIPCHK(hipMemcpy(s.d->reserved, res.data(), 512, hipMemcpyHostToDevice));
-    s.grid = s.cus * 24u;                                               // 24 one-wave workgroups fill a CU's LDS: the launch covers the chip once
+    s.grid = (g_cfg.svc_cu_mask && g_cfg.reserved_cus && cus > 16 ? s.cus - taken : s.cus) * 24u;                                               // 24 one-wave workgroups fill a CU's LDS: the launch covers the chip once
     return TSX_OK;
 }
 
@@ -1005,6 +1015,7 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
     if (hipMemcpy(w, &s.d->stat_chunks, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
         out->device_chunks = w[0]; out->wave_starts = w[1]; out->reserved_exits = w[2]; out->skipped_tickets = w[3];
     } else (void)hipGetLastError();
+    if (hipMemcpy(w, &s.d->live, 8, hipMemcpyDeviceToHost) == hipSuccess) { out->live_waves = w[0]; out->live_waves_max = w[1]; } else (void)hipGetLastError();
     return TSX_OK;
 }
 

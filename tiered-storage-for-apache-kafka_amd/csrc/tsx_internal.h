@@ -120,6 +120,7 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
     uint32_t stat_chunks, stat_wave_starts, stat_reserved_exits, stat_skipped;
     uint32_t entered, exited;        // waves of the current launch that have started / left (the last one to leave reports the launch's end)
     uint32_t t_first_lo, t_first_hi; // clock at the first wave's start
+    uint32_t live, live_max, pad3_[2];   // waves resident right now / the most ever (statistics: is the whole launch resident at once?)
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
 };

@@ -1777,6 +1777,7 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
 static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
 // A wave leaves: the last one of the launch tells the host (pinned memory) that the launch is over, and when it began and ended.
 __device__ ZS_NOINLINE static void svc_wave_exit(tsx_svc_host* H, tsx_svc_dev* D, uint32_t launch_id) {
+    atomicSub(&D->live, 1u);
     if (atomicAdd(&D->exited, 1u) + 1u != gridDim.x) return;
     const uint64_t now = svc_now();
     const uint64_t first = ((uint64_t)SVC_LD_DEV(&D->t_first_hi) << 32) | SVC_LD_DEV(&D->t_first_lo);
@@ -1795,7 +1796,10 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     __shared__ EncLds L;
     const uint32_t lane = threadIdx.x;
     const uint64_t t_start = svc_now();
-    if (lane == 0 && atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
+    if (lane == 0) {
+        if (atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
+        atomicMax(&D->live_max, atomicAdd(&D->live, 1u) + 1u);
+    }
     if (a.dry) { if (lane == 0) svc_wave_exit(H, D, a.launch_id); return; }
     const uint32_t key = UNI(svc_cu_key());
     if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h)

@@ -28,6 +28,9 @@ def run(args):
     from numa_bind import bind_to_gpu_numa_node
     nat = tsxform._native
     N = nat.Native()
+    for kv in (args.config or "").split(","):
+        if kv:
+            N.debug_config(kv.split("=")[0], int(kv.split("=")[1]))
     N.init(1, [0], fetch_reserved_cus=None if args.reserved_cus < 0 else args.reserved_cus, service_max_launch_ms=None if args.max_launch_ms < 0 else args.max_launch_ms)
     affinity = bind_to_gpu_numa_node(0)
     CH, B = args.chunk, 256
@@ -96,6 +99,15 @@ def run(args):
             rows.append({"phase": phase, "at_s": round(time.perf_counter() - t0, 2), "ms": round(v, 2), "service_launches": N.service_stats(0)["launches"]}); print(json.dumps(rows[-1]), flush=True)
         th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
         t0 = time.perf_counter()
+        sampling = [True]
+
+        def sampler():
+            while sampling[0]:
+                st_ = N.service_stats(0)
+                print(json.dumps({"sample_at_s": round(time.perf_counter() - t0, 2), **{k: st_[k] for k in ("launches", "watchdog_launches", "running", "device_chunks", "wave_starts", "reserved_exits", "live_waves", "live_waves_max")}}), flush=True)
+                time.sleep(1.0)
+
+        sth = threading.Thread(target=sampler); sth.start()
         [x.start() for x in th]
         time.sleep(2.0)
         note("A first fetch after uploads began", fetch(1))
@@ -109,6 +121,9 @@ def run(args):
         note("C again", fetch(1))
         stop[0] = True
         [x.join() for x in th]
+        sampling[0] = False; sth.join()
+        if args.phases_short:
+            return rows
         time.sleep(1.0)
         for _ in range(3):
             note("D uploads stopped, fetch side stays warm", fetch(1)); time.sleep(0.3)
@@ -164,6 +179,8 @@ if __name__ == "__main__":
     ap.add_argument("--reserved-cus", type=int, default=-1)
     ap.add_argument("--max-launch-ms", type=int, default=-1)
     ap.add_argument("--no-fetch", action="store_true")
+    ap.add_argument("--config", default="", help="key=value,... for tsx_debug_config before tsx_init (measurement variants)")
     ap.add_argument("--phases", action="store_true")
+    ap.add_argument("--phases-short", action="store_true", help="with --phases: stop after phase C")
     ap.add_argument("--tag", default="")
     run(ap.parse_args())
