@@ -26,7 +26,7 @@
 struct tsx_cfg {
     uint32_t reserved_cus = 8;            // compute units the compressor service leaves to everything else (one per XCD); TSX_FETCH_RESERVED_CUS
     uint32_t svc_max_launch_ms = 60000;   // age limit of one launch of the service kernel (0 = none); TSX_SERVICE_MAX_LAUNCH_MS
-    uint32_t svc_idle_exit_us = 300;      // the service kernel ends when it has had nothing to do for this long
+    uint32_t svc_idle_exit_us = 2000;     // the service kernel ends when it has had nothing to do for this long (callers in a closed loop need ~1 ms to come back)
     long long pool_idle_bytes = -1;       // idle pooled workspace kept per device (-1: 4/9 of its memory); TSX_POOL_IDLE_BYTES
     uint32_t zstd_sched = 0;              // parser speculation schedule k0 | k1 << 8 (0 = the kernel's default; same bytes); TSX_ZSTD_SCHED
     bool debug = false;                   // TSX_DEBUG: HIP failures go to stderr as they happen
@@ -41,8 +41,7 @@ struct tsx_cfg {
     bool zero_copy_packed = false;        // explicit contexts: packed output in place too
     bool gcm_setup_kernel = false;        // key schedule by gcm_setup_kernel instead of on the host
     bool no_dec_pieces = false;           // block-form fetches in one piece
-    bool svc_cu_mask = false;             // the reservation as a CU mask on the service's stream instead of waves that leave (measurements)
-    bool svc_no_primer = false;           // cold starts of the service kernel without the dry launch in front (measurements)
+    uint32_t svc_waves_per_cu = 0;        // workgroups of a service launch per CU (0 = what the runtime says is resident at once; measurements only)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
 };
@@ -71,7 +70,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_no_primer, bool) CFG_FIELD(svc_cu_mask, bool) CFG_FIELD(trace, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(trace, bool)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -110,7 +109,7 @@ struct tsx_service {
     bool launched = false;                                           // a launch is out whose end this side has not seen yet
     bool stop_dirty = false;                                         // the device's stop word must be cleared in front of the next launch
     uint32_t paused = 0;                                             // > 0: no launches (memory management in progress)
-    uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0;
+    uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0, waves_per_cu = 0;
     uint32_t published = 0;
     uint64_t next_id = 1;
     std::deque<tsx_svc_member> out;                                  // members published and not yet retired, oldest first
@@ -260,15 +259,6 @@ static int svc_launch_locked(tsx_service& s) {
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
     (void)hipGetLastError();
-    if (!g_cfg.svc_no_primer) {
-        // A primer in front of every start: the same kernel, every wave leaving at once (microseconds).  Measured on the device (gpurun r05k,
-        // profiles/r05_cold_start_of_the_service.txt): while a service launch that began on a device that had been IDLE was alive - up to its
-        // age limit - the first command other streams issued did not start; a launch that follows another one within a millisecond (the
-        // watchdog's relaunch) never had that effect.  With the primer every real launch is one of the second kind.
-        tsx_svc_launch p = a;
-        p.dry = 1; p.launch_id = ++s.launch_id;
-        tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, p);
-    }
     a.launch_id = s.launch_id + 1;
     tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_last_err, sizeof g_last_err, "launch of the compressor service kernel failed"); return TSX_E_DEVICE; }
@@ -307,14 +297,7 @@ static int svc_create(tsx_device& d, int cus) {
     // priority and multiplexes a process's streams onto them - a stream that shared the service's hardware queue would sit behind a kernel
     // that lives as long as uploads go on, and nothing else in this library (or, normally, in the process) creates low-priority streams;
     // and between a compressor wave and a fetch's workgroup that could both be placed, the fetch's goes first.
-    if (g_cfg.svc_cu_mask && g_cfg.reserved_cus && cus > 16) {
-        // measurement variant: the hardware keeps the service off the last `reserved` CUs of the numbering (bit i of the mask belongs to XCD i mod 8)
-        const uint32_t r = g_cfg.reserved_cus > (uint32_t)cus / 4 ? (uint32_t)cus / 4 : g_cfg.reserved_cus, words = ((uint32_t)cus + 31) / 32;
-        uint32_t mask[64] = {0};
-        for (uint32_t i = 0; i + r < (uint32_t)cus && i < 64 * 32; i++) mask[i / 32] |= 1u << (i % 32);
-        if (hipExtStreamCreateWithCUMask(&s.st, words, mask) != hipSuccess) { (void)hipGetLastError(); s.st = nullptr; }
-    }
-    if (!s.st) {
+    {
         int least = 0, greatest = 0;
         if (g_cfg.svc_normal_priority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
             hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, least) != hipSuccess) {
@@ -358,10 +341,18 @@ static int svc_create(tsx_device& d, int cus) {
             }
         }
     (void)xccs;
-    if (g_cfg.svc_cu_mask && g_cfg.reserved_cus && cus > 16) { std::fill(res.begin(), res.end(), 0u); }      // (the mask does it)
     s.cus_reserved = taken;
     HIPCHK(hipMemcpy(s.d->reserved, res.data(), 512, hipMemcpyHostToDevice));
-    s.grid = (g_cfg.svc_cu_mask && g_cfg.reserved_cus && cus > 16 ? s.cus - taken : s.cus) * 24u;                                               // 24 one-wave workgroups fill a CU's LDS: the launch covers the chip once
+    // A launch covers the chip exactly once - never more workgroups than are resident at the same time.  The waves stay for as long as there
+    // is work, so workgroups that did not fit would stay PENDING for as long, and a dispatch that is still in progress holds its hardware
+    // pipe: the first command of every stream whose queue sat on that pipe did not start until the launch was over.  Measured (gpurun
+    // r05a-r05n, profiles/r05_service_resident_waves_and_pending_workgroups.txt): launches of 256 x 24 against the 256 x 21 that fit (the
+    // kernel's 6704 bytes of LDS are allocated as 7680) kept 768 workgroups pending, and a fetch issued meanwhile came back when the launch
+    // ended - up to its age limit later.
+    uint32_t per_cu = g_cfg.svc_waves_per_cu ? g_cfg.svc_waves_per_cu : tsx_zstd_service_waves_per_cu();
+    if (per_cu == 0 || per_cu > 32) per_cu = 16;                        // (the runtime would not say: stay on the safe side)
+    s.waves_per_cu = per_cu;
+    s.grid = s.cus * per_cu;
     return TSX_OK;
 }
 

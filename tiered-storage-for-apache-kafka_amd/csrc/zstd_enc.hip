@@ -1800,7 +1800,6 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         if (atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
         atomicMax(&D->live_max, atomicAdd(&D->live, 1u) + 1u);
     }
-    if (a.dry) { if (lane == 0) svc_wave_exit(H, D, a.launch_id); return; }
     const uint32_t key = UNI(svc_cu_key());
     if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h)
         if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }
@@ -1880,6 +1879,15 @@ void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, u
                        , g_prof_out
 #endif
                        );
+}
+uint32_t tsx_zstd_service_waves_per_cu(void) {
+#ifdef HIPEMU
+    return ZS_WAVES_PER_SIMD * 4;
+#else
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zstd_service_kernel, LANES, 0) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
+    return (uint32_t)n;
+#endif
 }
 void tsx_launch_cu_probe(hipStream_t st, tsx_svc_dev* d, uint32_t grid) {
     if (grid) hipLaunchKernelGGL(cu_probe_kernel, dim3(grid), dim3(LANES), 0, st, d);
