@@ -109,7 +109,7 @@ struct tsx_service {
     bool launched = false;                                           // a launch is out whose end this side has not seen yet
     bool stop_dirty = false;                                         // the device's stop word must be cleared in front of the next launch
     uint32_t paused = 0;                                             // > 0: no launches (memory management in progress)
-    uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0, waves_per_cu = 0;
+    uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0, waves_per_cu = 0, resident = 0;
     uint32_t published = 0;
     uint64_t next_id = 1;
     std::deque<tsx_svc_member> out;                                  // members published and not yet retired, oldest first
@@ -349,8 +349,21 @@ static int svc_create(tsx_device& d, int cus) {
     // r05a-r05n, profiles/r05_service_resident_waves_and_pending_workgroups.txt): launches of 256 x 24 against the 256 x 21 that fit (the
     // kernel's 6704 bytes of LDS are allocated as 7680) kept 768 workgroups pending, and a fetch issued meanwhile came back when the launch
     // ended - up to its age limit later.
-    uint32_t per_cu = g_cfg.svc_waves_per_cu ? g_cfg.svc_waves_per_cu : tsx_zstd_service_waves_per_cu();
-    if (per_cu == 0 || per_cu > 32) per_cu = 16;                        // (the runtime would not say: stay on the safe side)
+    // How many fit is MEASURED: a launch of 32 workgroups per CU whose waves just stay for 300 us counts the most that were ever resident
+    // at once (registers, LDS with its allocation granularity, scratch slots - whatever limits it; the runtime's occupancy query said 24
+    // where 21 fit).  tsx_init runs on a device this process is not using yet.
+    {
+        tsx_svc_launch c{}; c.launch_id = ++s.launch_id; c.calibrate_ticks = 30000;
+        (void)hipGetLastError();
+        tsx_launch_zstd_service(s.st, s.hd, s.d, s.cus * 32u, c);
+        HIPCHK(hipStreamSynchronize(s.st));
+        uint32_t lm[2] = {0, 0};
+        HIPCHK(hipMemcpy(lm, &s.d->live, 8, hipMemcpyDeviceToHost));
+        s.resident = lm[1];
+        HIPCHK(hipMemcpy(&s.d->live_max, s.h_zero, 4, hipMemcpyHostToDevice));
+    }
+    uint32_t per_cu = g_cfg.svc_waves_per_cu ? g_cfg.svc_waves_per_cu : s.resident / s.cus;
+    if (per_cu == 0 || per_cu > 32) per_cu = 16;                        // (a measurement that cannot be: stay on the safe side)
     s.waves_per_cu = per_cu;
     s.grid = s.cus * per_cu;
     return TSX_OK;

@@ -126,16 +126,13 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
 };
 struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t launch_id;              // what the last wave writes to tsx_svc_host.ended_launch
+    uint32_t calibrate_ticks;        // != 0: every wave just stays this long and leaves (tsx_svc_dev.live_max then says how many fit at once)
     uint32_t sched;                  // parser speculation schedule (0 = default)
     uint32_t poll_ticks;             // 100 MHz ticks between two host polls (device-wide)
     uint32_t idle_exit_ticks;        // a wave leaves when the queue has been dry and no wave busy for this long
     uint32_t max_age_ticks_lo, max_age_ticks_hi;   // != 0: waves stop taking tickets when the launch is older (the host starts the next one)
 };
 void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, uint32_t grid, tsx_svc_launch a);
-// One-wave workgroups of the service kernel that ONE compute unit holds at the same time, as the runtime computes it from the kernel's
-// registers and LDS (allocation granularity included: 6704 bytes of LDS occupy 7680 on gfx950 - 21 per CU, not the 24 that 160 KiB / 6704
-// suggests).  A launch must never be larger than what is resident at once: see svc_create.
-uint32_t tsx_zstd_service_waves_per_cu(void);
 void tsx_launch_cu_probe(hipStream_t st, tsx_svc_dev* d, uint32_t grid);
 
 struct tsx_gcm_chunk {           // per-chunk work item (device)

@@ -176,12 +176,15 @@ struct EncLds {
                 FseTable ml;            // sequence stage
                 uint32_t hist[256];     // literal stage (and the pre-splitter): byte histogram, dead before ml is built
             };
-            uint32_t hist2[256];        // second histogram (pre-splitter / sampling); sequence-code histograms
-            uint32_t cnt[16];           // histogram of Huffman weights
+            // second histogram (pre-splitter / sampling of the literals); sequence-code histograms; and, while the description of a new
+            // Huffman table is written (huf_writeCTable: the sampling is over, the sequence stage has not begun), the table's weights
+            // (bytes 0 .. 255) and their histogram (words 64 .. 79).  With those two arrays inside hist2 the wave's LDS is 6384 bytes: the
+            // hardware allocates LDS in 1280-byte granules on gfx950, so 6704 bytes occupied 7680 and a CU held 21 chunks - not the 24 its
+            // registers allow (measured: at most 5376 = 21 x 256 waves of a 6144-wave launch were ever resident at once).
+            uint32_t hist2[256];
             uint8_t tableSymbol[512];
             uint16_t cumul[64];
             short norm[64];
-            uint8_t weights[256];
         };
         struct {                // parse stage of a block (re-primed per block): source window + collision scoreboard
             uint32_t ring[ZS_RING / 4 + 4];     // + 16-byte mirror of the first bytes
@@ -1025,12 +1028,12 @@ __device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint3
 
 // HUF_compressWeights + HUF_writeCTable; returns header size, 0xFFFFFFFF when the table cannot be described
 __device__ ZS_NOINLINE static uint32_t huf_writeCTable(uint8_t* dst, const HufTable& ct, uint32_t maxSym, uint32_t huffLog, EncLds& L) {
-    uint8_t* const hw = L.weights;
+    uint8_t* const hw = reinterpret_cast<uint8_t*>(L.hist2);            // 256 weights + one pad byte ...
     for (uint32_t n = 0; n < maxSym; n++) { const uint32_t nb = ct.nb[n]; hw[n] = nb ? (uint8_t)(huffLog + 1 - nb) : 0; }
     uint32_t hSize = 0;
     {   // HUF_compressWeights(dst + 1, hw, maxSym)
         uint8_t* op = dst + 1; const uint32_t wtSize = maxSym;
-        uint32_t maxSV = ZS_HUF_TABLELOG_MAX; uint32_t* cnt = L.cnt;
+        uint32_t maxSV = ZS_HUF_TABLELOG_MAX; uint32_t* cnt = L.hist2 + 68;    // ... and behind them the 13 counters of the weights' histogram
         if (wtSize > 1) {
             for (int i = 0; i <= ZS_HUF_TABLELOG_MAX; i++) cnt[i] = 0;
             for (uint32_t i = 0; i < wtSize; i++) cnt[hw[i]]++;
@@ -1774,7 +1777,7 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
     }
 }
 
-static_assert(sizeof(EncLds) * 4 * ZS_WAVES_PER_SIMD <= 160u * 1024, "LDS of ZS_WAVES_PER_SIMD chunks per SIMD fits the CU");
+static_assert(sizeof(EncLds) <= 5 * 1280, "five 1280-byte LDS granules per chunk: 25 chunks fit a CU's 160 KiB, the registers allow 24");
 // A wave leaves: the last one of the launch tells the host (pinned memory) that the launch is over, and when it began and ended.
 __device__ ZS_NOINLINE static void svc_wave_exit(tsx_svc_host* H, tsx_svc_dev* D, uint32_t launch_id) {
     atomicSub(&D->live, 1u);
@@ -1799,6 +1802,10 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     if (lane == 0) {
         if (atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
         atomicMax(&D->live_max, atomicAdd(&D->live, 1u) + 1u);
+    }
+    if (a.calibrate_ticks) {                                              // how many of these workgroups does the chip hold at once?  (svc_create)
+        if (lane == 0) { while (svc_now() - t_start < a.calibrate_ticks) svc_nap(1); svc_wave_exit(H, D, a.launch_id); }
+        return;
     }
     const uint32_t key = UNI(svc_cu_key());
     if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h)
@@ -1879,15 +1886,6 @@ void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, u
                        , g_prof_out
 #endif
                        );
-}
-uint32_t tsx_zstd_service_waves_per_cu(void) {
-#ifdef HIPEMU
-    return ZS_WAVES_PER_SIMD * 4;
-#else
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, zstd_service_kernel, LANES, 0) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
-    return (uint32_t)n;
-#endif
 }
 void tsx_launch_cu_probe(hipStream_t st, tsx_svc_dev* d, uint32_t grid) {
     if (grid) hipLaunchKernelGGL(cu_probe_kernel, dim3(grid), dim3(LANES), 0, st, d);
