@@ -138,7 +138,10 @@ typedef struct tsx_config {
     uint32_t struct_size;            /* sizeof(tsx_config) as the caller was compiled                                           */
     uint32_t fetch_reserved_cus;     /* compute units the compressor never occupies, so that a fetch (fetchLogSegment ->
                                         ChunkCache.java:85-108, get.timeout.ms 10 s) finds room at once while uploads fill the
-                                        chip; spread over the XCDs; default 8 = one per XCD; 0 = no reservation               */
+                                        chip.  Default: one per SHADER ENGINE (32 of an MI355X's 256) - the hardware hands a
+                                        kernel's workgroups to the engines in turn and a workgroup waits for room in its own;
+                                        a smaller number is spread over the engines and leaves some without a free CU (a fetch
+                                        can then wait for the end of a compressor launch); 0 = no reservation                  */
     uint32_t service_max_launch_ms;  /* one launch of the compressor service kernel stops taking chunks at this age (the next
                                         launch takes over): bounds how long a device-wide synchronisation made by OTHER code in
                                         the process (hipFree, hipDeviceSynchronize) can wait under continuous uploads; default
@@ -178,6 +181,7 @@ typedef struct tsx_service_info {
     uint32_t compute_units, cu_keys_seen, reserved_cus;   /* CUs of the device, distinct CU ids a probe launch met, CUs left alone */
     uint32_t device_chunks, wave_starts, reserved_exits, skipped_tickets;   /* device-side counters (mod 2^32)                   */
     uint32_t live_waves, live_waves_max;   /* waves of the service resident right now / the most ever                              */
+    uint32_t shader_engines, reserved_;    /* shader engines the probe launch met (groups of CUs the hardware fills separately)        */
 } tsx_service_info;
 int  tsx_service_stats(int device_index, tsx_service_info* out);
 /* Returns when the device's service kernel has ended (a moment after its last chunk): brackets a measurement. */

@@ -24,7 +24,7 @@
 // want to change without touching code (INTEGRATION.md 5 lists them).  No entry point on a data path reads the environment.  The
 // fields under "test hooks" have no environment variable: tests and measurement tools set them through tsx_debug_config().
 struct tsx_cfg {
-    uint32_t reserved_cus = 8;            // compute units the compressor service leaves to everything else (one per XCD); TSX_FETCH_RESERVED_CUS
+    uint32_t reserved_cus = 0xFFFFFFFFu;  // compute units the compressor service leaves to everything else (0xFFFFFFFF: one per shader engine); TSX_FETCH_RESERVED_CUS
     uint32_t svc_max_launch_ms = 60000;   // age limit of one launch of the service kernel (0 = none); TSX_SERVICE_MAX_LAUNCH_MS
     uint32_t svc_idle_exit_us = 2000;     // the service kernel ends when it has had nothing to do for this long (callers in a closed loop need ~1 ms to come back)
     long long pool_idle_bytes = -1;       // idle pooled workspace kept per device (-1: 4/9 of its memory); TSX_POOL_IDLE_BYTES
@@ -110,7 +110,7 @@ struct tsx_service {
     bool launched = false;                                           // a launch is out whose end this side has not seen yet
     bool stop_dirty = false;                                         // the device's stop word must be cleared in front of the next launch
     uint32_t paused = 0;                                             // > 0: no launches (memory management in progress)
-    uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0, waves_per_cu = 0, resident = 0;
+    uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0, waves_per_cu = 0, resident = 0, engines = 0;
     bool masked = false;                                             // the reservation is a CU mask on the stream (no wave ever starts on a reserved CU)
     uint32_t published = 0;
     uint64_t next_id = 1;
@@ -330,28 +330,35 @@ static int svc_create(tsx_device& d, int cus) {
         if ((int)k >= cus) break;
     }
     s.cus = (uint32_t)cus;
-    // the reservation: the highest keys of every XCD, as evenly as the number asked for divides (8 = one per XCD on an MI355X).  Never more
-    // than a quarter of the chip, and nothing at all when the probe did not find one key per CU (a key that stood for two CUs would take both).
+    // The reservation: ONE CU OF EVERY SHADER ENGINE first.  The hardware hands a kernel's workgroups to the shader engines in a fixed
+    // rotation and a workgroup waits for room in ITS engine: next to waves that stay for seconds, a fetch kernel's workgroup that falls to
+    // an engine without a free CU waits until the compressor launch ends (measured: kernels of a fetch each stuck for exactly one service
+    // launch, with 8 reserved CUs as well as with a CU mask that kept the service off 8 CUs - profiles/r05_kernel_trace_blocked_fetch.csv.gz,
+    // r05_cu_mask_variant_phases.txt).  A key's upper bits name the engine: xcc_id | se_id | sh_id (key >> 4).  Round r takes the r-th
+    // highest CU of every engine: the default (0xFFFFFFFF = "one per engine") stops after round 0; a number asked for is spread the same way.
+    // Never more than a quarter of the chip, and nothing at all when the probe did not find one key per CU (a key that stood for two CUs
+    // would take both).
     std::vector<uint32_t> res(128, 0);
-    uint32_t want = g_cfg.reserved_cus;
+    uint32_t engines = 0;
+    for (uint32_t g = 0; g < 256; g++) { bool any = false; for (uint32_t c = 0; c < 16; c++) { const uint32_t key = g << 4 | c; any |= ((seen[key >> 5] >> (key & 31)) & 1) != 0; } engines += any; }
+    s.engines = engines;
+    uint32_t want = g_cfg.reserved_cus == 0xFFFFFFFFu ? engines : g_cfg.reserved_cus;
     if (want > s.cus / 4) want = s.cus / 4;
     if (s.masked) want = 0;                                             // (the mask does it: no bitmap)
     else if (s.cu_keys != s.cus) {
         if (g_cfg.debug || want) fprintf(stderr, "[tsxform] device %d: %u CU keys seen for %u compute units - no CU reservation\n", d.hip_id, s.cu_keys, s.cus);
         want = 0;
     }
-    uint32_t xccs = 0; for (uint32_t x = 0; x < 16; x++) { bool any = false; for (uint32_t w = 0; w < 8; w++) any |= seen[x * 8 + w] != 0; xccs += any; }
     uint32_t taken = 0;
-    for (uint32_t round = 0; taken < want && round < 256; round++)      // round r takes the r-th highest key of every XCD that has one
-        for (uint32_t x = 0; x < 16 && taken < want; x++) {
+    for (uint32_t round = 0; taken < want && round < 16; round++)
+        for (uint32_t g = 0; g < 256 && taken < want; g++) {
             uint32_t nth = 0;
-            for (int k = 255; k >= 0; k--) {
-                const uint32_t key = x << 8 | (uint32_t)k;
+            for (int c = 15; c >= 0; c--) {
+                const uint32_t key = g << 4 | (uint32_t)c;
                 if (!((seen[key >> 5] >> (key & 31)) & 1)) continue;
                 if (nth++ == round) { res[key >> 5] |= 1u << (key & 31); taken++; break; }
             }
         }
-    (void)xccs;
     if (!s.masked) s.cus_reserved = taken;
     HIPCHK(hipMemcpy(s.d->reserved, res.data(), 512, hipMemcpyHostToDevice));
     // A launch covers the chip exactly once - never more workgroups than are resident at the same time.  The waves stay for as long as there
@@ -1026,7 +1033,7 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
     memset(out, 0, sizeof *out);
     out->launches = s.launches; out->watchdog_launches = s.watchdog_launches; out->members = s.members; out->chunks = s.chunks;
     out->kernel_ms = s.kernel_ms; out->running = running ? 1u : 0u;
-    out->waves = s.grid; out->compute_units = s.cus; out->cu_keys_seen = s.cu_keys; out->reserved_cus = s.cus_reserved;
+    out->waves = s.grid; out->compute_units = s.cus; out->cu_keys_seen = s.cu_keys; out->reserved_cus = s.cus_reserved; out->shader_engines = s.engines;
     uint32_t w[4] = {0, 0, 0, 0};
     if (hipMemcpy(w, &s.d->stat_chunks, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
         out->device_chunks = w[0]; out->wave_starts = w[1]; out->reserved_exits = w[2]; out->skipped_tickets = w[3];
