@@ -216,7 +216,7 @@ def test_a_launch_that_met_only_reserved_cus_is_started_again(emu):
     ref, _ = pc.run_transform(emu, flags, chunks)
     s0 = emu.service_stats(0)
     emu.lib.hipemu_force_reserved_launches.argtypes = [ctypes.c_int]; emu.lib.hipemu_force_reserved_launches.restype = None
-    emu.lib.hipemu_force_reserved_launches(4)                          # (every start is two grid launches: the dry primer, then the kernel proper)
+    emu.lib.hipemu_force_reserved_launches(2)
     got, d = pc.run_transform(emu, flags, chunks)
     s1 = emu.service_stats(0)
     assert got == ref and (d["status"] == 0).all()
