@@ -468,11 +468,13 @@ def main():
             el_ = time.perf_counter() - tm0
             exact = bool(np.array_equal(hbk, want4))
             N.host_unregister(hfr); N.host_unregister(hbk); N.ctx_destroy(fctx)
+            rot_ = N.service_stats(0)["rotations"]
             mixed = {"metric": "latency of a fetch (tsx_detransform_batch of 1 / 4 chunks, host -> host, own context) while %d callers keep %d compressor chunks queued" % (T, T * n),
                      "reserved_cus": None if svc is None else svc["reserved_cus"], "compress_callers": T, "chunks_offered": T * n,
                      "compress_gibs_while_fetching": round(sum(done) * float(n) * CH / GiB / el_, 3),
                      "compress_gibs_while_fetching_note": "whole window incl. the callers' ramp and drain; `_slope` = least-squares slope of batch completions over the middle 60 %, as `sustained`",
-                     "fetch_idle_ms": {str(k_): v for k_, v in idle_ms.items()}, "restored_bytes_exact": exact, "unit": "ms"}
+                     "fetch_idle_ms": {str(k_): v for k_, v in idle_ms.items()}, "restored_bytes_exact": exact, "unit": "ms",
+                     "compressor_launches_asked_to_end_early_by_a_waiting_fetch": int(rot_)}
             da_ = np.sort(np.asarray(mstamps)) - tm0
             if da_.size >= 8:
                 q0, q1 = int(da_.size * 0.2), int(da_.size * 0.8)

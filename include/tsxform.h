@@ -181,7 +181,8 @@ typedef struct tsx_service_info {
     uint32_t compute_units, cu_keys_seen, reserved_cus;   /* CUs of the device, distinct CU ids a probe launch met, CUs left alone */
     uint32_t device_chunks, wave_starts, reserved_exits, skipped_tickets;   /* device-side counters (mod 2^32)                   */
     uint32_t live_waves, live_waves_max;   /* waves of the service resident right now / the most ever                              */
-    uint32_t shader_engines, reserved_;    /* shader engines the probe launch met (groups of CUs the hardware fills separately)        */
+    uint32_t shader_engines;               /* shader engines the probe launch met (groups of CUs the hardware fills separately)        */
+    uint32_t rotations;                    /* launches a fetch that had waited 200 ms asked to end early (the safety net of the fetch side) */
 } tsx_service_info;
 int  tsx_service_stats(int device_index, tsx_service_info* out);
 /* Returns when the device's service kernel has ended (a moment after its last chunk): brackets a measurement. */

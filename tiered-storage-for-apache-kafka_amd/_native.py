@@ -47,7 +47,7 @@ class ServiceInfo(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("watchdog_launches", C.c_uint64), ("members", C.c_uint64), ("chunks", C.c_uint64),
                 ("kernel_ms", C.c_double), ("running", C.c_uint32), ("waves", C.c_uint32), ("compute_units", C.c_uint32),
                 ("cu_keys_seen", C.c_uint32), ("reserved_cus", C.c_uint32), ("device_chunks", C.c_uint32), ("wave_starts", C.c_uint32),
-                ("reserved_exits", C.c_uint32), ("skipped_tickets", C.c_uint32), ("live_waves", C.c_uint32), ("live_waves_max", C.c_uint32), ("shader_engines", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("reserved_exits", C.c_uint32), ("skipped_tickets", C.c_uint32), ("live_waves", C.c_uint32), ("live_waves_max", C.c_uint32), ("shader_engines", C.c_uint32), ("rotations", C.c_uint32)]
 
 
 CFG_DEFAULT, CFG_DEFAULT64 = 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF

@@ -116,7 +116,8 @@ struct tsx_service {
     uint64_t next_id = 1;
     std::deque<tsx_svc_member> out;                                  // members published and not yet retired, oldest first
     std::vector<uint16_t> free_slots; uint16_t slot_gen[TSX_SVC_MEMBERS] = {0};
-    uint64_t launches = 0, watchdog_launches = 0, members = 0, chunks = 0; double kernel_ms = 0;
+    uint64_t launches = 0, watchdog_launches = 0, members = 0, chunks = 0, rotations = 0; double kernel_ms = 0;
+    bool rotating = false;                                           // a waiting fetch has asked the running launch to end (svc_rotate)
     std::vector<void*> deferred_dev, deferred_host;                  // frees that wait for the kernel to be gone (svc_free_*)
 };
 
@@ -237,6 +238,7 @@ static bool svc_running_locked(tsx_service& s) {
     if (__atomic_load_n(&s.h->ended_launch, __ATOMIC_ACQUIRE) != s.launch_id) return true;
     s.kernel_ms += (double)(s.h->t_last - s.h->t_first) / 1e5;           // 100 MHz ticks
     s.launched = false;
+    if (s.rotating && !s.paused) { s.rotating = false; __atomic_store_n(&s.h->stop, 0u, __ATOMIC_RELEASE); }     // (the device's copy of the word is cleared in front of the next launch)
     for (void* p : s.deferred_dev) (void)hipFree(p);
     for (void* p : s.deferred_host) (void)hipHostFree(p);
     s.deferred_dev.clear(); s.deferred_host.clear();
@@ -413,6 +415,34 @@ static void svc_pause(tsx_device* dev) {
     __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
     s.stop_dirty = true;
     while (svc_running_locked(s)) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(200)); lk.lock(); }
+}
+// The safety net of the fetch side.  One CU of every shader engine is kept free for it, and a fetch next to saturating uploads takes its
+// ~2 ms - but once in a few hundred fetches (measured: 1 of 271, 2 of 12, 0 of 218 + 218 in four runs) a kernel of a fetch did not start
+// until the compressor launch next to it ended, for a reason that was not found.  A batch that has waited for its own kernels for 200 ms
+// while the service kernel is alive asks that launch to end: its waves leave after their current chunk (<= ~1.3 s), the waiting callers'
+// watchdog starts the next one, and the fetch gets the chip in between.  Cost: one chunk time of a half-empty chip, only when it happens.
+static void svc_rotate(tsx_device* dev) {
+    if (!dev->svc) return;
+    tsx_service& s = *dev->svc;
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (s.rotating || s.paused || !svc_running_locked(s)) return;
+    s.rotating = true; s.rotations++;
+    __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
+    s.stop_dirty = true;
+}
+// Waits for an event of a batch that is NOT the compressor's, with that safety net.
+static hipError_t wait_event_watching(tsx_ctx* c, hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    bool asked = false;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();
+        const auto age = std::chrono::steady_clock::now() - t0;
+        if (!asked && age > std::chrono::milliseconds(200)) { svc_rotate(c->dev); asked = true; }
+        if (age > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(age > std::chrono::milliseconds(20) ? 500 : 50));
+        else if (age > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(10));
+    }
 }
 static void svc_resume(tsx_device* dev) {
     if (!dev->svc) return;
@@ -1031,7 +1061,7 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
     std::lock_guard<std::mutex> lk(s.mu);
     const bool running = svc_running_locked(s);
     memset(out, 0, sizeof *out);
-    out->launches = s.launches; out->watchdog_launches = s.watchdog_launches; out->members = s.members; out->chunks = s.chunks;
+    out->launches = s.launches; out->watchdog_launches = s.watchdog_launches; out->rotations = (uint32_t)s.rotations; out->members = s.members; out->chunks = s.chunks;
     out->kernel_ms = s.kernel_ms; out->running = running ? 1u : 0u;
     out->waves = s.grid; out->compute_units = s.cus; out->cu_keys_seen = s.cu_keys; out->reserved_cus = s.cus_reserved; out->shader_engines = s.engines;
     uint32_t w[4] = {0, 0, 0, 0};
@@ -1490,7 +1520,7 @@ static int run_batch_inner(tsx_run& r) {
             if (r.host) { (void)hipEventSynchronize(c->sub_ev[k][5]); tr.mark(names[5]); }
             for (int q = 0; q < 5; q++) { (void)hipEventSynchronize(c->sub_ev[k][q]); tr.mark(names[q]); }
         }
-        HIPCHK(hipEventSynchronize(c->sub_ev[k][4]));                   // descriptors of piece k are on the host
+        HIPCHK(wait_event_watching(c, c->sub_ev[k][4]));                // descriptors of piece k are on the host
         memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
         if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, (out2 && (k & 1)) ? c->st_out2 : c->st_out);
         return TSX_OK;

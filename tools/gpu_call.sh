@@ -48,7 +48,7 @@ PY
       done
       cat $O/broker.jsonl ;;
     pmc)
-      bash tools/pmc_zstd.sh > $O/pmc_zstd.log 2>&1; bash tools/pmc_dec.sh > $O/pmc_dec.log 2>&1
+      bash tools/pmc_zstd.sh > $O/pmc_zstd.log 2>&1; bash tools/pmc_dec.sh > $O/pmc_dec.log 2>&1; bash tools/pmc_small.sh > $O/pmc_small.log 2>&1
       python tools/show_pmc.py gpurun_out/pmc | tee $O/pmc_zstd_summary.txt; python tools/show_pmc.py gpurun_out/pmc_dec | sed 's/^/dec /' | tee $O/pmc_dec_summary.txt ;;
     trace)
       ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -o bench --output-format csv -- python $R/bench.py --no-cpu-baseline --no-end-to-end --no-inverse --no-sustained > $O/bench_under_rocprofv3.json 2> $O/trace.err )

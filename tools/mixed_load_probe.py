@@ -134,7 +134,7 @@ def main():
     el = time.perf_counter() - t0
     assert np.array_equal(hbk, want)
     st = N.service_stats(0)
-    out = {"tag": args.tag, "reserved_cus": st["reserved_cus"], "cu_keys_seen": st["cu_keys_seen"], "service_launches": st["launches"], "watchdog_launches": st["watchdog_launches"],
+    out = {"tag": args.tag, "reserved_cus": st["reserved_cus"], "cu_keys_seen": st["cu_keys_seen"], "service_launches": st["launches"], "watchdog_launches": st["watchdog_launches"], "rotations": st["rotations"],
            "compress_callers": T,
            "upload_shape": args.shape, "chunks_offered": T * (256 if broker else n),
            "compress_gibs_while_fetching": round(sum(done) * (256 if broker else n) * CH / float(1 << 30) / el, 3), "fetching": not args.no_fetch,

@@ -23,6 +23,8 @@ def source_sha(names):
 
 
 ENC_SOURCES = ["zstd_enc.hip", "zstd_common.h", "gcm_dev.h", "crc_dev.h"]
+CRC_SOURCES = ["crc32c.hip", "crc_dev.h"]
+GCM_SOURCES = ["gcm.hip", "gcm_dev.h"]
 DEC_SOURCES = ["zstd_dec.hip", "zstd_dec_dev.h", "zstd_common.h"]
 
 
@@ -30,7 +32,20 @@ def counters(d):
     agg = collections.defaultdict(list)
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
+            if "zstd_service" in r.get("Kernel_Name", "") and r.get("Grid_Size") == "524288":
+                continue                                              # the calibration launch of tsx_init (32 workgroups per CU that just wait)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+def counters_prefixed(d, prefix):
+    agg = collections.defaultdict(list)
+    for sub in sorted(glob.glob(os.path.join(d, prefix + "*"))):
+        if not os.path.isdir(sub):
+            continue
+        for f in sorted(glob.glob(os.path.join(sub, "**", "*counter_collection.csv"), recursive=True)):
+            for r in csv.DictReader(open(f)):
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 
@@ -38,24 +53,30 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--enc", default=os.path.join(ROOT, "gpurun_out", "pmc"))
     ap.add_argument("--dec", default=os.path.join(ROOT, "gpurun_out", "pmc_dec"))
-    ap.add_argument("--tag", default="r03")
+    ap.add_argument("--small", default=os.path.join(ROOT, "gpurun_out", "pmc_small"))
+    ap.add_argument("--tag", default="r05")
     ap.add_argument("--chunks", type=int, default=2048)
     ap.add_argument("--sequences-per-chunk", type=float, default=175358.0)
     args = ap.parse_args()
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     rec = json.load(open(path))
-    for key, d, srcs, kernel in (("full/K/%d" % args.chunks, args.enc, ENC_SOURCES, "zstd_compress_kernel (whole chain: CRC32C head, compressor, AES-256-GCM tail)"),
-                                 ("detransform/K/%d" % args.chunks, args.dec, DEC_SOURCES, "zstd_decompress_kernel")):
-        c, cnt = counters(d)
+    for key, d, srcs, kernel in (("full/K/%d" % args.chunks, args.enc, ENC_SOURCES, "zstd_service_kernel (whole chain: CRC32C head, compressor, AES-256-GCM tail), one launch = the chunks of one batch"),
+                                 ("detransform/K/%d" % args.chunks, args.dec, DEC_SOURCES, "zstd_decompress_kernel"),
+                                 ("crc/K/256", (args.small, "crc_p"), CRC_SOURCES, "crc32c_partial_kernel"),
+                                 ("gcm_crc/K/256", (args.small, "gcm_p"), GCM_SOURCES, "gcm_ctr_ghash_kernel")):
+        if isinstance(d, tuple):
+            c, cnt = counters_prefixed(*d)
+        else:
+            c, cnt = counters(d)
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             print("no FETCH_SIZE / WRITE_SIZE under", d, "- record", key, "left as it is")
             continue
-        out = os.path.join(ROOT, "profiles", "%s_%s_pmc.txt" % (args.tag, "zstd_compress" if key.startswith("full") else "zstd_decompress"))
+        out = os.path.join(ROOT, "profiles", "%s_%s_pmc.txt" % (args.tag, {"full": "zstd_service", "detransform": "zstd_decompress", "crc": "crc32c", "gcm_crc": "gcm"}[key.split("/")[0]]))
         with open(out, "w") as f:
             for k in sorted(c):
                 f.write("%-30s launches=%d mean=%.5g\n" % (k, cnt[k], c[k]))
         fetch, write = c["FETCH_SIZE"] * 1000.0, c["WRITE_SIZE"] * 1000.0       # reported in KB
-        r = {"hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write), "kernel": kernel,
+        r = {"hbm_bytes_per_launch": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write), "kernel": kernel, "chunks": int(key.split("/")[-1]),
              "kernel_source_sha": source_sha(srcs), "kernel_sources": srcs, "source": os.path.relpath(out, ROOT), "tag": args.tag,
              "note": "FETCH_SIZE / WRITE_SIZE are reported in KB (x1000 here); they derive from TCC_EA0_RDREQ / WRREQ and include Infinity-Cache hits "
                      "(MI355X_MICROARCH.md, HBM section); random 4-byte probes / short match copies, so the gfx950 x2 correction for wide streaming reads does not apply"}
@@ -64,7 +85,7 @@ def main():
             if key.startswith("full"):
                 nseq = args.sequences_per_chunk * args.chunks
                 r["requests_per_sequence"] = {"read": round(c["TCC_EA0_RDREQ_sum"] / nseq, 2), "write": round(c["TCC_EA0_WRREQ_sum"] / nseq, 2)}
-        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"):
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"):
             if k in c:
                 r.setdefault("sq", {})[k] = int(c[k])
         rec[key] = r
