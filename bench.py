@@ -484,7 +484,7 @@ def main():
             for k_ in (1, 4):
                 a_ = np.asarray(lat[k_])
                 mixed["fetch_%d_under_load_ms" % k_] = {"n": int(a_.size), "p50": round(float(np.median(a_)), 2), "p95": round(float(np.percentile(a_, 95)), 2), "max": round(float(a_.max()), 2)}
-        except (nat.TsxError, AssertionError) as ex:                     # reported, never fatal for the line
+        except Exception as ex:                                          # noqa: BLE001 - reported, never fatal for the line
             mixed = {"error": repr(ex)[:300]}
     # the timed region's extra callers are done: their workspaces (12.7 GiB each) and output buffers (8.5 GiB each) go back before the
     # legs below allocate their own (pooled contexts of the broker leg, host staging buffers)
@@ -938,7 +938,7 @@ def main():
                                               "traffic": rec_["hbm_bytes_per_launch"] if rec_ and fresh_ else None,
                                               "traffic_source": None if not rec_ else (rec_.get("source") if fresh_ else "STALE: measured on another build of the kernel")}}
                 del outb, hs_, hd_
-            except (nat.TsxError, AssertionError) as ex:                 # reported, never fatal for the line
+            except Exception as ex:                                      # noqa: BLE001 - reported, never fatal for the line
                 configs[name] = {"error": repr(ex)[:300]}
 
     if rank == 0:
