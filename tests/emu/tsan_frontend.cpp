@@ -1,6 +1,6 @@
-// TEST HARNESS ONLY: the front end of libtsxform (csrc/tsx_api.hip: launch combiner, context pools, device hints, copy pipeline) under
+// TEST HARNESS ONLY: the front end of libtsxform (csrc/tsx_api.hip: compressor service, context pools, device hints, copy pipeline) under
 // ThreadSanitizer.  The kernel sources are compiled for the CPU emulator (tests/emu) with -fsanitize=thread and linked with this driver
-// (`make -C csrc emu-tsan`): T threads issue context-less compressing batches (the broker's shape: the combiner groups them), inverse
+// (`make -C csrc emu-tsan`): T threads issue context-less compressing batches (the broker's shape: members of the device's service queue), inverse
 // batches, CRC-only batches and batches on explicit contexts at the same time; every result must equal the single-threaded one, and the
 // tool must stay silent.  The emulator runs one grid at a time under a mutex, so what is examined is the library's own host code.
 #include <tsxform.h>

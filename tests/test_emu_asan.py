@@ -63,8 +63,8 @@ def test_compressor_is_memory_safe_and_exact_on_structured_inputs():
 @pytest.mark.timeout(900)
 def test_front_end_is_race_free():
     """tsx_api.hip's host code under ThreadSanitizer (`make emu-tsan`: the emulated kernel sources and tests/emu/tsan_frontend.cpp in one
-    executable; the emulator's lane fibers are announced to the tool): threads issue context-less compressing batches (launch combiner:
-    leader / pending / lanes), inverse and CRC-only batches on pooled contexts, batches on an explicit context and device hints at the
+    executable; the emulator's lane fibers are announced to the tool): threads issue context-less compressing batches (compressor service:
+    ticket ring, member slots, watchdog), inverse and CRC-only batches on pooled contexts, batches on an explicit context and device hints at the
     same time.  Every result equals the single-threaded one, every pooled context comes back, the tool reports nothing.  (A longer run -
     6 threads x 2 rounds - is recorded in profiles/r03_fuzz_emu.txt.)"""
     probe = subprocess.run(["g++", "-fsanitize=thread", "-x", "c++", "-", "-o", "/dev/null"], input="int main(){return 0;}", text=True, capture_output=True)

@@ -121,14 +121,7 @@ def main():
         el = time.perf_counter() - t0
         ok = all(bool((d["status"] == 0).all()) for d in descs)
         allat = np.concatenate([np.asarray(x) for x in lat]) if sum(done) else np.zeros(1)
-        phases = None
-        if args.ctxless and hasattr(N.lib, "tsx_debug_combined_phases"):
-            import ctypes
-            ph = (ctypes.c_uint64 * 4)(); N.lib.tsx_debug_combined_phases.restype = None
-            N.lib.tsx_debug_combined_phases(ph, 1)
-            if ph[3]:
-                phases = {"calls": int(ph[3]), "input_copy_ms": round(ph[0] / ph[3] / 1e6, 1), "launch_to_own_chunks_done_ms": round(ph[1] / ph[3] / 1e6, 1),
-                          "output_copy_ms": round(ph[2] / ph[3] / 1e6, 1)}
+        phases = None                                                    # (round 4's per-phase hook went with the launch combiner; tsx_ctx_timing has h2d / zstd / d2h per call)
         print(json.dumps({"tag": args.tag, "phases_mean_per_call": phases, "torch_in_process": "torch" in sys.modules, "threads": T, "batch_chunks": B, "mem": args.mem, "ctxless": args.ctxless, "layout": args.layout if args.mem == "host" else None,
                           "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "batches": int(sum(done)), "seconds": round(el, 3),
                           "gibs": round(sum(done) * B * CH / GiB / el, 3), "ms_per_call_median": round(float(np.median(allat)) * 1e3, 1),

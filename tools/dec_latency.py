@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fetch-side latency of the inverse chain (GCM verify + decrypt, Zstd frame decode, CRC32C) for small batches: 1 .. 256 chunks of
 4 MiB, device resident and host -> host (registered buffers), with the block-parallel decoder form (csrc/zstd_dec_blocks.hip, the
-default for batches of <= 256 chunks) and with the chunk-serial form alone (TSX_DEC_BLOCK_CHUNKS=0).  One JSON line per row."""
+default for batches of <= 256 chunks) and with the chunk-serial form alone (test hook dec_block_chunks = 0).  One JSON line per row."""
 import json
 import os
 import sys
@@ -42,7 +42,7 @@ back = torch.empty(NMAX * CH, dtype=torch.uint8, device=dev)
 hmid = mid.cpu().numpy(); hback = np.zeros(NMAX * CH, np.uint8)
 N.host_register(hmid); N.host_register(hback)
 for form in ("blocks", "chunks"):
-    os.environ["TSX_DEC_BLOCK_CHUNKS"] = "256" if form == "blocks" else "0"
+    N.debug_config("dec_block_chunks", 256 if form == "blocks" else 0)
     for n in [x for x in (1, 2, 4, 8, 16, 64, 256) if x <= NMAX]:
         e = np.zeros(n, nat.DESC_DTYPE); e["src_off"] = d["dst_off"][:n]; e["src_len"] = d["dst_len"][:n]
         e["dst_off"] = np.arange(n, dtype=np.uint64) * CH; e["dst_cap"] = CH

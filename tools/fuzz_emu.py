@@ -53,17 +53,13 @@ def main():
                 bad += 1
                 print("DECODE MISMATCH seed %d case %d size %d status %d" % (args.seed, n_cases + i, c.size, d2["status"][i]), file=log, flush=True)
         if (n_cases // args.batch) % 4 == 0:                       # the chain, fused and with one launch per stage
-            for sep in ("", "1"):
-                if sep:
-                    os.environ["TSX_STAGES_SEPARATE"] = "1"
-                else:
-                    os.environ.pop("TSX_STAGES_SEPARATE", None)
+            for sep in (0, 1):
                 try:
-                    pc.check_transform_vs_oracle(emu, o, nat.COMPRESS | nat.ENCRYPT | nat.CRC, cases[:3])
+                    with emu.configured(stages_separate=sep):
+                        pc.check_transform_vs_oracle(emu, o, nat.COMPRESS | nat.ENCRYPT | nat.CRC, cases[:3])
                 except AssertionError as e:
                     bad += 1
                     print("CHAIN MISMATCH seed %d case %d sep=%r: %s" % (args.seed, n_cases, sep, e), file=log, flush=True)
-            os.environ.pop("TSX_STAGES_SEPARATE", None)
         n_cases += len(cases); n_bytes += sum(int(c.size) for c in cases)
         if (n_cases // args.batch) % 10 == 0:
             print("[%6.0fs] seed %d: %d cases, %.1f MB, %d bad" % (time.time() - t0, args.seed, n_cases, n_bytes / 1e6, bad), file=log, flush=True)

@@ -35,9 +35,7 @@ def measure(N, n=256, reps=3, modes=("gcm+crc", "zstd+gcm+crc"), verbose=True):
                 for a in (src, dst, back):
                     N.host_register(a)
             for pipe in ((True, False) if name == "gcm+crc" else (True,)):
-                os.environ.pop("TSX_NO_PIPELINE", None)
-                if not pipe:
-                    os.environ["TSX_NO_PIPELINE"] = "1"
+                N.debug_config("no_pipeline", 0 if pipe else 1)
                 d = np.zeros(n, nat.DESC_DTYPE); d["src_off"] = np.arange(n, dtype=np.uint64) * CH; d["src_len"] = CH
                 d["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d["dst_cap"] = slot
                 for i in range(n):
@@ -74,7 +72,7 @@ def measure(N, n=256, reps=3, modes=("gcm+crc", "zstd+gcm+crc"), verbose=True):
             if pinned:
                 for a in (src, dst, back):
                     N.host_unregister(a)
-        os.environ.pop("TSX_NO_PIPELINE", None)
+        N.debug_config("no_pipeline", 0)
         N.ctx_destroy(ctx)
     return rows
 
