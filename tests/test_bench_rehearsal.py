@@ -162,3 +162,24 @@ def test_force_dist_runs_the_collectives_with_one_rank(emu, oracle):
     whole = b"".join(oracle.transform_chunk(of, synth.KEY, synth.AAD, synth.iv_for(0, k), synth.gen_chunk("K", 1000, 0, k, CH).tobytes())[0] for k in range(cps))
     assert j["config"]["object_gathered_on_rank0_sha"] == hashlib.sha256(whole).hexdigest()[:16]     # what came back through the loop-back IS the object
     assert j["detransform"]["round_trip_exact"] is True
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_as_the_driver_launches_them(emu, oracle):
+    """BASELINE configs[4] in small: `bench.py --gpus 8` under the driver's own launcher, eight gloo ranks on the emulator - segment-major
+    (64 segments over 8 ranks in the real run: rank r owns segments r, r + 8, ...) and a segment count below the rank count
+    (--split-segments: every segment cut by chunk range over all eight ranks, sizes all-gathered, object gathered on rank 0)."""
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    CH, cps, nseg = 6000, 2, 2
+    j = _launch(8, ["--chunk-bytes", str(CH), "--chunks-per-segment", str(cps), "--segments", str(nseg), "--inflight", "2"])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and c["segments_of_rank0"] == [0, 8] and c["segments_total"] == 16
+    assert c["verified_chunks_vs_oracle"] == nseg * cps and j["detransform"]["round_trip_exact"] is True
+    assert abs(j["value"] - 8 * nseg * cps * CH / 2**30 / (j["ms_per_step"] * 1e-3)) <= 5.1e-5 + 1e-3 * j["value"]
+    cps = 16
+    j = _launch(8, ["--chunk-bytes", str(CH), "--chunks-per-segment", str(cps), "--segments", "1", "--split-segments", "--gather-object"])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and c["segments_total"] == 1 and c["chunks_of_rank0"] == 2
+    assert c["process_group"]["world"] == 8 and c["process_group"]["ran"][:3] == ["barrier", "all_reduce(MAX)", "all_gather(sizes)"]
+    assert c["chunk_index_positions_sha"] and c["object_gathered_on_rank0_sha"] and j["detransform"]["round_trip_exact"] is True
