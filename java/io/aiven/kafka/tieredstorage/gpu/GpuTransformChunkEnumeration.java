@@ -64,7 +64,16 @@ public class GpuTransformChunkEnumeration implements TransformChunkEnumeration {
      *                    from {@code inner} and on the device: an upload thread keeps two batches in flight and its uploads
      *                    overlap the device.  Chunks, IVs and failures keep their order.  false: {@code inner} is read exactly
      *                    when the reference would read it.  (C++ twin, tested: tsx::GpuTransformChunkEnumeration, readAhead.)
+     *                    ON in the constructor without this argument and as the default of {@code gpu.read.ahead}: the reference's default
+     *                    of 10 upload threads offers the device 2560 chunks without it (0.41 of the device's rate: bench.py, end_to_end.broker),
+     *                    5120 with it (0.81).  Costs one more batch of pinned host memory per upload thread (2.1 GiB for a 1 GiB segment).
      */
+    public GpuTransformChunkEnumeration(final TransformChunkEnumeration inner, final boolean compress,
+                                        final DataKeyAndAAD keyAndAad, final int batchChunks,
+                                        final SecureRandom random, final int zstdProfile, final int segmentHash) {
+        this(inner, compress, keyAndAad, batchChunks, random, zstdProfile, segmentHash, true);
+    }
+
     public GpuTransformChunkEnumeration(final TransformChunkEnumeration inner, final boolean compress,
                                         final DataKeyAndAAD keyAndAad, final int batchChunks,
                                         final SecureRandom random, final int zstdProfile, final int segmentHash,

@@ -246,7 +246,7 @@ public:
     // fed by a handful of threads ("stragglers").  Off: `inner` is read exactly when the reference would read it.
     GpuTransformChunkEnumeration(std::shared_ptr<Backend> backend, std::shared_ptr<TransformChunkEnumeration> inner, bool compress,
                                  std::optional<DataKeyAndAAD> encryption, IvSupplier ivSupplier = secureRandomIvSupplier(),
-                                 int batchChunks = 64, bool withCrc = false, uint32_t zstdProfile = TSX_ZSTD_PROFILE_1_5_7, bool readAhead = false);
+                                 int batchChunks = 64, bool withCrc = false, uint32_t zstdProfile = TSX_ZSTD_PROFILE_1_5_7, bool readAhead = true);
     ~GpuTransformChunkEnumeration() override;
     int originalChunkSize() const override { return inner_->originalChunkSize(); }
     std::optional<int> transformedChunkSize() const override { return transformedChunkSize_; }
