@@ -440,8 +440,8 @@ static hipError_t wait_event_watching(tsx_ctx* c, hipEvent_t ev) {
         (void)hipGetLastError();
         const auto age = std::chrono::steady_clock::now() - t0;
         if (!asked && age > std::chrono::milliseconds(200)) { svc_rotate(c->dev); asked = true; }
-        if (age > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(age > std::chrono::milliseconds(20) ? 500 : 50));
-        else if (age > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(10));
+        // (a single-chunk fetch is 1.6 ms: the first 3 ms are polled without a sleep - a sleep's granularity is tens of microseconds)
+        if (age > std::chrono::milliseconds(3)) std::this_thread::sleep_for(std::chrono::microseconds(age > std::chrono::milliseconds(20) ? 500 : 50));
     }
 }
 static void svc_resume(tsx_device* dev) {
@@ -1436,11 +1436,17 @@ static int run_batch_inner(tsx_run& r) {
     }
     r.max_len = max_len; r.max_out = max_out;
     const tsx_trace tr;
-    rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, out_bytes);
+    // Zero-copy output for the encrypt-only forward chain (producers compress: RemoteStorageManager.java:381-398 leaves Zstd out): the GCM
+    // kernel's waves write IV || C || TAG straight into the caller's slots when the device can address the WHOLE buffer - the compress path
+    // got this in round 4.  Slot layout only (a packed batch still travels through the device buffer: its chunks are packed by the copies).
+    uint8_t* zc_dst = nullptr;
+    if (r.mode == 0 && r.enc && r.host && !r.packed && !g_cfg.no_zero_copy_out) zc_dst = device_alias_of_range(r.dst, r.dst_size);
+    c->last_zero_copy = zc_dst != nullptr;
+    rc = reserve_or_drain(c, n, max_len, r.mode == 1 ? max_out : 0, r.flags, r.host, in_bytes, zc_dst ? 0 : out_bytes);
     if (rc) return rc;
     tr.mark("workspace reserved");
     r.d_src = r.host ? c->d_in : (const uint8_t*)r.src;
-    r.d_dst = r.host ? c->d_out : (uint8_t*)r.dst;
+    r.d_dst = zc_dst ? zc_dst : r.host ? c->d_out : (uint8_t*)r.dst;
     hipStream_t st = c->st;
     memset(&c->timing, 0, sizeof c->timing);
     // ---- sub-batches: a host-memory batch is cut into pieces whose H2D copy, kernels and D2H copy overlap (device-memory batches have
@@ -1522,6 +1528,7 @@ static int run_batch_inner(tsx_run& r) {
         }
         HIPCHK(wait_event_watching(c, c->sub_ev[k][4]));                // descriptors of piece k are on the host
         memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
+        if (zc_dst) return TSX_OK;                                      // the bytes are in the caller's buffer already
         if (r.host && r.mode != 2) return copy_back(r, sb, &packed_at, &packed_full, (out2 && (k & 1)) ? c->st_out2 : c->st_out);
         return TSX_OK;
     };
