@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="auto", choices=["auto", "full", "gcm_crc", "crc"])
     ap.add_argument("--segments", type=int, default=0, help="1 GiB segments per GPU (default: 8 for full, 1 otherwise)")
-    ap.add_argument("--dist", default="K", choices=["K", "R"], help="synthetic content: K Kafka-like, R random")
+    ap.add_argument("--dist", default="K", choices=["K", "B", "R"], help="synthetic content: K Kafka-like JSON lines, B Kafka v2 record batches (binary), R random")
+    ap.add_argument("--no-value-b", action="store_true", help="skip the extra leg on Kafka-shaped binary content (value_B)")
     ap.add_argument("--profile", default="1.5.7", choices=["1.5.6", "1.5.7"], help="libzstd release reproduced")
     ap.add_argument("--inflight", type=int, default=5,
                     help="caller threads, each with its own tsx_ctx + output buffer, that submit the steps concurrently (the reference "
@@ -486,6 +487,46 @@ def main():
                 mixed["fetch_%d_under_load_ms" % k_] = {"n": int(a_.size), "p50": round(float(np.median(a_)), 2), "p95": round(float(np.percentile(a_, 95)), 2), "max": round(float(a_.max()), 2)}
         except Exception as ex:                                          # noqa: BLE001 - reported, never fatal for the line
             mixed = {"error": repr(ex)[:300]}
+    # ---- the same chain on Kafka-shaped BINARY content (never `value`): v2 record batches, tsxform/synth.py "B" ------------------------
+    # How far does K's number carry?  Sequence density sets the GiB/s; B has binary headers, varint framing and incompressible payloads.
+    value_b = None
+    if rank == 0 and world == 1 and workload == "full" and T > 1 and not split and not args.no_value_b and not rehearse and args.dist == "K" and n >= 256:
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            DIST = 4                                                      # distinct chunks (generated on the host: ~5 s each), replicated over the batch
+            with ThreadPoolExecutor(DIST) as ex:
+                hb = list(ex.map(lambda c_: synth.gen_chunk("B", 1000, 0, c_, CH), range(DIST)))
+            srcb = Mem.empty(n * CH)
+            for i in range(n):
+                srcb[i * CH:(i + 1) * CH] = torch.from_numpy(hb[i % DIST]).to(dev)
+            dbs = [d.copy() for _ in range(T)]
+            for x_ in dbs:
+                x_["status"] = 0; x_["dst_len"] = 0
+
+            def bstep(t):
+                N.transform_batch(params, dbs[t], Mem.ptr(srcb), Mem.ptr(dsts[t]), dsts[t].numel(), MEM, ctx=ctxs[t])
+
+            bstep(0); fence()
+            reps_b = 2
+            tb0 = time.perf_counter()
+            th = [threading.Thread(target=lambda t=t: [bstep(t) for _ in range(reps_b)]) for t in range(T)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            fence()
+            el_b = time.perf_counter() - tb0
+            okb = all(bool((x_["status"] == 0).all()) for x_ in dbs)
+            from oracle import oracle as o
+            for i in range(DIST):                                         # byte equality with libzstd + OpenSSL on every distinct chunk
+                got = Mem.host(dsts[0], i * slot, i * slot + int(dbs[0]["dst_len"][i])).tobytes()
+                exp, _ = o.transform_chunk(o.COMPRESS | o.ENCRYPT | o.OPENSSL, synth.KEY, synth.AAD, dbs[0]["iv"][i].tobytes(), hb[i].tobytes())
+                okb = okb and got == exp
+            value_b = {"metric": "GiB/s of original bytes, same chain and batch shape, content B (Kafka v2 record batches, %d distinct chunks replicated)" % DIST,
+                       "value": round(T * reps_b * float(n) * CH / GiB / el_b, 4), "unit": "GiB/s", "batches": T * reps_b,
+                       "mean_transformed_chunk_bytes": round(float(dbs[0]["dst_len"].astype(np.int64).mean()), 1), "exact_vs_oracle": bool(okb),
+                       "note": "the timed batches include the ramp and drain of %d callers x %d batches (compare with sustained.whole_run_gibs_incl_ramp_and_drain, not with value)" % (T, reps_b)}
+            del srcb
+        except Exception as ex:                                          # noqa: BLE001 - reported, never fatal for the line
+            value_b = {"error": repr(ex)[:300]}
     # the timed region's extra callers are done: their workspaces (12.7 GiB each) and output buffers (8.5 GiB each) go back before the
     # legs below allocate their own (pooled contexts of the broker leg, host staging buffers)
     for c_ in ctxs[1:]:
@@ -967,7 +1008,7 @@ def main():
                            "backend": args.backend + (" (= RCCL)" if args.backend == "nccl" else ""), "world": world, "forced_on_one_rank": bool(args.force_dist and world == 1),
                            "ran": ["barrier", "all_reduce(MAX)"] + (["all_gather(sizes)"] if split else []) + (["p2p slice -> owner"] if split and args.gather_object and (world > 1 or args.backend == "nccl") else [])},
                        "verified_chunks_vs_oracle": verified},
-            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "mixed_load": mixed, "configs": configs, "end_to_end": e2e, "detransform": inverse,
+            "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "value_B": value_b, "mixed_load": mixed, "configs": configs, "end_to_end": e2e, "detransform": inverse,
         }
         print(json.dumps(line))
     for c in ctxs:

@@ -466,3 +466,31 @@ def test_concurrent_ctxless_host_batches(gpu, oracle):
         assert s["in_use"] == 0 and 1 <= s["idle"] <= 32
     finally:
         gpu.debug_config("sub_bytes", old_sub)
+
+
+def test_kafka_shaped_binary_content_on_the_device(gpu, oracle):
+    """Content "B" (v2 record batches: binary headers, varint-framed records, one record in 32 with an incompressible payload - tsxform/synth.py):
+    the full chain equals libzstd 1.5.7 + OpenSSL on full-size and smaller chunks, both Zstd profiles hold what they promise (1.5.7's
+    pre-splitter cuts on this content: the profiles differ and both decode), everything round-trips, and the CRC kernel confirms the
+    batch CRCs of a chunk as SegmentCompressionChecker.java:37-53 would check the first batch of a segment."""
+    if not oracle.zstd_version().startswith("1.5.7"):
+        pytest.skip("libzstd 1.5.7 not available")
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    sizes = [CHUNK, CHUNK, CHUNK - 4099] + [131072 + 29989 * i for i in range(21)]
+    chunks = [synth.gen_chunk("B", 41, 2, i, s) for i, s in enumerate(sizes)]
+    outs, d = pc.check_transform_vs_oracle(gpu, oracle, flags, chunks)
+    back, d2 = pc.run_detransform(gpu, flags, outs, sizes)
+    assert (d2["status"] == 0).all() and back == [c.tobytes() for c in chunks] and (d2["crc32c"] == d["crc32c"]).all()
+    pinned, differ = pc.check_profile_1_5_6(gpu, oracle, {"B%d_%d" % (i, c.size): c for i, c in enumerate(chunks[1:10])})
+    assert differ >= 1, "the pre-splitter never cut on B content: the test does not exercise the difference between the profiles"
+    ratio = sum(len(o_) for o_ in outs) / float(sum(sizes))
+    print("B content: %d chunks, transformed / original = %.3f, profile 1.5.6: %d pinned to the real library, %d differ through the pre-splitter" % (len(chunks), ratio, pinned, differ))
+    c = chunks[3]
+    batches = synth.record_batches_of(c)
+    buf = np.zeros(2 * c.size + 64, np.uint8); lens, offs, at = [], [], 0
+    for p, l in batches:
+        buf[at:at + l - 21] = c[p + 21:p + l]; offs.append(at); lens.append(l - 21); at += (l - 21 + 15) // 16 * 16
+    dd = pc.make_descs(lens, offs, [0] * len(lens), [0] * len(lens))
+    gpu.crc32c_batch(dd, buf)
+    cb = c.tobytes()
+    assert [int(x) for x in dd["crc32c"]] == [int.from_bytes(cb[p + 17:p + 21], "big") for p, _ in batches]

@@ -1,10 +1,15 @@
 """Deterministic synthetic log-segment content, identical on numpy (CPU) and torch (GPU).
 
-Two distributions, both functions of (seed, segment, chunk, byte position) through a counter-based hash so
-that a chunk can be generated anywhere — on the host for the oracle, directly in HBM for bench.py:
+Three distributions, all functions of (seed, segment, chunk, byte position) through a counter-based hash so
+that a chunk can be generated anywhere — on the host for the oracle, directly in HBM for bench.py (B: on the host, then uploaded):
   K  Kafka-like compressible: newline-delimited JSON-ish records
          {"id":0000001234,"user":"u00042","event":"click","ts":1700000000123,"payload":"<8-63 x a-z>"}
      every chunk starts on a record boundary; the last record of a chunk is cut at the chunk end.
+  B  Kafka-shaped binary: back-to-back v2 RECORD BATCHES as a broker's log segment holds them (SURVEY.md 8d "v2 record batches") -
+     61-byte header (baseOffset, batchLength, magic 2, CRC32C over attributes .. end, timestamps, producer fields, record count), 8 - 63
+     records each: varint-framed (length, attributes, timestamp / offset deltas, 8-byte binary key, value, no headers); a value is a 24-byte
+     binary struct + JSON-ish text of 40 - 500 bytes, and one record in 32 carries a 1 - 6 KiB incompressible payload (a producer that
+     compressed or encrypted its own messages).  Every chunk starts on a batch boundary; the last batch is cut at the chunk end.
   R  incompressible: uniform random bytes (what the reference's own tests use,
      core/src/test/java/io/aiven/kafka/tieredstorage/transform/TransformsEndToEndTest.java:38-42).
 Crypto material (deterministic for parity; production takes IVs from SecureRandom):
@@ -168,6 +173,129 @@ def _gen_kafka(xp, n, key, segment, chunk):
     return xp.to_u8(out)
 
 
+_B_TEMPLATE = (b'{"orderId":"A0000000","sku":"ZX-44110","qty":3,"price":"19.99","currency":"EUR","status":"SHIPPED","warehouse":"FRA-2",'
+               b'"customer":{"id":"c-000000","tier":"gold"},"notes":"')
+_CRC32C_TABLE = None
+
+
+def _crc32c_table():
+    global _CRC32C_TABLE
+    if _CRC32C_TABLE is None:
+        t = np.arange(256, dtype=np.uint32)
+        for _ in range(8):
+            t = np.where(t & 1, (t >> 1) ^ np.uint32(0x82F63B78), t >> 1).astype(np.uint32)
+        _CRC32C_TABLE = t
+    return _CRC32C_TABLE
+
+
+def _be(value, width):
+    """(len(value), width) uint8: big-endian bytes of an int64 array (two's complement)."""
+    v = value.astype(np.int64)
+    return np.stack([((v >> (8 * (width - 1 - k))) & 0xFF) for k in range(width)], axis=1).astype(np.uint8)
+
+
+def record_batches_of(buf):
+    """(start, length) of every COMPLETE v2 record batch in a B chunk (numpy uint8): what a reader of the segment walks."""
+    out, p, n = [], 0, len(buf)
+    while p + 61 <= n:
+        blen = int.from_bytes(bytes(buf[p + 8:p + 12]), "big") + 12
+        if p + blen > n:
+            break
+        out.append((p, blen)); p += blen
+    return out
+
+
+def _gen_record_batches(n, key, segment, chunk):
+    """numpy only (the per-batch CRC32C is a byte-serial recurrence: vectorised across the chunk's batches, not along them)."""
+    xp = _NP
+    B = n // (61 + 8 * 81) + 2                                       # upper bound of batches: the shortest has 8 records of 64 + 17 bytes
+    b = xp.arange(B)
+    nrec = 8 + (_mix(b, key ^ 0xB001) % 56)                          # 8..63 records per batch
+    rec_base = np.cumsum(nrec) - nrec                                # index of a batch's first record among the chunk's records
+    R = int(nrec.sum())
+    r = xp.arange(R)
+    rb = np.searchsorted(np.cumsum(nrec), r, side="right").astype(np.int64)      # batch of every record
+    ri = r - rec_base[rb]                                            # its index inside the batch
+    h = _mix(r, key ^ 0xB002)
+    big = (h % 32) == 0
+    vlen = np.where(big, 1024 + (_mix(r, key ^ 0xB003) % 5120), 64 + (_mix(r, key ^ 0xB004) % 460)).astype(np.int64)
+    rtot = vlen + 17                                                 # length varint (2) + body (vlen + 15)
+    blen = 61 + np.bincount(rb, weights=rtot, minlength=B).astype(np.int64)
+    bend = np.cumsum(blen); bstart = bend - blen
+    rec_off = np.cumsum(rtot) - rtot - (np.cumsum(np.bincount(rb, weights=rtot, minlength=B).astype(np.int64)) - np.bincount(rb, weights=rtot, minlength=B).astype(np.int64))[rb]
+    rstart = bstart[rb] + 61 + rec_off                               # position of every record in the chunk
+    rend = rstart + rtot
+    pos = xp.arange(n)
+    pb = np.minimum(np.searchsorted(bend, pos, side="right"), B - 1).astype(np.int64)
+    ob = pos - bstart[pb]
+    # ---- headers ----
+    base_off = (segment * 1000003 + chunk * 70001) * 64 + rec_base
+    base_ts = 1700000000000 + (segment * 256 + chunk) * 100000 + rec_base * 3
+    hdr = np.zeros((B, 61), np.uint8)
+    hdr[:, 0:8] = _be(base_off, 8)
+    hdr[:, 8:12] = _be(blen - 12, 4)                                 # batchLength: everything behind this field
+    hdr[:, 16] = 2                                                   # magic (partitionLeaderEpoch 12..15 = 0; crc 17..20 below; attributes 21..22 = 0: no compression)
+    hdr[:, 23:27] = _be(nrec - 1, 4)                                 # lastOffsetDelta
+    hdr[:, 27:35] = _be(base_ts, 8)
+    hdr[:, 35:43] = _be(base_ts + nrec - 1, 8)
+    hdr[:, 43:57] = 0xFF                                             # producerId, producerEpoch, baseSequence = -1
+    hdr[:, 57:61] = _be(nrec, 4)
+    out = np.zeros(n, np.int64)
+    in_hdr = ob < 61
+    out[in_hdr] = hdr[pb[in_hdr], ob[in_hdr]]
+    # ---- records ----
+    pr = np.minimum(np.searchsorted(rend, pos, side="right"), R - 1).astype(np.int64)
+    col = pos - rstart[pr]
+    inrec = (~in_hdr) & (col >= 0)
+    L = vlen[pr] + 15
+    zzL = 2 * L; zzV = 2 * vlen[pr]
+    v = col - 16
+    vl = vlen[pr]
+    ts = base_ts[rb][pr] + ri[pr]
+    body = np.zeros(n, np.int64)
+    body = np.where(col == 0, (zzL & 0x7F) | 0x80, body)
+    body = np.where(col == 1, zzL >> 7, body)
+    body = np.where(col == 3, 2 * ri[pr], body)                      # timestampDelta (zigzag, one byte: < 64 records)
+    body = np.where(col == 4, 2 * ri[pr], body)                      # offsetDelta
+    body = np.where(col == 5, 16, body)                              # keyLength 8
+    kk = col - 6
+    kid = (_mix(pr, key ^ 0xB005) % 5000) + 100000 * (segment % 7)
+    body = np.where((kk >= 0) & (kk < 8), (kid >> (8 * np.clip(7 - kk, 0, 7))) & 0xFF, body)
+    body = np.where(col == 14, (zzV & 0x7F) | 0x80, body)
+    body = np.where(col == 15, zzV >> 7, body)
+    # value: 24-byte struct, then text - or, for the big records, incompressible bytes
+    sv = np.clip(v, 0, None)
+    struct = np.where(sv < 8, (ts >> (8 * np.clip(sv, 0, 7))) & 0xFF,
+             np.where(sv < 12, ((pr % 7) >> (8 * np.clip(sv - 8, 0, 3))) & 0xFF,
+             np.where(sv < 16, ((ri[pr] * 13 + 5) >> (8 * np.clip(sv - 12, 0, 3))) & 0xFF, (0x0101000000000001 >> (8 * np.clip(sv - 16, 0, 7))) & 0xFF)))
+    tmpl = np.frombuffer(_B_TEMPLATE, np.uint8).astype(np.int64)
+    tpos = (np.clip(sv - 24, 0, None) + (h[pr] % 7)) % len(tmpl)
+    letter = np.where((_mix(pos, key ^ 0xB006) % 5) == 0, 97 + (_mix(pos, key ^ 0xB007) % 26), tmpl[tpos])
+    text = np.where(sv < 24, struct, letter)
+    rnd = _mix(pos, key ^ 0xB008) & 0xFF
+    in_val = (v >= 0) & (v < vl)
+    body = np.where(in_val, np.where(big[pr], rnd, text), body)     # (the last byte of a record, headers count, stays 0; attributes at col 2 too)
+    out = np.where(inrec, body, out)
+    out = out.astype(np.uint8)
+    # ---- CRC32C of every complete batch over [attributes .. end) -> header bytes 17..20 ----
+    T = _crc32c_table()
+    full = bend <= n
+    idx = np.nonzero(full)[0]
+    if idx.size:
+        st_, ln_ = bstart[idx] + 21, blen[idx] - 21
+        crc = np.full(idx.size, 0xFFFFFFFF, np.uint32)
+        for j in range(int(ln_.max())):
+            act = j < ln_
+            byte = out[np.where(act, st_ + j, 0)].astype(np.uint32)
+            nxt = T[(crc ^ byte) & 0xFF] ^ (crc >> 8)
+            crc = np.where(act, nxt, crc)
+        crc = ~crc
+        cb = _be(crc.astype(np.int64), 4)
+        for k in range(4):
+            out[bstart[idx] + 17 + k] = cb[:, k]
+    return out
+
+
 def gen_chunk(dist: str, seed: int, segment: int, chunk: int, n: int = CHUNK, device=None):
     """One chunk of synthetic content.  device None -> numpy uint8 array; else a torch uint8 tensor there."""
     xp = _NP if device is None else _torch_ops(device)
@@ -178,7 +306,13 @@ def gen_chunk(dist: str, seed: int, segment: int, chunk: int, n: int = CHUNK, de
         return _gen_random(xp, n, key)
     if dist == "K":
         return _gen_kafka(xp, n, key, segment, chunk)
-    raise ValueError("dist must be 'K' or 'R'")
+    if dist == "B":
+        host = _gen_record_batches(n, key, segment, chunk)
+        if device is None:
+            return host
+        import torch
+        return torch.from_numpy(host).to(device)
+    raise ValueError("dist must be 'K', 'B' or 'R'")
 
 
 def gen_segment(dist: str, seed: int, segment: int, nchunks: int, chunk_size: int = CHUNK, device=None):
