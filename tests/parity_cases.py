@@ -179,3 +179,40 @@ def check_profile_1_5_6(N, o, named_chunks):
             differ += 1
             assert outs0[i] != outs1[i] and o.zstd_decompress_chunk(outs1[i], len(raw)) == raw, n
     return pinned, differ
+
+
+def check_encrypt_only_zero_copy(N, o, sizes):
+    """Encrypt-only host batches in slot layout (chunk 3 of `sizes` gets a slot that is too small): whole buffer registered -> the GCM waves
+    write into it (tsx_debug_last_zero_copy says so); unregistered / switched off -> the copies; same bytes, same failure behaviour."""
+    import ctypes
+    flags = nat.ENCRYPT | nat.CRC
+    chunks = [synth.gen_chunk("K" if i % 2 else "R", 23, 0, i, s) for i, s in enumerate(sizes)]
+    soff, doff, caps, st, dt = layout(sizes, flags, N)
+    src = np.zeros(st, np.uint8)
+    for c, o_ in zip(chunks, soff):
+        src[o_:o_ + c.size] = c
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    ctx = N.ctx_create(0, 0, 0)
+    zc = N.lib.tsx_debug_last_zero_copy; zc.restype = ctypes.c_int; zc.argtypes = [ctypes.c_void_p]
+    try:
+        res = {}
+        for mode in ("registered", "unregistered", "copies"):
+            dst = np.full(dt + 64, 0xEE, np.uint8)
+            if mode != "unregistered":
+                N.host_register(dst)
+            try:
+                d = make_descs(sizes, soff, doff, caps); d["dst_cap"][3] = 20          # chunk 3 needs 17 + 28 bytes
+                with N.configured(no_zero_copy_out=1 if mode == "copies" else 0):
+                    N.transform_batch(p, d, src, dst, dst.size, nat.MEM_HOST, ctx=ctx)
+                assert zc(ctx) == (1 if mode == "registered" else 0), mode
+            finally:
+                if mode != "unregistered":
+                    N.host_unregister(dst)
+            assert d["status"][3] == nat.E_DST_TOO_SMALL and d["dst_len"][3] == 0 and (np.delete(d["status"], 3) == 0).all(), (mode, d["status"])
+            assert (dst[doff[3]:doff[3] + 64] == 0xEE).all(), mode
+            res[mode] = ([dst[doff[i]:doff[i] + int(d["dst_len"][i])].tobytes() for i in range(len(sizes))], d["crc32c"].copy())
+        assert res["registered"][0] == res["copies"][0] == res["unregistered"][0] and (res["registered"][1] == res["copies"][1]).all()
+        for i in (0, 2, 4):
+            assert res["registered"][0][i] == oracle_transform(o, flags, chunks[i], i)
+    finally:
+        N.ctx_destroy(ctx)

@@ -482,36 +482,4 @@ def test_encrypt_only_batches_write_into_registered_buffers_too(emu, oracle):
     """Producers compress -> the broker's chain is encryption only (RemoteStorageManager.java:381-398): the GCM kernel's waves write
     IV || C || TAG straight into the caller's slots when the whole buffer is registered (slot layout); same bytes as the copy path and the
     oracle, a too-small slot fails its chunk only and leaves the slot untouched, an unregistered buffer takes the copies."""
-    import ctypes
-    flags = nat.ENCRYPT | nat.CRC
-    sizes = [5000, 0, 70001, 17, 131072, 4096]
-    chunks = [synth.gen_chunk("K" if i % 2 else "R", 23, 0, i, s) for i, s in enumerate(sizes)]
-    soff, doff, caps, st, dt = pc.layout(sizes, flags, emu)
-    src = np.zeros(st, np.uint8)
-    for c, o_ in zip(chunks, soff):
-        src[o_:o_ + c.size] = c
-    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
-    ctx = emu.ctx_create(0, 0, 0)
-    zc = emu.lib.tsx_debug_last_zero_copy; zc.restype = ctypes.c_int; zc.argtypes = [ctypes.c_void_p]
-    try:
-        res = {}
-        for mode in ("registered", "unregistered", "copies"):
-            dst = np.full(dt + 64, 0xEE, np.uint8)
-            if mode != "unregistered":
-                emu.host_register(dst)
-            try:
-                d = pc.make_descs(sizes, soff, doff, caps); d["dst_cap"][3] = 20          # chunk 3 needs 17 + 28 bytes
-                with emu.configured(no_zero_copy_out=1 if mode == "copies" else 0):
-                    emu.transform_batch(p, d, src, dst, dst.size, nat.MEM_HOST, ctx=ctx)
-                assert zc(ctx) == (1 if mode == "registered" else 0), mode
-            finally:
-                if mode != "unregistered":
-                    emu.host_unregister(dst)
-            assert d["status"][3] == nat.E_DST_TOO_SMALL and d["dst_len"][3] == 0 and (np.delete(d["status"], 3) == 0).all(), (mode, d["status"])
-            assert (dst[doff[3]:doff[3] + 64] == 0xEE).all(), mode
-            res[mode] = ([dst[doff[i]:doff[i] + int(d["dst_len"][i])].tobytes() for i in range(len(sizes))], d["crc32c"].copy())
-        assert res["registered"][0] == res["copies"][0] == res["unregistered"][0] and (res["registered"][1] == res["copies"][1]).all()
-        for i in (0, 2, 4):
-            assert res["registered"][0][i] == pc.oracle_transform(oracle, flags, chunks[i], i)
-    finally:
-        emu.ctx_destroy(ctx)
+    pc.check_encrypt_only_zero_copy(emu, oracle, [5000, 0, 70001, 17, 131072, 4096])

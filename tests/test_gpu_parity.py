@@ -360,6 +360,13 @@ def _staged_host_pipeline(gpu, oracle, flags, chunks, ref, dref):
         gpu.host_unregister(src); gpu.host_unregister(dst)
 
 
+def test_encrypt_only_batches_write_into_registered_buffers_on_the_device(gpu, oracle):
+    """The producers-compress chain (RemoteStorageManager.java:381-398: encryption only): the GCM kernel's waves store IV || C || TAG through
+    the device alias of the caller's registered buffer - full-size chunks, an empty one, one whose slot is too small; same bytes as the copy
+    path and the oracle (the body is the emulator test's: tests/parity_cases.py)."""
+    pc.check_encrypt_only_zero_copy(gpu, oracle, [CHUNK, 0, 70001, 17, CHUNK - 5, 4096, 1 << 20, 3])
+
+
 @pytest.mark.parametrize("kind", ["K6", "K10", "mixed6", "mixed10", "sparse64", "K64"])
 def test_chunks_beyond_4_MiB(gpu, oracle, kind):
     """chunk.size above 4 MiB - up to a whole segment as ONE chunk (RemoteStorageManagerConfig.java:122-130, chunk.size = 0 in
