@@ -43,6 +43,7 @@ struct tsx_cfg {
     bool no_dec_pieces = false;           // block-form fetches in one piece
     bool svc_cu_mask = false;             // the reservation as a CU mask on the service's stream (the hardware keeps the kernel off the reserved CUs) instead of waves that leave
     uint32_t svc_waves_per_cu = 0;        // workgroups of a service launch per CU (0 = what the runtime says is resident at once; measurements only)
+    uint32_t svc_keep_waves = 0;          // compressor waves that stay on a reserved CU all the same (tsx_svc_launch.keep_waves; measurements)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
 };
@@ -71,7 +72,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_cu_mask, bool) CFG_FIELD(trace, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_cu_mask, bool) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(trace, bool)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -262,6 +263,7 @@ static int svc_launch_locked(tsx_service& s) {
 #endif
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
+    a.keep_waves = g_cfg.svc_keep_waves;
     (void)hipGetLastError();
     a.launch_id = s.launch_id + 1;
     tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);

@@ -123,6 +123,7 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
     uint32_t live, live_max, pad3_[2];   // waves resident right now / the most ever (statistics: is the whole launch resident at once?)
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
+    uint32_t kept[256];              // per shader engine (key >> 4): waves of the current launch that stayed on the engine's reserved CU (tsx_svc_launch.keep_waves)
 };
 struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t launch_id;              // what the last wave writes to tsx_svc_host.ended_launch
@@ -131,6 +132,7 @@ struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t poll_ticks;             // 100 MHz ticks between two host polls (device-wide)
     uint32_t idle_exit_ticks;        // a wave leaves when the queue has been dry and no wave busy for this long
     uint32_t max_age_ticks_lo, max_age_ticks_hi;   // != 0: waves stop taking tickets when the launch is older (the host starts the next one)
+    uint32_t keep_waves;             // waves that stay on a reserved CU all the same (0 = the CU is left alone; the rest of it - LDS, registers, wave slots - is the room a fetch's workgroups find)
 };
 void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, uint32_t grid, tsx_svc_launch a);
 void tsx_launch_cu_probe(hipStream_t st, tsx_svc_dev* d, uint32_t grid);

@@ -1785,6 +1785,7 @@ __device__ ZS_NOINLINE static void svc_wave_exit(tsx_svc_host* H, tsx_svc_dev* D
     const uint64_t now = svc_now();
     const uint64_t first = ((uint64_t)SVC_LD_DEV(&D->t_first_hi) << 32) | SVC_LD_DEV(&D->t_first_lo);
     SVC_ST_DEV(&D->entered, 0u); SVC_ST_DEV(&D->exited, 0u);            // the next launch counts from zero (it is only started once this one is seen ended)
+    for (uint32_t g = 0; g < 256u; g++) if (SVC_LD_DEV(&D->kept[g])) SVC_ST_DEV(&D->kept[g], 0u);
 #ifdef HIPEMU
     H->t_first = first; H->t_last = now;
 #else
@@ -1808,9 +1809,13 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         return;
     }
     const uint32_t key = UNI(svc_cu_key());
-    if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h)
-        if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }
-        return;
+    if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h) - but for the first keep_waves to arrive
+        uint32_t stay = 0;
+        if (a.keep_waves && lane == 0) stay = atomicAdd(&D->kept[key >> 4], 1u) < a.keep_waves;
+        if (!UNI(stay)) {
+            if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }
+            return;
+        }
     }
     if (lane == 0) atomicAdd(&D->stat_wave_starts, 1u);
     for (;;) {

@@ -181,6 +181,13 @@ PY
         nf=""; [ "$4" = "nofetch" ] && nf="--no-fetch"
         timeout 300 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape $1 --callers $2 ${3:+--reserved-cus $3} $nf --seconds ${MIXED_SECONDS:-12} ${MIXED_MAX_LAUNCH_MS:+--max-launch-ms $MIXED_MAX_LAUNCH_MS} --tag "$cfg" 2>> $O/mixednt.err | tee -a $O/mixednt.jsonl
       done ;;
+    keepwaves)
+      # compressor waves that stay on the reserved CU of every shader engine (svc_keep_waves): fetch latency and upload rate, device-resident 2048-chunk batches, no torch
+      export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/keepwaves.err
+      for k in ${arg//,/ }; do
+        timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers 5 --seconds ${MIXED_SECONDS:-14} --config svc_keep_waves=$k --tag "keep_waves=$k" 2>> $O/keepwaves.err | tee -a $O/keepwaves.jsonl
+      done ;;
     *) echo "unknown section $name" ;;
   esac
 done
