@@ -131,7 +131,7 @@ int  tsx_init(int device_count, const int* device_ids);
 
 /* What a deployment may want to say about the device-side machinery; TSX_CFG_DEFAULT(64) in a field = the library's default.
  * The environment of the process, read once inside tsx_init(_ex), overrides both: TSX_FETCH_RESERVED_CUS,
- * TSX_SERVICE_MAX_LAUNCH_MS, TSX_POOL_IDLE_BYTES.  Nothing on a data path reads the environment. */
+ * TSX_FETCH_SHARED_CU_WAVES, TSX_SERVICE_MAX_LAUNCH_MS, TSX_POOL_IDLE_BYTES.  Nothing on a data path reads the environment. */
 #define TSX_CFG_DEFAULT   0xFFFFFFFFu
 #define TSX_CFG_DEFAULT64 0xFFFFFFFFFFFFFFFFull
 typedef struct tsx_config {
@@ -146,7 +146,11 @@ typedef struct tsx_config {
                                         launch takes over): bounds how long a device-wide synchronisation made by OTHER code in
                                         the process (hipFree, hipDeviceSynchronize) can wait under continuous uploads; default
                                         60000, 0 = no limit                                                                   */
-    uint32_t reserved_;
+    uint32_t fetch_shared_cu_waves;  /* compressor waves that stay on each reserved CU all the same (0 / default: none - the CU is left
+                                        alone).  A trade, measured under 5 upload callers (profiles/r05_keep_waves_on_reserved_cus.jsonl):
+                                        4 -> uploads + 3 %, a 4 MiB fetch 2.8 -> 3.7 ms; 8 -> + 6 %, 4.2 ms, and now and then a fetch that
+                                        waits ~0.5 s for the compressor launch to be rotated; 12 and more: such waits become regular.
+                                        At most 8 is accepted                                                                  */
     uint64_t pool_idle_bytes;        /* idle pooled workspace kept per device; default 4/9 of its memory                      */
 } tsx_config;
 int  tsx_init_ex(int device_count, const int* device_ids, const tsx_config* cfg);   /* cfg == NULL: tsx_init */

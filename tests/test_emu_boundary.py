@@ -459,7 +459,7 @@ def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
         from tests.emu import emu_native
         from tsxform import synth
         nat = tsxform._native
-        N = nat.Native(emu_native.build()); N.debug_config("svc_keep_waves", int(os.environ.get("KEEP", "0"))); N.init(%s)
+        N = nat.Native(emu_native.build()); N.init(%s)
         flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
         chunks = [synth.gen_chunk("K", 5, 0, i, 4000 + 1500 * i) for i in range(10)]
         ctx = N.ctx_create(0, 0, 0)
@@ -476,9 +476,9 @@ def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
     by_env = _run_py(code % "fetch_reserved_cus=0", TSX_FETCH_RESERVED_CUS=1).strip().splitlines()[-1].split()
     assert with_default[0] == without[0] == by_env[0]
     assert with_default[1:3] == ["1", "True"] and without[1:3] == ["0", "False"] and by_env[1:3] == ["1", "True"]      # (the harness has 4 CUs: at most one is reserved)
-    # ... and some of the compressor's waves may stay on a reserved CU all the same (svc_keep_waves: a CU shared between fetches and uploads):
-    # exactly that many per launch, counted afresh by every launch
-    kept = _run_py(code % "", KEEP=2).strip().splitlines()[-1].split()
+    # ... and some of the compressor's waves may stay on a reserved CU all the same (tsx_config.fetch_shared_cu_waves: a CU shared between
+    # fetches and uploads): exactly that many per launch, counted afresh by every launch
+    kept = _run_py(code % "fetch_shared_cu_waves=2").strip().splitlines()[-1].split()
     launches, starts, exits, waves = (int(x) for x in kept[3:7])
     dl, ds_, de, dw = (int(x) for x in with_default[3:7])
     assert kept[0] == with_default[0] and waves == dw and starts + exits == launches * waves and ds_ + de == dl * dw

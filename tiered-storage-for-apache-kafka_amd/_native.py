@@ -39,7 +39,7 @@ class Timing(C.Structure):
 
 class Config(C.Structure):
     """tsx_config of include/tsxform.h; fields left at CFG_DEFAULT take the library's default."""
-    _fields_ = [("struct_size", C.c_uint32), ("fetch_reserved_cus", C.c_uint32), ("service_max_launch_ms", C.c_uint32), ("reserved_", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("fetch_reserved_cus", C.c_uint32), ("service_max_launch_ms", C.c_uint32), ("fetch_shared_cu_waves", C.c_uint32),
                 ("pool_idle_bytes", C.c_uint64)]
 
 
@@ -120,13 +120,13 @@ class Native:
             raise TsxError(rc, self.lib.tsx_strerror(rc).decode())
         return rc
 
-    def init(self, device_count=0, device_ids=None, fetch_reserved_cus=None, service_max_launch_ms=None, pool_idle_bytes=None):
+    def init(self, device_count=0, device_ids=None, fetch_reserved_cus=None, service_max_launch_ms=None, pool_idle_bytes=None, fetch_shared_cu_waves=None):
         ids = (C.c_int * len(device_ids))(*device_ids) if device_ids else None
-        if fetch_reserved_cus is None and service_max_launch_ms is None and pool_idle_bytes is None:
+        if fetch_reserved_cus is None and service_max_launch_ms is None and pool_idle_bytes is None and fetch_shared_cu_waves is None:
             n = self.check(self.lib.tsx_init(device_count, ids))
         else:
             cfg = Config(C.sizeof(Config), CFG_DEFAULT if fetch_reserved_cus is None else fetch_reserved_cus,
-                         CFG_DEFAULT if service_max_launch_ms is None else service_max_launch_ms, 0,
+                         CFG_DEFAULT if service_max_launch_ms is None else service_max_launch_ms, CFG_DEFAULT if fetch_shared_cu_waves is None else fetch_shared_cu_waves,
                          CFG_DEFAULT64 if pool_idle_bytes is None else pool_idle_bytes)
             n = self.check(self.lib.tsx_init_ex(device_count, ids, C.byref(cfg)))
         self._inited = True

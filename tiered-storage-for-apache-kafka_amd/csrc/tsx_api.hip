@@ -27,6 +27,7 @@ struct tsx_cfg {
     uint32_t reserved_cus = 0xFFFFFFFFu;  // compute units the compressor service leaves to everything else (0xFFFFFFFF: one per shader engine); TSX_FETCH_RESERVED_CUS
     uint32_t svc_max_launch_ms = 60000;   // age limit of one launch of the service kernel (0 = none); TSX_SERVICE_MAX_LAUNCH_MS
     uint32_t svc_idle_exit_us = 2000;     // the service kernel ends when it has had nothing to do for this long (callers in a closed loop need ~1 ms to come back)
+    uint32_t svc_keep_waves = 0;          // tsx_config.fetch_shared_cu_waves: compressor waves that stay on a reserved CU all the same; TSX_FETCH_SHARED_CU_WAVES
     long long pool_idle_bytes = -1;       // idle pooled workspace kept per device (-1: 4/9 of its memory); TSX_POOL_IDLE_BYTES
     uint32_t zstd_sched = 0;              // parser speculation schedule k0 | k1 << 8 (0 = the kernel's default; same bytes); TSX_ZSTD_SCHED
     bool debug = false;                   // TSX_DEBUG: HIP failures go to stderr as they happen
@@ -43,7 +44,6 @@ struct tsx_cfg {
     bool no_dec_pieces = false;           // block-form fetches in one piece
     bool svc_cu_mask = false;             // the reservation as a CU mask on the service's stream (the hardware keeps the kernel off the reserved CUs) instead of waves that leave
     uint32_t svc_waves_per_cu = 0;        // workgroups of a service launch per CU (0 = what the runtime says is resident at once; measurements only)
-    uint32_t svc_keep_waves = 0;          // compressor waves that stay on a reserved CU all the same (tsx_svc_launch.keep_waves; measurements)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
 };
@@ -57,6 +57,7 @@ static void tsx_set_err(const char* what, hipError_t e) {
 
 static void cfg_from_env(tsx_cfg& c) {
     if (const char* e = getenv("TSX_FETCH_RESERVED_CUS")) { const long v = atol(e); c.reserved_cus = (uint32_t)(v < 0 ? 0 : v > 128 ? 128 : v); }
+    if (const char* e = getenv("TSX_FETCH_SHARED_CU_WAVES")) { const long v = atol(e); c.svc_keep_waves = (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }
     if (const char* e = getenv("TSX_SERVICE_MAX_LAUNCH_MS")) { const long v = atol(e); if (v >= 0) c.svc_max_launch_ms = (uint32_t)v; }
     if (const char* e = getenv("TSX_POOL_IDLE_BYTES")) { const long long v = atoll(e); if (v >= 0) c.pool_idle_bytes = v; }
     if (const char* e = getenv("TSX_ZSTD_SCHED")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) c.zstd_sched = a | b << 8; }
@@ -518,6 +519,7 @@ extern "C" int tsx_init_ex(int device_count, const int* device_ids, const tsx_co
         if (cfg && cfg->struct_size >= sizeof(tsx_config)) {
             if (cfg->fetch_reserved_cus != TSX_CFG_DEFAULT) c.reserved_cus = cfg->fetch_reserved_cus > 128 ? 128 : cfg->fetch_reserved_cus;
             if (cfg->service_max_launch_ms != TSX_CFG_DEFAULT) c.svc_max_launch_ms = cfg->service_max_launch_ms;
+            if (cfg->fetch_shared_cu_waves != TSX_CFG_DEFAULT) c.svc_keep_waves = cfg->fetch_shared_cu_waves > 8 ? 8 : cfg->fetch_shared_cu_waves;
             if (cfg->pool_idle_bytes != TSX_CFG_DEFAULT64) c.pool_idle_bytes = (long long)cfg->pool_idle_bytes;
         } else if (cfg) return TSX_E_INVAL;
         cfg_from_env(c);
