@@ -47,8 +47,10 @@ __device__ static inline void crc_chunk_span(const tsx_chunk_desc* d, int use_ds
 __global__ __launch_bounds__(TSX_CRC_THREADS) void crc32c_partial_kernel(
         const tsx_crc_tables* __restrict__ tab, const uint8_t* __restrict__ src, const tsx_chunk_desc* __restrict__ descs,
         uint32_t max_sub, uint32_t* __restrict__ partials, int use_dst_side) {
+    // 20 KiB = exactly 16 of the 1280-byte granules LDS is allocated in: 8 workgroups per CU.  (The fold's four words live in the tables'
+    // first bytes once every lane is done with the tables: 16 bytes more cost a whole granule and the eighth workgroup.)
     __shared__ uint32_t lds_tab[20 * 256];
-    __shared__ uint32_t lds_red[TSX_CRC_THREADS / 64];
+    static_assert(sizeof(lds_tab) == 16 * 1280, "LDS granules");
     const uint32_t t = threadIdx.x;
     const uint32_t chunk = blockIdx.x / max_sub, sub = blockIdx.x % max_sub;
     uint64_t off; uint32_t len;
@@ -89,11 +91,12 @@ __global__ __launch_bounds__(TSX_CRC_THREADS) void crc32c_partial_kernel(
     // align every thread's remainder to the end of the sub-block's last piece and fold the workgroup
     uint32_t v = any ? crc_mulmod(acc, tab->piece_pow[p1 - 1 - last]) : 0u;
     for (int o = 32; o; o >>= 1) v ^= __shfl_xor(v, o);
-    if ((t & 63) == 0) lds_red[t >> 6] = v;
+    __syncthreads();                                       // every lane has made its last table lookup (crc_mulmod reads no table)
+    if ((t & 63) == 0) lds_tab[t >> 6] = v;
     __syncthreads();
     if (t == 0) {
         uint32_t r = 0;
-        for (int w = 0; w < TSX_CRC_THREADS / 64; w++) r ^= lds_red[w];
+        for (int w = 0; w < TSX_CRC_THREADS / 64; w++) r ^= lds_tab[w];
         partials[(size_t)chunk * max_sub + sub] = r;
     }
 }

@@ -264,7 +264,10 @@ __global__ __launch_bounds__(TSX_GCM_THREADS) void gcm_ctr_ghash_kernel(
         uint32_t max_sub, const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t* __restrict__ partials, int decrypt) {
     __shared__ uint32_t lds_t0[256 * 32];          // T0 replicated per bank: entry x, copy b at [x*32 + b]
     __shared__ tsx_gf128 lds_hs[32 * 16];          // Shoup tables of H^256
-    __shared__ tsx_gf128 lds_red[TSX_GCM_THREADS / 64];
+    // 40 KiB = exactly 32 of the 1280-byte granules LDS is allocated in: 4 workgroups per CU (the registers allow 4 waves per SIMD).  The
+    // fold's four values reuse the Shoup tables' first entries once every lane is done with them: 64 bytes more cost a granule and the
+    // fourth workgroup.
+    static_assert(sizeof(lds_t0) + sizeof(lds_hs) == 32 * 1280, "LDS granules");
     const uint32_t t = threadIdx.x;
     const uint32_t ci = blockIdx.x / max_sub, sub = blockIdx.x % max_sub;
     const tsx_gcm_chunk ch = chunks[ci];
@@ -328,11 +331,12 @@ __global__ __launch_bounds__(TSX_GCM_THREADS) void gcm_ctr_ghash_kernel(
     tsx_gf128 r; r.hi = 0; r.lo = 0;
     if (any) r = gf_mul(y, key->hpow[j1 - 1 - last]);
     for (int o = 32; o; o >>= 1) { r.hi ^= __shfl_xor(r.hi, o); r.lo ^= __shfl_xor(r.lo, o); }
-    if ((t & 63) == 0) lds_red[t >> 6] = r;
+    __syncthreads();                                                    // every lane has made its last lookup in lds_hs (gf_mul reads no table)
+    if ((t & 63) == 0) lds_hs[t >> 6] = r;
     __syncthreads();
     if (t == 0) {
         tsx_gf128 s; s.hi = 0; s.lo = 0;
-        for (int w = 0; w < TSX_GCM_THREADS / 64; w++) { s.hi ^= lds_red[w].hi; s.lo ^= lds_red[w].lo; }
+        for (int w = 0; w < TSX_GCM_THREADS / 64; w++) { s.hi ^= lds_hs[w].hi; s.lo ^= lds_hs[w].lo; }
         my_partial[0] = (uint32_t)s.hi; my_partial[1] = (uint32_t)(s.hi >> 32);
         my_partial[2] = (uint32_t)s.lo; my_partial[3] = (uint32_t)(s.lo >> 32);
     }

@@ -181,6 +181,10 @@ PY
         nf=""; [ "$4" = "nofetch" ] && nf="--no-fetch"
         timeout 300 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape $1 --callers $2 ${3:+--reserved-cus $3} $nf --seconds ${MIXED_SECONDS:-12} ${MIXED_MAX_LAUNCH_MS:+--max-launch-ms $MIXED_MAX_LAUNCH_MS} --tag "$cfg" 2>> $O/mixednt.err | tee -a $O/mixednt.jsonl
       done ;;
+    pmctraffic)
+      # profiles/pmc_traffic.json from the PMC passes just made (the bench that follows quotes roofline.traffic for the sources as they are);
+      # the same command at home over the merged gpurun_out/pmc* gives the same file
+      python tools/pmc_traffic.py --tag ${arg:-r05} > $O/pmc_traffic.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; tail -4 $O/pmc_traffic.log | cut -c1-200 ;;
     keepwaves)
       # compressor waves that stay on the reserved CU of every shader engine (svc_keep_waves): fetch latency and upload rate, device-resident 2048-chunk batches, no torch
       export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
