@@ -131,7 +131,7 @@ int  tsx_init(int device_count, const int* device_ids);
 
 /* What a deployment may want to say about the device-side machinery; TSX_CFG_DEFAULT(64) in a field = the library's default.
  * The environment of the process, read once inside tsx_init(_ex), overrides both: TSX_FETCH_RESERVED_CUS,
- * TSX_FETCH_SHARED_CU_WAVES, TSX_SERVICE_MAX_LAUNCH_MS, TSX_POOL_IDLE_BYTES.  Nothing on a data path reads the environment. */
+ * TSX_FETCH_SHARED_CU_WAVES, TSX_FETCH_QUIET_MS, TSX_SERVICE_MAX_LAUNCH_MS, TSX_POOL_IDLE_BYTES.  Nothing on a data path reads the environment. */
 #define TSX_CFG_DEFAULT   0xFFFFFFFFu
 #define TSX_CFG_DEFAULT64 0xFFFFFFFFFFFFFFFFull
 typedef struct tsx_config {
@@ -152,6 +152,12 @@ typedef struct tsx_config {
                                         waits ~0.5 s for the compressor launch to be rotated; 12 and more: such waits become regular.
                                         At most 8 is accepted                                                                  */
     uint64_t pool_idle_bytes;        /* idle pooled workspace kept per device; default 4/9 of its memory                      */
+    uint32_t fetch_quiet_ms;         /* the reservation follows the traffic: once no fetch (no batch of ordinary kernels) has run
+                                        for this long, the compressor's waves work on the reserved CUs too, as guests - the next
+                                        fetch makes them hand their chunks back and leave, which costs that ONE fetch up to a
+                                        block time of a chunk (~30 ms); from then on the CUs stay reserved until it has been quiet
+                                        again.  Default 10000; 0 = the reserved CUs are never used by the compressor              */
+    uint32_t reserved2_;
 } tsx_config;
 int  tsx_init_ex(int device_count, const int* device_ids, const tsx_config* cfg);   /* cfg == NULL: tsx_init */
 /* Every tsx_ctx must have been destroyed and no batch may be in flight.  No entry point of this library changes the calling
@@ -187,6 +193,10 @@ typedef struct tsx_service_info {
     uint32_t live_waves, live_waves_max;   /* waves of the service resident right now / the most ever                              */
     uint32_t shader_engines;               /* shader engines the probe launch met (groups of CUs the hardware fills separately)        */
     uint32_t rotations;                    /* launches a fetch that had waited 200 ms asked to end early (the safety net of the fetch side) */
+    uint32_t guest_launches;               /* launches whose waves used the reserved CUs too (no fetch had been seen for fetch_quiet_ms)  */
+    uint32_t yielded_waves;                /* guest waves that handed their chunk back and left when a fetch arrived                      */
+    uint32_t returned_chunks;              /* ... chunks handed back that way (each was started again by another wave)                   */
+    uint32_t readmissions;                 /* launches asked to end so that the next one could use the reserved CUs again (quiet again)   */
 } tsx_service_info;
 int  tsx_service_stats(int device_index, tsx_service_info* out);
 /* Returns when the device's service kernel has ended (a moment after its last chunk): brackets a measurement. */

@@ -182,9 +182,15 @@ template <class T> inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p
 // A steady clock in 10 ns units, and the "compute unit" a block runs on: block b of a launch is on CU b mod 4 of the one XCD
 // (hipGetDeviceProperties reports 4 CUs).  hipemu_force_reserved_launches(k): every block of the next k launches reports the
 // LAST CU - the one a reservation of one CU takes - so that a whole launch can be made to leave without doing any work.
+// hipemu_cu_key_shift(k): block b is on CU (b + k) mod 4 (k = 3: block 0, the first to run, is on the reserved CU).
+// hipemu_force_yield_after(n): the n-th look at a yield word that is still 0 finds it raised (and raises it): a fetch that arrives while a
+// guest wave is in the middle of its chunk.
 uint64_t hipemu_clock_100mhz();
 uint32_t hipemu_cu_key();
+uint32_t hipemu_yield_probe(const uint32_t* p);
 extern "C" void hipemu_force_reserved_launches(int k);
+extern "C" void hipemu_cu_key_shift(int k);
+extern "C" void hipemu_force_yield_after(int n);
 
 // ---- host runtime -------------------------------------------------------------------------------
 hipError_t hipGetDeviceCount(int* n);

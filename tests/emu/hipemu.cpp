@@ -136,8 +136,20 @@ static void init_fiber(Fiber& f) {
 static std::atomic<int> g_force_reserved{0};
 }  // namespace hipemu
 uint64_t hipemu_clock_100mhz() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10; }
-uint32_t hipemu_cu_key() { return hipemu::g_force_reserved.load(std::memory_order_relaxed) > 0 ? 3u : hipemu::g_ctx->bid.x % 4u; }
+static std::atomic<int> g_hipemu_key_shift{0}, g_hipemu_yield_after{0};
+uint32_t hipemu_cu_key() { return hipemu::g_force_reserved.load(std::memory_order_relaxed) > 0 ? 3u : (hipemu::g_ctx->bid.x + (unsigned)g_hipemu_key_shift.load(std::memory_order_relaxed)) % 4u; }
 extern "C" void hipemu_force_reserved_launches(int k) { hipemu::g_force_reserved = k; }
+extern "C" void hipemu_cu_key_shift(int k) { g_hipemu_key_shift = k; }
+extern "C" void hipemu_force_yield_after(int n) { g_hipemu_yield_after = n; }
+uint32_t hipemu_yield_probe(const uint32_t* p) {
+    const uint32_t v = __atomic_load_n(p, __ATOMIC_ACQUIRE);
+    if (v) return v;
+    if (g_hipemu_yield_after.load(std::memory_order_relaxed) > 0 && g_hipemu_yield_after.fetch_sub(1) == 1) {
+        __atomic_store_n(const_cast<uint32_t*>(p), 1u, __ATOMIC_RELEASE);     // as if a fetch had arrived on the host at this very moment
+        return 1u;
+    }
+    return 0u;
+}
 namespace hipemu {
 
 // One grid at a time: the scheduler state (and `__shared__` = static storage) is process-wide, while the front end under test is

@@ -6,6 +6,8 @@ import subprocess
 import sys
 import textwrap
 
+import time
+
 import numpy as np
 import pytest
 
@@ -217,7 +219,8 @@ def test_a_launch_that_met_only_reserved_cus_is_started_again(emu):
     s0 = emu.service_stats(0)
     emu.lib.hipemu_force_reserved_launches.argtypes = [ctypes.c_int]; emu.lib.hipemu_force_reserved_launches.restype = None
     emu.lib.hipemu_force_reserved_launches(2)
-    got, d = pc.run_transform(emu, flags, chunks)
+    with emu.configured(fetch_quiet_ms=0):                              # (the reserved CUs are left alone whether or not a fetch has been seen lately)
+        got, d = pc.run_transform(emu, flags, chunks)
     s1 = emu.service_stats(0)
     assert got == ref and (d["status"] == 0).all()
     assert s1["watchdog_launches"] - s0["watchdog_launches"] == 2 and s1["launches"] - s0["launches"] == 3
@@ -449,9 +452,10 @@ def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, flags
 
 
 def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
-    """tsx_config.fetch_reserved_cus (default 8: one compute unit per XCD that the compressor never occupies - a fetch under full upload load
-    finds room at once) decides which waves of the service leave at once; bytes and statuses are the same with a reservation,
-    without one, and with the environment's override, context-less and with a context, slot and packed layout; the fetch side is untouched."""
+    """tsx_config.fetch_reserved_cus (default: one compute unit per shader engine that a fetch under full upload load finds free)
+    decides which waves of the service leave at once - while fetches are about (fetch_quiet_ms = 0: always); bytes and statuses are the same
+    with a reservation, without one, and with the environment's override, context-less and with a context, slot and packed layout; the fetch
+    side is untouched.  A process that has never fetched compresses on the reserved CUs too (guest waves: the default)."""
     code = """
         import os, hashlib, numpy as np
         import tsxform
@@ -466,23 +470,68 @@ def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
         a, da = pc.run_transform(N, flags, chunks)
         b, db = pc.run_transform(N, flags, chunks, ctx=ctx)
         c, dc = pc.run_transform(N, flags, chunks, mem="packed")
+        s = N.service_stats(0)
         back, d2 = pc.run_detransform(N, flags, a, [int(x.size) for x in chunks], ctx=ctx)
         assert a == b == c and (da["status"] == 0).all() and back == [x.tobytes() for x in chunks]
-        s = N.service_stats(0)
-        print(hashlib.sha256(b"".join(a)).hexdigest(), s["reserved_cus"], s["reserved_exits"] > 0, s["launches"], s["wave_starts"], s["reserved_exits"], s["waves"])
+        e, de = pc.run_transform(N, flags, chunks)                      # after a fetch: the reserved CUs are left alone
+        s2 = N.service_stats(0)
+        assert e == a
+        print(hashlib.sha256(b"".join(a)).hexdigest(), s["reserved_cus"], s["reserved_exits"] > 0, s["launches"], s["wave_starts"], s["reserved_exits"], s["waves"],
+              s["guest_launches"], s2["launches"] - s["launches"], s2["guest_launches"] - s["guest_launches"], s2["reserved_exits"] - s["reserved_exits"])
         """
-    with_default = _run_py(code % "").strip().splitlines()[-1].split()
+    engaged = _run_py(code % "fetch_quiet_ms=0").strip().splitlines()[-1].split()
     without = _run_py(code % "fetch_reserved_cus=0").strip().splitlines()[-1].split()
-    by_env = _run_py(code % "fetch_reserved_cus=0", TSX_FETCH_RESERVED_CUS=1).strip().splitlines()[-1].split()
-    assert with_default[0] == without[0] == by_env[0]
-    assert with_default[1:3] == ["1", "True"] and without[1:3] == ["0", "False"] and by_env[1:3] == ["1", "True"]      # (the harness has 4 CUs: at most one is reserved)
+    by_env = _run_py(code % "fetch_reserved_cus=0", TSX_FETCH_RESERVED_CUS=1, TSX_FETCH_QUIET_MS=0).strip().splitlines()[-1].split()
+    assert engaged[0] == without[0] == by_env[0]
+    assert engaged[1:3] == ["1", "True"] and without[1:3] == ["0", "False"] and by_env[1:3] == ["1", "True"]      # (the harness has 4 CUs: at most one is reserved)
+    assert engaged[7] == "0" and without[7] == "0"
+    # the default: nobody has fetched yet - every launch's waves use the reserved CU as well; after the first fetch they leave it alone
+    guests = _run_py(code % "").strip().splitlines()[-1].split()
+    assert guests[0] == engaged[0] and guests[1:3] == ["1", "False"] and guests[7] == guests[3] and int(guests[3]) >= 3
+    assert int(guests[8]) >= 1 and guests[9] == "0" and int(guests[10]) > 0
     # ... and some of the compressor's waves may stay on a reserved CU all the same (tsx_config.fetch_shared_cu_waves: a CU shared between
     # fetches and uploads): exactly that many per launch, counted afresh by every launch
-    kept = _run_py(code % "fetch_shared_cu_waves=2").strip().splitlines()[-1].split()
+    kept = _run_py(code % "fetch_shared_cu_waves=2, fetch_quiet_ms=0").strip().splitlines()[-1].split()
     launches, starts, exits, waves = (int(x) for x in kept[3:7])
-    dl, ds_, de, dw = (int(x) for x in with_default[3:7])
-    assert kept[0] == with_default[0] and waves == dw and starts + exits == launches * waves and ds_ + de == dl * dw
+    dl, ds_, de, dw = (int(x) for x in engaged[3:7])
+    assert kept[0] == engaged[0] and waves == dw and starts + exits == launches * waves and ds_ + de == dl * dw
     assert exits == launches * (de // dl - 2) and launches >= 2
+
+
+def test_guest_waves_hand_their_chunks_back_when_a_fetch_arrives(emu, oracle):
+    """The reservation follows the traffic: with no fetch about, the waves on a reserved CU compress too - as guests that look at the host's
+    yield word before every block of their chunk.  Here the first workgroup of every launch sits on the reserved CU (hipemu_cu_key_shift) and
+    the word is raised while it is in the middle of a chunk (hipemu_force_yield_after: after its third block): the chunk goes back to the
+    queue with half-built tables, frame and entropy state in its workspace, another wave starts it again from its first byte - the bytes are
+    the oracle's all the same, every chunk is counted once, and the next launch (nobody has fetched: the word was raised by the harness, and
+    the front end clears it) has guests again."""
+    import ctypes
+    for f, t in (("hipemu_cu_key_shift", [ctypes.c_int]), ("hipemu_force_yield_after", [ctypes.c_int])):
+        getattr(emu.lib, f).argtypes = t; getattr(emu.lib, f).restype = None
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    sizes = [600000, 400000, 131072 * 2 + 5, 70001, 17, 0, 300000, 500000]
+    chunks = [synth.gen_chunk("K" if i % 3 else "B", 31, 1, i, s) for i, s in enumerate(sizes)]
+    with emu.configured(fetch_quiet_ms=1):
+        time.sleep(0.01)                                                # (whatever fetched before this test: quiet again)
+        ref, dref = pc.check_transform_vs_oracle(emu, oracle, flags, chunks)
+        emu.service_quiesce(0)
+        s0 = emu.service_stats(0)
+        emu.lib.hipemu_cu_key_shift(3)
+        try:
+            for after in (5, 3, 9):                                     # looks: at the wave's start, in svc_take, then one per block
+                time.sleep(0.01)
+                emu.lib.hipemu_force_yield_after(after)
+                got, d = pc.run_transform(emu, flags, chunks)
+                assert got == ref and (d["status"] == 0).all() and (d["crc32c"] == dref["crc32c"]).all(), after
+                got, d = pc.run_transform(emu, flags, chunks, mem="packed")      # the launch after: guests again (yield cleared), nothing forced
+                assert got == ref and (d["status"] == 0).all()
+        finally:
+            emu.lib.hipemu_cu_key_shift(0); emu.lib.hipemu_force_yield_after(0)
+        emu.service_quiesce(0)
+        s1 = emu.service_stats(0)
+    assert s1["yielded_waves"] - s0["yielded_waves"] >= 2 and s1["returned_chunks"] - s0["returned_chunks"] >= 2, (s0, s1)
+    assert s1["device_chunks"] - s0["device_chunks"] == 6 * len(chunks) and s1["skipped_tickets"] == s0["skipped_tickets"]
+    assert s1["guest_launches"] - s0["guest_launches"] >= 6
 
 
 def test_encrypt_only_batches_write_into_registered_buffers_too(emu, oracle):

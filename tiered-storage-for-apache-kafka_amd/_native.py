@@ -40,14 +40,15 @@ class Timing(C.Structure):
 class Config(C.Structure):
     """tsx_config of include/tsxform.h; fields left at CFG_DEFAULT take the library's default."""
     _fields_ = [("struct_size", C.c_uint32), ("fetch_reserved_cus", C.c_uint32), ("service_max_launch_ms", C.c_uint32), ("fetch_shared_cu_waves", C.c_uint32),
-                ("pool_idle_bytes", C.c_uint64)]
+                ("pool_idle_bytes", C.c_uint64), ("fetch_quiet_ms", C.c_uint32), ("reserved2_", C.c_uint32)]
 
 
 class ServiceInfo(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("watchdog_launches", C.c_uint64), ("members", C.c_uint64), ("chunks", C.c_uint64),
                 ("kernel_ms", C.c_double), ("running", C.c_uint32), ("waves", C.c_uint32), ("compute_units", C.c_uint32),
                 ("cu_keys_seen", C.c_uint32), ("reserved_cus", C.c_uint32), ("device_chunks", C.c_uint32), ("wave_starts", C.c_uint32),
-                ("reserved_exits", C.c_uint32), ("skipped_tickets", C.c_uint32), ("live_waves", C.c_uint32), ("live_waves_max", C.c_uint32), ("shader_engines", C.c_uint32), ("rotations", C.c_uint32)]
+                ("reserved_exits", C.c_uint32), ("skipped_tickets", C.c_uint32), ("live_waves", C.c_uint32), ("live_waves_max", C.c_uint32), ("shader_engines", C.c_uint32), ("rotations", C.c_uint32),
+                ("guest_launches", C.c_uint32), ("yielded_waves", C.c_uint32), ("returned_chunks", C.c_uint32), ("readmissions", C.c_uint32)]
 
 
 CFG_DEFAULT, CFG_DEFAULT64 = 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF
@@ -120,14 +121,14 @@ class Native:
             raise TsxError(rc, self.lib.tsx_strerror(rc).decode())
         return rc
 
-    def init(self, device_count=0, device_ids=None, fetch_reserved_cus=None, service_max_launch_ms=None, pool_idle_bytes=None, fetch_shared_cu_waves=None):
+    def init(self, device_count=0, device_ids=None, fetch_reserved_cus=None, service_max_launch_ms=None, pool_idle_bytes=None, fetch_shared_cu_waves=None, fetch_quiet_ms=None):
         ids = (C.c_int * len(device_ids))(*device_ids) if device_ids else None
-        if fetch_reserved_cus is None and service_max_launch_ms is None and pool_idle_bytes is None and fetch_shared_cu_waves is None:
+        if fetch_reserved_cus is None and service_max_launch_ms is None and pool_idle_bytes is None and fetch_shared_cu_waves is None and fetch_quiet_ms is None:
             n = self.check(self.lib.tsx_init(device_count, ids))
         else:
             cfg = Config(C.sizeof(Config), CFG_DEFAULT if fetch_reserved_cus is None else fetch_reserved_cus,
                          CFG_DEFAULT if service_max_launch_ms is None else service_max_launch_ms, CFG_DEFAULT if fetch_shared_cu_waves is None else fetch_shared_cu_waves,
-                         CFG_DEFAULT64 if pool_idle_bytes is None else pool_idle_bytes)
+                         CFG_DEFAULT64 if pool_idle_bytes is None else pool_idle_bytes, CFG_DEFAULT if fetch_quiet_ms is None else fetch_quiet_ms, 0)
             n = self.check(self.lib.tsx_init_ex(device_count, ids, C.byref(cfg)))
         self._inited = True
         return n

@@ -27,6 +27,7 @@ struct tsx_cfg {
     uint32_t reserved_cus = 0xFFFFFFFFu;  // compute units the compressor service leaves to everything else (0xFFFFFFFF: one per shader engine); TSX_FETCH_RESERVED_CUS
     uint32_t svc_max_launch_ms = 60000;   // age limit of one launch of the service kernel (0 = none); TSX_SERVICE_MAX_LAUNCH_MS
     uint32_t svc_idle_exit_us = 2000;     // the service kernel ends when it has had nothing to do for this long (callers in a closed loop need ~1 ms to come back)
+    uint32_t fetch_quiet_ms = 10000;      // tsx_config.fetch_quiet_ms: the reserved CUs work for the compressor too (guest waves) once no fetch has been seen for this long; 0 = never; TSX_FETCH_QUIET_MS
     uint32_t svc_keep_waves = 0;          // tsx_config.fetch_shared_cu_waves: compressor waves that stay on a reserved CU all the same; TSX_FETCH_SHARED_CU_WAVES
     long long pool_idle_bytes = -1;       // idle pooled workspace kept per device (-1: 4/9 of its memory); TSX_POOL_IDLE_BYTES
     uint32_t zstd_sched = 0;              // parser speculation schedule k0 | k1 << 8 (0 = the kernel's default; same bytes); TSX_ZSTD_SCHED
@@ -58,6 +59,7 @@ static void tsx_set_err(const char* what, hipError_t e) {
 static void cfg_from_env(tsx_cfg& c) {
     if (const char* e = getenv("TSX_FETCH_RESERVED_CUS")) { const long v = atol(e); c.reserved_cus = (uint32_t)(v < 0 ? 0 : v > 128 ? 128 : v); }
     if (const char* e = getenv("TSX_FETCH_SHARED_CU_WAVES")) { const long v = atol(e); c.svc_keep_waves = (uint32_t)(v < 0 ? 0 : v > 8 ? 8 : v); }
+    if (const char* e = getenv("TSX_FETCH_QUIET_MS")) { const long v = atol(e); if (v >= 0) c.fetch_quiet_ms = (uint32_t)v; }
     if (const char* e = getenv("TSX_SERVICE_MAX_LAUNCH_MS")) { const long v = atol(e); if (v >= 0) c.svc_max_launch_ms = (uint32_t)v; }
     if (const char* e = getenv("TSX_POOL_IDLE_BYTES")) { const long long v = atoll(e); if (v >= 0) c.pool_idle_bytes = v; }
     if (const char* e = getenv("TSX_ZSTD_SCHED")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 1 && a <= 59 && b >= 1 && b <= 59) c.zstd_sched = a | b << 8; }
@@ -73,7 +75,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_cu_mask, bool) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(trace, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_cu_mask, bool) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(fetch_quiet_ms, uint32_t) CFG_FIELD(trace, bool)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -120,6 +122,13 @@ struct tsx_service {
     std::vector<uint16_t> free_slots; uint16_t slot_gen[TSX_SVC_MEMBERS] = {0};
     uint64_t launches = 0, watchdog_launches = 0, members = 0, chunks = 0, rotations = 0; double kernel_ms = 0;
     bool rotating = false;                                           // a waiting fetch has asked the running launch to end (svc_rotate)
+    // The reservation follows the traffic.  "Foreground" = every batch that runs ordinary kernels (fetches above all): while one is in flight,
+    // and for fetch_quiet_ms after the last one, tsx_svc_host.yield is raised - guest waves on the reserved CUs hand their chunks back and
+    // leave (<= one block of their chunk later, ~30 ms), launches made meanwhile leave the reserved CUs alone.  A device that only uploads
+    // compresses on every CU.
+    std::atomic<uint32_t> fg_inflight{0};
+    std::atomic<int64_t> fg_last_ns{INT64_MIN / 2};                  // steady clock at the end of the last foreground batch
+    uint64_t guest_launches = 0, readmissions = 0;
     std::vector<void*> deferred_dev, deferred_host;                  // frees that wait for the kernel to be gone (svc_free_*)
 };
 
@@ -230,6 +239,25 @@ extern "C" const char* tsx_strerror(int code) {
     }
 }
 
+// ---- service: whose turn the reserved CUs are ----------------------------------------------------------------------------------------
+static int64_t steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// A batch of ordinary kernels begins / is over (no lock: this is the fetch path).  The counter first, the word second - svc_launch_locked
+// clears the word first and looks at the counter second, so one of the two always sees the other.
+static void svc_foreground_begin(tsx_device* dev) {
+    if (!dev->svc) return;
+    dev->svc->fg_inflight.fetch_add(1, std::memory_order_seq_cst);
+    __atomic_store_n(&dev->svc->h->yield, 1u, __ATOMIC_SEQ_CST);
+}
+static void svc_foreground_end(tsx_device* dev) {
+    if (!dev->svc) return;
+    dev->svc->fg_last_ns.store(steady_ns(), std::memory_order_seq_cst);
+    dev->svc->fg_inflight.fetch_sub(1, std::memory_order_seq_cst);
+}
+static bool svc_quiet(const tsx_service& s) {
+    return g_cfg.fetch_quiet_ms != 0 && s.fg_inflight.load(std::memory_order_seq_cst) == 0 &&
+           steady_ns() - s.fg_last_ns.load(std::memory_order_seq_cst) > (int64_t)g_cfg.fetch_quiet_ms * 1000000;
+}
+
 // ---- service: lifetime ------------------------------------------------------------------------------------------------------------------
 // Is the service kernel of this device still out?  (mu held.)  When its end is seen for the first time, its duration joins the statistics
 // and what waited for it to be gone is freed: hipFree / hipHostFree wait for EVERY stream of the device, i.e. for a kernel that lives
@@ -265,12 +293,18 @@ static int svc_launch_locked(tsx_service& s) {
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
     a.keep_waves = g_cfg.svc_keep_waves;
+    if (s.cus_reserved && !s.masked && svc_quiet(s)) {
+        // no fetch for a while: the waves on the reserved CUs work as guests.  Word first, counter second (svc_foreground_begin)
+        __atomic_store_n(&s.h->yield, 0u, __ATOMIC_SEQ_CST);
+        if (s.fg_inflight.load(std::memory_order_seq_cst) != 0) __atomic_store_n(&s.h->yield, 1u, __ATOMIC_SEQ_CST);
+        else a.guests = 1;
+    }
     (void)hipGetLastError();
     a.launch_id = s.launch_id + 1;
     tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_last_err, sizeof g_last_err, "launch of the compressor service kernel failed"); return TSX_E_DEVICE; }
     s.launch_id = a.launch_id;
-    s.launched = true; s.launches++;
+    s.launched = true; s.launches++; s.guest_launches += a.guests;
     return TSX_OK;
 }
 
@@ -516,10 +550,11 @@ extern "C" int tsx_init_ex(int device_count, const int* device_ids, const tsx_co
     tsx_device_scope keep;
     {   // what the process has (defaults, or what tsx_debug_config set), then the caller's structure, then the environment - a deployment's last word
         tsx_cfg c = g_cfg;
-        if (cfg && cfg->struct_size >= sizeof(tsx_config)) {
+        if (cfg && cfg->struct_size >= offsetof(tsx_config, fetch_quiet_ms)) {      // (the struct as it was before fetch_quiet_ms is accepted too)
             if (cfg->fetch_reserved_cus != TSX_CFG_DEFAULT) c.reserved_cus = cfg->fetch_reserved_cus > 128 ? 128 : cfg->fetch_reserved_cus;
             if (cfg->service_max_launch_ms != TSX_CFG_DEFAULT) c.svc_max_launch_ms = cfg->service_max_launch_ms;
             if (cfg->fetch_shared_cu_waves != TSX_CFG_DEFAULT) c.svc_keep_waves = cfg->fetch_shared_cu_waves > 8 ? 8 : cfg->fetch_shared_cu_waves;
+            if (cfg->struct_size >= offsetof(tsx_config, fetch_quiet_ms) + 4 && cfg->fetch_quiet_ms != TSX_CFG_DEFAULT) c.fetch_quiet_ms = cfg->fetch_quiet_ms;
             if (cfg->pool_idle_bytes != TSX_CFG_DEFAULT64) c.pool_idle_bytes = (long long)cfg->pool_idle_bytes;
         } else if (cfg) return TSX_E_INVAL;
         cfg_from_env(c);
@@ -1003,6 +1038,14 @@ static int svc_submit(tsx_device* dev, const tsx_zseg& proto, const uint32_t* h_
     s.out.push_back({*id, first, n, slot, false, h_flag});
     s.members++;
     if (!svc_running_locked(s)) return svc_launch_locked(s);           // (on failure the caller abandons the member: svc_retire)
+    // The running launch left the reserved CUs to fetches (it began that way, or its guests have gone) and no fetch has been seen since
+    // fetch_quiet_ms: it is asked to end - its waves leave after their chunk, the waiting members' watchdog starts the next launch, whose
+    // waves use every CU again.  One chunk time of a thinning chip, once per quiet period.
+    if (s.cus_reserved && !s.masked && !s.rotating && !s.paused && __atomic_load_n(&s.h->yield, __ATOMIC_RELAXED) && svc_quiet(s)) {
+        s.rotating = true; s.readmissions++;
+        __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
+        s.stop_dirty = true;
+    }
     return TSX_OK;
 }
 
@@ -1068,7 +1111,9 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
     out->launches = s.launches; out->watchdog_launches = s.watchdog_launches; out->rotations = (uint32_t)s.rotations; out->members = s.members; out->chunks = s.chunks;
     out->kernel_ms = s.kernel_ms; out->running = running ? 1u : 0u;
     out->waves = s.grid; out->compute_units = s.cus; out->cu_keys_seen = s.cu_keys; out->reserved_cus = s.cus_reserved; out->shader_engines = s.engines;
+    out->guest_launches = (uint32_t)s.guest_launches; out->readmissions = (uint32_t)s.readmissions;
     uint32_t w[4] = {0, 0, 0, 0};
+    if (hipMemcpy(w, &s.d->stat_yields, 8, hipMemcpyDeviceToHost) == hipSuccess) { out->yielded_waves = w[0]; out->returned_chunks = w[1]; } else (void)hipGetLastError();
     if (hipMemcpy(w, &s.d->stat_chunks, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
         out->device_chunks = w[0]; out->wave_starts = w[1]; out->reserved_exits = w[2]; out->skipped_tickets = w[3];
     } else (void)hipGetLastError();
@@ -1598,6 +1643,11 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     r.enc = mode != 2 && (flags & TSX_ENCRYPT); r.comp = mode != 2 && (flags & TSX_COMPRESS);
     r.fuse_stages = r.comp && !g_cfg.stages_separate;
     const bool service = mode == 0 && r.comp;
+    struct fg_scope {                                                   // every batch of ordinary kernels claims the reserved CUs for its duration (+ fetch_quiet_ms)
+        tsx_device* d;
+        explicit fg_scope(tsx_device* dev) : d(dev) { if (d) svc_foreground_begin(d); }
+        ~fg_scope() { if (d) svc_foreground_end(d); }
+    } fg(service && r.fuse_stages ? nullptr : c->dev);
     const int rc = service ? run_compress(r) : run_batch_inner(r);
     // Whatever happened: nothing of this call is still in flight when it returns (the copies reference the caller's buffers), and
     // the data key does not stay behind in a context that may serve another segment next (the native side zeroises its

@@ -94,11 +94,14 @@ struct tsx_zseg {                // one caller's batch ("member") in the device'
 #define TSX_SVC_MEMBERS 2048u         /* member slots (a caller holds up to 8 until it has collected its pieces) */
 #define TSX_SVC_TICKETS 65536u        /* ticket ring (power of two): chunks published and not yet completed never exceed it */
 #define TSX_SVC_MEMBER_MAX 16384u     /* chunks per member (a larger batch goes as several members) */
+#define TSX_SVC_RETURNED_MAX 4096u    /* chunks handed back by guest waves and not yet taken again: never more than waves on reserved CUs (<= 128 x 32) */
 struct tsx_svc_ticket { uint32_t member_gen; uint32_t chunk; };   // member slot in the low 16 bits, the slot's generation (16 bits) above
 struct tsx_svc_host {                // pinned host memory, written by the host, read by the device (through its device alias) ...
     uint32_t published;              // tickets [.., published) are valid; release-stored after their records and member entries
     uint32_t stop;                   // != 0: waves leave after their current chunk (shutdown / pause for memory management)
-    uint32_t pad_[14];
+    uint32_t yield;                  // != 0: a fetch (any batch of ordinary kernels) is or has lately been on the device - GUEST waves, the ones that
+                                     // work on a reserved CU while the device does nothing but compress, hand their chunk back and leave (see below)
+    uint32_t pad_[13];
     // ... except this line, which the LAST wave of a launch writes: the launch is over.  The service's stream carries no HIP event: a marker
     // queued behind the kernel is a barrier packet that waits, at the head of its hardware queue, for as long as the kernel lives - and
     // while it waited, the first command of every stream whose hardware queue shares that queue's pipe did not start either (measured:
@@ -124,6 +127,11 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
     uint32_t kept[256];              // per shader engine (key >> 4): waves of the current launch that stayed on the engine's reserved CU (tsx_svc_launch.keep_waves)
+    // chunks that guest waves handed back (the ticket's CONTENT: its ring record may be reused once its member has been abandoned); every
+    // wave looks here before it takes a fresh ticket.  A spin lock (lane 0 only, a handful of instructions inside) - this happens once per
+    // guest wave when a fetch arrives after a quiet time
+    uint32_t ret_lock, ret_n, stat_yields, stat_returned;
+    tsx_svc_ticket ret[TSX_SVC_RETURNED_MAX];
 };
 struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t launch_id;              // what the last wave writes to tsx_svc_host.ended_launch
@@ -132,6 +140,9 @@ struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t poll_ticks;             // 100 MHz ticks between two host polls (device-wide)
     uint32_t idle_exit_ticks;        // a wave leaves when the queue has been dry and no wave busy for this long
     uint32_t max_age_ticks_lo, max_age_ticks_hi;   // != 0: waves stop taking tickets when the launch is older (the host starts the next one)
+    uint32_t guests;                 // != 0: the other waves on reserved CUs work too, as GUESTS - they look at tsx_svc_host.yield before every block of
+                                     // their chunk (~30 ms apart) and while idle; once it is raised they hand the chunk back (another wave starts it
+                                     // again from its first byte) and leave for good.  0: they leave at once (the reservation is in force from the start)
     uint32_t keep_waves;             // waves that stay on a reserved CU all the same (0 = the CU is left alone; the rest of it - LDS, registers, wave slots - is the room a fetch's workgroups find)
 };
 void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, uint32_t grid, tsx_svc_launch a);

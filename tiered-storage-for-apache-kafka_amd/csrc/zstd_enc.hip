@@ -1540,12 +1540,22 @@ __device__ static ZS_NOINLINE void finish_frame(tsx_chunk_desc* __restrict__ des
     if (lane == 0) { descs[chunk].dst_len = flen + 28; if (fuse.self_status) descs[chunk].status = TSX_OK; }
 }
 
+// A guest wave's look at the host's yield word (tsx_svc_host.yield, pinned memory: one PCIe read)
+#ifdef HIPEMU
+__device__ static inline uint32_t zs_yield_asked(const uint32_t* p) { return hipemu_yield_probe(p); }
+#else
+__device__ static inline uint32_t zs_yield_asked(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#endif
+
 // One chunk, start to finish, in the calling wave: CRC32C head, frame, GCM tail (or the copy into the caller's slot), descriptor.
 // Every argument is the same in all lanes (the service kernel hands them over in SGPRs).
-__device__ __forceinline__ static void zstd_compress_chunk(EncLds& L, const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
+// `yield` != nullptr (a guest wave): looked at before every block; raised -> true is returned with the chunk unfinished.  Nothing the
+// caller can see has been written by then but the chunk's CRC32C and TSX_OK in status[] (both the same again next time); hash tables,
+// frame and entropy state live in the chunk's own workspace and are set up afresh by whoever starts the chunk again.
+__device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
                                                            uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
                                                            int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
-                                                           const tsx_chain_fuse fuse, const uint32_t chunk
+                                                           const tsx_chain_fuse fuse, const uint32_t chunk, const uint32_t* yield
 #ifdef TSX_PROF
                                                            , unsigned long long* __restrict__ prof_out
 #endif
@@ -1571,7 +1581,7 @@ __device__ __forceinline__ static void zstd_compress_chunk(EncLds& L, const uint
         if (lane == 0) descs[chunk].crc32c = crc;
     }
     if (fuse.self_status) { if (lane == 0) status[chunk] = TSX_OK; }    // (finish_frame publishes the chunk's final status in its descriptor)
-    else if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } return; }
+    else if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } return false; }
 
     const zs_cparams cp = zs_level3_cparams(srcSize);
     {   // fresh tables (ZSTD_reset_matchState): zero hashLong[1 << hashLog] and hashSmall[1 << chainLog]
@@ -1599,7 +1609,7 @@ __device__ __forceinline__ static void zstd_compress_chunk(EncLds& L, const uint
     if (srcSize == 0) {
         if (lane == 0) { op[0] = 1; op[1] = 0; op[2] = 0; }
         finish_frame(descs, chunk, frame, hdr + 3, zlen, status, fuse, ws + ZS_WS_KEYCOPY, L, lane);
-        return;
+        return false;
     }
     uint32_t* const hufSave = (uint32_t*)(ws + ZS_WS_HUFSAVE);
     static_assert(sizeof(L.huf) % 4 == 0 && sizeof(L.huf) <= 2048, "Huffman tables fit their place in the workspace");
@@ -1616,6 +1626,11 @@ __device__ __forceinline__ static void zstd_compress_chunk(EncLds& L, const uint
     int cur = 0;                 // index of the confirmed Huffman table (L.huf[cur]); a candidate is built in L.huf[cur ^ 1]
     bool first = true;
     while (remaining) {
+        if (yield) {                                                    // a guest: is the CU wanted back?
+            uint32_t y = 0;
+            if (lane == 0) y = zs_yield_asked(yield);
+            if (UNI(y)) return true;
+        }
         // ---- block size (ZSTD_optimalBlockSize) ----
         uint32_t blockSize = remaining < blockSizeMax ? remaining : blockSizeMax;
         if (profile == TSX_ZSTD_PROFILE_1_5_7 && remaining >= ZS_BLOCK_MAX && blockSizeMax >= ZS_BLOCK_MAX && savings >= 3)
@@ -1686,6 +1701,7 @@ __device__ __forceinline__ static void zstd_compress_chunk(EncLds& L, const uint
 #ifdef TSX_PROF
     if (lane == 0 && prof_out) { g_prof[14] = (unsigned long long)clock64() - g_prof[22]; for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i]; }
 #endif
+    return false;
 }
 
 
@@ -1712,6 +1728,7 @@ __device__ static inline uint32_t svc_cu_key() { return hipemu_cu_key(); }
 __device__ static inline void svc_nap(uint32_t) {}
 __device__ static inline void svc_acquire_chunk() {}
 __device__ static inline void svc_release_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }   // (the harness's __threadfence_system is a wave rendezvous: lane 0 is alone here)
+__device__ static inline void svc_fence_device() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #else
 #define SVC_LD_SYS(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #define SVC_LD_DEV(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -1733,6 +1750,7 @@ __device__ static inline void svc_acquire_chunk() {
     asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 __device__ static inline void svc_release_system() { __threadfence_system(); }
+__device__ static inline void svc_fence_device() { __threadfence(); }
 #endif
 static_assert(sizeof(tsx_zseg) == 128 && offsetof(tsx_zseg, src_base) == 16 && offsetof(tsx_zseg, fuse) == 72 && offsetof(tsx_zseg, done) == 112,
               "zstd_service_kernel reads a member entry as 16 eight-byte words, one per lane");
@@ -1746,7 +1764,20 @@ __device__ static inline uint64_t svc_word(uint64_t w, int k) {            // wo
 // Lane 0 of an idle wave: the next ticket (1), or leave (2).  A wave leaves when the device is told to stop, when its launch has
 // reached its age limit, or when the queue has been dry AND no wave has held a ticket for idle_exit_ticks - as long as anyone is
 // still compressing, the idle waves stay (napping): the next member finds the whole supply of waves, not the stragglers' kernel.
-__device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a, const uint64_t t_start, uint32_t* ticket) {
+__device__ static inline void svc_ret_lock(tsx_svc_dev* D) { while (atomicCAS(&D->ret_lock, 0u, 1u) != 0u) svc_nap(1); svc_fence_device(); }
+__device__ static inline void svc_ret_unlock(tsx_svc_dev* D) { svc_fence_device(); atomicExch(&D->ret_lock, 0u); }
+// A guest hands its chunk back (lane 0, after the wave's last access to the chunk's workspace).
+__device__ ZS_NOINLINE static void svc_return_chunk(tsx_svc_dev* D, uint32_t member_gen, uint32_t chunk) {
+    svc_ret_lock(D);
+    const uint32_t n = SVC_LD_DEV(&D->ret_n);
+    if (n < TSX_SVC_RETURNED_MAX) { SVC_ST_DEV(&D->ret[n].member_gen, member_gen); SVC_ST_DEV(&D->ret[n].chunk, chunk); SVC_ST_DEV(&D->ret_n, n + 1u); }
+    svc_ret_unlock(D);
+    atomicAdd(&D->stat_returned, 1u);
+}
+// (3): a chunk that a guest handed back, in *ticket / *chunk_out (member slot | generation, chunk index) - taken before any fresh ticket.
+// `yield` != nullptr: this wave is a guest and leaves (2) as soon as the word is raised.
+__device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a, const uint64_t t_start, const uint32_t* yield,
+                                                uint32_t* ticket, uint32_t* chunk_out) {
     const uint64_t max_age = ((uint64_t)a.max_age_ticks_hi << 32) | a.max_age_ticks_lo;
     uint64_t quiet_since = 0;
     uint32_t nap = 1;
@@ -1754,6 +1785,16 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
         const uint64_t now = svc_now();
         if (SVC_LD_DEV(&D->stop)) return 2;
         if (max_age && now - t_start > max_age) return 2;
+        if (yield && zs_yield_asked(yield)) return 2;
+        if (SVC_LD_DEV(&D->ret_n)) {
+            atomicAdd(&D->busy, 1u);
+            svc_ret_lock(D);
+            const uint32_t n = SVC_LD_DEV(&D->ret_n);
+            if (n) { *ticket = SVC_LD_DEV(&D->ret[n - 1u].member_gen); *chunk_out = SVC_LD_DEV(&D->ret[n - 1u].chunk); SVC_ST_DEV(&D->ret_n, n - 1u); }
+            svc_ret_unlock(D);
+            if (n) return 3;
+            atomicSub(&D->busy, 1u);
+        }
         const uint32_t nx = SVC_LD_DEV(&D->next), pb = SVC_LD_DEV(&D->pub);
         if ((int32_t)(pb - nx) > 0) {
             atomicAdd(&D->busy, 1u);                                     // before the ticket is taken: busy >= waves that hold one
@@ -1809,25 +1850,33 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         return;
     }
     const uint32_t key = UNI(svc_cu_key());
-    if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU: not ours (see tsx_internal.h) - but for the first keep_waves to arrive
-        uint32_t stay = 0;
-        if (a.keep_waves && lane == 0) stay = atomicAdd(&D->kept[key >> 4], 1u) < a.keep_waves;
-        if (!UNI(stay)) {
+    const uint32_t* yield = nullptr;                                     // != nullptr: this wave is a guest on a reserved CU
+    if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU (see tsx_internal.h): the first keep_waves to arrive stay for good,
+        uint32_t stay = 0;                                               // the others work as guests while no fetch is about, or leave at once
+        if (lane == 0) {
+            if (a.keep_waves && atomicAdd(&D->kept[key >> 4], 1u) < a.keep_waves) stay = 1;
+            else if (a.guests && !zs_yield_asked(&H->yield)) stay = 2;
+        }
+        stay = UNI(stay);
+        if (!stay) {
             if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }
             return;
         }
+        if (stay == 2) yield = &H->yield;
     }
     if (lane == 0) atomicAdd(&D->stat_wave_starts, 1u);
     for (;;) {
-        uint32_t got = 0, ticket = 0;
-        if (lane == 0) got = svc_take(H, D, a, t_start, &ticket);
-        got = UNI(got); ticket = UNI(ticket);
-        if (got != 1) break;
+        uint32_t got = 0, ticket = 0, chunk = 0;
+        if (lane == 0) got = svc_take(H, D, a, t_start, yield, &ticket, &chunk);
+        got = UNI(got); ticket = UNI(ticket); chunk = UNI(chunk);
+        if (got != 1 && got != 3) break;
         svc_acquire_chunk();
-        // the ticket's record and its member's entry, straight from host memory
-        uint32_t mg = 0, chunk = 0;
-        if (lane == 0) { const tsx_svc_ticket* t = &H->ticket[ticket & (TSX_SVC_TICKETS - 1)]; mg = SVC_LD_SYS(&t->member_gen); chunk = SVC_LD_SYS(&t->chunk); }
-        mg = UNI(mg); chunk = UNI(chunk);
+        // the ticket's record (a chunk that was handed back comes with its content) and its member's entry, straight from host memory
+        uint32_t mg = ticket;
+        if (got == 1) {
+            if (lane == 0) { const tsx_svc_ticket* t = &H->ticket[ticket & (TSX_SVC_TICKETS - 1)]; mg = SVC_LD_SYS(&t->member_gen); chunk = SVC_LD_SYS(&t->chunk); }
+            mg = UNI(mg); chunk = UNI(chunk);
+        }
         const uint32_t slot = mg & 0xFFFFu;
         uint64_t w = 0;
         if (lane < 16 && slot < TSX_SVC_MEMBERS) w = SVC_LD_SYS(reinterpret_cast<const uint64_t*>(&H->member[slot]) + lane);
@@ -1842,8 +1891,15 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         fuse.key = (const tsx_gcm_key*)svc_word(w, 11); fuse.out = (uint8_t*)svc_word(w, 12);
         { const uint64_t f = svc_word(w, 13); fuse.self_status = (uint32_t)f; fuse.key_on_host = (uint32_t)(f >> 32); }
         uint32_t* const done = (uint32_t*)svc_word(w, 14); uint32_t* const flag = (uint32_t*)svc_word(w, 15);
-        zstd_compress_chunk(L, (const uint8_t*)svc_word(w, 2), (tsx_chunk_desc*)svc_word(w, 3), (uint8_t*)svc_word(w, 4), svc_word(w, 5),
-                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk ZS_PROF_ARG);
+        const bool handed_back = zstd_compress_chunk(L, (const uint8_t*)svc_word(w, 2), (tsx_chunk_desc*)svc_word(w, 3), (uint8_t*)svc_word(w, 4), svc_word(w, 5),
+                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, yield ZS_PROF_ARG);
+        if (handed_back) {
+            // a fetch has arrived: the chunk goes back to the queue - every lane's stores into its workspace are complete and released before
+            // another wave can start it again - and this wave leaves its CU to the fetch's kernels
+            __syncthreads();
+            if (lane == 0) { svc_fence_device(); svc_return_chunk(D, mg, chunk); atomicAdd(&D->stat_yields, 1u); atomicSub(&D->busy, 1u); }
+            break;
+        }
         // ---- this chunk is done: tell its member's caller when it was the member's last one ----
         // The kernel goes on, so nothing here may rely on an end-of-kernel release: every lane's stores (ciphertext in device memory, which
         // the caller's copy engine reads next, or in the caller's registered buffer; descriptor in pinned host memory) are complete at the
