@@ -363,7 +363,7 @@ def main():
     if svc0 is not None:
         N.service_quiesce(0)
         svc1 = N.service_stats(0)
-        svc = {k: svc1[k] - svc0[k] for k in ("launches", "watchdog_launches", "members", "chunks", "kernel_ms", "device_chunks", "wave_starts", "reserved_exits")}
+        svc = {k: svc1[k] - svc0[k] for k in ("launches", "watchdog_launches", "members", "chunks", "kernel_ms", "device_chunks", "wave_starts", "reserved_exits", "guest_launches", "yielded_waves")}
         svc.update({k: svc1[k] for k in ("waves", "compute_units", "cu_keys_seen", "reserved_cus")})
     for t in range(1, T):
         assert (ds[t]["status"] == 0).all() and (ds[t]["dst_len"] == d["dst_len"]).all() and (ds[t]["crc32c"] == d["crc32c"]).all()
@@ -443,6 +443,11 @@ def main():
             for k_ in (1, 4):
                 fetch(k_)
             idle_ms = {k_: round(float(np.median([fetch(k_) for _ in range(7)])), 3) for k_ in (1, 4)}
+            # the uploads begin on a device that has not fetched for a while (tsx_config.fetch_quiet_ms, 10 s by default - half a second here):
+            # their launch has guest waves on the reserved CUs, and the FIRST fetch is the one that sends them away
+            old_quiet = N.debug_config("fetch_quiet_ms", 500)
+            time.sleep(0.7)
+            msv0 = N.service_stats(0)
             stop = [False]
             done = [0] * T
 
@@ -459,6 +464,7 @@ def main():
             tm0 = time.perf_counter()
             [x.start() for x in th]
             time.sleep(2.0)                                              # the chip is full
+            first_ms = fetch(1)
             lat = {1: [], 4: []}
             while time.perf_counter() - tm0 < 2.0 + args.mixed_load_seconds:
                 for k_ in (1, 4):
@@ -469,13 +475,18 @@ def main():
             el_ = time.perf_counter() - tm0
             exact = bool(np.array_equal(hbk, want4))
             N.host_unregister(hfr); N.host_unregister(hbk); N.ctx_destroy(fctx)
-            rot_ = N.service_stats(0)["rotations"]
+            N.debug_config("fetch_quiet_ms", old_quiet)
+            msv1 = N.service_stats(0)
+            rot_ = msv1["rotations"] - msv0["rotations"]
             mixed = {"metric": "latency of a fetch (tsx_detransform_batch of 1 / 4 chunks, host -> host, own context) while %d callers keep %d compressor chunks queued" % (T, T * n),
                      "reserved_cus": None if svc is None else svc["reserved_cus"], "compress_callers": T, "chunks_offered": T * n,
                      "compress_gibs_while_fetching": round(sum(done) * float(n) * CH / GiB / el_, 3),
-                     "compress_gibs_while_fetching_note": "whole window incl. the callers' ramp and drain; `_slope` = least-squares slope of batch completions over the middle 60 %, as `sustained`",
+                     "compress_gibs_while_fetching_note": "whole window incl. the callers' ramp and drain; `_slope` = least-squares slope of batch completions over the middle 60 %, as `sustained`; `frac_of_sustained` sets it against the upload-only rate (guest waves on the reserved CUs): what the reservation costs WHILE fetches go on",
                      "fetch_idle_ms": {str(k_): v for k_, v in idle_ms.items()}, "restored_bytes_exact": exact, "unit": "ms",
-                     "compressor_launches_asked_to_end_early_by_a_waiting_fetch": int(rot_)}
+                     "compressor_launches_asked_to_end_early_by_a_waiting_fetch": int(rot_),
+                     "first_fetch_after_a_quiet_time_ms": round(first_ms, 2),
+                     "first_fetch_note": "the uploads had begun with guest waves on the reserved CUs (no fetch for fetch_quiet_ms): this fetch made %d of them hand back their chunks (%d, compressed again by other waves) and leave; the latencies below are the fetches after it" %
+                                         (msv1["yielded_waves"] - msv0["yielded_waves"], msv1["returned_chunks"] - msv0["returned_chunks"])}
             da_ = np.sort(np.asarray(mstamps)) - tm0
             if da_.size >= 8:
                 q0, q1 = int(da_.size * 0.2), int(da_.size * 0.8)
@@ -659,7 +670,8 @@ def main():
         ms = svc["kernel_ms"] / svc["launches"]
         alg = cpl * (CH + mean_out)
         launches_meta = {"launches_in_timed_region": int(svc["launches"]), "chunks_per_launch": round(cpl, 1), "started_by_watchdog": int(svc["watchdog_launches"]),
-                         "waves_per_launch": int(svc["waves"]), "reserved_cus": int(svc["reserved_cus"]), "compute_units": int(svc["compute_units"]), "cu_keys_seen": int(svc["cu_keys_seen"])}
+                         "waves_per_launch": int(svc["waves"]), "reserved_cus": int(svc["reserved_cus"]),
+                         "launches_with_guest_waves_on_the_reserved_cus": int(svc["guest_launches"]), "compute_units": int(svc["compute_units"]), "cu_keys_seen": int(svc["cu_keys_seen"])}
     achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_zstd.sh -> profiles/pmc_traffic.json:
     # FETCH_SIZE + WRITE_SIZE of the same kernel build and workload); null when no such measurement is recorded

@@ -176,11 +176,13 @@ def test_compressing_batches_are_members_of_one_service(emu, oracle):
     s0 = emu.service_stats(0)
     T, reps = 12, 5
     sets = []
+    old_quiet = emu.debug_config("fetch_quiet_ms", 0)                   # the reservation in force whether or not something has fetched lately
     for t in range(T):
         chunks = [synth.gen_chunk("K" if (t + i) % 3 else "R", 40 + t, t, i, sz) for i, sz in enumerate([30000, 1, 0, 70001, 4096, 12345][: 3 + t % 4])]
         key = bytes((b + t) & 0xFF for b in synth.KEY)
         mem = (None, "packed", "device")[t % 3]
         sets.append((chunks, key, mem, pc.run_transform(emu, flags, chunks, key=key, mem=mem)[0]))
+    emu.debug_config("fetch_quiet_ms", old_quiet)
     s1 = emu.service_stats(0)
     nchunks = sum(len(x[0]) for x in sets)
     assert s1["members"] - s0["members"] == T and s1["chunks"] - s0["chunks"] == nchunks == s1["device_chunks"] - s0["device_chunks"]

@@ -25,29 +25,40 @@ CHUNK = synth.CHUNK
 
 def test_cu_probe_found_every_compute_unit_and_the_reservation_holds(gpu):
     """HW_ID[15:8] + XCC_ID is a key per compute unit: the probe launch of tsx_init met exactly as many keys as the device has CUs, in 32
-    shader engines; one CU of every engine is left to everything but the compressor, and a launch of the service is exactly as large as
-    the chip holds at once (24 one-wave workgroups per CU: measured by the calibration launch), so that no workgroup of it is ever pending."""
+    shader engines; one CU of every engine is left to everything but the compressor while fetches are about (fetch_quiet_ms = 0: always), and a
+    launch of the service is exactly as large as the chip holds at once (24 one-wave workgroups per CU: measured by the calibration launch),
+    so that no workgroup of it is ever pending.  With no fetch about, the waves on the reserved CUs stay and compress (guest waves)."""
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     s0 = gpu.service_stats(0)
     assert s0["compute_units"] == 256 and s0["cu_keys_seen"] == 256, s0
     assert s0["shader_engines"] == 32 and s0["reserved_cus"] == 32, s0
     assert s0["waves"] == 256 * 24, s0                                 # (6384 B of LDS = five 1280-byte granules: 25 fit, the registers allow 24)
     per_cu = s0["waves"] // 256
-    gpu.service_quiesce(0)
-    s0 = gpu.service_stats(0)
     chunks = [synth.gen_chunk("K", 3, 0, i, 100000) for i in range(32)]
-    pc.run_transform(gpu, flags, chunks, mem="device")
-    gpu.service_quiesce(0)
-    s1 = gpu.service_stats(0)
+    with gpu.configured(fetch_quiet_ms=0):
+        gpu.service_quiesce(0)
+        s0 = gpu.service_stats(0)
+        pc.run_transform(gpu, flags, chunks, mem="device")
+        gpu.service_quiesce(0)
+        s1 = gpu.service_stats(0)
     launches = s1["launches"] - s0["launches"]
-    assert launches >= 1 and s1["device_chunks"] - s0["device_chunks"] == 32
+    assert launches >= 1 and s1["device_chunks"] - s0["device_chunks"] == 32 and s1["guest_launches"] == s0["guest_launches"]
     # on an idle chip a launch covers it once - as many workgroups per CU as are resident at the same time, never one more (a pending
-    # workgroup would hold the launch's hardware pipe for as long as the waves stay) - and those that land on the 8 reserved CUs leave at once
+    # workgroup would hold the launch's hardware pipe for as long as the waves stay) - and those that land on the 32 reserved CUs leave at once
     starts, exits = s1["wave_starts"] - s0["wave_starts"], s1["reserved_exits"] - s0["reserved_exits"]
     print("service launches %d: %d waves stayed, %d left a reserved CU; most waves resident at once %d of %d" % (launches, starts, exits, s1["live_waves_max"], s1["waves"]))
     assert starts + exits == launches * s1["waves"], (s0, s1)
     assert exits >= launches * 32 * per_cu * 0.9 and starts >= launches * 224 * per_cu * 0.95, (s0, s1)
     assert s1["live_waves_max"] >= 0.97 * 256 * per_cu and s1["live_waves"] == 0, s1      # (resident at once, for a moment, before the reserved CUs' waves left)
+    # nobody fetches: every wave of the launch stays, wherever it landed
+    with gpu.configured(fetch_quiet_ms=1):
+        time.sleep(0.05)
+        pc.run_transform(gpu, flags, chunks, mem="device")
+        gpu.service_quiesce(0)
+        s2 = gpu.service_stats(0)
+    launches2 = s2["launches"] - s1["launches"]
+    assert launches2 >= 1 and s2["guest_launches"] - s1["guest_launches"] == launches2, (s1, s2)
+    assert s2["reserved_exits"] == s1["reserved_exits"] and s2["wave_starts"] - s1["wave_starts"] == launches2 * s2["waves"], (s1, s2)
 
 
 @pytest.mark.timeout(600)
@@ -56,7 +67,9 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     host -> host, again and again: median <= 5 ms, 95th percentile <= 50 ms (round 4, no reservation: 50-80 s; profiles/r04_mixed_load.txt),
     and never more than 3 s: once in a few hundred fetches a kernel of a fetch still does not start next to a compressor launch (cause not
     found); the fetch then asks that launch to end after 200 ms and runs when its waves have left (tsx_api.hip, svc_rotate).  The restored
-    bytes are right."""
+    bytes are right.  The uploads begin on a device that has not fetched for a while (fetch_quiet_ms, shortened here): their launch has
+    guest waves on the reserved CUs, and the FIRST fetch is the one that makes them hand their chunks back and leave - it may take a
+    block time of a chunk longer (asked: <= 1 s), the chunks handed back are compressed all the same."""
     import torch
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     dev = torch.device("cuda", 0)
@@ -92,6 +105,9 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
 
     for _ in range(3):
         fetch()
+    old_quiet = gpu.debug_config("fetch_quiet_ms", 400)
+    time.sleep(0.7)                                                     # quiet: the launch the uploads start has guests
+    sv0 = gpu.service_stats(0)
     stop = [False]
     errors = []
 
@@ -106,6 +122,7 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     [x.start() for x in th]
     try:
         time.sleep(2.5)                                                 # the chip is full
+        first = fetch()
         lat = []
         t_end = time.perf_counter() + 8.0
         while time.perf_counter() < t_end:
@@ -114,8 +131,11 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     finally:
         stop[0] = True
         [x.join() for x in th]
+        gpu.debug_config("fetch_quiet_ms", old_quiet)
     a = np.asarray(lat)
-    print("fetch under load: n=%d p50=%.2f ms p95=%.2f ms max=%.2f ms; launches asked to end early: %d" % (a.size, np.median(a), np.percentile(a, 95), a.max(), gpu.service_stats(0)["rotations"]))
+    sv1 = gpu.service_stats(0)
+    print("fetch under load: first (guests leave) %.2f ms, then n=%d p50=%.2f ms p95=%.2f ms max=%.2f ms; launches asked to end early: %d; guest waves that left %d, chunks handed back %d" %
+          (first, a.size, np.median(a), np.percentile(a, 95), a.max(), sv1["rotations"], sv1["yielded_waves"] - sv0["yielded_waves"], sv1["returned_chunks"] - sv0["returned_chunks"]))
     ok_bytes = np.array_equal(hbk, want)
     gpu.host_unregister(hfr); gpu.host_unregister(hbk)
     gpu.ctx_destroy(fctx)
@@ -125,6 +145,8 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     assert ok_bytes
     assert all((x["status"] == 0).all() for x in ds)
     assert np.median(a) <= 5.0 and np.percentile(a, 95) <= 50.0 and a.max() <= 3000.0, (float(np.median(a)), float(np.percentile(a, 95)), float(a.max()))
+    assert first <= 1000.0, first
+    assert sv1["guest_launches"] > sv0["guest_launches"] and sv1["yielded_waves"] - sv0["yielded_waves"] >= 32 * 20, (sv0, sv1)
 
 
 @pytest.mark.timeout(600)

@@ -1780,12 +1780,12 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
                                                 uint32_t* ticket, uint32_t* chunk_out) {
     const uint64_t max_age = ((uint64_t)a.max_age_ticks_hi << 32) | a.max_age_ticks_lo;
     uint64_t quiet_since = 0;
-    uint32_t nap = 1;
+    uint32_t nap = 1, looks = 0;
     for (;;) {
         const uint64_t now = svc_now();
         if (SVC_LD_DEV(&D->stop)) return 2;
         if (max_age && now - t_start > max_age) return 2;
-        if (yield && zs_yield_asked(yield)) return 2;
+        if (yield && (looks++ & 7u) == 0u && zs_yield_asked(yield)) return 2;     // (an idle guest: one PCIe read per eight looks, <= 2 ms apart)
         if (SVC_LD_DEV(&D->ret_n)) {
             atomicAdd(&D->busy, 1u);
             svc_ret_lock(D);
@@ -1894,10 +1894,11 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         const bool handed_back = zstd_compress_chunk(L, (const uint8_t*)svc_word(w, 2), (tsx_chunk_desc*)svc_word(w, 3), (uint8_t*)svc_word(w, 4), svc_word(w, 5),
                             (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, yield ZS_PROF_ARG);
         if (handed_back) {
-            // a fetch has arrived: the chunk goes back to the queue - every lane's stores into its workspace are complete and released before
-            // another wave can start it again - and this wave leaves its CU to the fetch's kernels
+            // a fetch has arrived: the chunk goes back to the queue - every lane's stores into its workspace are complete and released (as
+            // at the end of a finished chunk: the next wave may sit on another XCD, behind another L2) before another wave can start it
+            // again - and this wave leaves its CU to the fetch's kernels
             __syncthreads();
-            if (lane == 0) { svc_fence_device(); svc_return_chunk(D, mg, chunk); atomicAdd(&D->stat_yields, 1u); atomicSub(&D->busy, 1u); }
+            if (lane == 0) { svc_release_system(); svc_return_chunk(D, mg, chunk); atomicAdd(&D->stat_yields, 1u); atomicSub(&D->busy, 1u); }
             break;
         }
         // ---- this chunk is done: tell its member's caller when it was the member's last one ----

@@ -150,6 +150,10 @@ def run(args):
         [x.join() for x in th]
         return rows
     th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    quiet_ms = [int(kv.split("=")[1]) for kv in (args.config or "").split(",") if kv.startswith("fetch_quiet_ms=")]
+    if quiet_ms and quiet_ms[0] > 0:
+        time.sleep(quiet_ms[0] / 1e3 + 0.2)                              # the warm-up fetches are forgotten: the uploads begin with guest waves on the reserved CUs
+    sv0 = N.service_stats(0)
     t0 = time.perf_counter()
     [x.start() for x in th]
     time.sleep(2.0)
@@ -169,6 +173,7 @@ def run(args):
     out = {"tag": args.tag, "process": "no torch: the system's HIP runtime", "upload_shape": args.shape, "compress_callers": T, "chunks_offered": T * n, "reserved_cus": st["reserved_cus"],
            "service_launches": st["launches"], "watchdog_launches": st["watchdog_launches"], "cpu_affinity": affinity, "fetching": not args.no_fetch,
            "compress_gibs_whole_window": round(sum(done) * n * CH / GiB / el, 3), "fetch_idle_ms": idle}
+    out["service"] = {k: st[k] - sv0[k] for k in ("launches", "guest_launches", "yielded_waves", "returned_chunks", "readmissions", "rotations")}
     da = np.sort(np.asarray(stamps)) - t0
     if da.size >= 8:
         k0, k1 = int(da.size * 0.2), int(da.size * 0.8)
