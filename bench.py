@@ -443,10 +443,6 @@ def main():
             for k_ in (1, 4):
                 fetch(k_)
             idle_ms = {k_: round(float(np.median([fetch(k_) for _ in range(7)])), 3) for k_ in (1, 4)}
-            # the uploads begin on a device that has not fetched for a while (tsx_config.fetch_quiet_ms, 10 s by default - half a second here):
-            # their launch has guest waves on the reserved CUs, and the FIRST fetch is the one that sends them away
-            old_quiet = N.debug_config("fetch_quiet_ms", 500)
-            time.sleep(0.7)
             msv0 = N.service_stats(0)
             stop = [False]
             done = [0] * T
@@ -464,7 +460,6 @@ def main():
             tm0 = time.perf_counter()
             [x.start() for x in th]
             time.sleep(2.0)                                              # the chip is full
-            first_ms = fetch(1)
             lat = {1: [], 4: []}
             while time.perf_counter() - tm0 < 2.0 + args.mixed_load_seconds:
                 for k_ in (1, 4):
@@ -475,18 +470,14 @@ def main():
             el_ = time.perf_counter() - tm0
             exact = bool(np.array_equal(hbk, want4))
             N.host_unregister(hfr); N.host_unregister(hbk); N.ctx_destroy(fctx)
-            N.debug_config("fetch_quiet_ms", old_quiet)
             msv1 = N.service_stats(0)
             rot_ = msv1["rotations"] - msv0["rotations"]
             mixed = {"metric": "latency of a fetch (tsx_detransform_batch of 1 / 4 chunks, host -> host, own context) while %d callers keep %d compressor chunks queued" % (T, T * n),
                      "reserved_cus": None if svc is None else svc["reserved_cus"], "compress_callers": T, "chunks_offered": T * n,
                      "compress_gibs_while_fetching": round(sum(done) * float(n) * CH / GiB / el_, 3),
-                     "compress_gibs_while_fetching_note": "whole window incl. the callers' ramp and drain; `_slope` = least-squares slope of batch completions over the middle 60 %, as `sustained`; `frac_of_sustained` sets it against the upload-only rate (guest waves on the reserved CUs): what the reservation costs WHILE fetches go on",
+                     "compress_gibs_while_fetching_note": "whole window incl. the callers' ramp and drain; `_slope` = least-squares slope of batch completions over the middle 60 %, as `sustained`",
                      "fetch_idle_ms": {str(k_): v for k_, v in idle_ms.items()}, "restored_bytes_exact": exact, "unit": "ms",
-                     "compressor_launches_asked_to_end_early_by_a_waiting_fetch": int(rot_),
-                     "first_fetch_after_a_quiet_time_ms": round(first_ms, 2),
-                     "first_fetch_note": "the uploads had begun with guest waves on the reserved CUs (no fetch for fetch_quiet_ms): this fetch made %d of them hand back their chunks (%d, compressed again by other waves) and leave; the latencies below are the fetches after it" %
-                                         (msv1["yielded_waves"] - msv0["yielded_waves"], msv1["returned_chunks"] - msv0["returned_chunks"])}
+                     "compressor_launches_asked_to_end_early_by_a_waiting_fetch": int(rot_)}
             da_ = np.sort(np.asarray(mstamps)) - tm0
             if da_.size >= 8:
                 q0, q1 = int(da_.size * 0.2), int(da_.size * 0.8)

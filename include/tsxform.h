@@ -152,11 +152,14 @@ typedef struct tsx_config {
                                         waits ~0.5 s for the compressor launch to be rotated; 12 and more: such waits become regular.
                                         At most 8 is accepted                                                                  */
     uint64_t pool_idle_bytes;        /* idle pooled workspace kept per device; default 4/9 of its memory                      */
-    uint32_t fetch_quiet_ms;         /* the reservation follows the traffic: once no fetch (no batch of ordinary kernels) has run
-                                        for this long, the compressor's waves work on the reserved CUs too, as guests - the next
-                                        fetch makes them hand their chunks back and leave, which costs that ONE fetch up to a
-                                        block time of a chunk (~30 ms); from then on the CUs stay reserved until it has been quiet
-                                        again.  Default 10000; 0 = the reserved CUs are never used by the compressor              */
+    uint32_t fetch_quiet_ms;         /* OPT-IN: the reservation follows the traffic.  != 0: once no fetch (no batch of ordinary
+                                        kernels) has run for this long, the compressor's waves work on the reserved CUs too, as
+                                        guests - the next fetch makes them hand their chunks back and leave, which costs that ONE
+                                        fetch a block time of a chunk (measured: 29 ms), and the CUs stay reserved until it has been
+                                        quiet again.  Measured (profiles/r05_guest_waves_probe.jsonl): the upload rate between batch
+                                        completions rises 19.2 -> 21.6 GiB/s, but the whole-window rate of the same run FELL (a few
+                                        seconds in which nothing completed, cause not found): default 0 = the reserved CUs are never
+                                        used by the compressor                                                                  */
     uint32_t reserved2_;
 } tsx_config;
 int  tsx_init_ex(int device_count, const int* device_ids, const tsx_config* cfg);   /* cfg == NULL: tsx_init */

@@ -455,9 +455,9 @@ def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, flags
 
 def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
     """tsx_config.fetch_reserved_cus (default: one compute unit per shader engine that a fetch under full upload load finds free)
-    decides which waves of the service leave at once - while fetches are about (fetch_quiet_ms = 0: always); bytes and statuses are the same
+    decides which waves of the service leave at once (fetch_quiet_ms = 0, the default: always; otherwise while fetches are about); bytes and statuses are the same
     with a reservation, without one, and with the environment's override, context-less and with a context, slot and packed layout; the fetch
-    side is untouched.  A process that has never fetched compresses on the reserved CUs too (guest waves: the default)."""
+    side is untouched.  With fetch_quiet_ms set, a process that has not fetched for that long compresses on the reserved CUs too (guest waves)."""
     code = """
         import os, hashlib, numpy as np
         import tsxform
@@ -481,14 +481,14 @@ def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
         print(hashlib.sha256(b"".join(a)).hexdigest(), s["reserved_cus"], s["reserved_exits"] > 0, s["launches"], s["wave_starts"], s["reserved_exits"], s["waves"],
               s["guest_launches"], s2["launches"] - s["launches"], s2["guest_launches"] - s["guest_launches"], s2["reserved_exits"] - s["reserved_exits"])
         """
-    engaged = _run_py(code % "fetch_quiet_ms=0").strip().splitlines()[-1].split()
+    engaged = _run_py(code % "").strip().splitlines()[-1].split()
     without = _run_py(code % "fetch_reserved_cus=0").strip().splitlines()[-1].split()
     by_env = _run_py(code % "fetch_reserved_cus=0", TSX_FETCH_RESERVED_CUS=1, TSX_FETCH_QUIET_MS=0).strip().splitlines()[-1].split()
     assert engaged[0] == without[0] == by_env[0]
     assert engaged[1:3] == ["1", "True"] and without[1:3] == ["0", "False"] and by_env[1:3] == ["1", "True"]      # (the harness has 4 CUs: at most one is reserved)
     assert engaged[7] == "0" and without[7] == "0"
-    # the default: nobody has fetched yet - every launch's waves use the reserved CU as well; after the first fetch they leave it alone
-    guests = _run_py(code % "").strip().splitlines()[-1].split()
+    # opt-in (fetch_quiet_ms != 0): nobody has fetched yet - every launch's waves use the reserved CU as well; after the first fetch they leave it alone
+    guests = _run_py(code % "fetch_quiet_ms=10000").strip().splitlines()[-1].split()
     assert guests[0] == engaged[0] and guests[1:3] == ["1", "False"] and guests[7] == guests[3] and int(guests[3]) >= 3
     assert int(guests[8]) >= 1 and guests[9] == "0" and int(guests[10]) > 0
     # ... and some of the compressor's waves may stay on a reserved CU all the same (tsx_config.fetch_shared_cu_waves: a CU shared between

@@ -146,7 +146,7 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     assert all((x["status"] == 0).all() for x in ds)
     assert np.median(a) <= 5.0 and np.percentile(a, 95) <= 50.0 and a.max() <= 3000.0, (float(np.median(a)), float(np.percentile(a, 95)), float(a.max()))
     assert first <= 1000.0, first
-    assert sv1["guest_launches"] > sv0["guest_launches"] and sv1["yielded_waves"] - sv0["yielded_waves"] >= 32 * 20, (sv0, sv1)
+    assert sv1["guest_launches"] > sv0["guest_launches"] and sv1["yielded_waves"] - sv0["yielded_waves"] >= 32 * 8, (sv0, sv1)
 
 
 @pytest.mark.timeout(600)

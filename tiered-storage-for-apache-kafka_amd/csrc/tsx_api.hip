@@ -27,7 +27,7 @@ struct tsx_cfg {
     uint32_t reserved_cus = 0xFFFFFFFFu;  // compute units the compressor service leaves to everything else (0xFFFFFFFF: one per shader engine); TSX_FETCH_RESERVED_CUS
     uint32_t svc_max_launch_ms = 60000;   // age limit of one launch of the service kernel (0 = none); TSX_SERVICE_MAX_LAUNCH_MS
     uint32_t svc_idle_exit_us = 2000;     // the service kernel ends when it has had nothing to do for this long (callers in a closed loop need ~1 ms to come back)
-    uint32_t fetch_quiet_ms = 10000;      // tsx_config.fetch_quiet_ms: the reserved CUs work for the compressor too (guest waves) once no fetch has been seen for this long; 0 = never; TSX_FETCH_QUIET_MS
+    uint32_t fetch_quiet_ms = 0;          // tsx_config.fetch_quiet_ms: the reserved CUs work for the compressor too (guest waves) once no fetch has been seen for this long; 0 = never (default); TSX_FETCH_QUIET_MS
     uint32_t svc_keep_waves = 0;          // tsx_config.fetch_shared_cu_waves: compressor waves that stay on a reserved CU all the same; TSX_FETCH_SHARED_CU_WAVES
     long long pool_idle_bytes = -1;       // idle pooled workspace kept per device (-1: 4/9 of its memory); TSX_POOL_IDLE_BYTES
     uint32_t zstd_sched = 0;              // parser speculation schedule k0 | k1 << 8 (0 = the kernel's default; same bytes); TSX_ZSTD_SCHED

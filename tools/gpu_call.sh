@@ -190,7 +190,7 @@ PY
       # reservation always in force (fetch_quiet_ms=0) for comparison.  Device-resident 2048-chunk batches, 5 callers, no torch
       export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
       [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/guests.err
-      for v in ${arg:-"500,nofetch 500,fetch 0,nofetch"}; do set -- ${v//,/ }
+      for v in ${arg:-500,nofetch 500,fetch 0,nofetch}; do set -- ${v//,/ }
         nf=""; [ "$2" = "nofetch" ] && nf="--no-fetch"
         timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers 5 --seconds ${MIXED_SECONDS:-12} --config fetch_quiet_ms=$1 $nf --tag "fetch_quiet_ms=$1 $2" 2>> $O/guests.err | tee -a $O/guests.jsonl
       done ;;
