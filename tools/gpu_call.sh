@@ -155,6 +155,17 @@ PY
       timeout 300 python -c "
 import torch, tsxform, json
 N = tsxform.get(); print(N.version()); print(json.dumps(N.service_stats(0)))" 2>&1 | grep -v amdgpu.ids | tee $O/probe.txt ;;
+    guestbench)
+      # the timed region and the sustained leg with the opt-in guest waves (TSX_FETCH_QUIET_MS: no fetch ever runs in this process before them)
+      TSX_FETCH_QUIET_MS=10000 timeout 300 python bench.py --steps ${arg:-30} --no-cpu-baseline --no-end-to-end --no-inverse --no-configs --no-mixed-load --no-value-b --no-verify > $O/bench_guests.json 2> $O/bench_guests.err
+      python - <<PY
+import json
+try:
+    j = json.loads(open("$O/bench_guests.json").read().strip().splitlines()[-1])
+    print("guests: value", j["value"], "ms/step", j["ms_per_step"], "sustained", (j.get("sustained") or {}).get("value"), (j.get("sustained") or {}).get("whole_run_gibs_incl_ramp_and_drain"), "launch meta", json.dumps(j["roofline"].get("service"))[:500])
+except Exception as e: print("guestbench failed", e)
+PY
+      tail -2 $O/bench_guests.err ;;
     benchq)
       # the timed region + sustained + mixed-load legs only (no CPU baseline, no host-path legs, no broker children)
       timeout 600 python bench.py ${arg:+--steps $arg} --no-cpu-baseline --no-end-to-end --no-inverse --no-configs > $O/bench_quick.json 2> $O/bench_quick.err
