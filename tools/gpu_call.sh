@@ -192,6 +192,10 @@ PY
         nf=""; [ "$4" = "nofetch" ] && nf="--no-fetch"
         timeout 300 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape $1 --callers $2 ${3:+--reserved-cus $3} $nf --seconds ${MIXED_SECONDS:-12} ${MIXED_MAX_LAUNCH_MS:+--max-launch-ms $MIXED_MAX_LAUNCH_MS} --tag "$cfg" 2>> $O/mixednt.err | tee -a $O/mixednt.jsonl
       done ;;
+    pmcenc)
+      # the passes the forward-side records of profiles/pmc_traffic.json need (service kernel, CRC32C, GCM); the decoder's are tools/pmc_dec.sh
+      bash tools/pmc_zstd.sh > $O/pmc_zstd.log 2>&1; bash tools/pmc_small.sh > $O/pmc_small.log 2>&1
+      python tools/show_pmc.py gpurun_out/pmc | tee $O/pmc_zstd_summary.txt | tail -5 ;;
     pmctraffic)
       # profiles/pmc_traffic.json from the PMC passes just made (the bench that follows quotes roofline.traffic for the sources as they are);
       # the same command at home over the merged gpurun_out/pmc* gives the same file
