@@ -174,6 +174,7 @@ def run(args):
            "service_launches": st["launches"], "watchdog_launches": st["watchdog_launches"], "cpu_affinity": affinity, "fetching": not args.no_fetch,
            "compress_gibs_whole_window": round(sum(done) * n * CH / GiB / el, 3), "fetch_idle_ms": idle}
     out["service"] = {k: st[k] - sv0[k] for k in ("launches", "guest_launches", "yielded_waves", "returned_chunks", "readmissions", "rotations")}
+    out["completions_at_s"] = [round(float(x - t0), 2) for x in sorted(stamps)]; out["window_s"] = round(el, 2)
     da = np.sort(np.asarray(stamps)) - t0
     if da.size >= 8:
         k0, k1 = int(da.size * 0.2), int(da.size * 0.8)
