@@ -74,3 +74,17 @@ def test_chain_on_b_content_vs_oracle(emu, oracle):
     pc.check_roundtrip(emu, nat.COMPRESS | nat.ENCRYPT | nat.CRC, chunks)
     pinned, differ = pc.check_profile_1_5_6(emu, oracle, {"B%d" % c.size: c for c in chunks})
     assert pinned + differ == 3
+
+
+def test_b_chunks_are_the_committed_ones():
+    """tests/golden/synth_b.json (made by tests/golden/make_synth_b.py): the generator's chunks are pinned by hash - bench.py's value_B and
+    the device parity test stand on them."""
+    import hashlib
+    import json
+    import os
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synth_b.json")))
+    assert len(cases) >= 4
+    for c in cases:
+        chunk = synth.gen_chunk("B", c["seed"], c["segment"], c["chunk"], c["size"])
+        assert chunk.size == c["size"] and hashlib.sha256(chunk.tobytes()).hexdigest() == c["sha256"], c
+        assert len(synth.record_batches_of(chunk)) == c["record_batches"]
