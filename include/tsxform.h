@@ -156,10 +156,10 @@ typedef struct tsx_config {
                                         kernels) has run for this long, the compressor's waves work on the reserved CUs too, as
                                         guests - the next fetch makes them hand their chunks back and leave, which costs that ONE
                                         fetch a block time of a chunk (measured: 29 ms), and the CUs stay reserved until it has been
-                                        quiet again.  Measured (profiles/r05_guest_waves_probe.jsonl): the upload rate between batch
-                                        completions rises 19.2 -> 21.6 GiB/s, but the whole-window rate of the same run FELL (a few
-                                        seconds in which nothing completed, cause not found): default 0 = the reserved CUs are never
-                                        used by the compressor                                                                  */
+                                        quiet again.  Measured: bench.py value 19.8 -> 21.5 GiB/s; in a torch-free probe the rate
+                                        between batch completions rose 19.2 -> 21-22, but two of four runs lost seconds somewhere
+                                        (whole-window 12-14; profiles/r05_guest_waves_probe.jsonl), cause not found: default 0 =
+                                        the reserved CUs are never used by the compressor                                        */
     uint32_t reserved2_;
 } tsx_config;
 int  tsx_init_ex(int device_count, const int* device_ids, const tsx_config* cfg);   /* cfg == NULL: tsx_init */
