@@ -43,7 +43,6 @@ struct tsx_cfg {
     bool zero_copy_packed = false;        // explicit contexts: packed output in place too
     bool gcm_setup_kernel = false;        // key schedule by gcm_setup_kernel instead of on the host
     bool no_dec_pieces = false;           // block-form fetches in one piece
-    bool svc_cu_mask = false;             // the reservation as a CU mask on the service's stream (the hardware keeps the kernel off the reserved CUs) instead of waves that leave
     uint32_t svc_waves_per_cu = 0;        // workgroups of a service launch per CU (0 = what the runtime says is resident at once; measurements only)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
@@ -75,7 +74,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_cu_mask, bool) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(fetch_quiet_ms, uint32_t) CFG_FIELD(trace, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(fetch_quiet_ms, uint32_t) CFG_FIELD(trace, bool)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -115,7 +114,6 @@ struct tsx_service {
     bool stop_dirty = false;                                         // the device's stop word must be cleared in front of the next launch
     uint32_t paused = 0;                                             // > 0: no launches (memory management in progress)
     uint32_t grid = 0, cu_keys = 0, cus = 0, cus_reserved = 0, waves_per_cu = 0, resident = 0, engines = 0;
-    bool masked = false;                                             // the reservation is a CU mask on the stream (no wave ever starts on a reserved CU)
     uint32_t published = 0;
     uint64_t next_id = 1;
     std::deque<tsx_svc_member> out;                                  // members published and not yet retired, oldest first
@@ -293,7 +291,7 @@ static int svc_launch_locked(tsx_service& s) {
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
     a.keep_waves = g_cfg.svc_keep_waves;
-    if (s.cus_reserved && !s.masked && svc_quiet(s)) {
+    if (s.cus_reserved && svc_quiet(s)) {
         // no fetch for a while: the waves on the reserved CUs work as guests.  Word first, counter second (svc_foreground_begin)
         __atomic_store_n(&s.h->yield, 0u, __ATOMIC_SEQ_CST);
         if (s.fg_inflight.load(std::memory_order_seq_cst) != 0) __atomic_store_n(&s.h->yield, 1u, __ATOMIC_SEQ_CST);
@@ -338,15 +336,7 @@ static int svc_create(tsx_device& d, int cus) {
     // priority and multiplexes a process's streams onto them - a stream that shared the service's hardware queue would sit behind a kernel
     // that lives as long as uploads go on, and nothing else in this library (or, normally, in the process) creates low-priority streams;
     // and between a compressor wave and a fetch's workgroup that could both be placed, the fetch's goes first.
-    s.masked = false;
-    if (g_cfg.svc_cu_mask && g_cfg.reserved_cus && cus > 16) {
-        // bit i of a stream's CU mask belongs to XCD i mod 8 (measured in round 4): leaving out the last r bits leaves out r / 8 CUs of every XCD
-        const uint32_t r = g_cfg.reserved_cus > (uint32_t)cus / 4 ? (uint32_t)cus / 4 : g_cfg.reserved_cus, words = ((uint32_t)cus + 31) / 32;
-        uint32_t mask[64] = {0};
-        for (uint32_t i = 0; i + r < (uint32_t)cus && i < 64 * 32; i++) mask[i / 32] |= 1u << (i % 32);
-        if (hipExtStreamCreateWithCUMask(&s.st, words, mask) == hipSuccess) { s.masked = true; s.cus_reserved = r; } else { (void)hipGetLastError(); s.st = nullptr; }
-    }
-    if (!s.st) {
+    {
         int least = 0, greatest = 0;
         if (g_cfg.svc_normal_priority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
             hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, least) != hipSuccess) {
@@ -383,8 +373,7 @@ static int svc_create(tsx_device& d, int cus) {
     s.engines = engines;
     uint32_t want = g_cfg.reserved_cus == 0xFFFFFFFFu ? engines : g_cfg.reserved_cus;
     if (want > s.cus / 4) want = s.cus / 4;
-    if (s.masked) want = 0;                                             // (the mask does it: no bitmap)
-    else if (s.cu_keys != s.cus) {
+    if (s.cu_keys != s.cus) {
         if (g_cfg.debug || want) fprintf(stderr, "[tsxform] device %d: %u CU keys seen for %u compute units - no CU reservation\n", d.hip_id, s.cu_keys, s.cus);
         want = 0;
     }
@@ -398,7 +387,7 @@ static int svc_create(tsx_device& d, int cus) {
                 if (nth++ == round) { res[key >> 5] |= 1u << (key & 31); taken++; break; }
             }
         }
-    if (!s.masked) s.cus_reserved = taken;
+    s.cus_reserved = taken;
     HIPCHK(hipMemcpy(s.d->reserved, res.data(), 512, hipMemcpyHostToDevice));
     // A launch covers the chip exactly once - never more workgroups than are resident at the same time.  The waves stay for as long as there
     // is work, so workgroups that did not fit would stay PENDING for as long, and a dispatch that is still in progress holds its hardware
@@ -419,7 +408,7 @@ static int svc_create(tsx_device& d, int cus) {
         s.resident = lm[1];
         HIPCHK(hipMemcpy(&s.d->live_max, s.h_zero, 4, hipMemcpyHostToDevice));
     }
-    const uint32_t usable = s.masked ? s.cus - s.cus_reserved : s.cus;
+    const uint32_t usable = s.cus;
     uint32_t per_cu = g_cfg.svc_waves_per_cu ? g_cfg.svc_waves_per_cu : s.resident / usable;
     if (per_cu == 0 || per_cu > 32) per_cu = 16;                        // (a measurement that cannot be: stay on the safe side)
     s.waves_per_cu = per_cu;
@@ -1041,7 +1030,7 @@ static int svc_submit(tsx_device* dev, const tsx_zseg& proto, const uint32_t* h_
     // The running launch left the reserved CUs to fetches (it began that way, or its guests have gone) and no fetch has been seen since
     // fetch_quiet_ms: it is asked to end - its waves leave after their chunk, the waiting members' watchdog starts the next launch, whose
     // waves use every CU again.  One chunk time of a thinning chip, once per quiet period.
-    if (s.cus_reserved && !s.masked && !s.rotating && !s.paused && __atomic_load_n(&s.h->yield, __ATOMIC_RELAXED) && svc_quiet(s)) {
+    if (s.cus_reserved && !s.rotating && !s.paused && __atomic_load_n(&s.h->yield, __ATOMIC_RELAXED) && svc_quiet(s)) {
         s.rotating = true; s.readmissions++;
         __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
         s.stop_dirty = true;
@@ -1119,21 +1108,6 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
     } else (void)hipGetLastError();
     if (hipMemcpy(w, &s.d->live, 8, hipMemcpyDeviceToHost) == hipSuccess) { out->live_waves = w[0]; out->live_waves_max = w[1]; } else (void)hipGetLastError();
     return TSX_OK;
-}
-
-// Test hook (not part of the ABI): one 64-thread do-nothing kernel on a stream of its own, not waited for (tools/mixed_load_notorch.py
-// --heartbeat: does a wave that ENDS somewhere on the chip get workgroups moving that the dispatcher could not place?)
-extern "C" int tsx_debug_heartbeat(int device_index) {
-    tsx_device* dev;
-    { std::lock_guard<std::mutex> lk(g_mu); if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL; dev = &g_devs[device_index]; }
-    tsx_device_scope keep;
-    if (hipSetDevice(dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
-    static hipStream_t hb = nullptr;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!hb && hipStreamCreateWithFlags(&hb, hipStreamNonBlocking) != hipSuccess) return TSX_E_DEVICE;
-    hipLaunchKernelGGL(init_status_kernel, dim3(1), dim3(64), 0, hb, (int32_t*)nullptr, 0u);
-    return hipGetLastError() == hipSuccess ? TSX_OK : TSX_E_DEVICE;
 }
 
 // Test hook (not part of the ABI): put the device's ticket counters at `published` (an idle service only) - the wrap-around of the 32-bit

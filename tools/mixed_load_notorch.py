@@ -91,17 +91,6 @@ def run(args):
             with lock:
                 stamps.append(time.perf_counter())
 
-    if args.heartbeat_us > 0:
-        import ctypes
-        N.lib.tsx_debug_heartbeat.restype = ctypes.c_int; N.lib.tsx_debug_heartbeat.argtypes = [ctypes.c_int]
-        beating = [True]
-
-        def beat():
-            while beating[0]:
-                N.lib.tsx_debug_heartbeat(0)
-                time.sleep(args.heartbeat_us * 1e-6)
-
-        threading.Thread(target=beat, daemon=True).start()
     if args.phases:
         # what makes a fetch wait for the END of a service launch?  A: the first fetch after uploads began; B: fetches every 50 ms; C: one after a
         # pause of the fetch side; D: uploads stop, the service kernel goes, fetches go on, uploads start again - the first fetch 2 s later
@@ -197,7 +186,6 @@ if __name__ == "__main__":
     ap.add_argument("--max-launch-ms", type=int, default=-1)
     ap.add_argument("--no-fetch", action="store_true")
     ap.add_argument("--config", default="", help="key=value,... for tsx_debug_config before tsx_init (measurement variants)")
-    ap.add_argument("--heartbeat-us", type=int, default=0, help="a do-nothing one-wave kernel every so many microseconds, from a thread of its own")
     ap.add_argument("--phases", action="store_true")
     ap.add_argument("--phases-short", action="store_true", help="with --phases: stop after phase C")
     ap.add_argument("--tag", default="")
