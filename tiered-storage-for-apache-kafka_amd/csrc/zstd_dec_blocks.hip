@@ -557,7 +557,7 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
-// execution by pointer jumping: scatter -> log2(size) jump rounds -> emit
+// execution by pointer jumping: scatter -> ceil(log3(size)) + 1 jump passes -> emit
 //
 // Executing sequences in order is a dependency chain through the whole chunk: in log-like content every record copies its field
 // names from the record before it (offset ~ one record), so byte p of record r is a copy of a copy ... of record 0 - the first
@@ -565,8 +565,9 @@ __global__ __launch_bounds__(2 * LANES) void zb_decode_kernel(const uint8_t* __r
 // (measured: 24 ms per chunk with cross-block waits against 33 ms for the chunk-serial kernel).  What breaks the chain is not
 // order but TRANSITIVITY: give every output byte a word - the byte itself when it is a literal, else the position it copies
 // from (p - offset, always < p) - and replace "where I copy from" by "where THAT copies from" until every word is a literal:
-// pointer doubling, log2(chain depth) <= log2(size) rounds, all bytes of all blocks at once, no ordering between workgroups at
-// all (a word read while another thread replaces it holds either ancestor - both are valid - so the update is done in place).
+// pointer jumping, two jumps per pass = three hops guaranteed (zb_jump_kernel): ceil(log3(chain depth)) + 1 <= ceil(log3(size)) + 1
+// passes, all bytes of all blocks at once, no ordering between workgroups at all (a word read while another thread replaces it
+// holds either ancestor - both are valid - so the update is done in place).
 // ---------------------------------------------------------------------------------------------------
 #define ZB_LIT 0x80000000u                      /* src word: ZB_LIT | byte (resolved), else the chunk position this byte copies from */
 
