@@ -183,7 +183,7 @@ int  tsx_set_thread_device(int device_index);
 int  tsx_pool_stats(int device_index, uint32_t* idle, uint32_t* in_use, uint64_t* batches);
 
 /* The compressor service of a device (every compressing batch is a member of ONE device-wide queue that persistent waves pull
- * chunks from; csrc/tsx_internal.h).  Counters since tsx_init; kernel_ms is measured with HIP events on the service's own stream. */
+ * chunks from; csrc/tsx_internal.h).  Counters since tsx_init; kernel_ms is the device's own clock (the last wave of a launch reports its begin and end through pinned memory). */
 typedef struct tsx_service_info {
     uint64_t launches;           /* launches of the service kernel that have been started                                       */
     uint64_t watchdog_launches;  /* ... of which a waiting caller made because the kernel had ended with work still queued       */
