@@ -541,3 +541,33 @@ def test_encrypt_only_batches_write_into_registered_buffers_too(emu, oracle):
     IV || C || TAG straight into the caller's slots when the whole buffer is registered (slot layout); same bytes as the copy path and the
     oracle, a too-small slot fails its chunk only and leaves the slot untouched, an unregistered buffer takes the copies."""
     pc.check_encrypt_only_zero_copy(emu, oracle, [5000, 0, 70001, 17, 131072, 4096])
+
+
+def test_tsx_config_sizes_and_the_environment():
+    """tsx_init_ex reads tsx_config by its struct_size: the struct as it was before fetch_quiet_ms (24 bytes) is accepted and leaves the new
+    field at its default, a shorter one is refused; a field at TSX_CFG_DEFAULT keeps the library's default; the environment has the last word."""
+    out = _run_py("""
+        import ctypes as C
+        import tsxform
+        from tests.emu import emu_native
+        nat = tsxform._native
+        N = nat.Native(emu_native.build())
+        class Old(C.Structure):
+            _fields_ = [("struct_size", C.c_uint32), ("fetch_reserved_cus", C.c_uint32), ("service_max_launch_ms", C.c_uint32), ("fetch_shared_cu_waves", C.c_uint32), ("pool_idle_bytes", C.c_uint64)]
+        assert C.sizeof(Old) == 24 and C.sizeof(nat.Config) == 32
+        f = N.lib.tsx_init_ex; f.argtypes = [C.c_int, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+        short = Old(16, 0, 0, 0, 0)
+        assert f(1, None, C.byref(short)) == nat.E_INVAL and N.lib.tsx_device_count() == 0
+        old = Old(24, 0, 1234, 3, nat.CFG_DEFAULT64)
+        assert f(1, None, C.byref(old)) == 1
+        vals = {k: N.debug_config(k, 7) for k in ("reserved_cus", "svc_max_launch_ms", "svc_keep_waves", "fetch_quiet_ms")}
+        print(vals["reserved_cus"], vals["svc_max_launch_ms"], vals["svc_keep_waves"], vals["fetch_quiet_ms"])
+        N.lib.tsx_shutdown()
+        new = nat.Config(32, nat.CFG_DEFAULT, nat.CFG_DEFAULT, 99, nat.CFG_DEFAULT64, 2500, 0)
+        assert f(1, None, C.byref(new)) == 1
+        vals = {k: N.debug_config(k, 7) for k in ("reserved_cus", "svc_max_launch_ms", "svc_keep_waves", "fetch_quiet_ms")}
+        print(vals["reserved_cus"], vals["svc_max_launch_ms"], vals["svc_keep_waves"], vals["fetch_quiet_ms"])
+        N.lib.tsx_shutdown()
+        """, TSX_SERVICE_MAX_LAUNCH_MS=777).strip().splitlines()
+    assert out[-2].split() == ["0", "777", "3", "0"]                    # the environment overrides service_max_launch_ms; fetch_quiet_ms untouched by the old struct
+    assert out[-1].split() == ["7", "777", "8", "2500"]                 # (7: what the first process-wide debug_config left - reserved_cus at TSX_CFG_DEFAULT keeps the current value; 99 waves are capped at 8)
