@@ -658,7 +658,20 @@ static void backendTests(bool full) {
 
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
-    if (argc < 2) { printf("usage: host_tests cpu | backend <libtsxform path> [full]\n"); return 2; }
+    if (argc < 2) { printf("usage: host_tests cpu | backend <libtsxform path> [full] | segment <libtsxform path> <file>\n"); return 2; }
+    if (std::string(argv[1]) == "segment") {
+        // SegmentCompressionChecker.check on the head of a segment file someone else made (tests/test_synth_b.py: content "B" of synth.py):
+        // prints what the twin says - "compressed=0|1" - or the exception's text
+        if (argc < 4) return 2;
+        try {
+            Backend be(argv[2]);
+            FILE* f = fopen(argv[3], "rb"); if (!f) { printf("cannot open %s\n", argv[3]); return 2; }
+            Bytes head((size_t)1 << 20); head.resize(fread(head.data(), 1, head.size(), f)); fclose(f);
+            printf("compressed=%d\n", segmentIsCompressed(be, head) ? 1 : 0);
+            return 0;
+        } catch (const InvalidRecordBatchException& e) { printf("InvalidRecordBatchException: %s\n", e.what()); return 3; }
+          catch (const std::exception& e) { printf("error: %s\n", e.what()); return 4; }
+    }
     if (std::string(argv[1]) == "cpu") { cpuTests(); segmentIndexesBuilderTests(); fetchEnumerationTests(); }
     else { if (argc < 3) return 2; g_lib = argv[2]; try { backendTests(argc > 3 && std::string(argv[3]) == "full"); } catch (const std::exception& e) { printf("  FAIL backend: %s\n", e.what()); g_failed++; } }
     printf("%d run, %d failed\n", g_run, g_failed);

@@ -56,3 +56,38 @@ def test_host_chain_on_gpu(host_tests):
     import tsxform
     out = _run([host_tests, "backend", tsxform._native.LIB_PATH, "full"])
     assert "gfx950" in out and "ChunkManager.getChunk" in out and "SegmentManifestV1SerdeTest" in out and "GpuChunkCache" in out
+
+
+def _segment_checker_on_b(host_tests, lib, tmp_path, env=None):
+    """SegmentCompressionChecker.check (core/.../SegmentCompressionChecker.java:37-53; host twin tsx::segmentIsCompressed, whose CRC32C of
+    the first batch runs through the library's CRC kernel) on segments of the synthetic content "B" (Kafka v2 record batches, synth.py):
+    accepted, not compressed; with the compression bits of the first batch's attributes set (and its CRC made right again) compressed; one
+    flipped payload byte: InvalidRecordBatchException naming both CRCs."""
+    import numpy as np
+    from oracle import oracle as o
+    from tsxform import synth
+    seg = synth.gen_chunk("B", 77, 4, 0, 300000)
+    pos, length = synth.record_batches_of(seg)[0]
+    assert pos == 0
+    def run(buf):
+        path = tmp_path / "seg.bin"; buf.tofile(path)
+        p = subprocess.run([host_tests, "segment", lib, str(path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
+        return p.returncode, p.stdout.strip().splitlines()[-1]
+    assert run(seg) == (0, "compressed=0")
+    z = seg.copy(); z[22] |= 4                                           # attributes: low three bits = the codec (4 = zstd)
+    z[17:21] = np.frombuffer(int(o.crc32c(z[21:length])).to_bytes(4, "big"), np.uint8)
+    assert run(z) == (0, "compressed=1")
+    bad = seg.copy(); bad[length - 3] ^= 1
+    rc, line = run(bad)
+    assert rc == 3 and line.startswith("InvalidRecordBatchException: Record is corrupt (stored crc = "), line
+
+
+def test_segment_compression_checker_accepts_a_b_segment(host_tests, emu, tmp_path):
+    from tests.emu import emu_native
+    _segment_checker_on_b(host_tests, emu_native.EMU_LIB, tmp_path, env=dict(os.environ, TSX_ALLOW_ANY_ARCH="1"))
+
+
+@pytest.mark.gpu
+def test_segment_compression_checker_accepts_a_b_segment_on_gpu(host_tests, tmp_path):
+    import tsxform
+    _segment_checker_on_b(host_tests, tsxform._native.LIB_PATH, tmp_path)
