@@ -216,3 +216,21 @@ def check_encrypt_only_zero_copy(N, o, sizes):
             assert res["registered"][0][i] == oracle_transform(o, flags, chunks[i], i)
     finally:
         N.ctx_destroy(ctx)
+
+
+def b_batch_256():
+    """256 chunks of content "B" (Kafka v2 record batches), 40-400 KB each: the batch VERDICT r4 #7 asks the device parity set to hold."""
+    sizes = [40000 + (i * 7919) % 360000 for i in range(256)]
+    return [synth.gen_chunk("B", 43, 3, i, s) for i, s in enumerate(sizes)]
+
+
+def check_b_batch_256(N, o):
+    """... through the full chain (= libzstd 1.5.7 + OpenSSL, byte for byte), back again, and through both Zstd profiles.  Returns
+    (transformed / original, #chunks where 1.5.7's pre-splitter cut, #chunks pinned to the real library under profile 1.5.6)."""
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    chunks = b_batch_256()
+    outs, d = check_transform_vs_oracle(N, o, flags, chunks)
+    back, d2 = run_detransform(N, flags, outs, [int(c.size) for c in chunks])
+    assert (d2["status"] == 0).all() and back == [c.tobytes() for c in chunks] and (d2["crc32c"] == d["crc32c"]).all()
+    pinned, differ = check_profile_1_5_6(N, o, {"B256_%d" % i: c for i, c in enumerate(chunks)})
+    return sum(len(x) for x in outs) / float(sum(int(c.size) for c in chunks)), differ, pinned
