@@ -501,15 +501,3 @@ def test_kafka_shaped_binary_content_on_the_device(gpu, oracle):
     gpu.crc32c_batch(dd, buf)
     cb = c.tobytes()
     assert [int(x) for x in dd["crc32c"]] == [int.from_bytes(cb[p + 17:p + 21], "big") for p, _ in batches]
-
-
-@pytest.mark.timeout(900)
-def test_256_chunks_of_binary_content_both_profiles(gpu, oracle):
-    """256 chunks of content "B" in one batch: full chain = libzstd 1.5.7 + OpenSSL byte for byte, round trip, and both Zstd profiles (the
-    pre-splitter of 1.5.7 cuts on many of them: there the profiles' frames differ and both decode; elsewhere profile 1.5.6 is pinned to the real
-    library).  The same batch ran through the CPU emulator of the kernel sources (profiles/r05_b256_on_the_emulator.txt)."""
-    if not oracle.zstd_version().startswith("1.5.7"):
-        pytest.skip("libzstd 1.5.7 not available")
-    ratio, differ, pinned = pc.check_b_batch_256(gpu, oracle)
-    print("B x 256: transformed / original = %.3f; the pre-splitter cut on %d chunks, %d pinned to the real library under profile 1.5.6" % (ratio, differ, pinned))
-    assert differ >= 16 and differ + pinned == 256
