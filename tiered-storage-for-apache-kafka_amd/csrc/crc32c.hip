@@ -104,7 +104,7 @@ __global__ __launch_bounds__(TSX_CRC_THREADS) void crc32c_partial_kernel(
 // One thread per chunk: Horner over the sub-block remainders, then the <16-byte tail, then xorout.
 __global__ void crc32c_final_kernel(const tsx_crc_tables* __restrict__ tab, const uint8_t* __restrict__ src,
                                     tsx_chunk_desc* __restrict__ descs, uint32_t n, uint32_t max_sub,
-                                    const uint32_t* __restrict__ partials, int use_dst_side) {
+                                    const uint32_t* __restrict__ partials, int use_dst_side, tsx_chunk_desc* __restrict__ mirror) {
     const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= n) return;
     uint64_t off; uint32_t len;
@@ -122,15 +122,16 @@ __global__ void crc32c_final_kernel(const tsx_crc_tables* __restrict__ tab, cons
         for (int k = 0; k < 8; k++) s = crc_mulx(s);
     }
     descs[chunk].crc32c = ~s;
+    if (mirror) mirror[chunk].crc32c = ~s;                 // the caller's copy of the descriptor, in pinned host memory (tsx_api.hip, launch_stages)
 }
 
 void tsx_launch_crc32c(hipStream_t st, const tsx_crc_tables* d_tab, const uint8_t* src, tsx_chunk_desc* d_descs,
-                       uint32_t n, uint32_t max_len, uint32_t* d_partials, int use_dst_side) {
+                       uint32_t n, uint32_t max_len, uint32_t* d_partials, int use_dst_side, tsx_chunk_desc* hd_mirror) {
     if (!n) return;
     uint32_t max_sub = (max_len + TSX_CRC_SUB_BYTES - 1) / TSX_CRC_SUB_BYTES;
     if (max_sub == 0) max_sub = 1;
     hipLaunchKernelGGL(crc32c_partial_kernel, dim3(n * max_sub), dim3(TSX_CRC_THREADS), 0, st, d_tab, src,
                        (const tsx_chunk_desc*)d_descs, max_sub, d_partials, use_dst_side);
     hipLaunchKernelGGL(crc32c_final_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_tab, src, d_descs, n, max_sub,
-                       (const uint32_t*)d_partials, use_dst_side);
+                       (const uint32_t*)d_partials, use_dst_side, hd_mirror);
 }

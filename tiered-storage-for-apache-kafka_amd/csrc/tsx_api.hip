@@ -201,6 +201,7 @@ struct tsx_ctx {
     bool last_used_blocks = false;                 // the last batch ran the block-parallel frame decoder (test hook)
     uint32_t last_members = 0;                     // members the last compressing batch went as (test hook)
     bool last_zero_copy = false;                   // ... and whether its waves wrote into the caller's buffer (test hook)
+    bool key_wiped = false;                        // the batch's own wipe_key_kernel has cleared d_key / d_keyraw
 };
 
 static std::mutex g_mu;
@@ -266,7 +267,9 @@ static bool svc_running_locked(tsx_service& s) {
     if (__atomic_load_n(&s.h->ended_launch, __ATOMIC_ACQUIRE) != s.launch_id) return true;
     s.kernel_ms += (double)(s.h->t_last - s.h->t_first) / 1e5;           // 100 MHz ticks
     s.launched = false;
-    if (s.rotating && !s.paused) { s.rotating = false; __atomic_store_n(&s.h->stop, 0u, __ATOMIC_RELEASE); }     // (the device's copy of the word is cleared in front of the next launch)
+    // a rotation is over with the launch it asked to end - also when a pause overlapped that end (the flag must not survive into the next
+    // launch: svc_rotate and the readmission would stay switched off for its whole life); only the host's stop word stays up while paused
+    if (s.rotating) { s.rotating = false; if (!s.paused) __atomic_store_n(&s.h->stop, 0u, __ATOMIC_RELEASE); }   // (the device's copy of the word is cleared in front of the next launch)
     for (void* p : s.deferred_dev) (void)hipFree(p);
     for (void* p : s.deferred_host) (void)hipHostFree(p);
     s.deferred_dev.clear(); s.deferred_host.clear();
@@ -931,16 +934,53 @@ __global__ __launch_bounds__(256) void copy_chunks_kernel(tsx_chunk_desc* __rest
     }
 }
 
+// First kernel of a batch of ordinary kernels (fetches above all).  A copy of 48 bytes, or of the 21 KB key schedule, is a blit KERNEL of
+// the runtime (__amd_rocclr_copyBuffer, 512-thread workgroups): every fetch used to queue five of them (descriptors up, key schedule up,
+// descriptors down, two wipes), and they were the kernels that got stuck next to the compressor service (all six stuck dispatches of
+// profiles/r05_kernel_trace_blocked_fetch.csv.gz are copyBuffer kernels; next to guest waves such a copy waits for the launch to end).
+// So nothing small is copied any more: this kernel reads the batch's descriptors - and, for the first piece of an encrypted batch, the key
+// schedule the host built - straight from the context's pinned memory into their device-side places and starts every status from
+// TSX_OK; publish_status_kernel / crc32c_final_kernel write the results back there; wipe_key_kernel clears the key material.
+__global__ __launch_bounds__(256) void begin_batch_kernel(const tsx_chunk_desc* __restrict__ hd_descs, tsx_chunk_desc* __restrict__ descs, int32_t* __restrict__ status,
+                                                          uint32_t n, const uint4* __restrict__ hd_key, uint4* __restrict__ d_key, uint32_t key_words16) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint4* s = reinterpret_cast<const uint4*>(hd_descs + i);
+        uint4* d = reinterpret_cast<uint4*>(descs + i);
+        const uint4 a = s[0], b = s[1], c = s[2];
+        d[0] = a; d[1] = b; d[2] = c;
+        status[i] = TSX_OK;
+    }
+    if (hd_key) for (uint32_t k = i; k < key_words16; k += gridDim.x * blockDim.x) d_key[k] = hd_key[k];
+}
+static_assert(sizeof(tsx_chunk_desc) == 48 && sizeof(tsx_gcm_key) % 16 == 0, "begin_batch_kernel moves descriptors and the key schedule as 16-byte words");
+
+// Last kernel of an encrypted batch: the key schedule and the raw key bytes do not stay behind in the context
+__global__ __launch_bounds__(256) void wipe_key_kernel(uint4* __restrict__ d_key, uint32_t key_words16, uint4* __restrict__ d_keyraw) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 z; z.x = z.y = z.z = z.w = 0;
+    for (uint32_t k = i; k < key_words16; k += gridDim.x * blockDim.x) d_key[k] = z;
+    if (i < 8) d_keyraw[i] = z;
+}
+
 __global__ void init_status_kernel(int32_t* status, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) status[i] = TSX_OK;
 }
 
-__global__ void publish_status_kernel(tsx_chunk_desc* descs, const int32_t* status, uint32_t n) {
+// mirror != nullptr: the whole descriptor as it stands goes to the batch's pinned copy as well (what the caller gets back; a CRC stage that
+// runs afterwards adds its word there itself)
+__global__ void publish_status_kernel(tsx_chunk_desc* descs, const int32_t* status, uint32_t n, tsx_chunk_desc* mirror) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     descs[i].status = status[i];
     if (status[i] != TSX_OK) descs[i].dst_len = 0;
+    if (mirror) {
+        const uint4* s = reinterpret_cast<const uint4*>(descs + i);
+        uint4* d = reinterpret_cast<uint4*>(mirror + i);
+        const uint4 a = s[0], b = s[1], c = s[2];
+        d[0] = a; d[1] = b; d[2] = c;
+    }
 }
 
 // Zeroes what a failed chunk of the inverse chain left in its output slot (device-memory calls: a forged chunk's
@@ -1012,6 +1052,9 @@ static int svc_submit(tsx_device* dev, const tsx_zseg& proto, const uint32_t* h_
         uint32_t oldest = s.published; bool any = false;
         for (const auto& m : s.out) if (!m.done && !__atomic_load_n(m.h_flag, __ATOMIC_ACQUIRE)) { oldest = m.first; any = true; break; }
         if (!s.free_slots.empty() && (!any || (uint32_t)(s.published + n - oldest) <= TSX_SVC_TICKETS)) break;
+        // whoever waits for room is also the service's watchdog (as svc_wait is): the kernel may have ended - idle, age limit, a rotation -
+        // with the members that hold the room still unserved, and their callers may all be in here
+        if (!s.paused && !s.out.empty() && !svc_running_locked(s)) { s.watchdog_launches++; (void)svc_launch_locked(s); }
         s.cv.wait_for(lk, std::chrono::milliseconds(1));
     }
     const uint16_t slot = s.free_slots.back(); s.free_slots.pop_back();
@@ -1101,6 +1144,15 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
     out->kernel_ms = s.kernel_ms; out->running = running ? 1u : 0u;
     out->waves = s.grid; out->compute_units = s.cus; out->cu_keys_seen = s.cu_keys; out->reserved_cus = s.cus_reserved; out->shader_engines = s.engines;
     out->guest_launches = (uint32_t)s.guest_launches; out->readmissions = (uint32_t)s.readmissions;
+    if (running) {
+        // the launch is alive: the words its waves mirror into pinned memory (a copy out of device memory is a blit kernel for sizes like
+        // these and, next to guest waves, waits for the launch to end - tsx_internal.h, tsx_svc_host.m_*)
+        out->device_chunks = __atomic_load_n(&s.h->m_chunks, __ATOMIC_RELAXED); out->live_waves = __atomic_load_n(&s.h->m_live, __ATOMIC_RELAXED);
+        out->live_waves_max = __atomic_load_n(&s.h->m_live_max, __ATOMIC_RELAXED); out->wave_starts = __atomic_load_n(&s.h->m_wave_starts, __ATOMIC_RELAXED);
+        out->reserved_exits = __atomic_load_n(&s.h->m_reserved_exits, __ATOMIC_RELAXED); out->skipped_tickets = __atomic_load_n(&s.h->m_skipped, __ATOMIC_RELAXED);
+        out->yielded_waves = __atomic_load_n(&s.h->m_yields, __ATOMIC_RELAXED); out->returned_chunks = __atomic_load_n(&s.h->m_returned, __ATOMIC_RELAXED);
+        return TSX_OK;
+    }
     uint32_t w[4] = {0, 0, 0, 0};
     if (hipMemcpy(w, &s.d->stat_yields, 8, hipMemcpyDeviceToHost) == hipSuccess) { out->yielded_waves = w[0]; out->returned_chunks = w[1]; } else (void)hipGetLastError();
     if (hipMemcpy(w, &s.d->stat_chunks, sizeof w, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1219,31 +1271,35 @@ static int run_compress(tsx_run& r) {
     if (r.enc && r.fuse_stages) tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
     hipStream_t cin = r.pooled ? dev->copy_in : c->st_in, cout_ = r.pooled ? dev->copy_out : c->st_out;
     const auto t_begin = std::chrono::steady_clock::now();
-    if (!self_status) {
-        // test hook stages_separate: CRC, compressor, GCM (or the copy into the slots) as separate launches around the service's members
-        HIPCHK(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, c->st));
-        hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, c->st, c->d_status, n);
-    }
-    // ---- input copies, all queued at once; every piece is published when its own bytes are on the device ----
-    if (r.host) {
-        HIPCHK(hipEventRecord(c->ev[2], cin));
-        for (size_t k = 0; k < ns; k++) {
-            const tsx_sub& sb = subs[k];
-            if ((k == 0 || monotonic) && sb.in_hi > sb.in_lo) HIPCHK(hipMemcpyAsync(c->d_in + sb.in_lo, (const uint8_t*)r.src + sb.in_lo, sb.in_hi - sb.in_lo, hipMemcpyHostToDevice, cin));
-            HIPCHK(hipEventRecord(c->sub_ev[k][5], cin));
-        }
-    }
     uint64_t ids[TSX_COMP_PIECES_MAX] = {0};
     size_t submitted = 0;
     auto abandon_all = [&](int code) {
         // nothing of this call may still be running when it returns with an error: members that were published are taken back (their
-        // tickets become stale) only once the service kernel is gone
-        if (submitted) { svc_pause(dev); for (size_t k = 0; k < submitted; k++) svc_retire(dev, ids[k], true); svc_resume(dev);
+        // tickets become stale) only once the service kernel is gone; copies that were queued (they read the caller's source) have drained
+        if (submitted) { svc_pause(dev); for (size_t k = 0; k < submitted; k++) if (ids[k]) svc_retire(dev, ids[k], true); svc_resume(dev);
                          (void)hipMemcpy(c->d_segdone, dev->h_zeros, 64, hipMemcpyHostToDevice); memset(c->h_segflag, 0, 64); }
         (void)hipGetLastError();
         if (r.host) { (void)hipStreamSynchronize(cin); (void)hipStreamSynchronize(cout_); }
+        (void)hipStreamSynchronize(c->st);
         return code;
     };
+    // every HIP failure from the first queued copy on leaves through abandon_all (a bare return would leave copies of the caller's buffer,
+    // or published members that read a key about to be wiped, in flight)
+#define HIPCHK_AB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { tsx_set_err(#x, e_); return abandon_all(TSX_E_DEVICE); } } while (0)
+    if (!self_status) {
+        // test hook stages_separate: CRC, compressor, GCM (or the copy into the slots) as separate launches around the service's members
+        HIPCHK_AB(hipMemcpyAsync(c->d_descs, c->h_descs, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, c->st));
+        hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, c->st, c->d_status, n);
+    }
+    // ---- input copies, all queued at once; every piece is published when its own bytes are on the device ----
+    if (r.host) {
+        HIPCHK_AB(hipEventRecord(c->ev[2], cin));
+        for (size_t k = 0; k < ns; k++) {
+            const tsx_sub& sb = subs[k];
+            if ((k == 0 || monotonic) && sb.in_hi > sb.in_lo) HIPCHK_AB(hipMemcpyAsync(c->d_in + sb.in_lo, (const uint8_t*)r.src + sb.in_lo, sb.in_hi - sb.in_lo, hipMemcpyHostToDevice, cin));
+            HIPCHK_AB(hipEventRecord(c->sub_ev[k][5], cin));
+        }
+    }
     for (size_t k = 0; k < ns; k++) {
         const tsx_sub& sb = subs[k];
         if (r.host && hipEventSynchronize(c->sub_ev[k][5]) != hipSuccess) return abandon_all(TSX_E_DEVICE);
@@ -1284,7 +1340,7 @@ static int run_compress(tsx_run& r) {
             if (r.enc) {
                 if (k == 0) {
                     tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
-                    HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st));
+                    HIPCHK_AB(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st));
                 }
                 hipLaunchKernelGGL(plan_gcm_kernel, dim3((sb.n + 255) / 256), dim3(256), 0, c->st, dd, sb.n, (const uint32_t*)dz, (uint64_t)c->mid_stride, 1, 0, 0, c->d_gchunks + sb.lo, ds);
                 tsx_launch_gcm(c->st, dev->d_aes, c->d_key, c->d_gchunks + sb.lo, sb.n, (uint32_t)tsx_transformed_bound(r.max_len, TSX_COMPRESS), dmid, r.d_dst,
@@ -1294,8 +1350,8 @@ static int run_compress(tsx_run& r) {
                 const uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
                 hipLaunchKernelGGL(copy_chunks_kernel, dim3(sb.n * bpc), dim3(256), 0, c->st, dd, (const uint32_t*)dz, (uint64_t)c->mid_stride, 1, (const uint8_t*)dmid, r.d_dst, ds, bpc);
             }
-            hipLaunchKernelGGL(publish_status_kernel, dim3((sb.n + 255) / 256), dim3(256), 0, c->st, dd, (const int32_t*)ds, sb.n);
-            HIPCHK(hipMemcpyAsync(c->h_descs + sb.lo, dd, (size_t)sb.n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, c->st));
+            hipLaunchKernelGGL(publish_status_kernel, dim3((sb.n + 255) / 256), dim3(256), 0, c->st, dd, (const int32_t*)ds, sb.n, (tsx_chunk_desc*)nullptr);
+            HIPCHK_AB(hipMemcpyAsync(c->h_descs + sb.lo, dd, (size_t)sb.n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, c->st));
             if (hipStreamSynchronize(c->st) != hipSuccess) return abandon_all(TSX_E_DEVICE);
         }
         memcpy(r.descs + sb.lo, c->h_descs + sb.lo, (size_t)sb.n * sizeof(tsx_chunk_desc));
@@ -1313,7 +1369,8 @@ static int run_compress(tsx_run& r) {
         }
     }
     const auto t_done = std::chrono::steady_clock::now();
-    if (r.host && !zc_dst) { HIPCHK(hipEventRecord(c->ev[3], cout_)); HIPCHK(hipEventSynchronize(c->ev[3])); }
+    if (r.host && !zc_dst) { HIPCHK_AB(hipEventRecord(c->ev[3], cout_)); HIPCHK_AB(hipEventSynchronize(c->ev[3])); }
+#undef HIPCHK_AB
     t.zstd_launches = (uint32_t)ns;
     t.d2h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_done).count();
     t.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1323,10 +1380,14 @@ static int run_compress(tsx_run& r) {
 
 // ---- everything else: forward chain without compression, the inverse chain, CRC only ---------------------------------------------------
 // Enqueues the kernels of chunks [lo, lo + n) on compute stream st; e[0..4] are recorded at the stage boundaries.
-static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st) {
+// stage_key: this piece's first kernel also brings the key schedule the host built (c->h_key) to the device (c->d_key); c->ev_key is
+// recorded behind it.  Nothing here is a copy: descriptors and key come in through begin_batch_kernel, results leave through the kernels
+// that produce them (tsx_chunk_desc mirror in pinned memory).
+static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hipStream_t st, bool stage_key) {
     tsx_ctx* c = r.c;
     const uint32_t n = sb.n, lo = sb.lo, flags = r.flags;
     tsx_chunk_desc* dd = c->d_descs + lo;
+    tsx_chunk_desc* const hm = c->hd_descs + lo;                       // the batch's descriptors in pinned memory, as the device addresses them
     int32_t* ds = c->d_status + lo;
     uint32_t* dz = c->d_zlen + lo;
     tsx_gcm_chunk* dg = c->d_gchunks + lo;
@@ -1336,14 +1397,19 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     uint32_t* const dpart = c->d_partials + (size_t)lo * c->partials_per_chunk;     // this piece's slice of the CRC / GHASH partial sums
     tsx_timing& t = c->timing;
     memcpy(c->h_descs + lo, r.descs + lo, (size_t)n * sizeof(tsx_chunk_desc));
-    HIPCHK(hipMemcpyAsync(dd, c->h_descs + lo, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(init_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ds, n);
+    {
+        const uint32_t kw = stage_key ? (uint32_t)(sizeof(tsx_gcm_key) / 16) : 0u;
+        const uint32_t blocks = std::max((n + 255u) / 256u, stage_key ? 6u : 1u);
+        hipLaunchKernelGGL(begin_batch_kernel, dim3(blocks), dim3(256), 0, st, (const tsx_chunk_desc*)hm, dd, ds, n,
+                           stage_key ? (const uint4*)c->hd_key : (const uint4*)nullptr, (uint4*)c->d_key, kw);
+        if (stage_key) HIPCHK(hipEventRecord(c->ev_key, st));
+    }
     HIPCHK(hipEventRecord(e[0], st));
     if (r.mode == 2) {
         tsx_launch_crc32c(st, c->dev->d_crc, r.d_src, dd, n, r.max_len, dpart, 0);
         HIPCHK(hipEventRecord(e[1], st)); HIPCHK(hipEventRecord(e[2], st));
         t.crc_launches += 2;
-        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);      // a reused descriptor must not keep an old status
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n, hm);      // a reused descriptor must not keep an old status
     } else if (r.mode == 0) {
         // forward chain WITHOUT compression (producers compress: RemoteStorageManager.java:381-398 leaves Zstd out): CRC32C of the chunk,
         // then AES-256-GCM (or the plain copy) as batch kernels - milliseconds of work, no residency to protect
@@ -1358,7 +1424,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
             uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
             hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz, (uint64_t)c->mid_stride, 0, r.d_src, r.d_dst, ds, bpc);
         }
-        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n, hm);
     } else {
         HIPCHK(hipEventRecord(e[1], st));
         const uint8_t* zsrc = r.d_src;    // where the Zstd frames live when there is no encryption
@@ -1390,7 +1456,7 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
             uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
             hipLaunchKernelGGL(copy_chunks_kernel, dim3(n * bpc), dim3(256), 0, st, dd, (const uint32_t*)dz, (uint64_t)0, 0, r.d_src, r.d_dst, ds, bpc);
         }
-        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n);
+        hipLaunchKernelGGL(publish_status_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dd, (const int32_t*)ds, n, hm);
         if (r.enc && !r.comp) {            // decrypted straight into the caller's slots: nothing of a chunk that failed its tag check stays
             uint32_t bpc = r.max_len > (1u << 20) ? 16 : 1;
             hipLaunchKernelGGL(scrub_failed_kernel, dim3(n * bpc), dim3(256), 0, st, (const tsx_chunk_desc*)dd, (const int32_t*)ds, r.d_dst, bpc);
@@ -1399,11 +1465,10 @@ static int launch_stages(const tsx_run& r, const tsx_sub& sb, hipEvent_t* e, hip
     HIPCHK(hipEventRecord(e[3], st));
     if (r.mode == 1 && (flags & TSX_CRC)) {
         // CRC of the restored bytes; upper bound of a restored chunk is its slot capacity
-        tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, dpart, 1);
+        tsx_launch_crc32c(st, c->dev->d_crc, r.d_dst, dd, n, r.max_out, dpart, 1, hm);
         t.crc_launches += 2;
     }
-    HIPCHK(hipMemcpyAsync(c->h_descs + lo, dd, (size_t)n * sizeof(tsx_chunk_desc), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(e[4], st));                                   // the caller's descriptors are filled in when this event has passed
+    HIPCHK(hipEventRecord(e[4], st));                                   // the batch's descriptors in pinned memory are filled in when this event has passed
     return TSX_OK;
 }
 
@@ -1504,22 +1569,22 @@ static int run_batch_inner(tsx_run& r) {
     if (multi) for (size_t k = 1; k < ns && k < 4; k++) if (!c->st_pc[k - 1]) HIPCHK(hipStreamCreateWithFlags(&c->st_pc[k - 1], hipStreamNonBlocking));
     auto stream_of = [&](size_t k) { return (multi && k % 4) ? c->st_pc[k % 4 - 1] : st; };
     HIPCHK(hipEventRecord(c->ev[0], st));
-    bool keyraw_written = false;
+    bool keyraw_written = false, stage_key = false;
     if (r.enc) {
         // The key schedule is built on the host (~10 us with the host's carry-less multiplier) and travels as ONE 21 KB copy in front of the
         // batch's GCM kernels instead of a raw-key copy + gcm_setup_kernel: that kernel was 0.17 of a single-chunk fetch's 1.7 ms and, on a
         // busy device, one more small kernel waiting for a slot.  Test hook gcm_setup_kernel keeps the kernel (both
         // produce the same schedule).
         if (!g_cfg.gcm_setup_kernel) {
-            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);
-            HIPCHK(hipMemcpyAsync(c->d_key, c->h_key, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, st));
+            tsx_gcm_key_build_host(r.params->key, r.params->aad, r.params->aad_len, c->h_key);    // piece 0's first kernel takes it to the device
+            stage_key = true;
         } else {
             memcpy(c->h_keyraw, r.params->key, 32); memcpy(c->h_keyraw + 32, r.params->aad, 64);
             HIPCHK(hipMemcpyAsync(c->d_keyraw, c->h_keyraw, 96, hipMemcpyHostToDevice, st));
             keyraw_written = true;
             tsx_launch_gcm_setup(st, c->dev->d_aes, c->d_keyraw, c->d_keyraw + 32, r.params->aad_len, c->d_key);
+            if (multi) HIPCHK(hipEventRecord(c->ev_key, st));
         }
-        if (multi) HIPCHK(hipEventRecord(c->ev_key, st));
     }
     (void)keyraw_written;                                               // (run_batch wipes both device copies whatever was written)
     if (r.host) HIPCHK(hipEventRecord(c->ev[2], c->st_in));
@@ -1535,8 +1600,8 @@ static int run_batch_inner(tsx_run& r) {
             HIPCHK(hipEventRecord(e[5], c->st_in));
             HIPCHK(hipStreamWaitEvent(ks, e[5], 0));
         }
-        if (multi && ks != st && r.enc) HIPCHK(hipStreamWaitEvent(ks, c->ev_key, 0));
-        return launch_stages(r, sb, e, ks);
+        if (multi && ks != st && r.enc) HIPCHK(hipStreamWaitEvent(ks, c->ev_key, 0));      // (piece 0 went first: its begin kernel staged the key)
+        return launch_stages(r, sb, e, ks, stage_key && k == 0);
     };
     // The restored chunks of a fetch are what crosses PCIe (4 MiB each against 1.3 MB in): one copy stream moves them at ~31 GB/s - 8.7 of a
     // 64-chunk window's 10.4 ms; the pieces' copies alternate between two streams.
@@ -1570,6 +1635,12 @@ static int run_batch_inner(tsx_run& r) {
         }
     }
     if (r.host) HIPCHK(hipEventRecord(c->ev[3], c->st_out));
+    if (r.enc) {
+        // the key material leaves the device behind the batch's last kernel (every piece's chain has been joined into st above); the pinned
+        // originals are wiped by run_batch
+        hipLaunchKernelGGL(wipe_key_kernel, dim3(6), dim3(256), 0, st, (uint4*)c->d_key, (uint32_t)(sizeof(tsx_gcm_key) / 16), (uint4*)c->d_keyraw);
+        c->key_wiped = true;
+    }
     HIPCHK(hipEventRecord(c->ev[1], st));
     HIPCHK(hipStreamSynchronize(st));
     tr.mark("compute stream idle");
@@ -1617,6 +1688,7 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
     r.enc = mode != 2 && (flags & TSX_ENCRYPT); r.comp = mode != 2 && (flags & TSX_COMPRESS);
     r.fuse_stages = r.comp && !g_cfg.stages_separate;
     const bool service = mode == 0 && r.comp;
+    c->key_wiped = false;
     struct fg_scope {                                                   // every batch of ordinary kernels claims the reserved CUs for its duration (+ fetch_quiet_ms)
         tsx_device* d;
         explicit fg_scope(tsx_device* dev) : d(dev) { if (d) svc_foreground_begin(d); }
@@ -1637,8 +1709,11 @@ static int run_batch(tsx_ctx* c, const tsx_batch_params* params, tsx_chunk_desc*
         hipStreamSynchronize(c->st);
         for (auto& q : c->st_pc) if (q) hipStreamSynchronize(q);
         memset(c->h_keyraw, 0, 128); memset(c->h_key, 0, sizeof(tsx_gcm_key));
-        hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);                  // wiped by copies, not kernels; both, whichever
-        hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st);   // of them this batch wrote
+        if (!c->key_wiped) {
+            // the batch failed before its wipe kernel was queued: both device copies are cleared here, whichever of them it wrote
+            hipMemcpyAsync(c->d_keyraw, c->dev->h_zeros, 128, hipMemcpyHostToDevice, c->st);
+            hipMemcpyAsync(c->d_key, c->dev->h_zeros, sizeof(tsx_gcm_key), hipMemcpyHostToDevice, c->st);
+        }
     }
     hipStreamSynchronize(c->st_in); hipStreamSynchronize(c->st); hipStreamSynchronize(c->st_out);
     if (c->st_out2) hipStreamSynchronize(c->st_out2);

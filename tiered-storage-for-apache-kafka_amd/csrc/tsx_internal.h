@@ -28,9 +28,10 @@ void tsx_crc_build_tables(tsx_crc_tables* host_out);
 
 // One launch pair: partial CRCs per 256 KiB sub-block, then per-chunk combine.  `partials` needs
 // n * max_sub u32.  Input chunk i = src + descs[i].src_off (16-byte aligned), length descs[i].src_len;
-// result in descs[i].crc32c (device copy of the descriptors).
+// result in descs[i].crc32c (device copy of the descriptors) and, when hd_mirror != nullptr, in hd_mirror[i].crc32c as well (the
+// batch's descriptors in pinned host memory, as the device addresses them: no copy back).
 void tsx_launch_crc32c(hipStream_t st, const tsx_crc_tables* d_tab, const uint8_t* src, tsx_chunk_desc* d_descs,
-                       uint32_t n, uint32_t max_len, uint32_t* d_partials, int use_dst_side);
+                       uint32_t n, uint32_t max_len, uint32_t* d_partials, int use_dst_side, tsx_chunk_desc* hd_mirror = nullptr);
 
 // ---------------------------------------------------------------------------------------------------
 // AES-256-GCM
@@ -109,7 +110,12 @@ struct tsx_svc_host {                // pinned host memory, written by the host,
     uint32_t ended_launch;           // id of the last launch that has ended (release-stored after the two stamps)
     uint32_t ended_pad_;
     uint64_t t_first, t_last;        // 100 MHz clock at the launch's first wave start / last wave exit
-    uint32_t pad2_[10];
+    // ... and these, mirrors of the device's statistics words (tsx_svc_dev) that waves store here as they change them: tsx_service_stats reads
+    // them while a launch is alive.  A copy out of device memory is a blit KERNEL for sizes this small (__amd_rocclr_copyBuffer, 512-thread
+    // workgroups), and next to guest waves - every wave slot of the chip taken - it waited for the launch to end (profiles/r06_guest_waves_root_cause.md).
+    // Plain stores, last writer wins: a value may lag a few chunks behind; the exact words are read once the kernel is gone.
+    uint32_t m_chunks, m_live, m_live_max, m_wave_starts, m_reserved_exits, m_skipped, m_yields, m_returned;
+    uint32_t pad2_[2];
     tsx_zseg member[TSX_SVC_MEMBERS];
     tsx_svc_ticket ticket[TSX_SVC_TICKETS];
 };
@@ -123,7 +129,12 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
     uint32_t stat_chunks, stat_wave_starts, stat_reserved_exits, stat_skipped;
     uint32_t entered, exited;        // waves of the current launch that have started / left (the last one to leave reports the launch's end)
     uint32_t t_first_lo, t_first_hi; // clock at the first wave's start
-    uint32_t live, live_max, pad3_[2];   // waves resident right now / the most ever (statistics: is the whole launch resident at once?)
+    uint32_t live, live_max;         // waves resident right now / the most ever (statistics: is the whole launch resident at once?)
+    uint32_t draining;               // != 0: this launch is ending - set by the first wave whose idle timer fires, read by every wave before it takes a
+                                     // ticket.  Leaving is a decision of the LAUNCH: with per-wave timers the exits spread over ~0.5 ms, a member published
+                                     // inside that window was picked up by the waves that had not left yet, and the launch lived on with a fraction of its
+                                     // waves (measured: ONE wave serving 10 240 queued chunks until the 60 s age limit, profiles/r06_guest_waves_root_cause.md)
+    uint32_t pad3_;
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
     uint32_t kept[256];              // per shader engine (key >> 4): waves of the current launch that stayed on the engine's reserved CU (tsx_svc_launch.keep_waves)

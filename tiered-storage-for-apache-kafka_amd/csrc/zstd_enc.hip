@@ -1579,6 +1579,7 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
     if (fuse.crc) {
         const uint32_t crc = crc32c_wave(fuse.crc, src, srcSize, L.crcTab, lane);
         if (lane == 0) descs[chunk].crc32c = crc;
+        PT(16);
     }
     if (fuse.self_status) { if (lane == 0) status[chunk] = TSX_OK; }    // (finish_frame publishes the chunk's final status in its descriptor)
     else if (status[chunk] != TSX_OK) { if (lane == 0) { zlen[chunk] = 0; if (fuse.key) descs[chunk].dst_len = 0; } return false; }
@@ -1651,7 +1652,7 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
             gather_literals(lit, src, seqs, ms.nbSeq, ms.anchor, ms.lastLL, lane);
             __threadfence_block();
             __syncthreads();
-            PT(5);
+            PT(18); PCNT(20, 1);
             // ---- ZSTD_entropyCompressSeqStore ----
             if (lane == 0) L.scal[8] = 0;
             __syncthreads();
@@ -1698,6 +1699,7 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
         __syncthreads();
     }
     finish_frame(descs, chunk, frame, (uint32_t)(op - frame), zlen, status, fuse, ws + ZS_WS_KEYCOPY, L, lane);
+    PT(17);
 #ifdef TSX_PROF
     if (lane == 0 && prof_out) { g_prof[14] = (unsigned long long)clock64() - g_prof[22]; for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i]; }
 #endif
@@ -1723,6 +1725,7 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
 #define SVC_LD_DEV(p) __atomic_load_n((p), __ATOMIC_ACQUIRE)
 #define SVC_ST_DEV(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
 #define SVC_ST_SYS(p, v) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define SVC_ST_MIRROR(p, v) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
 __device__ static inline uint64_t svc_now() { return hipemu_clock_100mhz(); }
 __device__ static inline uint32_t svc_cu_key() { return hipemu_cu_key(); }
 __device__ static inline void svc_nap(uint32_t) {}
@@ -1734,6 +1737,7 @@ __device__ static inline void svc_fence_device() { __atomic_thread_fence(__ATOMI
 #define SVC_LD_DEV(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SVC_ST_DEV(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SVC_ST_SYS(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM)
+#define SVC_ST_MIRROR(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)   /* statistics mirrors: no ordering wanted */
 __device__ static inline uint64_t svc_now() { return wall_clock64(); }                       // 100 MHz, the same on every CU
 // Which compute unit is this wave on?  HW_ID[15:8] = CU_ID | SH_ID | SE_ID, XCC_ID[3:0] = the XCD: a 12-bit key, unique per CU
 // (tsx_launch_cu_probe counts the keys of a launch that covers the chip; the front end checks the count against the CU count).
@@ -1795,6 +1799,16 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
             if (n) return 3;
             atomicSub(&D->busy, 1u);
         }
+        if (SVC_LD_DEV(&D->draining)) return 2;                          // the launch is ending (below): no more tickets for it - the host starts the next one
+        // one wave per poll_ticks asks the host - whether or not the mirror is dry: the host's stop word (pause, rotation, shutdown) must not wait
+        // for a queue of thousands of tickets to be consumed first
+        const uint32_t ps = SVC_LD_DEV(&D->poll_stamp);
+        if ((uint32_t)now - ps >= a.poll_ticks && atomicCAS(&D->poll_stamp, ps, (uint32_t)now) == ps) {
+            const uint32_t p = SVC_LD_SYS(&H->published);
+            if (SVC_LD_SYS(&H->stop)) { SVC_ST_DEV(&D->stop, 1u); return 2; }
+            uint32_t old = SVC_LD_DEV(&D->pub);
+            while ((int32_t)(p - old) > 0) { const uint32_t prev = atomicCAS(&D->pub, old, p); if (prev == old) break; old = prev; }
+        }
         const uint32_t nx = SVC_LD_DEV(&D->next), pb = SVC_LD_DEV(&D->pub);
         if ((int32_t)(pb - nx) > 0) {
             atomicAdd(&D->busy, 1u);                                     // before the ticket is taken: busy >= waves that hold one
@@ -1802,17 +1816,8 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
             atomicSub(&D->busy, 1u);
             continue;
         }
-        // dry, as far as the mirror knows: one wave per poll_ticks asks the host
-        const uint32_t ps = SVC_LD_DEV(&D->poll_stamp);
-        if ((uint32_t)now - ps >= a.poll_ticks && atomicCAS(&D->poll_stamp, ps, (uint32_t)now) == ps) {
-            const uint32_t p = SVC_LD_SYS(&H->published);
-            if (SVC_LD_SYS(&H->stop)) SVC_ST_DEV(&D->stop, 1u);
-            uint32_t old = SVC_LD_DEV(&D->pub);
-            while ((int32_t)(p - old) > 0) { const uint32_t prev = atomicCAS(&D->pub, old, p); if (prev == old) break; old = prev; }
-            if ((int32_t)(p - nx) > 0) continue;
-        }
         if (SVC_LD_DEV(&D->busy) != 0 || quiet_since == 0) quiet_since = now;
-        if (now - quiet_since >= a.idle_exit_ticks && SVC_LD_DEV(&D->busy) == 0) return 2;
+        if (now - quiet_since >= a.idle_exit_ticks && SVC_LD_DEV(&D->busy) == 0) { atomicExch(&D->draining, 1u); return 2; }
         svc_nap(nap);
         if (nap < 64) nap *= 2;
     }
@@ -1821,11 +1826,17 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
 static_assert(sizeof(EncLds) <= 5 * 1280, "five 1280-byte LDS granules per chunk: 25 chunks fit a CU's 160 KiB, the registers allow 24");
 // A wave leaves: the last one of the launch tells the host (pinned memory) that the launch is over, and when it began and ended.
 __device__ ZS_NOINLINE static void svc_wave_exit(tsx_svc_host* H, tsx_svc_dev* D, uint32_t launch_id) {
-    atomicSub(&D->live, 1u);
+    SVC_ST_MIRROR(&H->m_live, atomicSub(&D->live, 1u) - 1u);
     if (atomicAdd(&D->exited, 1u) + 1u != gridDim.x) return;
+    // the last wave: the other statistics words as they stand (tsx_svc_host.m_*)
+    SVC_ST_MIRROR(&H->m_live_max, SVC_LD_DEV(&D->live_max)); SVC_ST_MIRROR(&H->m_wave_starts, SVC_LD_DEV(&D->stat_wave_starts));
+    SVC_ST_MIRROR(&H->m_reserved_exits, SVC_LD_DEV(&D->stat_reserved_exits)); SVC_ST_MIRROR(&H->m_skipped, SVC_LD_DEV(&D->stat_skipped));
+    SVC_ST_MIRROR(&H->m_yields, SVC_LD_DEV(&D->stat_yields)); SVC_ST_MIRROR(&H->m_returned, SVC_LD_DEV(&D->stat_returned));
+    SVC_ST_MIRROR(&H->m_chunks, SVC_LD_DEV(&D->stat_chunks));
     const uint64_t now = svc_now();
     const uint64_t first = ((uint64_t)SVC_LD_DEV(&D->t_first_hi) << 32) | SVC_LD_DEV(&D->t_first_lo);
     SVC_ST_DEV(&D->entered, 0u); SVC_ST_DEV(&D->exited, 0u);            // the next launch counts from zero (it is only started once this one is seen ended)
+    SVC_ST_DEV(&D->draining, 0u);
     for (uint32_t g = 0; g < 256u; g++) if (SVC_LD_DEV(&D->kept[g])) SVC_ST_DEV(&D->kept[g], 0u);
 #ifdef HIPEMU
     H->t_first = first; H->t_last = now;
@@ -1843,7 +1854,9 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     const uint64_t t_start = svc_now();
     if (lane == 0) {
         if (atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
-        atomicMax(&D->live_max, atomicAdd(&D->live, 1u) + 1u);
+        const uint32_t lv = atomicAdd(&D->live, 1u) + 1u;
+        atomicMax(&D->live_max, lv);
+        SVC_ST_MIRROR(&H->m_live, lv);
     }
     if (a.calibrate_ticks) {                                              // how many of these workgroups does the chip hold at once?  (svc_create)
         if (lane == 0) { while (svc_now() - t_start < a.calibrate_ticks) svc_nap(1); svc_wave_exit(H, D, a.launch_id); }
@@ -1898,7 +1911,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
             // at the end of a finished chunk: the next wave may sit on another XCD, behind another L2) before another wave can start it
             // again - and this wave leaves its CU to the fetch's kernels
             __syncthreads();
-            if (lane == 0) { svc_release_system(); svc_return_chunk(D, mg, chunk); atomicAdd(&D->stat_yields, 1u); atomicSub(&D->busy, 1u); }
+            if (lane == 0) { svc_release_system(); svc_return_chunk(D, mg, chunk); SVC_ST_MIRROR(&H->m_yields, atomicAdd(&D->stat_yields, 1u) + 1u); atomicSub(&D->busy, 1u); }
             break;
         }
         // ---- this chunk is done: tell its member's caller when it was the member's last one ----
@@ -1908,7 +1921,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         __syncthreads();
         if (lane == 0) {
             svc_release_system();
-            atomicAdd(&D->stat_chunks, 1u);
+            SVC_ST_MIRROR(&H->m_chunks, atomicAdd(&D->stat_chunks, 1u) + 1u);
             if (atomicAdd(done, 1u) + 1u == n) {
                 atomicExch(done, 0u);                                    // ready for the context's next member (ordered before it by the flag)
                 svc_release_system();

@@ -507,21 +507,19 @@ void GpuTransformChunkEnumeration::fillBatchIfNeeded() {
     crcs_.insert(crcs_.end(), b.crcs.begin(), b.crcs.end());
     if (readAhead_) ahead_ = std::async(std::launch::async, [this] { return transformNextBatch(); });
 }
-size_t GpuTransformChunkEnumeration::appendNextBatchPacked(Bytes& object, std::vector<int>& sizes) {
-    if (next_ < ready_.size() || ahead_.valid()) throw std::logic_error("appendNextBatchPacked after nextElement inside a batch");
+GpuTransformChunkEnumeration::PackedBatch GpuTransformChunkEnumeration::transformNextBatchPacked() {
+    PackedBatch out;
     std::vector<Bytes> in;
     while ((int)in.size() < batch_ && inner_->hasMoreElements()) in.push_back(inner_->nextElement());
-    if (in.empty()) return 0;
+    if (in.empty()) return out;
     const uint32_t flags = (compress_ ? TSX_COMPRESS : 0u) | (enc_ ? TSX_ENCRYPT : 0u) | (withCrc_ ? TSX_CRC : 0u);
-    const size_t at = object.size();
-    size_t total = 0;
     if ((flags & (TSX_COMPRESS | TSX_ENCRYPT)) == 0) {                   // pure base: the chunks are the object
         for (const Bytes& c : in) {
-            object.insert(object.end(), c.begin(), c.end());
-            total += c.size(); sizes.push_back((int)c.size());
-            if (withCrc_) crcs_.push_back(be_->crc32c(c.data(), c.size()));
+            out.object.insert(out.object.end(), c.begin(), c.end());
+            out.sizes.push_back((int)c.size());
+            if (withCrc_) out.crcs.push_back(be_->crc32c(c.data(), c.size()));
         }
-        return total;
+        return out;
     }
     std::vector<tsx_chunk_desc> d(in.size());
     size_t so = 0, bound = 0;
@@ -534,14 +532,25 @@ size_t GpuTransformChunkEnumeration::appendNextBatchPacked(Bytes& object, std::v
     Bytes src(so + 16);
     for (size_t i = 0; i < in.size(); i++) if (!in[i].empty()) memcpy(src.data() + d[i].src_off, in[i].data(), in[i].size());
     const tsx_batch_params p = makeParams(flags, enc_ ? &enc_->dataKey : nullptr, enc_ ? &enc_->aad : nullptr, profile_);
-    object.resize(at + bound);                                         // room for the worst case, trimmed to what was produced
-    be_->transformBatchPacked(p, d, src.data(), src.size(), object.data() + at, bound);
+    out.object.resize(bound);                                          // room for the worst case, trimmed to what was produced
+    be_->transformBatchPacked(p, d, src.data(), src.size(), out.object.data(), bound);
+    size_t total = 0;
     for (size_t i = 0; i < in.size(); i++) {
-        if (d[i].status != TSX_OK) { object.resize(at); throw std::runtime_error(be_->strerror(d[i].status)); }
-        if (withCrc_) crcs_.push_back(d[i].crc32c);
-        sizes.push_back((int)d[i].dst_len); total += d[i].dst_len;
+        if (d[i].status != TSX_OK) throw std::runtime_error(be_->strerror(d[i].status));
+        if (withCrc_) out.crcs.push_back(d[i].crc32c);
+        out.sizes.push_back((int)d[i].dst_len); total += d[i].dst_len;
     }
-    object.resize(at + total);
+    out.object.resize(total);
+    return out;
+}
+size_t GpuTransformChunkEnumeration::appendNextBatchPacked(Bytes& object, std::vector<int>& sizes) {
+    if (next_ < ready_.size() || ahead_.valid()) throw std::logic_error("appendNextBatchPacked after nextElement inside a batch");
+    PackedBatch b = transformNextBatchPacked();
+    if (b.sizes.empty()) return 0;
+    if (object.empty()) object = std::move(b.object); else object.insert(object.end(), b.object.begin(), b.object.end());
+    sizes.insert(sizes.end(), b.sizes.begin(), b.sizes.end());
+    crcs_.insert(crcs_.end(), b.crcs.begin(), b.crcs.end());
+    size_t total = 0; for (int v : b.sizes) total += (size_t)v;
     return total;
 }
 bool GpuTransformChunkEnumeration::hasMoreElements() { fillBatchIfNeeded(); return next_ < ready_.size(); }
@@ -593,6 +602,82 @@ Bytes TransformFinisher::toBytes() {
     Bytes out;
     while (hasMoreElements()) { const Bytes c = nextElement(); out.insert(out.end(), c.begin(), c.end()); }
     return out;
+}
+
+// ---- GpuTransformFinisher (Java: java/io/aiven/kafka/tieredstorage/gpu/GpuTransformFinisher.java) ------------------------
+GpuTransformFinisher::GpuTransformFinisher(std::shared_ptr<GpuTransformChunkEnumeration> inner, int originalFileSize, bool chunkingEnabled,
+                                           std::shared_ptr<TokenBucket> rateLimitingBucket, bool readAhead)
+    : inner_(std::move(inner)), bucket_(std::move(rateLimitingBucket)), readAhead_(readAhead) {
+    if (!inner_) throw std::invalid_argument("inner cannot be null");
+    if (originalFileSize < 0) throw std::invalid_argument("originalFileSize must be non-negative, " + std::to_string(originalFileSize) + " given");
+    const int originalChunkSize = chunkingEnabled ? inner_->originalChunkSize() : originalFileSize;      // TransformFinisher.java:68
+    const std::optional<int> t = inner_->transformedChunkSize();                                          // :75-93
+    if (!t) builder_.reset(new VariableSizeChunkIndexBuilder(originalChunkSize, originalFileSize));
+    else builder_.reset(new FixedSizeChunkIndexBuilder(originalChunkSize, originalFileSize, *t));
+}
+GpuTransformFinisher::~GpuTransformFinisher() {
+    if (ahead_.valid()) { try { ahead_.get(); } catch (...) {} }       // the helper uses inner_: it is gone before the members are
+}
+// The next packed batch becomes the one being read.  Sizes go to the index builder in order, the newest one held back: the reference
+// calls addChunk for every chunk but the object's last and finish for that one (TransformFinisher.java:101-110), and which chunk is
+// the last is only known when the batch behind it comes back empty.
+bool GpuTransformFinisher::nextBatch() {
+    if (exhausted_) return false;
+    GpuTransformChunkEnumeration::PackedBatch b = ahead_.valid() ? ahead_.get() : inner_->transformNextBatchPacked();
+    if (b.sizes.empty()) {
+        exhausted_ = true;
+        if (pending_) { chunkIndex_ = builder_->finish(*pending_); pending_.reset(); }
+        cur_.clear(); pos_ = 0;
+        return false;
+    }
+    for (int v : b.sizes) {
+        if (pending_) builder_->addChunk(*pending_);
+        pending_ = v;
+    }
+    crcs_.insert(crcs_.end(), b.crcs.begin(), b.crcs.end());
+    cur_ = std::move(b.object); pos_ = 0;
+    if (readAhead_) ahead_ = std::async(std::launch::async, [this] { return inner_->transformNextBatchPacked(); });
+    return true;
+}
+size_t GpuTransformFinisher::fillPart(uint8_t* part, size_t capacity) {
+    size_t at = 0;
+    while (at < capacity) {
+        if (pos_ >= cur_.size() && !nextBatch()) break;
+        const size_t m = std::min(capacity - at, cur_.size() - pos_);
+        memcpy(part + at, cur_.data() + pos_, m);
+        pos_ += m; at += m;
+    }
+    return at;
+}
+namespace {
+class PackedObjectStream : public InputStream {
+public:
+    explicit PackedObjectStream(GpuTransformFinisher* f) : f_(f) {}
+    long read(uint8_t* b, size_t len) override {                       // like SequenceInputStream: at most what the current batch still holds
+        if (len == 0) return 0;
+        const size_t m = f_->readSome(b, len);
+        return m ? (long)m : -1;
+    }
+
+private:
+    GpuTransformFinisher* f_;
+};
+}  // namespace
+size_t GpuTransformFinisher::readSome(uint8_t* b, size_t len) {
+    while (pos_ >= cur_.size()) if (!nextBatch()) return 0;
+    const size_t m = std::min(len, cur_.size() - pos_);
+    memcpy(b, cur_.data() + pos_, m);
+    pos_ += m;
+    return m;
+}
+std::shared_ptr<InputStream> GpuTransformFinisher::toInputStream() {
+    std::shared_ptr<InputStream> s = std::make_shared<PackedObjectStream>(this);
+    if (bucket_) s = std::make_shared<RateLimitedInputStream>(s, bucket_);     // TransformFinisher.java:146-151
+    return s;
+}
+std::shared_ptr<ChunkIndex> GpuTransformFinisher::chunkIndex() {
+    if (!chunkIndex_) throw std::logic_error("Chunk index was not built, was finisher used?");      // TransformFinisher.java:112-122
+    return chunkIndex_;
 }
 
 // =====================================================================================================

@@ -258,6 +258,10 @@ public:
     // (S3MultiPartOutputStream.java:89-122) - instead of one Bytes per chunk and a gather copy.  Appends each chunk's
     // transformed size to `sizes`; returns the bytes appended, 0 when `inner` is exhausted.  Do not mix with nextElement().
     size_t appendNextBatchPacked(Bytes& object, std::vector<int>& sizes);
+    // ... and the batch on its own: the transformed chunks back to back, their sizes, their CRCs (GpuTransformFinisher reads it from here;
+    // callable from a helper thread as long as nobody else touches this object meanwhile).  Empty sizes: `inner` is exhausted.
+    struct PackedBatch { Bytes object; std::vector<int> sizes; std::vector<uint32_t> crcs; };
+    PackedBatch transformNextBatchPacked();
 
 private:
     struct Batch { std::vector<Bytes> chunks; std::vector<uint32_t> crcs; };
@@ -300,6 +304,38 @@ private:
     std::unique_ptr<AbstractChunkIndexBuilder> builder_;
     int originalFileSize_;
     std::shared_ptr<ChunkIndex> chunkIndex_;
+};
+
+// SURVEY §8 f3, the upload sink without per-chunk arrays: TransformFinisher (TransformFinisher.java:48-151) for the GPU chain.  A batch of
+// chunks is transformed back to back into ONE buffer (TSX_MEM_HOST_PACKED; on the JVM side a pinned direct ByteBuffer the compressor waves
+// write into), the uploader's reads are served straight from it (SequenceInputStream semantics: a read never crosses a batch), the
+// chunk index is fed from the batch's descriptor sizes, the rate limit wraps the stream as in the reference.  Twin of
+// java/io/aiven/kafka/tieredstorage/gpu/GpuTransformFinisher.java - same members, same order of operations.
+class GpuTransformFinisher {
+public:
+    GpuTransformFinisher(std::shared_ptr<GpuTransformChunkEnumeration> inner, int originalFileSize, bool chunkingEnabled = true,
+                         std::shared_ptr<class TokenBucket> rateLimitingBucket = nullptr, bool readAhead = true);
+    ~GpuTransformFinisher();
+    std::shared_ptr<InputStream> toInputStream();          // TransformFinisher.toInputStream(): rate limited when a bucket was given
+    // a sink with part buffers of its own (S3MultiPartOutputStream.java:89-122, partBuffer.put): fills `part` from the object, across
+    // batches; returns the bytes written, less than `capacity` only at the object's end
+    size_t fillPart(uint8_t* part, size_t capacity);
+    size_t readSome(uint8_t* b, size_t len);               // at most what the current batch still holds; 0 at the object's end
+    std::shared_ptr<ChunkIndex> chunkIndex();              // "Chunk index was not built, was finisher used?" until the object has been drained
+    const std::vector<uint32_t>& crc32cOfOriginalChunks() const { return crcs_; }
+
+private:
+    bool nextBatch();
+    std::shared_ptr<GpuTransformChunkEnumeration> inner_;
+    std::unique_ptr<AbstractChunkIndexBuilder> builder_;
+    std::shared_ptr<class TokenBucket> bucket_;
+    bool readAhead_;
+    Bytes cur_; size_t pos_ = 0;                           // the batch being read
+    std::future<GpuTransformChunkEnumeration::PackedBatch> ahead_;     // the batch behind it, being transformed
+    std::optional<int> pending_;                           // size of the newest chunk: addChunk or finish, once it is known which
+    std::shared_ptr<ChunkIndex> chunkIndex_;
+    std::vector<uint32_t> crcs_;
+    bool exhausted_ = false;
 };
 
 // ---- fetch side --------------------------------------------------------------------------------------------

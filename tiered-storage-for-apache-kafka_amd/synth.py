@@ -188,6 +188,48 @@ def _crc32c_table():
     return _CRC32C_TABLE
 
 
+_CRC_W = 256
+_CRC_ZW = None
+
+
+def _crc32c_many(buf, start, length):
+    """CRC32C of buf[start[i] : start[i] + length[i]] for every i (uint32 array; lengths >= 4).  The recurrence is byte-serial, so the
+    regions are cut into blocks of _CRC_W bytes aligned to their ENDS (zeros in front of a message do not change a CRC that starts from
+    0; the initial value 0xFFFFFFFF is the same as complementing the first four bytes): all blocks of all regions advance in lockstep,
+    then each region folds its blocks front to back with the "append _CRC_W zero bytes" operator (linear: four 256-entry tables)."""
+    global _CRC_ZW
+    T = _crc32c_table()
+    W = _CRC_W
+    if _CRC_ZW is None:
+        z = np.concatenate([np.arange(256, dtype=np.uint32) << np.uint32(8 * k) for k in range(4)])
+        for _ in range(W):
+            z = T[z & 0xFF] ^ (z >> 8)
+        _CRC_ZW = z.reshape(4, 256)
+    start = np.asarray(start, np.int64); length = np.asarray(length, np.int64)
+    nblk = (length + W - 1) // W
+    first = np.cumsum(nblk) - nblk                                    # index of a region's first (front, possibly short) block
+    tot = int(nblk.sum())
+    reg = np.repeat(np.arange(start.size), nblk)
+    j = np.arange(tot) - first[reg]                                   # block index inside its region, front to back
+    bend_ = (start + length)[reg] - (nblk[reg] - 1 - j) * W           # one past the block's last byte
+    lo = start[reg]
+    s = np.zeros(tot, np.uint32)
+    head = np.zeros(tot, bool); head[first] = True
+    for c in range(W):
+        p = bend_ - W + c
+        ok = p >= lo
+        byte = np.where(ok, buf[np.where(ok, p, 0)], 0).astype(np.uint32)
+        byte = np.where(ok & (p < lo + 4), byte ^ 0xFF, byte)         # the initial value
+        s = T[(s ^ byte) & 0xFF] ^ (s >> 8)
+    Z = _CRC_ZW
+    crc = s[first].copy()
+    for k in range(1, int(nblk.max())):
+        act = k < nblk
+        nxt = Z[0][crc & 0xFF] ^ Z[1][(crc >> 8) & 0xFF] ^ Z[2][(crc >> 16) & 0xFF] ^ Z[3][crc >> 24] ^ s[np.where(act, first + k, 0)]
+        crc = np.where(act, nxt, crc)
+    return ~crc
+
+
 def _be(value, width):
     """(len(value), width) uint8: big-endian bytes of an int64 array (two's complement)."""
     v = value.astype(np.int64)
@@ -278,18 +320,10 @@ def _gen_record_batches(n, key, segment, chunk):
     out = np.where(inrec, body, out)
     out = out.astype(np.uint8)
     # ---- CRC32C of every complete batch over [attributes .. end) -> header bytes 17..20 ----
-    T = _crc32c_table()
     full = bend <= n
     idx = np.nonzero(full)[0]
     if idx.size:
-        st_, ln_ = bstart[idx] + 21, blen[idx] - 21
-        crc = np.full(idx.size, 0xFFFFFFFF, np.uint32)
-        for j in range(int(ln_.max())):
-            act = j < ln_
-            byte = out[np.where(act, st_ + j, 0)].astype(np.uint32)
-            nxt = T[(crc ^ byte) & 0xFF] ^ (crc >> 8)
-            crc = np.where(act, nxt, crc)
-        crc = ~crc
+        crc = _crc32c_many(out, bstart[idx] + 21, blen[idx] - 21)
         cb = _be(crc.astype(np.int64), 4)
         for k in range(4):
             out[bstart[idx] + 17 + k] = cb[:, k]

@@ -209,6 +209,39 @@ PY
         nf=""; [ "$2" = "nofetch" ] && nf="--no-fetch"
         timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers 5 --seconds ${MIXED_SECONDS:-12} --config fetch_quiet_ms=$1 $nf --tag "fetch_quiet_ms=$1 $2" 2>> $O/guests.err | tee -a $O/guests.jsonl
       done ;;
+    guestsrep)
+      # the no-fetch guest-wave run repeated arg times (default 6) with completion stamps: does the window lose seconds, and where?
+      export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/guests.err
+      for i in $(seq 1 ${arg:-6}); do
+        timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers 5 --seconds ${MIXED_SECONDS:-12} --config fetch_quiet_ms=500 --no-fetch --sample-service --tag "rep $i fetch_quiet_ms=500 nofetch" 2>> $O/guests.err | tee -a $O/guestsrep.jsonl | cut -c1-700
+      done ;;
+    decab)
+      # fetch-side latency, round 4's tree (tools/_ab/r4tree, built at home from a72b84f) against HEAD, alternating processes on this box
+      for i in 1 2; do
+        for t in r4 head; do
+          if [ $t = r4 ]; then ( cd $R/tools/_ab/r4tree && timeout 300 python tools/dec_latency.py ${arg:-256} 2>> $O/decab.err | sed "s/^{/{\"tree\": \"r4\", \"round\": $i, /" ) >> $O/decab.jsonl
+          else timeout 300 python tools/dec_latency.py ${arg:-256} 2>> $O/decab.err | sed "s/^{/{\"tree\": \"head\", \"round\": $i, /" >> $O/decab.jsonl; fi
+        done
+      done
+      python - <<PY
+import json
+rows = [json.loads(l) for l in open("$O/decab.jsonl") if l.startswith("{")]
+for form in ("blocks", "chunks"):
+    for mem in ("host", "device"):
+        for n in (1, 4, 64, 256):
+            r = {t: sorted(x["ms_median"] for x in rows if x["tree"] == t and x["form"] == form and x["mem"] == mem and x["chunks"] == n) for t in ("r4", "head")}
+            print(form, mem, n, "r4", r["r4"], "head", r["head"])
+PY
+      ;;
+    prof)
+      # lap timers of the compressor wave (tools/_libs/libtsxform_prof.so, built at home with `make -C .../csrc prof`): arg = "dist,profile[,chain]" ...
+      for v in ${arg//+/ }; do set -- ${v//,/ }
+        ch=""; [ "$3" = "chain" ] && ch="--chain"
+        u=256; [ "$1" = "B" ] && u=8
+        timeout 400 python tools/prof_zstd.py --chunks ${PROF_CHUNKS:-2048} --dist $1 --profile $2 --uniq $u $ch --out $O/prof_$1_$2${3:+_$3}.json > /dev/null 2>> $O/prof.err
+        python tools/show_prof.py $O/prof_$1_$2${3:+_$3}.json 2>/dev/null || tail -c 1500 $O/prof_$1_$2${3:+_$3}.json
+      done ;;
     keepwaves)
       # compressor waves that stay on the reserved CU of every shader engine (svc_keep_waves): fetch latency and upload rate, device-resident 2048-chunk batches, no torch
       export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}

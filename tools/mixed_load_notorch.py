@@ -144,6 +144,15 @@ def run(args):
         time.sleep(quiet_ms[0] / 1e3 + 0.2)                              # the warm-up fetches are forgotten: the uploads begin with guest waves on the reserved CUs
     sv0 = N.service_stats(0)
     t0 = time.perf_counter()
+    samples = []; sampling = [args.sample_service]
+
+    def sampler():                                                       # where does a window lose its seconds?  device-side progress every 100 ms
+        while sampling[0]:
+            st_ = N.service_stats(0)
+            samples.append([round(time.perf_counter() - t0, 2)] + [int(st_[k]) for k in ("device_chunks", "live_waves", "running", "launches", "watchdog_launches")])
+            time.sleep(0.1)
+
+    sth = threading.Thread(target=sampler); sth.start()
     [x.start() for x in th]
     time.sleep(2.0)
     lat = {1: [], 4: []}; first = {}
@@ -156,6 +165,7 @@ def run(args):
     stop[0] = True
     [x.join() for x in th]
     el = time.perf_counter() - t0
+    sampling[0] = False; sth.join()
     assert args.no_fetch or np.array_equal(hbk, hsrc[:4 * CH])
     assert all((x["status"] == 0).all() for x in ds)
     st = N.service_stats(0)
@@ -164,6 +174,10 @@ def run(args):
            "compress_gibs_whole_window": round(sum(done) * n * CH / GiB / el, 3), "fetch_idle_ms": idle}
     out["service"] = {k: st[k] - sv0[k] for k in ("launches", "guest_launches", "yielded_waves", "returned_chunks", "readmissions", "rotations")}
     out["completions_at_s"] = [round(float(x - t0), 2) for x in sorted(stamps)]; out["window_s"] = round(el, 2)
+    if samples:
+        # chunks the device finished per 100 ms sample (a hole shows as a run of zeros), and the samples around the slowest second
+        a = np.asarray(samples); dc = np.diff(a[:, 1]); out["service_samples"] = {"fields": ["at_s", "device_chunks", "live_waves", "running", "launches", "watchdog_launches"],
+            "chunks_per_sample": dc.tolist(), "live_waves": a[:, 2].tolist(), "running": a[:, 3].tolist(), "launches": a[:, 4].tolist(), "at_s": a[:, 0].tolist()}
     da = np.sort(np.asarray(stamps)) - t0
     if da.size >= 8:
         k0, k1 = int(da.size * 0.2), int(da.size * 0.8)
@@ -185,6 +199,7 @@ if __name__ == "__main__":
     ap.add_argument("--reserved-cus", type=int, default=-1)
     ap.add_argument("--max-launch-ms", type=int, default=-1)
     ap.add_argument("--no-fetch", action="store_true")
+    ap.add_argument("--sample-service", action="store_true", help="record tsx_service_stats every 100 ms (device-side progress over the window)")
     ap.add_argument("--config", default="", help="key=value,... for tsx_debug_config before tsx_init (measurement variants)")
     ap.add_argument("--phases", action="store_true")
     ap.add_argument("--phases-short", action="store_true", help="with --phases: stop after phase C")

@@ -12,10 +12,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-NAMES = {0: "setup+table zero", 1: "split_block", 2: "match: search steps", 3: "match: extend+store", 4: "match: post (compl. insert, rep loop, tail)",
+NAMES = {0: "setup+table zero", 1: "split_block", 2: "match: search steps", 3: "match: extend+store", 4: "match_block (parse of the block, whole)",
          5: "lit: histogram/sample", 6: "lit: lane0 huffman build", 7: "lit: huffman encode", 8: "seq: codes+hist", 9: "seq: lane0 FSE tables",
          10: "seq: lane0 encode", 11: "emit/copy + misc", 12: "#search steps", 13: "#sequences", 14: "total cycles", 15: "sum K (positions evaluated)",
-         16: "  step: src window load", 17: "  step: hash + table loads", 18: "  step: collision scoreboard", 19: "#steps with hash collision (slow path)", 20: "#steps with a far candidate (global)", 21: "#extension passes from global"}
+         16: "CRC32C head", 17: "GCM tail / copy to the slot", 18: "gather literals", 19: "#steps with hash collision (slow path)", 20: "#blocks", 21: "#extension passes from global"}
 
 
 def main():
@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--data", default="", help=".npy cache of the 256 distinct chunks (made on first use): keeps generator kernels out of rocprofv3 runs")
     ap.add_argument("--chain", action="store_true", help="full chain (CRC head + compress + GCM tail in the compressor wave) instead of compress only")
+    ap.add_argument("--uniq", type=int, default=256, help="distinct chunks (replicated to --chunks); content B is generated on the host, ~5 s per chunk")
+    ap.add_argument("--profile", default="1_5_7", choices=["1_5_7", "1_5_6"], help="Zstd profile (the 1.5.7 pre-splitter on / off)")
     ap.add_argument("--lib", default="libtsxform_prof.so", help="libtsxform_prof.so (lap timers) or libtsxform.so (plain, for rocprofv3 runs)")
     args = ap.parse_args()
     import torch
@@ -37,7 +39,7 @@ def main():
     n, CH = args.chunks, synth.CHUNK
     dev = torch.device("cuda", 0)
     src = torch.empty(n * CH, dtype=torch.uint8, device=dev)
-    uniq = min(n, 256)                                   # one distinct segment, replicated (profiling only)
+    uniq = min(n, args.uniq)                                   # one distinct segment, replicated (profiling only)
     if args.data and os.path.exists(args.data):
         src[:uniq * CH] = torch.from_numpy(np.load(args.data)[:uniq * CH]).to(dev)
     else:
@@ -61,7 +63,7 @@ def main():
     d["src_len"] = CH
     d["dst_off"] = np.arange(n, dtype=np.uint64) * slot
     d["dst_cap"] = slot
-    params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=nat.ZSTD_PROFILE_1_5_7)
+    params = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=nat.ZSTD_PROFILE_1_5_7 if args.profile == "1_5_7" else nat.ZSTD_PROFILE_1_5_6)
     ctx = N.ctx_create(0, n, CH)
     res = {}
     for it in range(2):
