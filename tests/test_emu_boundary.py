@@ -455,9 +455,9 @@ def test_zero_copy_output_equals_the_copy_path(emu, oracle, kind, ctxless, flags
 
 def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
     """tsx_config.fetch_reserved_cus (default: one compute unit per shader engine that a fetch under full upload load finds free)
-    decides which waves of the service leave at once (fetch_quiet_ms = 0, the default: always; otherwise while fetches are about); bytes and statuses are the same
-    with a reservation, without one, and with the environment's override, context-less and with a context, slot and packed layout; the fetch
-    side is untouched.  With fetch_quiet_ms set, a process that has not fetched for that long compresses on the reserved CUs too (guest waves)."""
+    decides which waves of the service leave at once (fetch_quiet_ms = 0: always; otherwise - the default since round 6, 2000 ms - while fetches are about);
+    bytes and statuses are the same with a reservation, without one, and with the environment's override, context-less and with a context, slot and packed
+    layout; the fetch side is untouched.  With fetch_quiet_ms set, a process that has not fetched for that long compresses on the reserved CUs too (guest waves)."""
     code = """
         import os, hashlib, numpy as np
         import tsxform
@@ -481,16 +481,18 @@ def test_reserved_cus_change_nothing_but_where_the_waves_run(emu):
         print(hashlib.sha256(b"".join(a)).hexdigest(), s["reserved_cus"], s["reserved_exits"] > 0, s["launches"], s["wave_starts"], s["reserved_exits"], s["waves"],
               s["guest_launches"], s2["launches"] - s["launches"], s2["guest_launches"] - s["guest_launches"], s2["reserved_exits"] - s["reserved_exits"])
         """
-    engaged = _run_py(code % "").strip().splitlines()[-1].split()
+    engaged = _run_py(code % "fetch_quiet_ms=0").strip().splitlines()[-1].split()
     without = _run_py(code % "fetch_reserved_cus=0").strip().splitlines()[-1].split()
     by_env = _run_py(code % "fetch_reserved_cus=0", TSX_FETCH_RESERVED_CUS=1, TSX_FETCH_QUIET_MS=0).strip().splitlines()[-1].split()
     assert engaged[0] == without[0] == by_env[0]
     assert engaged[1:3] == ["1", "True"] and without[1:3] == ["0", "False"] and by_env[1:3] == ["1", "True"]      # (the harness has 4 CUs: at most one is reserved)
     assert engaged[7] == "0" and without[7] == "0"
-    # opt-in (fetch_quiet_ms != 0): nobody has fetched yet - every launch's waves use the reserved CU as well; after the first fetch they leave it alone
-    guests = _run_py(code % "fetch_quiet_ms=10000").strip().splitlines()[-1].split()
-    assert guests[0] == engaged[0] and guests[1:3] == ["1", "False"] and guests[7] == guests[3] and int(guests[3]) >= 3
-    assert int(guests[8]) >= 1 and guests[9] == "0" and int(guests[10]) > 0
+    # fetch_quiet_ms != 0 (the default is 2000): nobody has fetched yet - every launch's waves use the reserved CU as well (creating a context needs room
+    # for a moment but is no fetch); after the first fetch they leave it alone
+    for cfg in ("fetch_quiet_ms=10000", ""):
+        guests = _run_py(code % cfg).strip().splitlines()[-1].split()
+        assert guests[0] == engaged[0] and guests[1:3] == ["1", "False"] and guests[7] == guests[3] and int(guests[3]) >= 3, (cfg, guests)
+        assert int(guests[8]) >= 1 and guests[9] == "0" and int(guests[10]) > 0, (cfg, guests)
     # ... and some of the compressor's waves may stay on a reserved CU all the same (tsx_config.fetch_shared_cu_waves: a CU shared between
     # fetches and uploads): exactly that many per launch, counted afresh by every launch
     kept = _run_py(code % "fetch_shared_cu_waves=2, fetch_quiet_ms=0").strip().splitlines()[-1].split()
@@ -569,5 +571,5 @@ def test_tsx_config_sizes_and_the_environment():
         print(vals["reserved_cus"], vals["svc_max_launch_ms"], vals["svc_keep_waves"], vals["fetch_quiet_ms"])
         N.lib.tsx_shutdown()
         """, TSX_SERVICE_MAX_LAUNCH_MS=777).strip().splitlines()
-    assert out[-2].split() == ["0", "777", "3", "0"]                    # the environment overrides service_max_launch_ms; fetch_quiet_ms untouched by the old struct
+    assert out[-2].split() == ["0", "777", "3", "2000"]                 # the environment overrides service_max_launch_ms; fetch_quiet_ms untouched by the old struct (its default: 2000)
     assert out[-1].split() == ["7", "777", "8", "2500"]                 # (7: what the first process-wide debug_config left - reserved_cus at TSX_CFG_DEFAULT keeps the current value; 99 waves are capped at 8)

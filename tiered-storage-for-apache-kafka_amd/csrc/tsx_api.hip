@@ -27,7 +27,7 @@ struct tsx_cfg {
     uint32_t reserved_cus = 0xFFFFFFFFu;  // compute units the compressor service leaves to everything else (0xFFFFFFFF: one per shader engine); TSX_FETCH_RESERVED_CUS
     uint32_t svc_max_launch_ms = 60000;   // age limit of one launch of the service kernel (0 = none); TSX_SERVICE_MAX_LAUNCH_MS
     uint32_t svc_idle_exit_us = 2000;     // the service kernel ends when it has had nothing to do for this long (callers in a closed loop need ~1 ms to come back)
-    uint32_t fetch_quiet_ms = 0;          // tsx_config.fetch_quiet_ms: the reserved CUs work for the compressor too (guest waves) once no fetch has been seen for this long; 0 = never (default); TSX_FETCH_QUIET_MS
+    uint32_t fetch_quiet_ms = 2000;       // tsx_config.fetch_quiet_ms: the reserved CUs work for the compressor too (guest waves) once no fetch has been seen for this long; 0 = never; TSX_FETCH_QUIET_MS
     uint32_t svc_keep_waves = 0;          // tsx_config.fetch_shared_cu_waves: compressor waves that stay on a reserved CU all the same; TSX_FETCH_SHARED_CU_WAVES
     long long pool_idle_bytes = -1;       // idle pooled workspace kept per device (-1: 4/9 of its memory); TSX_POOL_IDLE_BYTES
     uint32_t zstd_sched = 0;              // parser speculation schedule k0 | k1 << 8 (0 = the kernel's default; same bytes); TSX_ZSTD_SCHED
@@ -247,9 +247,12 @@ static void svc_foreground_begin(tsx_device* dev) {
     dev->svc->fg_inflight.fetch_add(1, std::memory_order_seq_cst);
     __atomic_store_n(&dev->svc->h->yield, 1u, __ATOMIC_SEQ_CST);
 }
-static void svc_foreground_end(tsx_device* dev) {
+// traffic = false: something that only needed room while it ran (a new context's first small copies, a helper copy) - it does not count as
+// a fetch having been seen: the next member published finds the device quiet and asks the launch, whose guests have left, to make way for one
+// that uses every CU again (svc_submit, readmission)
+static void svc_foreground_end(tsx_device* dev, bool traffic = true) {
     if (!dev->svc) return;
-    dev->svc->fg_last_ns.store(steady_ns(), std::memory_order_seq_cst);
+    if (traffic) dev->svc->fg_last_ns.store(steady_ns(), std::memory_order_seq_cst);
     dev->svc->fg_inflight.fetch_sub(1, std::memory_order_seq_cst);
 }
 static bool svc_quiet(const tsx_service& s) {
@@ -744,7 +747,10 @@ extern "C" int tsx_ctx_create(int device_index, uint32_t max_chunks, uint32_t ma
     if (!c) return TSX_E_NOMEM;
     tsx_device_scope keep;
     c->dev_index = device_index; c->dev = dev;
+    // a new context zeroes a few device words with small copies (blit kernels of the runtime): like a fetch, it asks guest waves for room
+    svc_foreground_begin(dev);
     int rc = ctx_init_device_objects(c);
+    svc_foreground_end(dev, false);
     if (rc == TSX_OK && max_chunks && max_chunk_size) rc = ctx_reserve(c, max_chunks, max_chunk_size, max_chunk_size, 0, false, 0, 0);
     if (rc) { ctx_free_device_mem(c); delete c; return rc; }     // a half-built context leaves nothing behind
     *out = c;
@@ -1840,13 +1846,22 @@ extern "C" int tsx_device_free(int device_index, void* p) {
     svc_free_dev(dev, p);                                               // (given back when the compressor service's kernel is gone: a free waits for every stream)
     return TSX_OK;
 }
+// (copies of pageable memory and small copies run as kernels of the runtime: guest waves make room for them as for a fetch)
 extern "C" int tsx_memcpy_h2d(int device_index, void* d, const void* s, size_t bytes) {
     tsx_device_scope keep;
-    int rc = set_dev(device_index); if (rc) return rc;
-    return hipMemcpy(d, s, bytes, hipMemcpyHostToDevice) == hipSuccess ? TSX_OK : TSX_E_DEVICE;
+    tsx_device* dev = nullptr;
+    int rc = set_dev(device_index, &dev); if (rc) return rc;
+    svc_foreground_begin(dev);
+    const hipError_t e = hipMemcpy(d, s, bytes, hipMemcpyHostToDevice);
+    svc_foreground_end(dev, false);
+    return e == hipSuccess ? TSX_OK : TSX_E_DEVICE;
 }
 extern "C" int tsx_memcpy_d2h(int device_index, void* d, const void* s, size_t bytes) {
     tsx_device_scope keep;
-    int rc = set_dev(device_index); if (rc) return rc;
-    return hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TSX_OK : TSX_E_DEVICE;
+    tsx_device* dev = nullptr;
+    int rc = set_dev(device_index, &dev); if (rc) return rc;
+    svc_foreground_begin(dev);
+    const hipError_t e = hipMemcpy(d, s, bytes, hipMemcpyDeviceToHost);
+    svc_foreground_end(dev, false);
+    return e == hipSuccess ? TSX_OK : TSX_E_DEVICE;
 }

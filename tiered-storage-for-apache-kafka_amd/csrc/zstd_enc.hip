@@ -158,9 +158,6 @@ struct HufTable { uint16_t val[256]; uint8_t nb[256]; uint32_t tableLog, maxSym;
 struct FseTable { uint16_t state[512]; uint32_t dnb[56]; int32_t dfs[56]; uint32_t tableLog; };
 struct NodeElt { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nbBits; };
 
-// Work arrays of the (lane-0, once per block) Huffman tree construction.  They live in the chunk's global workspace, not
-// in LDS: LDS per wave is what bounds how many chunks a CU can hold, and occupancy is this kernel's only latency cover.
-struct HufScratch { NodeElt nodes[514]; uint16_t rankBase[192], rankCurr[192]; };
 struct EncLds {
     int hufRepeat[2];           // 0 none, 1 check
     uint32_t scal[16];          // lane-0 -> wave broadcast slots
@@ -878,38 +875,56 @@ __device__ static inline void fse_encode(BitW& b, const FseTable& ct, uint32_t& 
 }
 
 // ---- Huffman (lane 0) -----------------------------------------------------------------------------------
+// HUF_buildCTable_wksp on lane 0, its work arrays in LDS.  Until round 6 they lived in the chunk's global workspace (a 514-node
+// array of structs needs 4112 contiguous bytes, more than any dead region of EncLds): ~2000 dependent global round trips per
+// table, 1.6 M cycles per block on content K and 3.0 M on content B, whose 4 MiB chunks are 164 blocks under profile 1.5.7 -
+// 14 % of a B chunk's time (profiles/r06_compressor_wave_laps_K_and_B.txt).  As separate arrays the nodes fit what is dead
+// while a table is built: leaves (sorted by count, index = rank) and internal nodes apart, `parent` and `nbBits` in ONE
+// 16-bit array (a node's depth replaces its parent index once it is known: depths are assigned from the root down and a
+// parent's index is always larger than its children's), the rank arrays of HUF_sort on top of the internal nodes' counts
+// (which do not exist yet while sorting).  3332 bytes: `of` holds 1280, the tail of `ml` .. `norm` 2052.
 #define RANK_TABLE 192
 #define RANK_LOG_BEGIN 158
 #define RANK_CUTOFF 165
+struct HufWork {
+    uint32_t* lcount;            // [-1 .. 255] leaves' counts in sorted order (lcount[-1] = the sentinel of HUF_buildTree)
+    uint8_t* lbyte;              // [256] ... and their symbols
+    uint32_t* icount;            // [256] internal nodes 256 .. 511
+    uint16_t* par;               // [512] parent index, then nbBits (leaves 0 .. 255, internal nodes 256 .. 511)
+    uint16_t* rankBase; uint16_t* rankCurr;      // [192] each, alias icount (HUF_sort only)
+};
 __device__ static inline uint32_t huf_getIndex(uint32_t c) { return c < RANK_CUTOFF ? c : hb32(c) + RANK_LOG_BEGIN; }
-__device__ static inline void huf_swap(NodeElt* a, NodeElt* b) { NodeElt t = *a; *a = *b; *b = t; }
-__device__ static void huf_insertionSort(NodeElt* h, int low, int high) {
+__device__ static inline void huf_swap(const HufWork& W, int a, int b) {
+    const uint32_t c = W.lcount[a]; const uint8_t y = W.lbyte[a];
+    W.lcount[a] = W.lcount[b]; W.lbyte[a] = W.lbyte[b]; W.lcount[b] = c; W.lbyte[b] = y;
+}
+__device__ static void huf_insertionSort(const HufWork& W, int base, int low, int high) {
     const int size = high - low + 1;
-    h += low;
+    const int h = base + low;
     for (int i = 1; i < size; ++i) {
-        const NodeElt key = h[i]; int j = i - 1;
-        while (j >= 0 && h[j].count < key.count) { h[j + 1] = h[j]; j--; }
-        h[j + 1] = key;
+        const uint32_t keyC = W.lcount[h + i]; const uint8_t keyB = W.lbyte[h + i]; int j = i - 1;
+        while (j >= 0 && W.lcount[h + j] < keyC) { W.lcount[h + j + 1] = W.lcount[h + j]; W.lbyte[h + j + 1] = W.lbyte[h + j]; j--; }
+        W.lcount[h + j + 1] = keyC; W.lbyte[h + j + 1] = keyB;
     }
 }
-__device__ static int huf_partition(NodeElt* arr, int low, int high) {
-    const uint32_t pivot = arr[high].count; int i = low - 1;
-    for (int j = low; j < high; j++) if (arr[j].count > pivot) { i++; huf_swap(&arr[i], &arr[j]); }
-    huf_swap(&arr[i + 1], &arr[high]);
+__device__ static int huf_partition(const HufWork& W, int base, int low, int high) {
+    const uint32_t pivot = W.lcount[base + high]; int i = low - 1;
+    for (int j = low; j < high; j++) if (W.lcount[base + j] > pivot) { i++; huf_swap(W, base + i, base + j); }
+    huf_swap(W, base + i + 1, base + high);
     return i + 1;
 }
 // HUF_simpleQuickSort with its recursion made explicit.  A CALL frame applies the insertion-sort threshold on
 // entry; a CONTinuation frame is the rest of the caller's `while (low < high)` loop, which partitions without
 // re-checking the threshold.  The two sides of a partition are disjoint, so their processing order is free.
-__device__ ZS_NOINLINE static void huf_quickSort(NodeElt* arr, int low0, int high0) {
+__device__ ZS_NOINLINE static void huf_quickSort(const HufWork& W, int base, int low0, int high0) {
     int stLo[64], stHi[64]; bool stCall[64]; int sp = 0;
     stLo[0] = low0; stHi[0] = high0; stCall[0] = true; sp = 1;
     while (sp) {
         --sp;
         const int low = stLo[sp], high = stHi[sp]; const bool call = stCall[sp];
-        if (call && high - low < 8) { huf_insertionSort(arr, low, high); continue; }
+        if (call && high - low < 8) { huf_insertionSort(W, base, low, high); continue; }
         if (!(low < high)) continue;
-        const int idx = huf_partition(arr, low, high);
+        const int idx = huf_partition(W, base, low, high);
         if (idx - low < high - idx) {
             stLo[sp] = idx + 1; stHi[sp] = high; stCall[sp] = false; sp++;
             stLo[sp] = low; stHi[sp] = idx - 1; stCall[sp] = true; sp++;
@@ -920,60 +935,65 @@ __device__ ZS_NOINLINE static void huf_quickSort(NodeElt* arr, int low0, int hig
     }
 }
 
-__device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint32_t* cnt, uint32_t maxSym, uint32_t maxNbBits, HufScratch& L) {
-    NodeElt* const huffNode0 = L.nodes; NodeElt* const huffNode = huffNode0 + 1;
-    for (int i = 0; i < 514; i++) { NodeElt z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
+__device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint32_t* cnt, uint32_t maxSym, uint32_t maxNbBits, const HufWork& W) {
+    // (huffNode[n] of the serial code: n < 256 a leaf - count lcount[n], symbol lbyte[n] -, else an internal node - count icount[n - 256];
+    //  parent / nbBits of either kind par[n])
+    {   uint32_t* const z = reinterpret_cast<uint32_t*>(W.par);
+        for (int i = 0; i < 256; i++) z[i] = 0;                       // nbBits of the symbols that do not occur stays 0
+    }
     // HUF_sort
     {   const uint32_t n1 = maxSym + 1;
-        for (int i = 0; i < RANK_TABLE; i++) { L.rankBase[i] = 0; L.rankCurr[i] = 0; }
-        for (uint32_t n = 0; n < n1; ++n) L.rankBase[huf_getIndex(cnt[n])]++;
-        for (int n = RANK_TABLE - 1; n > 0; --n) { L.rankBase[n - 1] += L.rankBase[n]; L.rankCurr[n - 1] = L.rankBase[n - 1]; }
+        for (int i = 0; i < RANK_TABLE; i++) { W.rankBase[i] = 0; W.rankCurr[i] = 0; }
+        for (uint32_t n = 0; n < n1; ++n) W.rankBase[huf_getIndex(cnt[n])]++;
+        for (int n = RANK_TABLE - 1; n > 0; --n) { W.rankBase[n - 1] += W.rankBase[n]; W.rankCurr[n - 1] = W.rankBase[n - 1]; }
         for (uint32_t n = 0; n < n1; ++n) {
-            const uint32_t c = cnt[n], r = huf_getIndex(c) + 1, pos = L.rankCurr[r]++;
-            huffNode[pos].count = c; huffNode[pos].byte = (uint8_t)n;
+            const uint32_t c = cnt[n], r = huf_getIndex(c) + 1, pos = W.rankCurr[r]++;
+            W.lcount[pos] = c; W.lbyte[pos] = (uint8_t)n;
         }
         for (int n = RANK_CUTOFF; n < RANK_TABLE - 1; ++n) {
-            const int bucketSize = L.rankCurr[n] - L.rankBase[n];
-            if (bucketSize > 1) huf_quickSort(huffNode + L.rankBase[n], 0, bucketSize - 1);
+            const int bucketSize = W.rankCurr[n] - W.rankBase[n];
+            if (bucketSize > 1) huf_quickSort(W, (int)W.rankBase[n], 0, bucketSize - 1);
         }
     }
-    // HUF_buildTree
+    // HUF_buildTree (the rank arrays are dead from here: icount takes their place)
     int nonNullRank = (int)maxSym;
     {   const int STARTNODE = 256;
         int lowS, lowN, nodeNb = STARTNODE, n, nodeRoot;
-        while (huffNode[nonNullRank].count == 0) nonNullRank--;
+        while (W.lcount[nonNullRank] == 0) nonNullRank--;
         lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
-        huffNode[nodeNb].count = huffNode[lowS].count + huffNode[lowS - 1].count;
-        huffNode[lowS].parent = huffNode[lowS - 1].parent = (uint16_t)nodeNb;
+        W.icount[nodeNb - 256] = W.lcount[lowS] + W.lcount[lowS - 1];
+        W.par[lowS] = W.par[lowS - 1] = (uint16_t)nodeNb;
         nodeNb++; lowS -= 2;
-        for (n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = 1u << 30;
-        huffNode0[0].count = 1u << 31;
+        for (n = nodeNb; n <= nodeRoot; n++) W.icount[n - 256] = 1u << 30;
+        W.lcount[-1] = 1u << 31;
         while (nodeNb <= nodeRoot) {
-            const int a = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
-            const int b = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
-            huffNode[nodeNb].count = huffNode[a].count + huffNode[b].count;
-            huffNode[a].parent = huffNode[b].parent = (uint16_t)nodeNb;
+            uint32_t ca, cb; int a, b;
+            if (W.lcount[lowS] < W.icount[lowN - 256]) { a = lowS--; ca = W.lcount[a]; } else { a = lowN++; ca = W.icount[a - 256]; }
+            if (W.lcount[lowS] < W.icount[lowN - 256]) { b = lowS--; cb = W.lcount[b]; } else { b = lowN++; cb = W.icount[b - 256]; }
+            W.icount[nodeNb - 256] = ca + cb;
+            W.par[a] = W.par[b] = (uint16_t)nodeNb;
             nodeNb++;
         }
-        huffNode[nodeRoot].nbBits = 0;
-        for (n = nodeRoot - 1; n >= STARTNODE; n--) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
-        for (n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+        W.par[nodeRoot] = 0;                                          // nbBits of the root
+        for (n = nodeRoot - 1; n >= STARTNODE; n--) W.par[n] = (uint16_t)(W.par[W.par[n]] + 1);
+        for (n = 0; n <= nonNullRank; n++) W.par[n] = (uint16_t)(W.par[W.par[n]] + 1);
     }
+    uint16_t* const nbBits = W.par;                                    // leaves only from here
     // HUF_setMaxHeight
     {   const uint32_t lastNonNull = (uint32_t)nonNullRank, targetNbBits = maxNbBits;
-        const uint32_t largestBits = huffNode[lastNonNull].nbBits;
+        const uint32_t largestBits = nbBits[lastNonNull];
         if (largestBits <= targetNbBits) maxNbBits = largestBits;
         else {
             int totalCost = 0; const uint32_t baseCost = 1u << (largestBits - targetNbBits); int n = (int)lastNonNull;
-            while (huffNode[n].nbBits > targetNbBits) { totalCost += baseCost - (1 << (largestBits - huffNode[n].nbBits)); huffNode[n].nbBits = (uint8_t)targetNbBits; n--; }
-            while (huffNode[n].nbBits == targetNbBits) --n;
+            while (nbBits[n] > targetNbBits) { totalCost += baseCost - (1 << (largestBits - nbBits[n])); nbBits[n] = (uint16_t)targetNbBits; n--; }
+            while (nbBits[n] == targetNbBits) --n;
             totalCost >>= (largestBits - targetNbBits);
             {   const uint32_t noSymbol = 0xF0F0F0F0; uint32_t rankLast[ZS_HUF_TABLELOG_MAX + 2];
                 for (int i = 0; i < ZS_HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
                 {   uint32_t currentNbBits = targetNbBits;
                     for (int pos = n; pos >= 0; pos--) {
-                        if (huffNode[pos].nbBits >= currentNbBits) continue;
-                        currentNbBits = huffNode[pos].nbBits;
+                        if (nbBits[pos] >= currentNbBits) continue;
+                        currentNbBits = nbBits[pos];
                         rankLast[targetNbBits - currentNbBits] = (uint32_t)pos;
                     }
                 }
@@ -983,27 +1003,27 @@ __device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint3
                         const uint32_t highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
                         if (highPos == noSymbol) continue;
                         if (lowPos == noSymbol) break;
-                        if (huffNode[highPos].count <= 2 * huffNode[lowPos].count) break;
+                        if (W.lcount[highPos] <= 2 * W.lcount[lowPos]) break;
                     }
                     while (nBitsToDecrease <= ZS_HUF_TABLELOG_MAX && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
                     totalCost -= 1 << (nBitsToDecrease - 1);
-                    huffNode[rankLast[nBitsToDecrease]].nbBits++;
+                    nbBits[rankLast[nBitsToDecrease]]++;
                     if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
                     if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
                     else {
                         rankLast[nBitsToDecrease]--;
-                        if (huffNode[rankLast[nBitsToDecrease]].nbBits != targetNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+                        if (nbBits[rankLast[nBitsToDecrease]] != targetNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
                     }
                 }
                 while (totalCost < 0) {
                     if (rankLast[1] == noSymbol) {
-                        while (huffNode[n].nbBits == targetNbBits) n--;
-                        huffNode[n + 1].nbBits--;
+                        while (nbBits[n] == targetNbBits) n--;
+                        nbBits[n + 1]--;
                         rankLast[1] = (uint32_t)(n + 1);
                         totalCost++;
                         continue;
                     }
-                    huffNode[rankLast[1] + 1].nbBits--;
+                    nbBits[rankLast[1] + 1]--;
                     rankLast[1]++;
                     totalCost++;
                 }
@@ -1016,10 +1036,10 @@ __device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint3
         const int alphabetSize = (int)(maxSym + 1);
         for (int i = 0; i <= ZS_HUF_TABLELOG_MAX; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
         for (int i = 0; i < 256; i++) { ct.val[i] = 0; ct.nb[i] = 0; }
-        for (int n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+        for (int n = 0; n <= nonNullRank; n++) nbPerRank[nbBits[n]]++;
         {   uint16_t mn = 0;
             for (int n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
-        for (int n = 0; n < alphabetSize; n++) ct.nb[huffNode[n].byte] = huffNode[n].nbBits;
+        for (int n = 0; n < alphabetSize; n++) ct.nb[W.lbyte[n]] = (uint8_t)nbBits[n];
         for (int n = 0; n < alphabetSize; n++) ct.val[n] = valPerRank[ct.nb[n]]++;
         ct.tableLog = maxNbBits; ct.maxSym = maxSym;
     }
@@ -1175,7 +1195,7 @@ __device__ static uint32_t write_rle_literals(uint8_t* dst, const uint8_t* lit, 
 }
 
 __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uint8_t* __restrict__ lit, uint32_t n, EncLds& L, int cur, bool suspectUncompressible,
-                                             uint32_t* tmp, HufScratch* hufScratch, uint32_t lane) {
+                                             uint32_t* tmp, uint32_t lane) {
     const int nxt = cur ^ 1;
     const uint32_t lhSize = 3 + (n >= 1024) + (n >= 16384);
     bool single = n < 256;
@@ -1222,7 +1242,17 @@ __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uin
             PT(5);
             if (lane == 0) {
                 uint32_t huffLog = fse_optimalTableLog(ZS_LitHufLog, n, maxSym, 1);
-                huffLog = huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, *hufScratch);
+                // the work arrays in what is dead right now (huf_buildCTable): `of` (free until the weights are FSE-coded, below), and
+                // everything behind the counts in `hist` up to the end of `norm` (tail of `ml`, `hist2`, `tableSymbol`, `cumul`, `norm`)
+                HufWork W;
+                uint8_t* const regA = reinterpret_cast<uint8_t*>(&L.of); uint8_t* const regB = reinterpret_cast<uint8_t*>(L.hist) + sizeof(L.hist);
+                static_assert(sizeof(L.of) >= 1024 + 256, "icount + lbyte fit the OF table");
+                static_assert(offsetof(EncLds, norm) + sizeof(((EncLds*)0)->norm) - (offsetof(EncLds, hist) + sizeof(((EncLds*)0)->hist)) >= 1028 + 1024 && (offsetof(EncLds, hist) & 3) == 0,
+                              "lcount[-1 .. 255] + par[512] fit behind the byte histogram");
+                W.icount = reinterpret_cast<uint32_t*>(regA); W.lbyte = regA + 1024;
+                W.rankBase = reinterpret_cast<uint16_t*>(regA); W.rankCurr = W.rankBase + RANK_TABLE;
+                W.lcount = reinterpret_cast<uint32_t*>(regB) + 1; W.par = reinterpret_cast<uint16_t*>(regB + 1028);
+                huffLog = huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, W);
                 const uint32_t hSize = huf_writeCTable(ostart, L.huf[nxt], maxSym, huffLog, L);
                 uint32_t useOld = 0, fail = 0;
                 if (hSize == 0xFFFFFFFFu) fail = 1;
@@ -1660,7 +1690,7 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
             for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) reinterpret_cast<uint32_t*>(&L.huf[0])[i] = hufSave[i];     // back from the workspace
             __threadfence_block();
             __syncthreads();
-            uint32_t litBytes = UNI(compress_literals(blockout, lit, ms.litSize, L, cur, suspect, huftmp, (HufScratch*)(codes + 3 * ZS_WS_CODE_STRIDE), lane));
+            uint32_t litBytes = UNI(compress_literals(blockout, lit, ms.litSize, L, cur, suspect, huftmp, lane));
             __threadfence_block();
             __syncthreads();
             for (uint32_t i = lane; i < sizeof(L.huf) / 4; i += LANES) hufSave[i] = reinterpret_cast<const uint32_t*>(&L.huf[0])[i];     // the LL table takes their place
