@@ -104,6 +104,7 @@ def test_single_rank_line_has_every_leg(emu, oracle):
     assert s["callers"] == 5 and s["batches"] == 15 and s["value"] >= 0 and "slope" in s["method"]
     assert j["detransform"]["round_trip_exact"] is True and j["roofline"]["bound"] == "hbm"
     assert j["value_B"]["exact_vs_oracle"] is True and j["value_B"]["batches"] == 8 and j["value_B"]["value"] > 0, j["value_B"]
+    assert j["value_B"]["value_B_1_5_6"]["exact_vs_oracle"] is True and j["value_B"]["value_B_1_5_6"]["value"] > 0, j["value_B"]      # the profile a zstd-jni 1.5.6 broker selects
 
 
 def test_broker_leg_runs_without_torch_and_checks_sizes(emu, tmp_path):

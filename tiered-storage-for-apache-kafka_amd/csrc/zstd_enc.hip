@@ -1889,7 +1889,14 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         SVC_ST_MIRROR(&H->m_live, lv);
     }
     if (a.calibrate_ticks) {                                              // how many of these workgroups does the chip hold at once?  (svc_create)
-        if (lane == 0) { while (svc_now() - t_start < a.calibrate_ticks) svc_nap(1); svc_wave_exit(H, D, a.launch_id); }
+        // Every wave stays until no wave has ARRIVED for calibrate_ticks: live_max is then what fits at once, however slowly the dispatcher fills a
+        // cold chip.  (Until round 6 a wave stayed a fixed 300 us from its own start: on a box whose first launch placed one wave per ~20 us and CU
+        // the first waves had left before the sixteenth arrived - 15 per CU "measured", a grid of 3840 instead of 6144 for the life of the process.)
+        if (lane == 0) {
+            SVC_ST_DEV(&D->poll_stamp, (uint32_t)t_start);
+            while ((uint32_t)svc_now() - SVC_LD_DEV(&D->poll_stamp) < a.calibrate_ticks && svc_now() - t_start < 5000000u) svc_nap(1);     // (<= 50 ms whatever happens)
+            svc_wave_exit(H, D, a.launch_id);
+        }
         return;
     }
     const uint32_t key = UNI(svc_cu_key());

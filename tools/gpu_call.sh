@@ -242,6 +242,22 @@ PY
         timeout 400 python tools/prof_zstd.py --chunks ${PROF_CHUNKS:-2048} --dist $1 --profile $2 --uniq $u $ch --out $O/prof_$1_$2${3:+_$3}.json > /dev/null 2>> $O/prof.err
         python tools/show_prof.py $O/prof_$1_$2${3:+_$3}.json 2>/dev/null || tail -c 1500 $O/prof_$1_$2${3:+_$3}.json
       done ;;
+    enchost)
+      # encrypt-only host -> host: zero-copy output vs copy engines, piece sizes, system runtime vs torch's (tools/enc_host_probe.py)
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/enchost.err
+      timeout 300 python tools/enc_host_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --tag head 2>> $O/enchost.err | tee -a $O/enchost.jsonl | cut -c1-420
+      timeout 300 python tools/enc_host_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --with-torch --tag head 2>> $O/enchost.err | tee -a $O/enchost.jsonl | cut -c1-420
+      if [ -d tools/_ab/r4tree ]; then ( cd tools/_ab/r4tree && cp $R/tools/enc_host_probe.py tools/enc_host_probe.py && timeout 300 python tools/enc_host_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --tag r4tree 2>> $O/enchost.err | tee -a $O/enchost.jsonl | cut -c1-420 ); fi ;;
+    stucktrace)
+      # fetches next to saturating uploads under rocprofv3 --kernel-trace (torch-free process): which kernel of a fetch was not placed, and next to what?
+      export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/stuck.err
+      for i in $(seq 1 ${arg:-2}); do
+        ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace -d $O/stuck_$i -o m --output-format csv -- python $R/tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers 5 --seconds ${MIXED_SECONDS:-40} --config fetch_quiet_ms=0 --tag "traced $i" 2>> $O/stuck.err | tee -a $O/stucktrace.jsonl | cut -c1-900 )
+        f=$(find $O/stuck_$i -name "*kernel_trace.csv" | head -1)
+        [ -n "$f" ] && python tools/trace_gaps.py $f --ms 20 | tee $O/stuck_gaps_$i.txt && gzip -c $f > $O/stuck_kernel_trace_$i.csv.gz
+        rm -rf $O/stuck_$i
+      done ;;
     keepwaves)
       # compressor waves that stay on the reserved CU of every shader engine (svc_keep_waves): fetch latency and upload rate, device-resident 2048-chunk batches, no torch
       export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
