@@ -160,8 +160,9 @@ public class GpuTransformFinisher {
         this.rateLimitingBucket = rateLimitingBucket;
         this.device = Math.floorMod(segmentHash, TsxNative.deviceCount());
         final int flags = flags();
-        final long slot = align64(TsxNative.transformedBound(Math.max(inner.originalChunkSize(), originalFileSize > 0 && !chunkingEnabled
-            ? originalFileSize : inner.originalChunkSize()), flags));
+        // one bound-sized slot per chunk of a batch must fit one direct ByteBuffer (< 2 GiB); without chunking the one chunk is the whole file
+        final long largestChunk = chunkingEnabled ? inner.originalChunkSize() : originalFileSize;
+        final long slot = align64(TsxNative.transformedBound(largestChunk, flags));
         if (batchChunks < 1 || (long) batchChunks * (slot + 32) >= Integer.MAX_VALUE - 64) {
             throw new IllegalArgumentException("batchChunks * chunk size must stay below 2 GiB, got " + batchChunks + " chunks of "
                 + inner.originalChunkSize() + " bytes");

@@ -475,8 +475,12 @@ static hipError_t wait_event_watching(tsx_ctx* c, hipEvent_t ev) {
         (void)hipGetLastError();
         const auto age = std::chrono::steady_clock::now() - t0;
         if (!asked && age > std::chrono::milliseconds(200)) { svc_rotate(c->dev); asked = true; }
-        // (a single-chunk fetch is 1.6 ms: the first 3 ms are polled without a sleep - a sleep's granularity is tens of microseconds)
-        if (age > std::chrono::milliseconds(3)) std::this_thread::sleep_for(std::chrono::microseconds(age > std::chrono::milliseconds(20) ? 500 : 50));
+        // A single-chunk fetch is 1.6 ms.  Only the first 200 us are polled without a sleep (a piece that is nearly done); after that the thread
+        // sleeps between looks - 20 us while the batch is young (a sleep's real granularity is ~60 us: + <= 4 % on a single-chunk fetch), 50 us up
+        // to 20 ms, 500 us beyond.  Every ChunkCache worker (ForkJoinPool, parallelism = #cores by default) waits in here: round 5 spun for 3 ms,
+        // i.e. a whole core per fetch in flight.
+        if (age > std::chrono::microseconds(200))
+            std::this_thread::sleep_for(std::chrono::microseconds(age > std::chrono::milliseconds(20) ? 500 : age > std::chrono::milliseconds(3) ? 50 : 20));
     }
 }
 static void svc_resume(tsx_device* dev) {

@@ -874,25 +874,46 @@ __device__ static inline void fse_encode(BitW& b, const FseTable& ct, uint32_t& 
     value = ct.state[(value >> nbBitsOut) + ct.dfs[symbol]];
 }
 
-// ---- Huffman (lane 0) -----------------------------------------------------------------------------------
-// HUF_buildCTable_wksp on lane 0, its work arrays in LDS.  Until round 6 they lived in the chunk's global workspace (a 514-node
-// array of structs needs 4112 contiguous bytes, more than any dead region of EncLds): ~2000 dependent global round trips per
-// table, 1.6 M cycles per block on content K and 3.0 M on content B, whose 4 MiB chunks are 164 blocks under profile 1.5.7 -
-// 14 % of a B chunk's time (profiles/r06_compressor_wave_laps_K_and_B.txt).  As separate arrays the nodes fit what is dead
-// while a table is built: leaves (sorted by count, index = rank) and internal nodes apart, `parent` and `nbBits` in ONE
-// 16-bit array (a node's depth replaces its parent index once it is known: depths are assigned from the root down and a
-// parent's index is always larger than its children's), the rank arrays of HUF_sort on top of the internal nodes' counts
-// (which do not exist yet while sorting).  3332 bytes: `of` holds 1280, the tail of `ml` .. `norm` 2052.
+// ---- Huffman table construction (HUF_buildCTable_wksp), on the wave -----------------------------------------------
+// Until round 6 this ran on lane 0 alone with its work arrays (a 514-node array of structs) in the chunk's GLOBAL workspace: ~2000
+// dependent global round trips per table, 1.6 M cycles per block on content K and 3.0 M on content B, whose 4 MiB chunks are 164 blocks
+// under profile 1.5.7 - 14 % of a B chunk's time (profiles/r06_compressor_wave_laps_K_and_B.txt).  Now:
+//  * the nodes are separate arrays in what is dead in LDS while a table is built - leaves (sorted by count, index = rank) and internal
+//    nodes apart, `parent` and `nbBits` in ONE 16-bit array - 3.5 KB in `of` and in the tail of `ml` .. `norm`;
+//  * HUF_sort is a counting sort on all lanes: rank histogram by LDS atomics, suffix sums by a wave scan, a symbol's slot = start of
+//    its rank + the symbols before it with the same rank (the serial loop's stable order); only the quick sort INSIDE the log2 ranks
+//    (counts >= 165: its order among equal counts is the algorithm's own) stays serial;
+//  * the two-queue merge of HUF_buildTree is serial by nature (255 steps on lane 0); the depths follow by pointer jumping on all
+//    lanes (8 rounds) instead of a 511-step walk; HUF_setMaxHeight (rare) stays serial;
+//  * HUF_buildCTableFromTree: per-length counts by LDS atomics, a symbol's code = first code of its length + the symbols before it
+//    with the same length.
+// No array here is indexed dynamically in registers: a private array that is becomes scratch memory, i.e. global round trips.
 #define RANK_TABLE 192
 #define RANK_LOG_BEGIN 158
 #define RANK_CUTOFF 165
 struct HufWork {
     uint32_t* lcount;            // [-1 .. 255] leaves' counts in sorted order (lcount[-1] = the sentinel of HUF_buildTree)
     uint8_t* lbyte;              // [256] ... and their symbols
-    uint32_t* icount;            // [256] internal nodes 256 .. 511
+    uint32_t* icount;            // [256] internal nodes 256 .. 511 (tree build)
     uint16_t* par;               // [512] parent index, then nbBits (leaves 0 .. 255, internal nodes 256 .. 511)
-    uint16_t* rankBase; uint16_t* rankCurr;      // [192] each, alias icount (HUF_sort only)
+    uint32_t* rank;              // [192] HUF_sort: symbols per rank, then the first slot of each rank      (aliases icount)
+    uint8_t* idx8;               // [256] HUF_sort: rank of every symbol                                   (aliases icount)
+    uint8_t* qstack;             // [192] explicit stack of the quick sort: 64 frames of (low, high, kind)
+    uint16_t* dpt;               // [256] depths of the internal nodes while they are computed              (aliases icount, after the tree)
+    uint32_t* rankLast;          // [14]  HUF_setMaxHeight                                                 (aliases icount, after the tree)
+    uint32_t* nbPerRank;         // [16]  symbols per code length                                          (aliases icount, after the tree)
+    uint16_t* valStart;          // [16]  first code of each length                                        (aliases icount, after the tree)
 };
+#define HUF_WORK_A_BYTES 1472u   /* icount 1024 (rank 768 + idx8 256 / dpt 512 + rankLast + nbPerRank + valStart), lbyte 256, qstack 192 */
+#define HUF_WORK_B_BYTES 2052u   /* lcount 1028, par 1024 */
+__device__ static inline HufWork huf_work(uint8_t* regA, uint8_t* regB) {
+    HufWork W;
+    W.icount = reinterpret_cast<uint32_t*>(regA); W.rank = W.icount; W.idx8 = regA + 768; W.lbyte = regA + 1024; W.qstack = regA + 1280;
+    W.dpt = reinterpret_cast<uint16_t*>(regA); W.rankLast = reinterpret_cast<uint32_t*>(regA + 512); W.nbPerRank = reinterpret_cast<uint32_t*>(regA + 576);
+    W.valStart = reinterpret_cast<uint16_t*>(regA + 640);
+    W.lcount = reinterpret_cast<uint32_t*>(regB) + 1; W.par = reinterpret_cast<uint16_t*>(regB + 1028);
+    return W;
+}
 __device__ static inline uint32_t huf_getIndex(uint32_t c) { return c < RANK_CUTOFF ? c : hb32(c) + RANK_LOG_BEGIN; }
 __device__ static inline void huf_swap(const HufWork& W, int a, int b) {
     const uint32_t c = W.lcount[a]; const uint8_t y = W.lbyte[a];
@@ -913,51 +934,76 @@ __device__ static int huf_partition(const HufWork& W, int base, int low, int hig
     huf_swap(W, base + i + 1, base + high);
     return i + 1;
 }
-// HUF_simpleQuickSort with its recursion made explicit.  A CALL frame applies the insertion-sort threshold on
+// HUF_simpleQuickSort with its recursion made explicit (lane 0).  A CALL frame applies the insertion-sort threshold on
 // entry; a CONTinuation frame is the rest of the caller's `while (low < high)` loop, which partitions without
-// re-checking the threshold.  The two sides of a partition are disjoint, so their processing order is free.
-__device__ ZS_NOINLINE static void huf_quickSort(const HufWork& W, int base, int low0, int high0) {
-    int stLo[64], stHi[64]; bool stCall[64]; int sp = 0;
-    stLo[0] = low0; stHi[0] = high0; stCall[0] = true; sp = 1;
+// re-checking the threshold.  The two sides of a partition are disjoint, so their processing order is free.  Frames live in LDS
+// (low, high < 256: a byte each; high may be low - 1 = -1: stored + 1).
+__device__ ZS_NOINLINE static void huf_quickSort(const HufWork W, int base, int low0, int high0) {
+    uint8_t* const st = W.qstack;
+    int sp = 0;
+#define QPUSH(lo_, hi_, call_) do { st[3 * sp] = (uint8_t)(lo_); st[3 * sp + 1] = (uint8_t)((hi_) + 1); st[3 * sp + 2] = (uint8_t)(call_); sp++; } while (0)
+    QPUSH(low0, high0, 1);
     while (sp) {
         --sp;
-        const int low = stLo[sp], high = stHi[sp]; const bool call = stCall[sp];
+        const int low = st[3 * sp], high = (int)st[3 * sp + 1] - 1; const bool call = st[3 * sp + 2] != 0;
         if (call && high - low < 8) { huf_insertionSort(W, base, low, high); continue; }
         if (!(low < high)) continue;
         const int idx = huf_partition(W, base, low, high);
-        if (idx - low < high - idx) {
-            stLo[sp] = idx + 1; stHi[sp] = high; stCall[sp] = false; sp++;
-            stLo[sp] = low; stHi[sp] = idx - 1; stCall[sp] = true; sp++;
-        } else {
-            stLo[sp] = low; stHi[sp] = idx - 1; stCall[sp] = false; sp++;
-            stLo[sp] = idx + 1; stHi[sp] = high; stCall[sp] = true; sp++;
-        }
+        if (idx - low < high - idx) { QPUSH(idx + 1, high, 0); QPUSH(low, idx - 1, 1); }
+        else { QPUSH(low, idx - 1, 0); QPUSH(idx + 1, high, 1); }
     }
+#undef QPUSH
 }
 
-__device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint32_t* cnt, uint32_t maxSym, uint32_t maxNbBits, const HufWork& W) {
+// All lanes call it; returns the table's depth (the same in every lane).  `bc`: three broadcast words in LDS.
+__device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint32_t* cnt, const uint32_t maxSym, uint32_t maxNbBits, uint8_t* regA, uint8_t* regB, uint32_t* bc, const uint32_t lane) {
+    const HufWork W = huf_work(regA, regB);
     // (huffNode[n] of the serial code: n < 256 a leaf - count lcount[n], symbol lbyte[n] -, else an internal node - count icount[n - 256];
     //  parent / nbBits of either kind par[n])
-    {   uint32_t* const z = reinterpret_cast<uint32_t*>(W.par);
-        for (int i = 0; i < 256; i++) z[i] = 0;                       // nbBits of the symbols that do not occur stays 0
+    const uint32_t n1 = maxSym + 1;
+    for (uint32_t i = lane; i < RANK_TABLE; i += LANES) W.rank[i] = 0;
+    for (uint32_t i = lane; i < 256; i += LANES) reinterpret_cast<uint32_t*>(W.par)[i] = 0;       // nbBits of the symbols that do not occur stays 0
+    __syncthreads();
+    // ---- HUF_sort ----
+    uint32_t myC[4], myI[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t n = lane + 64u * (uint32_t)k;
+        myC[k] = 0; myI[k] = 0xFFFFu;
+        if (n < n1) { myC[k] = cnt[n]; myI[k] = huf_getIndex(myC[k]); W.idx8[n] = (uint8_t)myI[k]; atomicAdd(&W.rank[myI[k]], 1u); }
     }
-    // HUF_sort
-    {   const uint32_t n1 = maxSym + 1;
-        for (int i = 0; i < RANK_TABLE; i++) { W.rankBase[i] = 0; W.rankCurr[i] = 0; }
-        for (uint32_t n = 0; n < n1; ++n) W.rankBase[huf_getIndex(cnt[n])]++;
-        for (int n = RANK_TABLE - 1; n > 0; --n) { W.rankBase[n - 1] += W.rankBase[n]; W.rankCurr[n - 1] = W.rankBase[n - 1]; }
-        for (uint32_t n = 0; n < n1; ++n) {
-            const uint32_t c = cnt[n], r = huf_getIndex(c) + 1, pos = W.rankCurr[r]++;
-            W.lcount[pos] = c; W.lbyte[pos] = (uint8_t)n;
+    __syncthreads();
+    {   // rank[k] <- symbols in ranks ABOVE k = the first slot of rank k (the serial code's rankPosition[k + 1].base)
+        const uint32_t a = W.rank[3 * lane], b = W.rank[3 * lane + 1], c = W.rank[3 * lane + 2];
+        uint32_t t = a + b + c;
+        for (int o = 1; o < LANES; o <<= 1) { const uint32_t u = __shfl_down(t, o); if (lane + (uint32_t)o < LANES) t += u; }
+        const uint32_t above = t - (a + b + c);
+        __syncthreads();
+        W.rank[3 * lane + 2] = above; W.rank[3 * lane + 1] = above + c; W.rank[3 * lane] = above + c + b;
+    }
+    __syncthreads();
+    {   uint32_t before[4] = {0, 0, 0, 0};
+        for (uint32_t m = 0; m < n1; m++) {
+            const uint32_t v = W.idx8[m];
+#pragma unroll
+            for (int k = 0; k < 4; k++) before[k] += (v == myI[k]) & (m < lane + 64u * (uint32_t)k);
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t n = lane + 64u * (uint32_t)k;
+            if (n < n1) { const uint32_t pos = W.rank[myI[k]] + before[k]; W.lcount[pos] = myC[k]; W.lbyte[pos] = (uint8_t)n; }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        // (the serial code's bucket n holds the symbols of rank n - 1)
         for (int n = RANK_CUTOFF; n < RANK_TABLE - 1; ++n) {
-            const int bucketSize = W.rankCurr[n] - W.rankBase[n];
-            if (bucketSize > 1) huf_quickSort(W, (int)W.rankBase[n], 0, bucketSize - 1);
+            const int bucketStart = (int)W.rank[n - 1], bucketSize = (int)W.rank[n - 2] - bucketStart;
+            if (bucketSize > 1) huf_quickSort(W, bucketStart, 0, bucketSize - 1);
         }
-    }
-    // HUF_buildTree (the rank arrays are dead from here: icount takes their place)
-    int nonNullRank = (int)maxSym;
-    {   const int STARTNODE = 256;
+        // ---- HUF_buildTree (the rank arrays are dead from here: icount takes their place) ----
+        int nonNullRank = (int)maxSym;
+        const int STARTNODE = 256;
         int lowS, lowN, nodeNb = STARTNODE, n, nodeRoot;
         while (W.lcount[nonNullRank] == 0) nonNullRank--;
         lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
@@ -974,13 +1020,46 @@ __device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint3
             W.par[a] = W.par[b] = (uint16_t)nodeNb;
             nodeNb++;
         }
-        W.par[nodeRoot] = 0;                                          // nbBits of the root
-        for (n = nodeRoot - 1; n >= STARTNODE; n--) W.par[n] = (uint16_t)(W.par[W.par[n]] + 1);
-        for (n = 0; n <= nonNullRank; n++) W.par[n] = (uint16_t)(W.par[W.par[n]] + 1);
+        bc[0] = (uint32_t)nonNullRank; bc[1] = (uint32_t)nodeRoot;
     }
+    __syncthreads();
+    const uint32_t nonNullRank = bc[0], nodeRoot = bc[1], nIntern = nodeRoot - 255u;
+    __syncthreads();
+    {   // depths of the internal nodes by pointer jumping: par[256 + i] = an ancestor (relative index), dpt[i] = the distance to it; the root points at itself
+        uint32_t j[4], d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = lane + 64u * (uint32_t)k;
+            if (i < nIntern) { const bool root = i + 256u == nodeRoot; W.dpt[i] = root ? 0 : 1; if (root) W.par[256 + i] = (uint16_t)i; else W.par[256 + i] = (uint16_t)(W.par[256 + i] - 256u); }
+        }
+        __syncthreads();
+        for (int round = 0; round < 8; round++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = lane + 64u * (uint32_t)k;
+                j[k] = 0; d[k] = 0;
+                if (i < nIntern) { const uint32_t a = W.par[256 + i]; d[k] = (uint32_t)W.dpt[i] + W.dpt[a]; j[k] = W.par[256 + a]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = lane + 64u * (uint32_t)k;
+                if (i < nIntern) { W.dpt[i] = (uint16_t)d[k]; W.par[256 + i] = (uint16_t)j[k]; }
+            }
+            __syncthreads();
+        }
+        // leaves: one below their parent
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t n = lane + 64u * (uint32_t)k;
+            if (n <= nonNullRank) W.par[n] = (uint16_t)(W.dpt[W.par[n] - 256u] + 1u);
+        }
+    }
+    __syncthreads();
     uint16_t* const nbBits = W.par;                                    // leaves only from here
-    // HUF_setMaxHeight
-    {   const uint32_t lastNonNull = (uint32_t)nonNullRank, targetNbBits = maxNbBits;
+    if (lane == 0) {
+        // ---- HUF_setMaxHeight ----
+        const uint32_t lastNonNull = nonNullRank, targetNbBits = maxNbBits;
         const uint32_t largestBits = nbBits[lastNonNull];
         if (largestBits <= targetNbBits) maxNbBits = largestBits;
         else {
@@ -988,7 +1067,7 @@ __device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint3
             while (nbBits[n] > targetNbBits) { totalCost += baseCost - (1 << (largestBits - nbBits[n])); nbBits[n] = (uint16_t)targetNbBits; n--; }
             while (nbBits[n] == targetNbBits) --n;
             totalCost >>= (largestBits - targetNbBits);
-            {   const uint32_t noSymbol = 0xF0F0F0F0; uint32_t rankLast[ZS_HUF_TABLELOG_MAX + 2];
+            {   const uint32_t noSymbol = 0xF0F0F0F0; uint32_t* const rankLast = W.rankLast;
                 for (int i = 0; i < ZS_HUF_TABLELOG_MAX + 2; i++) rankLast[i] = noSymbol;
                 {   uint32_t currentNbBits = targetNbBits;
                     for (int pos = n; pos >= 0; pos--) {
@@ -1030,19 +1109,40 @@ __device__ ZS_NOINLINE static uint32_t huf_buildCTable(HufTable& ct, const uint3
             }
             maxNbBits = targetNbBits;
         }
+        bc[2] = maxNbBits;
     }
-    // HUF_buildCTableFromTree
-    {   uint16_t nbPerRank[ZS_HUF_TABLELOG_MAX + 1], valPerRank[ZS_HUF_TABLELOG_MAX + 1];
-        const int alphabetSize = (int)(maxSym + 1);
-        for (int i = 0; i <= ZS_HUF_TABLELOG_MAX; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
-        for (int i = 0; i < 256; i++) { ct.val[i] = 0; ct.nb[i] = 0; }
-        for (int n = 0; n <= nonNullRank; n++) nbPerRank[nbBits[n]]++;
-        {   uint16_t mn = 0;
-            for (int n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
-        for (int n = 0; n < alphabetSize; n++) ct.nb[W.lbyte[n]] = (uint8_t)nbBits[n];
-        for (int n = 0; n < alphabetSize; n++) ct.val[n] = valPerRank[ct.nb[n]]++;
+    // ---- HUF_buildCTableFromTree ----
+    if (lane < 16) W.nbPerRank[lane] = 0;
+    for (uint32_t i = lane; i < 256; i += LANES) { ct.val[i] = 0; ct.nb[i] = 0; }
+    __syncthreads();
+    maxNbBits = bc[2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t n = lane + 64u * (uint32_t)k;
+        if (n <= nonNullRank) atomicAdd(&W.nbPerRank[nbBits[n]], 1u);
+        if (n < n1) ct.nb[W.lbyte[n]] = (uint8_t)nbBits[n];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t mn = 0;
+        W.valStart[0] = 0;
+        for (int n = (int)maxNbBits; n > 0; n--) { W.valStart[n] = (uint16_t)mn; mn += W.nbPerRank[n]; mn >>= 1; }
         ct.tableLog = maxNbBits; ct.maxSym = maxSym;
     }
+    __syncthreads();
+    {   // ct.val[n] = valPerRank[ct.nb[n]]++ in symbol order: the first code of the length + the symbols before n with the same length
+        uint32_t before[4] = {0, 0, 0, 0}, myNb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t n = lane + 64u * (uint32_t)k; myNb[k] = n < n1 ? ct.nb[n] : 0xFFu; }
+        for (uint32_t m = 0; m < n1; m++) {
+            const uint32_t v = ct.nb[m];
+#pragma unroll
+            for (int k = 0; k < 4; k++) before[k] += (v == myNb[k]) & (m < lane + 64u * (uint32_t)k);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t n = lane + 64u * (uint32_t)k; if (n < n1) ct.val[n] = (uint16_t)(W.valStart[myNb[k]] + before[k]); }
+    }
+    __syncthreads();
     return maxNbBits;
 }
 
@@ -1240,26 +1340,24 @@ __device__ ZS_NOINLINE static uint32_t compress_literals(uint8_t* dst, const uin
         } else {
             // build the candidate table (lane 0), describe it, compare with reusing the old one
             PT(5);
+            // the work arrays in what is dead right now (huf_buildCTable): `of` (free until the weights are FSE-coded, below), and everything
+            // behind the counts in `hist` up to the end of `norm` (tail of `ml`, `hist2`, `tableSymbol`, `cumul`, `norm`)
+            static_assert(sizeof(L.of) >= HUF_WORK_A_BYTES, "the first group of work arrays fits the OF table");
+            static_assert(offsetof(EncLds, norm) + sizeof(((EncLds*)0)->norm) - (offsetof(EncLds, hist) + sizeof(((EncLds*)0)->hist)) >= HUF_WORK_B_BYTES && (offsetof(EncLds, hist) & 3) == 0,
+                          "lcount[-1 .. 255] + par[512] fit behind the byte histogram");
+            uint32_t huffLog = fse_optimalTableLog(ZS_LitHufLog, n, maxSym, 1);
+            huffLog = UNI(huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, reinterpret_cast<uint8_t*>(&L.of), reinterpret_cast<uint8_t*>(L.hist) + sizeof(L.hist), &L.scal[4], lane));
+            uint32_t oldBits = 0, newBits = 0;                             // (what reusing the old table / using the new one would cost: all lanes)
+            if (repeat != 0) {
+                for (uint32_t s_ = lane; s_ <= maxSym; s_ += LANES) { oldBits += L.huf[cur].nb[s_] * L.hist[s_]; newBits += L.huf[nxt].nb[s_] * L.hist[s_]; }
+                oldBits = wave_sum(oldBits); newBits = wave_sum(newBits);
+            }
             if (lane == 0) {
-                uint32_t huffLog = fse_optimalTableLog(ZS_LitHufLog, n, maxSym, 1);
-                // the work arrays in what is dead right now (huf_buildCTable): `of` (free until the weights are FSE-coded, below), and
-                // everything behind the counts in `hist` up to the end of `norm` (tail of `ml`, `hist2`, `tableSymbol`, `cumul`, `norm`)
-                HufWork W;
-                uint8_t* const regA = reinterpret_cast<uint8_t*>(&L.of); uint8_t* const regB = reinterpret_cast<uint8_t*>(L.hist) + sizeof(L.hist);
-                static_assert(sizeof(L.of) >= 1024 + 256, "icount + lbyte fit the OF table");
-                static_assert(offsetof(EncLds, norm) + sizeof(((EncLds*)0)->norm) - (offsetof(EncLds, hist) + sizeof(((EncLds*)0)->hist)) >= 1028 + 1024 && (offsetof(EncLds, hist) & 3) == 0,
-                              "lcount[-1 .. 255] + par[512] fit behind the byte histogram");
-                W.icount = reinterpret_cast<uint32_t*>(regA); W.lbyte = regA + 1024;
-                W.rankBase = reinterpret_cast<uint16_t*>(regA); W.rankCurr = W.rankBase + RANK_TABLE;
-                W.lcount = reinterpret_cast<uint32_t*>(regB) + 1; W.par = reinterpret_cast<uint16_t*>(regB + 1028);
-                huffLog = huf_buildCTable(L.huf[nxt], L.hist, maxSym, huffLog, W);
                 const uint32_t hSize = huf_writeCTable(ostart, L.huf[nxt], maxSym, huffLog, L);
                 uint32_t useOld = 0, fail = 0;
                 if (hSize == 0xFFFFFFFFu) fail = 1;
                 else {
                     if (repeat != 0) {
-                        uint32_t oldBits = 0, newBits = 0;
-                        for (uint32_t s = 0; s <= maxSym; s++) { oldBits += L.huf[cur].nb[s] * L.hist[s]; newBits += L.huf[nxt].nb[s] * L.hist[s]; }
                         if ((oldBits >> 3) <= hSize + (newBits >> 3) || hSize + 12 >= n) useOld = 1;
                     }
                     if (!useOld && hSize + 12 >= n) fail = 1;
