@@ -200,6 +200,9 @@ typedef struct tsx_service_info {
     uint32_t yielded_waves;                /* guest waves that handed their chunk back and left when a fetch arrived                      */
     uint32_t returned_chunks;              /* ... chunks handed back that way (each was started again by another wave)                   */
     uint32_t readmissions;                 /* launches asked to end so that the next one could use the reserved CUs again (quiet again)   */
+    uint32_t relocated_waves;              /* compressor waves that found themselves on a reserved CU they had not started on (the hardware's
+                                              scheduler saves and restores waves), handed their chunk back and left.  (Occupies what was the
+                                              struct's tail padding: its size, 112 bytes, is what it was.)                                  */
 } tsx_service_info;
 int  tsx_service_stats(int device_index, tsx_service_info* out);
 /* Returns when the device's service kernel has ended (a moment after its last chunk): brackets a measurement. */

@@ -191,6 +191,7 @@ uint32_t hipemu_yield_probe(const uint32_t* p);
 extern "C" void hipemu_force_reserved_launches(int k);
 extern "C" void hipemu_cu_key_shift(int k);
 extern "C" void hipemu_force_yield_after(int n);
+extern "C" void hipemu_relocate_after(int n);        // the n-th hipemu_cu_key() from now (and every later one of that block) answers "the reserved CU"
 
 // ---- host runtime -------------------------------------------------------------------------------
 hipError_t hipGetDeviceCount(int* n);

@@ -136,8 +136,16 @@ static void init_fiber(Fiber& f) {
 static std::atomic<int> g_force_reserved{0};
 }  // namespace hipemu
 uint64_t hipemu_clock_100mhz() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10; }
-static std::atomic<int> g_hipemu_key_shift{0}, g_hipemu_yield_after{0};
-uint32_t hipemu_cu_key() { return hipemu::g_force_reserved.load(std::memory_order_relaxed) > 0 ? 3u : (hipemu::g_ctx->bid.x + (unsigned)g_hipemu_key_shift.load(std::memory_order_relaxed)) % 4u; }
+static std::atomic<int> g_hipemu_key_shift{0}, g_hipemu_yield_after{0}, g_hipemu_relocate_after{0}, g_hipemu_relocated_block{-1};
+uint32_t hipemu_cu_key() {
+    if (hipemu::g_force_reserved.load(std::memory_order_relaxed) > 0) return 3u;
+    // hipemu_relocate_after(n): the n-th look from now finds its block on the reserved CU, and so does every later look of that block in this launch -
+    // a wave that the hardware's scheduler saved and restored somewhere else
+    if (g_hipemu_relocate_after.load(std::memory_order_relaxed) > 0 && g_hipemu_relocate_after.fetch_sub(1) == 1) g_hipemu_relocated_block = (int)hipemu::g_ctx->bid.x;
+    if (g_hipemu_relocated_block.load(std::memory_order_relaxed) == (int)hipemu::g_ctx->bid.x) return 3u;
+    return (hipemu::g_ctx->bid.x + (unsigned)g_hipemu_key_shift.load(std::memory_order_relaxed)) % 4u;
+}
+extern "C" void hipemu_relocate_after(int n) { g_hipemu_relocate_after = n; g_hipemu_relocated_block = -1; }
 extern "C" void hipemu_force_reserved_launches(int k) { hipemu::g_force_reserved = k; }
 extern "C" void hipemu_cu_key_shift(int k) { g_hipemu_key_shift = k; }
 extern "C" void hipemu_force_yield_after(int n) { g_hipemu_yield_after = n; }

@@ -538,6 +538,36 @@ def test_guest_waves_hand_their_chunks_back_when_a_fetch_arrives(emu, oracle):
     assert s1["guest_launches"] - s0["guest_launches"] >= 6
 
 
+def test_a_wave_that_finds_itself_on_a_reserved_cu_hands_its_chunk_back(emu, oracle):
+    """A compressor wave does not move by itself, but the hardware's scheduler may save a queue's waves and restore them on other compute units;
+    round 5's "kernel of a fetch that does not start, once in a few hundred fetches" was compressor waves sitting on the reserved CUs after
+    such a restore (profiles/r06_stuck_fetch_trace.txt).  So every wave asks where it is - between two chunks and before every block of a
+    chunk - and leaves a reserved CU it did not start on: the chunk in progress goes back to the queue like a guest's.  Here the harness
+    moves the first workgroup onto the reserved CU at its n-th look (hipemu_relocate_after): bytes and checksums stay the oracle's, every chunk
+    is counted once, the wave is counted as relocated."""
+    import ctypes
+    emu.lib.hipemu_relocate_after.argtypes = [ctypes.c_int]; emu.lib.hipemu_relocate_after.restype = None
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    sizes = [400000, 131072 * 2 + 5, 70001, 17, 0, 200000]
+    chunks = [synth.gen_chunk("K" if i % 3 else "B", 32, 1, i, s) for i, s in enumerate(sizes)]
+    with emu.configured(fetch_quiet_ms=0):
+        ref, dref = pc.check_transform_vs_oracle(emu, oracle, flags, chunks)
+        emu.service_quiesce(0)
+        s0 = emu.service_stats(0)
+        try:
+            for after in (65, 67, 68, 73):                              # looks: 64 at the wave's start (every lane), then lane 0's: before every ticket, before every block of a chunk
+                emu.lib.hipemu_relocate_after(after)
+                got, d = pc.run_transform(emu, flags, chunks)
+                assert got == ref and (d["status"] == 0).all() and (d["crc32c"] == dref["crc32c"]).all(), after
+        finally:
+            emu.lib.hipemu_relocate_after(0)
+        emu.service_quiesce(0)
+        s1 = emu.service_stats(0)
+    assert s1["relocated_waves"] - s0["relocated_waves"] >= 3, (s0, s1)
+    assert s1["returned_chunks"] - s0["returned_chunks"] >= 1 and s1["yielded_waves"] == s0["yielded_waves"], (s0, s1)      # handed back mid-chunk at least once; nobody was a guest
+    assert s1["device_chunks"] - s0["device_chunks"] == 4 * len(chunks) and s1["skipped_tickets"] == s0["skipped_tickets"]
+
+
 def test_encrypt_only_batches_write_into_registered_buffers_too(emu, oracle):
     """Producers compress -> the broker's chain is encryption only (RemoteStorageManager.java:381-398): the GCM kernel's waves write
     IV || C || TAG straight into the caller's slots when the whole buffer is registered (slot layout); same bytes as the copy path and the

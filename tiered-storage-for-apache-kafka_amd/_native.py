@@ -48,7 +48,8 @@ class ServiceInfo(C.Structure):
                 ("kernel_ms", C.c_double), ("running", C.c_uint32), ("waves", C.c_uint32), ("compute_units", C.c_uint32),
                 ("cu_keys_seen", C.c_uint32), ("reserved_cus", C.c_uint32), ("device_chunks", C.c_uint32), ("wave_starts", C.c_uint32),
                 ("reserved_exits", C.c_uint32), ("skipped_tickets", C.c_uint32), ("live_waves", C.c_uint32), ("live_waves_max", C.c_uint32), ("shader_engines", C.c_uint32), ("rotations", C.c_uint32),
-                ("guest_launches", C.c_uint32), ("yielded_waves", C.c_uint32), ("returned_chunks", C.c_uint32), ("readmissions", C.c_uint32)]
+                ("guest_launches", C.c_uint32), ("yielded_waves", C.c_uint32), ("returned_chunks", C.c_uint32), ("readmissions", C.c_uint32), ("relocated_waves", C.c_uint32)]
+assert C.sizeof(ServiceInfo) == 112
 
 
 CFG_DEFAULT, CFG_DEFAULT64 = 0xFFFFFFFF, 0xFFFFFFFFFFFFFFFF

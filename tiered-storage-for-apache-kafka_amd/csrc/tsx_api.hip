@@ -1143,6 +1143,7 @@ extern "C" int tsx_service_quiesce(int device_index) {
     }
 }
 
+static_assert(sizeof(tsx_service_info) == 112, "relocated_waves took the struct's tail padding: callers compiled before it hand in 112 bytes too");
 extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
     if (!out) return TSX_E_INVAL;
     tsx_device* dev;
@@ -1164,6 +1165,7 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
         out->live_waves_max = __atomic_load_n(&s.h->m_live_max, __ATOMIC_RELAXED); out->wave_starts = __atomic_load_n(&s.h->m_wave_starts, __ATOMIC_RELAXED);
         out->reserved_exits = __atomic_load_n(&s.h->m_reserved_exits, __ATOMIC_RELAXED); out->skipped_tickets = __atomic_load_n(&s.h->m_skipped, __ATOMIC_RELAXED);
         out->yielded_waves = __atomic_load_n(&s.h->m_yields, __ATOMIC_RELAXED); out->returned_chunks = __atomic_load_n(&s.h->m_returned, __ATOMIC_RELAXED);
+        out->relocated_waves = __atomic_load_n(&s.h->m_relocated, __ATOMIC_RELAXED);
         return TSX_OK;
     }
     uint32_t w[4] = {0, 0, 0, 0};
@@ -1172,6 +1174,7 @@ extern "C" int tsx_service_stats(int device_index, tsx_service_info* out) {
         out->device_chunks = w[0]; out->wave_starts = w[1]; out->reserved_exits = w[2]; out->skipped_tickets = w[3];
     } else (void)hipGetLastError();
     if (hipMemcpy(w, &s.d->live, 8, hipMemcpyDeviceToHost) == hipSuccess) { out->live_waves = w[0]; out->live_waves_max = w[1]; } else (void)hipGetLastError();
+    if (hipMemcpy(w, &s.d->stat_relocated, 4, hipMemcpyDeviceToHost) == hipSuccess) out->relocated_waves = w[0]; else (void)hipGetLastError();
     return TSX_OK;
 }
 

@@ -115,7 +115,7 @@ struct tsx_svc_host {                // pinned host memory, written by the host,
     // workgroups), and next to guest waves - every wave slot of the chip taken - it waited for the launch to end (profiles/r06_guest_waves_root_cause.md).
     // Plain stores, last writer wins: a value may lag a few chunks behind; the exact words are read once the kernel is gone.
     uint32_t m_chunks, m_live, m_live_max, m_wave_starts, m_reserved_exits, m_skipped, m_yields, m_returned;
-    uint32_t pad2_[2];
+    uint32_t m_relocated, pad2_;
     tsx_zseg member[TSX_SVC_MEMBERS];
     tsx_svc_ticket ticket[TSX_SVC_TICKETS];
 };
@@ -134,7 +134,7 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
                                      // ticket.  Leaving is a decision of the LAUNCH: with per-wave timers the exits spread over ~0.5 ms, a member published
                                      // inside that window was picked up by the waves that had not left yet, and the launch lived on with a fraction of its
                                      // waves (measured: ONE wave serving 10 240 queued chunks until the 60 s age limit, profiles/r06_guest_waves_root_cause.md)
-    uint32_t pad3_;
+    uint32_t stat_relocated;         // waves that found themselves on a reserved CU they had not started on (saved and restored by the hardware's scheduler) and left
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
     uint32_t kept[256];              // per shader engine (key >> 4): waves of the current launch that stayed on the engine's reserved CU (tsx_svc_launch.keep_waves)

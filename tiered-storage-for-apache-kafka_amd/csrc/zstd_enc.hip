@@ -1675,15 +1675,22 @@ __device__ static inline uint32_t zs_yield_asked(const uint32_t* p) { return hip
 __device__ static inline uint32_t zs_yield_asked(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #endif
 
+__device__ static inline uint32_t svc_cu_key();                        // (which compute unit is this wave on right now?  below, with the service)
+
 // One chunk, start to finish, in the calling wave: CRC32C head, frame, GCM tail (or the copy into the caller's slot), descriptor.
 // Every argument is the same in all lanes (the service kernel hands them over in SGPRs).
 // `yield` != nullptr (a guest wave): looked at before every block; raised -> true is returned with the chunk unfinished.  Nothing the
 // caller can see has been written by then but the chunk's CRC32C and TSX_OK in status[] (both the same again next time); hash tables,
 // frame and entropy state live in the chunk's own workspace and are set up afresh by whoever starts the chunk again.
+// `reserved` != nullptr (every other wave): the bitmap of reserved compute units - before every block the wave asks the hardware where it
+// IS, and hands the chunk back the same way when that is a reserved CU.  A wave does not move by itself, but the hardware's scheduler may
+// save a queue's waves and restore them later, anywhere (compute wave save / restore, when another queue's dispatch has waited long
+// enough): after that, compressor waves sat on the reserved CUs for the rest of their launch and a fetch found no room - the "kernel of
+// a fetch that does not start, once in a few hundred fetches" of round 5 (profiles/r06_stuck_fetch_trace.txt).
 __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint8_t* __restrict__ src_base, tsx_chunk_desc* __restrict__ descs,
                                                            uint8_t* __restrict__ mid, uint64_t mid_stride, uint32_t* __restrict__ zlen,
                                                            int32_t* __restrict__ status, uint8_t* __restrict__ work, uint32_t profile, uint32_t sched,
-                                                           const tsx_chain_fuse fuse, const uint32_t chunk, const uint32_t* yield
+                                                           const tsx_chain_fuse fuse, const uint32_t chunk, const uint32_t* yield, const uint32_t* reserved
 #ifdef TSX_PROF
                                                            , unsigned long long* __restrict__ prof_out
 #endif
@@ -1755,9 +1762,12 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
     int cur = 0;                 // index of the confirmed Huffman table (L.huf[cur]); a candidate is built in L.huf[cur ^ 1]
     bool first = true;
     while (remaining) {
-        if (yield) {                                                    // a guest: is the CU wanted back?
+        if (yield || reserved) {                                        // a guest: is the CU wanted back?  anybody else: am I (still) off the reserved CUs?
             uint32_t y = 0;
-            if (lane == 0) y = zs_yield_asked(yield);
+            if (lane == 0) {
+                if (yield) y = zs_yield_asked(yield);
+                else { const uint32_t k = svc_cu_key(); y = (reserved[k >> 5] >> (k & 31)) & 1u; }
+            }
             if (UNI(y)) return true;
         }
         // ---- block size (ZSTD_optimalBlockSize) ----
@@ -1999,6 +2009,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     }
     const uint32_t key = UNI(svc_cu_key());
     const uint32_t* yield = nullptr;                                     // != nullptr: this wave is a guest on a reserved CU
+    const uint32_t* off_limits = D->reserved;                            // != nullptr: this wave leaves when it finds itself on a reserved CU (see zstd_compress_chunk)
     if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU (see tsx_internal.h): the first keep_waves to arrive stay for good,
         uint32_t stay = 0;                                               // the others work as guests while no fetch is about, or leave at once
         if (lane == 0) {
@@ -2010,12 +2021,18 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
             if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }
             return;
         }
+        off_limits = nullptr;
         if (stay == 2) yield = &H->yield;
     }
     if (lane == 0) atomicAdd(&D->stat_wave_starts, 1u);
     for (;;) {
         uint32_t got = 0, ticket = 0, chunk = 0;
-        if (lane == 0) got = svc_take(H, D, a, t_start, yield, &ticket, &chunk);
+        if (lane == 0) {
+            // (between two chunks: where is this wave now?  Restored onto a reserved CU, it leaves before it takes another ticket)
+            const uint32_t k = svc_cu_key();
+            if (off_limits && ((off_limits[k >> 5] >> (k & 31)) & 1u)) { SVC_ST_MIRROR(&H->m_relocated, atomicAdd(&D->stat_relocated, 1u) + 1u); got = 2; }
+            else got = svc_take(H, D, a, t_start, yield, &ticket, &chunk);
+        }
         got = UNI(got); ticket = UNI(ticket); chunk = UNI(chunk);
         if (got != 1 && got != 3) break;
         svc_acquire_chunk();
@@ -2040,13 +2057,18 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         { const uint64_t f = svc_word(w, 13); fuse.self_status = (uint32_t)f; fuse.key_on_host = (uint32_t)(f >> 32); }
         uint32_t* const done = (uint32_t*)svc_word(w, 14); uint32_t* const flag = (uint32_t*)svc_word(w, 15);
         const bool handed_back = zstd_compress_chunk(L, (const uint8_t*)svc_word(w, 2), (tsx_chunk_desc*)svc_word(w, 3), (uint8_t*)svc_word(w, 4), svc_word(w, 5),
-                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, yield ZS_PROF_ARG);
+                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, yield, off_limits ZS_PROF_ARG);
         if (handed_back) {
             // a fetch has arrived: the chunk goes back to the queue - every lane's stores into its workspace are complete and released (as
             // at the end of a finished chunk: the next wave may sit on another XCD, behind another L2) before another wave can start it
             // again - and this wave leaves its CU to the fetch's kernels
             __syncthreads();
-            if (lane == 0) { svc_release_system(); svc_return_chunk(D, mg, chunk); SVC_ST_MIRROR(&H->m_yields, atomicAdd(&D->stat_yields, 1u) + 1u); atomicSub(&D->busy, 1u); }
+            if (lane == 0) {
+                svc_release_system(); svc_return_chunk(D, mg, chunk);
+                if (yield) SVC_ST_MIRROR(&H->m_yields, atomicAdd(&D->stat_yields, 1u) + 1u);
+                else SVC_ST_MIRROR(&H->m_relocated, atomicAdd(&D->stat_relocated, 1u) + 1u);      // (not a guest: it was moved onto a reserved CU)
+                atomicSub(&D->busy, 1u);
+            }
             break;
         }
         // ---- this chunk is done: tell its member's caller when it was the member's last one ----

@@ -258,6 +258,11 @@ PY
         [ -n "$f" ] && python tools/trace_gaps.py $f --ms 20 | tee $O/stuck_gaps_$i.txt && gzip -c $f > $O/stuck_kernel_trace_$i.csv.gz
         rm -rf $O/stuck_$i
       done ;;
+    lone)
+      # one batch at a time with / without guest waves (tools/lone_batch_probe.py), and with no reservation at all
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/lone.err
+      timeout 300 python tools/lone_batch_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --configs ${arg:-fetch_quiet_ms=0 fetch_quiet_ms=2000} 2>> $O/lone.err | tee -a $O/lone.jsonl | cut -c1-1500
+      TSX_FETCH_RESERVED_CUS=0 timeout 200 python tools/lone_batch_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --configs fetch_quiet_ms=0 --batches 3 2>> $O/lone.err | sed 's/^{/{"env": "TSX_FETCH_RESERVED_CUS=0", /' | tee -a $O/lone.jsonl | cut -c1-1500 ;;
     keepwaves)
       # compressor waves that stay on the reserved CU of every shader engine (svc_keep_waves): fetch latency and upload rate, device-resident 2048-chunk batches, no torch
       export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
