@@ -46,6 +46,7 @@ struct tsx_cfg {
     uint32_t svc_waves_per_cu = 0;        // workgroups of a service launch per CU (0 = what the runtime says is resident at once; measurements only)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
+    uint32_t svc_guest_looks = 3;         // measurements: which looks at the yield word guest waves make (1: before every block, 2: while idle)
 };
 static tsx_cfg g_cfg;
 
@@ -74,7 +75,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(fetch_quiet_ms, uint32_t) CFG_FIELD(trace, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(fetch_quiet_ms, uint32_t) CFG_FIELD(trace, bool) CFG_FIELD(svc_guest_looks, uint32_t)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -297,18 +298,19 @@ static int svc_launch_locked(tsx_service& s) {
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
     a.keep_waves = g_cfg.svc_keep_waves;
+    a.guest_idle_ticks = 100000;                                         // 1 ms
     if (s.cus_reserved && svc_quiet(s)) {
         // no fetch for a while: the waves on the reserved CUs work as guests.  Word first, counter second (svc_foreground_begin)
         __atomic_store_n(&s.h->yield, 0u, __ATOMIC_SEQ_CST);
         if (s.fg_inflight.load(std::memory_order_seq_cst) != 0) __atomic_store_n(&s.h->yield, 1u, __ATOMIC_SEQ_CST);
-        else a.guests = 1;
+        else a.guests = 1u | (g_cfg.svc_guest_looks << 1);               // (bit 1: guests look at the yield word before every block, bit 2: and while idle)
     }
     (void)hipGetLastError();
     a.launch_id = s.launch_id + 1;
     tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);
     if (hipGetLastError() != hipSuccess) { snprintf(g_last_err, sizeof g_last_err, "launch of the compressor service kernel failed"); return TSX_E_DEVICE; }
     s.launch_id = a.launch_id;
-    s.launched = true; s.launches++; s.guest_launches += a.guests;
+    s.launched = true; s.launches++; s.guest_launches += a.guests ? 1u : 0u;
     return TSX_OK;
 }
 
@@ -406,7 +408,7 @@ static int svc_create(tsx_device& d, int cus) {
     // where 21 fit).  tsx_init runs on a device this process is not using yet.
     for (int pass = 0; pass < 3; pass++) {
         // (twice at least, and a third time when the two disagree: the first launch of a process also loads the code object)
-        tsx_svc_launch c{}; c.launch_id = ++s.launch_id; c.calibrate_ticks = 20000;       // leave when nobody has arrived for 200 us
+        tsx_svc_launch c{}; c.launch_id = ++s.launch_id; c.calibrate_ticks = 50000;       // leave when nobody has arrived for 500 us
         (void)hipGetLastError();
         tsx_launch_zstd_service(s.st, s.hd, s.d, s.cus * 32u, c);
         HIPCHK(hipStreamSynchronize(s.st));

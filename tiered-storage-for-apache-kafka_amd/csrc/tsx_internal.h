@@ -154,6 +154,7 @@ struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t guests;                 // != 0: the other waves on reserved CUs work too, as GUESTS - they look at tsx_svc_host.yield before every block of
                                      // their chunk (~30 ms apart) and while idle; once it is raised they hand the chunk back (another wave starts it
                                      // again from its first byte) and leave for good.  0: they leave at once (the reservation is in force from the start)
+    uint32_t guest_idle_ticks;       // a guest that has found the queue dry for this long leaves (a chip whose every slot is held by mostly IDLE waves slows the busy ones down)
     uint32_t keep_waves;             // waves that stay on a reserved CU all the same (0 = the CU is left alone; the rest of it - LDS, registers, wave slots - is the room a fetch's workgroups find)
 };
 void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, uint32_t grid, tsx_svc_launch a);

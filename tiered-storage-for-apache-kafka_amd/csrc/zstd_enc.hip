@@ -1697,7 +1697,7 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
                                                            ) {
     const uint32_t lane = threadIdx.x;
 #ifdef TSX_PROF
-    if (lane == 0) { for (int i = 0; i < 24; i++) g_prof[i] = 0; g_prof[22] = g_prof[23] = (unsigned long long)clock64(); }
+    if (lane == 0) { for (int i = 0; i < 24; i++) g_prof[i] = 0; g_prof[22] = g_prof[23] = (unsigned long long)clock64(); g_prof[2] = wall_clock64(); }
     __syncthreads();
 #endif
     const uint8_t* __restrict__ src = src_base + descs[chunk].src_off;
@@ -1839,7 +1839,12 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
     finish_frame(descs, chunk, frame, (uint32_t)(op - frame), zlen, status, fuse, ws + ZS_WS_KEYCOPY, L, lane);
     PT(17);
 #ifdef TSX_PROF
-    if (lane == 0 && prof_out) { g_prof[14] = (unsigned long long)clock64() - g_prof[22]; for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i]; }
+    if (lane == 0 && prof_out) {
+        g_prof[14] = (unsigned long long)clock64() - g_prof[22];
+        g_prof[3] = wall_clock64();                                    // [2], [3]: the chunk's begin and end on the 100 MHz wall clock; [19]: where it ran (CU key | guest << 16)
+        g_prof[19] = svc_cu_key() | (yield ? 1u << 16 : 0u);
+        for (int i = 0; i < 24; i++) prof_out[(size_t)chunk * 24 + i] = g_prof[i];
+    }
 #endif
     return false;
 }
@@ -1921,13 +1926,13 @@ __device__ ZS_NOINLINE static void svc_return_chunk(tsx_svc_dev* D, uint32_t mem
 __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a, const uint64_t t_start, const uint32_t* yield,
                                                 uint32_t* ticket, uint32_t* chunk_out) {
     const uint64_t max_age = ((uint64_t)a.max_age_ticks_hi << 32) | a.max_age_ticks_lo;
-    uint64_t quiet_since = 0;
+    uint64_t quiet_since = 0, dry_since = 0;
     uint32_t nap = 1, looks = 0;
     for (;;) {
         const uint64_t now = svc_now();
         if (SVC_LD_DEV(&D->stop)) return 2;
         if (max_age && now - t_start > max_age) return 2;
-        if (yield && (looks++ & 7u) == 0u && zs_yield_asked(yield)) return 2;     // (an idle guest: one PCIe read per eight looks, <= 2 ms apart)
+        if (yield && (a.guests & 4u) && (looks++ & 7u) == 0u && zs_yield_asked(yield)) return 2;     // (an idle guest: one PCIe read per eight looks, <= 2 ms apart)
         if (SVC_LD_DEV(&D->ret_n)) {
             atomicAdd(&D->busy, 1u);
             svc_ret_lock(D);
@@ -1954,6 +1959,13 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
             atomicSub(&D->busy, 1u);
             continue;
         }
+        // A guest does not wait for work.  With EVERY wave slot of the chip held and most of the waves idle, the busy ones crawl: a lone
+        // 2048-chunk batch took 1.1 - 9.8 s instead of 1.1 s, whether the idle waves were guests, waves kept on the reserved CUs or ordinary
+        // waves of a launch without any reservation; with as little as a third of one CU per shader engine free it is 1.1 s every time
+        // (profiles/r06_full_chip_with_idle_waves.txt).  A chip that is full AND busy is fine (that is the saturated regime guests exist for).
+        // So a guest that has found nothing to do for guest_idle_ticks (1 ms: longer than the host's poll takes to arrive at a fresh launch)
+        // leaves its slot; the next launch - which begins when work arrives after a dry spell - has guests again.
+        if (yield) { if (dry_since == 0) dry_since = now; else if (now - dry_since >= a.guest_idle_ticks) return 2; }
         if (SVC_LD_DEV(&D->busy) != 0 || quiet_since == 0) quiet_since = now;
         if (now - quiet_since >= a.idle_exit_ticks && SVC_LD_DEV(&D->busy) == 0) { atomicExch(&D->draining, 1u); return 2; }
         svc_nap(nap);
@@ -2057,7 +2069,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         { const uint64_t f = svc_word(w, 13); fuse.self_status = (uint32_t)f; fuse.key_on_host = (uint32_t)(f >> 32); }
         uint32_t* const done = (uint32_t*)svc_word(w, 14); uint32_t* const flag = (uint32_t*)svc_word(w, 15);
         const bool handed_back = zstd_compress_chunk(L, (const uint8_t*)svc_word(w, 2), (tsx_chunk_desc*)svc_word(w, 3), (uint8_t*)svc_word(w, 4), svc_word(w, 5),
-                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, yield, off_limits ZS_PROF_ARG);
+                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, (a.guests & 2u) ? yield : nullptr, off_limits ZS_PROF_ARG);
         if (handed_back) {
             // a fetch has arrived: the chunk goes back to the queue - every lane's stores into its workspace are complete and released (as
             // at the end of a finished chunk: the next wave may sit on another XCD, behind another L2) before another wave can start it

@@ -263,6 +263,30 @@ PY
       [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/lone.err
       timeout 300 python tools/lone_batch_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --configs ${arg:-fetch_quiet_ms=0 fetch_quiet_ms=2000} 2>> $O/lone.err | tee -a $O/lone.jsonl | cut -c1-1500
       TSX_FETCH_RESERVED_CUS=0 timeout 200 python tools/lone_batch_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --configs fetch_quiet_ms=0 --batches 3 2>> $O/lone.err | sed 's/^{/{"env": "TSX_FETCH_RESERVED_CUS=0", /' | tee -a $O/lone.jsonl | cut -c1-1500 ;;
+    where)
+      # where do the chunks of a lone batch run, and which are slow?  prof flavour, guests on (default) and off
+      for cfg in ${arg:-fetch_quiet_ms=2000 fetch_quiet_ms=0}; do
+        for rep in 1 2 3; do
+          timeout 300 python tools/prof_zstd.py --chunks 2048 --dist K --chain --where --config $cfg --data /dev/shm/prof_k256.npy --out $O/where_${cfg}_$rep.json > /dev/null 2>> $O/where.err
+          python - <<PY
+import json
+j = json.load(open("$O/where_${cfg}_$rep.json")); print("$cfg rep $rep wall", round(j["wall_ms_1"]), json.dumps(j["where"])[:1400])
+PY
+        done
+      done ;;
+    lonev)
+      # lone batches under variants "ENVVALUE:config" (ENVVALUE = TSX_FETCH_RESERVED_CUS or - for the default), e.g. lonev:0:fetch_quiet_ms=0+-:fetch_quiet_ms=2000
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/lonev.err
+      for v in ${arg//+/ }; do
+        e=${v%%:*}; cfg=${v#*:}
+        ( [ "$e" != "-" ] && export TSX_FETCH_RESERVED_CUS=$e; timeout 200 python tools/lone_batch_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --no-sampler --batches ${LONE_BATCHES:-8} --configs $cfg 2>> $O/lonev.err | sed "s/^{/{\"reserved_cus_env\": \"$e\", /" >> $O/lonev.jsonl )
+      done
+      python - <<PY
+import json
+for l in open("$O/lonev.jsonl"):
+    j = json.loads(l); print("reserved env", j["reserved_cus_env"], j["config"], "waves", j["waves"], [b["ms"] for b in j["batches"]], "guest launches", sum(b["guest_launches"] for b in j["batches"]), "reserved exits", j["batches"][0]["reserved_exits"])
+PY
+      ;;
     keepwaves)
       # compressor waves that stay on the reserved CU of every shader engine (svc_keep_waves): fetch latency and upload rate, device-resident 2048-chunk batches, no torch
       export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}

@@ -26,12 +26,20 @@ def main():
     ap.add_argument("--batches", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=2048)
     ap.add_argument("--pause-ms", type=float, default=20.0)
+    ap.add_argument("--prof-lib", default="", help="tools/_libs/libtsxform_prof.so: per-chunk begin / end / CU of every batch (guest waves against the others)")
+    ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--bind", action="store_true", help="bind the process to the GPU's NUMA node first (as the other probes do)")
     a = ap.parse_args()
     assert "torch" not in sys.modules
     import tsxform
     from tsxform import synth
     nat = tsxform._native
-    N = nat.Native(); N.init(1, [0])
+    N = nat.Native(a.prof_lib) if a.prof_lib else nat.Native()
+    N.init(1, [0])
+    aff = None
+    if a.bind:
+        from numa_bind import bind_to_gpu_numa_node
+        aff = bind_to_gpu_numa_node(0)
     CH, B, n = 4 << 20, 256, a.chunks
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     params = nat.Native.make_params(flags, synth.KEY, synth.AAD)
@@ -44,6 +52,12 @@ def main():
     d0 = np.zeros(n, nat.DESC_DTYPE); d0["src_off"] = np.arange(n, dtype=np.uint64) * CH; d0["src_len"] = CH
     d0["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d0["dst_cap"] = slot; d0["iv"] = np.tile(ivs, (n // B, 1))
     ctx = N.ctx_create(0, n, CH)
+    dprof = None
+    if a.prof_lib:
+        import ctypes as C
+        dprof = N.device_malloc(n * 24 * 8)
+        N.lib.tsx_debug_set_prof.restype = None; N.lib.tsx_debug_set_prof.argtypes = [C.c_void_p]
+        N.lib.tsx_debug_set_prof(dprof)
     for cfg in a.configs:
         for kv in cfg.split(","):
             N.debug_config(kv.split("=")[0], int(kv.split("=")[1]))
@@ -60,19 +74,30 @@ def main():
                     s = N.service_stats(0)
                     samples.append((round((time.perf_counter() - t0) * 1e3), int(s["device_chunks"]) - int(s0["device_chunks"]), int(s["live_waves"]), int(s["running"])))
                     time.sleep(0.05)
-            th = threading.Thread(target=sampler); th.start()
+            th = threading.Thread(target=sampler if not a.no_sampler else (lambda: None)); th.start()
             t0 = time.perf_counter()
             N.transform_batch(params, d, dsrc, ddst, n * slot, nat.MEM_DEVICE, ctx=ctx, src_size=n * CH)
             ms = (time.perf_counter() - t0) * 1e3
             going[0] = False; th.join()
             s1 = N.service_stats(0)
             assert (d["status"] == 0).all()
-            rows.append({"ms": round(ms, 1), "launches": int(s1["launches"] - s0["launches"]), "guest_launches": int(s1["guest_launches"] - s0["guest_launches"]),
+            where = None
+            if dprof:
+                hp = np.zeros(n * 24, np.uint64); N.d2h(hp, dprof)
+                p = hp.reshape(n, 24).astype(np.int64)
+                t0_ = p[:, 2].min(); dur = (p[:, 3] - p[:, 2]) / 1e5; beg = (p[:, 2] - t0_) / 1e5; guest = (p[:, 19] >> 16) & 1
+
+                def q(x):
+                    return None if x.size == 0 else [round(float(v), 1) for v in np.percentile(x, [0, 50, 90, 99, 100])]
+                where = {"guest_chunks": int(guest.sum()), "chunk_ms_p0_50_90_99_100": {"guests": q(dur[guest == 1]), "others": q(dur[guest == 0])},
+                         "begin_ms_p0_50_90_99_100": {"guests": q(beg[guest == 1]), "others": q(beg[guest == 0])},
+                         "cycles_M_p50": {"guests": None if guest.sum() == 0 else round(float(np.median(p[guest == 1, 14])) / 1e6), "others": round(float(np.median(p[guest == 0, 14])) / 1e6)}}
+            rows.append({"ms": round(ms, 1), "where": where, "launches": int(s1["launches"] - s0["launches"]), "guest_launches": int(s1["guest_launches"] - s0["guest_launches"]),
                          "wave_starts": int(s1["wave_starts"] - s0["wave_starts"]), "reserved_exits": int(s1["reserved_exits"] - s0["reserved_exits"]),
                          "relocated": int(s1["relocated_waves"] - s0["relocated_waves"]),
                          "progress_ms_chunks_live_running": samples[::max(1, len(samples) // 12)]})
             time.sleep(a.pause_ms / 1e3)
-        print(json.dumps({"config": cfg, "chunks": n, "pause_ms": a.pause_ms, "waves": int(N.service_stats(0)["waves"]), "batches": rows}), flush=True)
+        print(json.dumps({"config": cfg, "cpu_affinity": aff, "sampler": not a.no_sampler, "chunks": n, "pause_ms": a.pause_ms, "waves": int(N.service_stats(0)["waves"]), "batches": rows}), flush=True)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--chain", action="store_true", help="full chain (CRC head + compress + GCM tail in the compressor wave) instead of compress only")
     ap.add_argument("--uniq", type=int, default=256, help="distinct chunks (replicated to --chunks); content B is generated on the host, ~5 s per chunk")
     ap.add_argument("--profile", default="1_5_7", choices=["1_5_7", "1_5_6"], help="Zstd profile (the 1.5.7 pre-splitter on / off)")
+    ap.add_argument("--config", default="", help="key=value,... for tsx_debug_config before the batches (e.g. fetch_quiet_ms=2000)")
+    ap.add_argument("--where", action="store_true", help="per-chunk wall time by where the chunk ran: guest waves (reserved CUs) against the others")
     ap.add_argument("--lib", default="libtsxform_prof.so", help="libtsxform_prof.so (lap timers) or libtsxform.so (plain, for rocprofv3 runs)")
     args = ap.parse_args()
     import torch
@@ -35,6 +37,9 @@ def main():
     nat = tsxform._native
     N = nat.Native(os.path.join(os.path.dirname(nat.LIB_PATH), args.lib) if args.lib == "libtsxform.so" else os.path.join(os.path.dirname(os.path.abspath(__file__)), "_libs", args.lib))
     has_prof = "_prof" in args.lib
+    for kv in (args.config or "").split(","):
+        if kv:
+            N.debug_config(kv.split("=")[0], int(kv.split("=")[1]))
     N.init(1, [0])
     n, CH = args.chunks, synth.CHUNK
     dev = torch.device("cuda", 0)
@@ -73,6 +78,18 @@ def main():
         res["wall_ms_%d" % it] = (time.perf_counter() - t0) * 1e3
         res["zstd_ms_%d" % it] = N.ctx_timing(ctx).zstd_ms
     p = prof.cpu().numpy().reshape(n, 24)
+    if args.where:
+        # the LAST batch: wall time of every chunk (100 MHz clock), begin relative to the batch's first begin, by kind of wave
+        t0 = p[:, 2].min()
+        dur = (p[:, 3] - p[:, 2]) / 1e5; beg = (p[:, 2] - t0) / 1e5; guest = (p[:, 19] >> 16) & 1; key = p[:, 19] & 0xFFF
+        def q(a):
+            return None if a.size == 0 else [round(float(x), 1) for x in np.percentile(a, [0, 50, 90, 99, 100])]
+        res["where"] = {"guest_chunks": int(guest.sum()), "other_chunks": int((1 - guest).sum()),
+                        "chunk_ms_p0_50_90_99_100": {"guests": q(dur[guest == 1]), "others": q(dur[guest == 0])},
+                        "begin_ms_p0_50_90_99_100": {"guests": q(beg[guest == 1]), "others": q(beg[guest == 0])},
+                        "batch_ms_first_begin_to_last_end": round(float((p[:, 3].max() - t0) / 1e5), 1),
+                        "slowest_20": sorted([(round(float(dur[i]), 1), round(float(beg[i]), 1), int(guest[i]), int(key[i])) for i in np.argsort(-dur)[:20]], reverse=True),
+                        "chunks_per_cu_max": int(np.bincount(key.astype(np.int64)).max()), "cus_used": int((np.bincount(key.astype(np.int64)) > 0).sum())}
     mean = p.mean(axis=0)
     res["chunks"] = n
     res["mean_out"] = float(d["dst_len"].mean())
