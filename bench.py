@@ -958,7 +958,7 @@ def main():
             if not args.broker_subprocess:
                 broker = broker_leg.run(N, nat, params, hsrc[:bseg * B * CH], d["iv"][:bseg * B], d["dst_len"][:bseg * B], (10, 20, 32), B, CH, 8.0)
             else:
-                import subprocess
+                pass  # (subprocess: module-level import)
                 import tempfile
                 shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
                 tmpd = tempfile.mkdtemp(prefix="tsx_broker_", dir=shm)

@@ -152,14 +152,15 @@ typedef struct tsx_config {
                                         waits ~0.5 s for the compressor launch to be rotated; 12 and more: such waits become regular.
                                         At most 8 is accepted                                                                  */
     uint64_t pool_idle_bytes;        /* idle pooled workspace kept per device; default 4/9 of its memory                      */
-    uint32_t fetch_quiet_ms;         /* OPT-IN: the reservation follows the traffic.  != 0: once no fetch (no batch of ordinary
-                                        kernels) has run for this long, the compressor's waves work on the reserved CUs too, as
-                                        guests - the next fetch makes them hand their chunks back and leave, which costs that ONE
-                                        fetch a block time of a chunk (measured: 29 ms), and the CUs stay reserved until it has been
-                                        quiet again.  Measured: bench.py value 19.8 -> 21.5 GiB/s; in a torch-free probe the rate
-                                        between batch completions rose 19.2 -> 21-22, but two of four runs lost seconds somewhere
-                                        (whole-window 12-14; profiles/r05_guest_waves_probe.jsonl), cause not found: default 0 =
-                                        the reserved CUs are never used by the compressor                                        */
+    uint32_t fetch_quiet_ms;         /* the reservation follows the traffic (default 2000; 0 = the reserved CUs are never used by the
+                                        compressor).  Once no fetch (no batch of ordinary kernels) has run for this long, a launch of the
+                                        compressor's kernel has waves on the reserved CUs too, as GUESTS: they work for as long as the
+                                        queue has work for them - a chip that is full AND busy is what they are for; a guest that finds
+                                        the queue dry for 1 ms gives its slot back - and the next fetch makes them hand their chunks
+                                        back and leave, which costs that ONE fetch a block time of a chunk (~30 ms); the CUs then stay
+                                        reserved until it has been quiet again.  Measured (round 6, MI355X): bench.py value 18.2 -> 20.5,
+                                        continuously fed 19.8 -> 22.3 GiB/s.  Why it was opt-in in round 5 and what was wrong then:
+                                        profiles/r06_guest_waves_root_cause.md, r06_full_chip_with_idle_waves.txt                      */
     uint32_t reserved2_;
 } tsx_config;
 int  tsx_init_ex(int device_count, const int* device_ids, const tsx_config* cfg);   /* cfg == NULL: tsx_init */

@@ -143,6 +143,11 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
     // guest wave when a fetch arrives after a quiet time
     uint32_t ret_lock, ret_n, stat_yields, stat_returned;
     tsx_svc_ticket ret[TSX_SVC_RETURNED_MAX];
+    // chunks in progress per compute unit (by CU key): a partial load is spread over the chip.  The hardware fills a launch's CUs one after the other,
+    // so the first waves to look - the ones that take a lone batch's tickets - sit on ~200 of 256 CUs, up to 21 on one (measured: profiles/r06_where_a_lone_batch_runs.txt);
+    // a chunk next to 20 others takes a third longer than one next to 8.  A wave whose CU already runs more chunks than the device-wide share + 2 lets the
+    // ticket go to a wave elsewhere, a few looks long (svc_take).
+    uint32_t cu_busy[4096];
 };
 struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t launch_id;              // what the last wave writes to tsx_svc_host.ended_launch
@@ -154,6 +159,7 @@ struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t guests;                 // != 0: the other waves on reserved CUs work too, as GUESTS - they look at tsx_svc_host.yield before every block of
                                      // their chunk (~30 ms apart) and while idle; once it is raised they hand the chunk back (another wave starts it
                                      // again from its first byte) and leave for good.  0: they leave at once (the reservation is in force from the start)
+    uint32_t spread_cus;             // != 0: compute units a partial load is spread over (the ones the compressor uses); 0 = tickets go to whoever asks first
     uint32_t guest_idle_ticks;       // a guest that has found the queue dry for this long leaves (a chip whose every slot is held by mostly IDLE waves slows the busy ones down)
     uint32_t keep_waves;             // waves that stay on a reserved CU all the same (0 = the CU is left alone; the rest of it - LDS, registers, wave slots - is the room a fetch's workgroups find)
 };

@@ -1924,10 +1924,10 @@ __device__ ZS_NOINLINE static void svc_return_chunk(tsx_svc_dev* D, uint32_t mem
 // (3): a chunk that a guest handed back, in *ticket / *chunk_out (member slot | generation, chunk index) - taken before any fresh ticket.
 // `yield` != nullptr: this wave is a guest and leaves (2) as soon as the word is raised.
 __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a, const uint64_t t_start, const uint32_t* yield,
-                                                uint32_t* ticket, uint32_t* chunk_out) {
+                                                const uint32_t key, uint32_t* ticket, uint32_t* chunk_out) {
     const uint64_t max_age = ((uint64_t)a.max_age_ticks_hi << 32) | a.max_age_ticks_lo;
     uint64_t quiet_since = 0, dry_since = 0;
-    uint32_t nap = 1, looks = 0;
+    uint32_t nap = 1, looks = 0, deferred = 0;
     for (;;) {
         const uint64_t now = svc_now();
         if (SVC_LD_DEV(&D->stop)) return 2;
@@ -1954,6 +1954,8 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
         }
         const uint32_t nx = SVC_LD_DEV(&D->next), pb = SVC_LD_DEV(&D->pub);
         if ((int32_t)(pb - nx) > 0) {
+            // spread a partial load (tsx_svc_dev.cu_busy): not me, if my CU is already ahead of the others - for three looks at most
+            if (a.spread_cus && deferred < 3u && SVC_LD_DEV(&D->cu_busy[key]) * a.spread_cus > SVC_LD_DEV(&D->busy) + 2u * a.spread_cus) { deferred++; svc_nap(1); continue; }
             atomicAdd(&D->busy, 1u);                                     // before the ticket is taken: busy >= waves that hold one
             if (atomicCAS(&D->next, nx, nx + 1u) == nx) { *ticket = nx; return 1; }
             atomicSub(&D->busy, 1u);
@@ -2037,14 +2039,17 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         if (stay == 2) yield = &H->yield;
     }
     if (lane == 0) atomicAdd(&D->stat_wave_starts, 1u);
+    uint32_t key_busy = 0;                                              // the CU this wave's chunk in progress is counted on (tsx_svc_dev.cu_busy)
     for (;;) {
         uint32_t got = 0, ticket = 0, chunk = 0;
         if (lane == 0) {
             // (between two chunks: where is this wave now?  Restored onto a reserved CU, it leaves before it takes another ticket)
             const uint32_t k = svc_cu_key();
             if (off_limits && ((off_limits[k >> 5] >> (k & 31)) & 1u)) { SVC_ST_MIRROR(&H->m_relocated, atomicAdd(&D->stat_relocated, 1u) + 1u); got = 2; }
-            else got = svc_take(H, D, a, t_start, yield, &ticket, &chunk);
+            else got = svc_take(H, D, a, t_start, yield, k, &ticket, &chunk);
+            if (got == 1 || got == 3) { atomicAdd(&D->cu_busy[k], 1u); key_busy = k; }
         }
+        key_busy = UNI(key_busy);
         got = UNI(got); ticket = UNI(ticket); chunk = UNI(chunk);
         if (got != 1 && got != 3) break;
         svc_acquire_chunk();
@@ -2060,7 +2065,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         const uint64_t w0 = svc_word(w, 0), w1 = svc_word(w, 1);
         const uint32_t n = (uint32_t)w0, profile = (uint32_t)(w0 >> 32), gen = (uint32_t)w1;
         if (slot >= TSX_SVC_MEMBERS || (gen & 0xFFFFu) != (mg >> 16) || chunk >= n) {          // an abandoned member's ticket
-            if (lane == 0) { atomicAdd(&D->stat_skipped, 1u); atomicSub(&D->busy, 1u); }
+            if (lane == 0) { atomicAdd(&D->stat_skipped, 1u); atomicSub(&D->cu_busy[key_busy], 1u); atomicSub(&D->busy, 1u); }
             continue;
         }
         tsx_chain_fuse fuse;
@@ -2079,6 +2084,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
                 svc_release_system(); svc_return_chunk(D, mg, chunk);
                 if (yield) SVC_ST_MIRROR(&H->m_yields, atomicAdd(&D->stat_yields, 1u) + 1u);
                 else SVC_ST_MIRROR(&H->m_relocated, atomicAdd(&D->stat_relocated, 1u) + 1u);      // (not a guest: it was moved onto a reserved CU)
+                atomicSub(&D->cu_busy[key_busy], 1u);
                 atomicSub(&D->busy, 1u);
             }
             break;
@@ -2098,6 +2104,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
                 // PCIe AtomicOps routed all the way to the root complex - not every server does that
                 SVC_ST_SYS(flag, 1u);
             }
+            atomicSub(&D->cu_busy[key_busy], 1u);
             atomicSub(&D->busy, 1u);
         }
         __syncthreads();

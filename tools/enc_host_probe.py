@@ -60,6 +60,7 @@ def main():
                 N.transform_batch(params, d, src, dst, dst.size, nat.MEM_HOST, ctx=ctx)
                 ts.append(time.perf_counter() - t0)
                 tm = N.ctx_timing(ctx)
+            took_zc = bool(N.lib.tsx_debug_last_zero_copy(ctx))          # (the inverse call below resets the context's flag)
             assert (d["status"] == 0).all()
             dig = int(np.bitwise_xor.reduce(d["crc32c"])) ^ int(dst[::4099].astype(np.uint64).sum() & 0xFFFFFFFF)
             ref = dig if ref is None else ref
@@ -70,7 +71,7 @@ def main():
                 N.detransform_batch(params, e, dst, back, back.size, nat.MEM_HOST, ctx=ctx)
                 ti.append(time.perf_counter() - t0)
             print(json.dumps({"tag": a.tag, "runtime": "torch's bundled HIP" if a.with_torch else "system HIP (no torch)", "zero_copy_output": bool(zc),
-                              "piece": "one piece" if sub_mib < 0 else "%d MiB" % (sub_mib or 64), "zero_copy_taken": bool(N.lib.tsx_debug_last_zero_copy(ctx)),
+                              "piece": "one piece" if sub_mib < 0 else "%d MiB" % (sub_mib or 64), "zero_copy_taken": took_zc,
                               "ms_best": round(min(ts) * 1e3, 2), "ms_median": round(float(np.median(ts)) * 1e3, 2), "gibs_best": round(1.0 / min(ts), 2),
                               "h2d_span_ms": round(tm.h2d_ms, 2), "d2h_span_ms": round(tm.d2h_ms, 2), "gcm_ms": round(tm.gcm_ms, 2), "crc_ms": round(tm.crc_ms, 2),
                               "inverse_ms_best": round(min(ti) * 1e3, 2), "inverse_gibs": round(1.0 / min(ti), 2), "same_bytes": dig == ref,
