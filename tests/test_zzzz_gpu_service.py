@@ -25,24 +25,27 @@ CHUNK = synth.CHUNK
 
 def test_cu_probe_found_every_compute_unit_and_the_reservation_holds(gpu):
     """HW_ID[15:8] + XCC_ID is a key per compute unit: the probe launch of tsx_init met exactly as many keys as the device has CUs, in 32
-    shader engines; one CU of every engine is left to everything but the compressor while fetches are about (fetch_quiet_ms = 0: always), and a
-    launch of the service is exactly as large as the chip holds at once (24 one-wave workgroups per CU: measured by the calibration launch),
-    so that no workgroup of it is ever pending.  With no fetch about, the waves on the reserved CUs stay and compress (guest waves)."""
+    shader engines; one CU of every engine is left to everything but the compressor, and a launch of the service is exactly as large as the
+    chip holds at once (23 or 24 one-wave workgroups per CU: measured by the calibration launch), so that no workgroup of it is ever pending.
+    The waves that land on the reserved CUs leave at once.  Guests - waves that compress on the reserved CUs while nobody fetches - come in
+    launches of their own, and only when the queue is deeper than the launch has waves (a chip without a free slot works well only while every
+    wave is busy: profiles/r06_full_chip_with_idle_waves.txt): a small batch gets none, two 2048-chunk-deep... here 3 x 2048 chunks do."""
+    import threading
+    import torch
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     s0 = gpu.service_stats(0)
     assert s0["compute_units"] == 256 and s0["cu_keys_seen"] == 256, s0
     assert s0["shader_engines"] == 32 and s0["reserved_cus"] == 32, s0
-    assert s0["waves"] == 256 * 24, s0                                 # (6384 B of LDS = five 1280-byte granules: 25 fit, the registers allow 24)
+    assert s0["waves"] in (256 * 23, 256 * 24), s0                     # (6384 B of LDS = five 1280-byte granules: 25 fit, the registers allow 24; some boxes hold 23)
     per_cu = s0["waves"] // 256
     chunks = [synth.gen_chunk("K", 3, 0, i, 100000) for i in range(32)]
-    with gpu.configured(fetch_quiet_ms=0):
-        gpu.service_quiesce(0)
-        s0 = gpu.service_stats(0)
-        pc.run_transform(gpu, flags, chunks, mem="device")
-        gpu.service_quiesce(0)
-        s1 = gpu.service_stats(0)
+    gpu.service_quiesce(0)
+    s0 = gpu.service_stats(0)
+    pc.run_transform(gpu, flags, chunks, mem="device")
+    gpu.service_quiesce(0)
+    s1 = gpu.service_stats(0)
     launches = s1["launches"] - s0["launches"]
-    assert launches >= 1 and s1["device_chunks"] - s0["device_chunks"] == 32 and s1["guest_launches"] == s0["guest_launches"]
+    assert launches >= 1 and s1["device_chunks"] - s0["device_chunks"] == 32 and s1["guest_launches"] == s0["guest_launches"]      # 32 chunks: no guests
     # on an idle chip a launch covers it once - as many workgroups per CU as are resident at the same time, never one more (a pending
     # workgroup would hold the launch's hardware pipe for as long as the waves stay) - and those that land on the 32 reserved CUs leave at once
     starts, exits = s1["wave_starts"] - s0["wave_starts"], s1["reserved_exits"] - s0["reserved_exits"]
@@ -50,26 +53,47 @@ def test_cu_probe_found_every_compute_unit_and_the_reservation_holds(gpu):
     assert starts + exits == launches * s1["waves"], (s0, s1)
     assert exits >= launches * 32 * per_cu * 0.9 and starts >= launches * 224 * per_cu * 0.95, (s0, s1)
     assert s1["live_waves_max"] >= 0.97 * 256 * per_cu and s1["live_waves"] == 0, s1      # (resident at once, for a moment, before the reserved CUs' waves left)
-    # nobody fetches: every wave of the launch stays, wherever it landed
+    # nobody fetches and three callers queue 6144 chunks - more than the launch has waves: guests arrive (a launch of their own), the bytes are the same
+    dev = torch.device("cuda", 0)
+    n, T = 2048, 3
+    slot = (gpu.transformed_bound(CHUNK, flags) + 63) // 64 * 64
+    p = nat.Native.make_params(flags, synth.KEY, synth.AAD)
+    src = torch.empty(n * CHUNK, dtype=torch.uint8, device=dev)
+    for i in range(16):
+        src[i * CHUNK:(i + 1) * CHUNK] = synth.gen_chunk("K", 1000, 0, i, CHUNK, device=dev)
+    for i in range(16, n, 16):
+        src[i * CHUNK:(i + 16) * CHUNK] = src[:16 * CHUNK]
+    d = np.zeros(n, nat.DESC_DTYPE); d["src_off"] = np.arange(n, dtype=np.uint64) * CHUNK; d["src_len"] = CHUNK
+    d["dst_off"] = np.arange(n, dtype=np.uint64) * slot; d["dst_cap"] = slot
+    for i in range(n):
+        d["iv"][i] = np.frombuffer(synth.iv_for(0, i % 16), np.uint8)
+    ctxs = [gpu.ctx_create(0, n, CHUNK) for _ in range(T)]
+    dsts = [torch.empty(n * slot, dtype=torch.uint8, device=dev) for _ in range(T)]
+    ds = [d.copy() for _ in range(T)]
     with gpu.configured(fetch_quiet_ms=1):
         time.sleep(0.05)
-        pc.run_transform(gpu, flags, chunks, mem="device")
+        th = [threading.Thread(target=lambda t=t: [gpu.transform_batch(p, ds[t], src.data_ptr(), dsts[t].data_ptr(), dsts[t].numel(), nat.MEM_DEVICE, ctx=ctxs[t]) for _ in range(2)]) for t in range(T)]
+        [x.start() for x in th]; [x.join() for x in th]
         gpu.service_quiesce(0)
         s2 = gpu.service_stats(0)
-    launches2 = s2["launches"] - s1["launches"]
-    assert launches2 >= 1 and s2["guest_launches"] - s1["guest_launches"] == launches2, (s1, s2)
-    assert s2["reserved_exits"] == s1["reserved_exits"] and s2["wave_starts"] - s1["wave_starts"] == launches2 * s2["waves"], (s1, s2)
+    assert all((x["status"] == 0).all() for x in ds) and all((x["dst_len"] == ds[0]["dst_len"]).all() and (x["crc32c"] == ds[0]["crc32c"]).all() for x in ds)
+    assert torch.equal(dsts[0][:16 * slot], dsts[1][:16 * slot])
+    assert s2["guest_launches"] > s1["guest_launches"], (s1, s2)
+    assert s2["live_waves"] == 0 and s2["device_chunks"] - s1["device_chunks"] == 2 * T * n, (s1, s2)
+    for c in ctxs:
+        gpu.ctx_destroy(c)
 
 
 @pytest.mark.timeout(600)
 def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     """Four callers keep 4 x 2048 four-MiB chunks queued at the compressor (more than the chip holds) while this thread restores one chunk
     host -> host, again and again: median <= 5 ms, 95th percentile <= 50 ms (round 4, no reservation: 50-80 s; profiles/r04_mixed_load.txt),
-    and never more than 3 s: once in a few hundred fetches a kernel of a fetch still does not start next to a compressor launch (cause not
-    found); the fetch then asks that launch to end after 200 ms and runs when its waves have left (tsx_api.hip, svc_rotate).  The restored
-    bytes are right.  The uploads begin on a device that has not fetched for a while (fetch_quiet_ms, shortened here): their launch has
-    guest waves on the reserved CUs, and the FIRST fetch is the one that makes them hand their chunks back and leave - it may take a
-    block time of a chunk longer, the chunks handed back are compressed all the same."""
+    never more than 200 ms, and no launch of the compressor asked to end early.  (Round 5 allowed 3 s here: once in a few hundred fetches a
+    kernel of a fetch did not start - compressor waves that the hardware's scheduler had saved and restored onto the reserved CUs,
+    profiles/r06_stuck_fetch_trace.txt; they notice at their next block boundary now, <= ~30 ms.)  The restored bytes are right.  The uploads
+    begin on a device that has not fetched for a while (fetch_quiet_ms, shortened here) and queue more chunks than the launch has waves:
+    guest waves are on the reserved CUs, and the FIRST fetch is the one that makes them hand their chunks back and leave - it takes a block
+    time of a chunk longer (<= 100 ms asserted, ~30 measured), the chunks handed back are compressed all the same."""
     import torch
     flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
     dev = torch.device("cuda", 0)
@@ -144,8 +168,9 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     assert not errors, errors[:3]
     assert ok_bytes
     assert all((x["status"] == 0).all() for x in ds)
-    assert np.median(a) <= 5.0 and np.percentile(a, 95) <= 50.0 and a.max() <= 3000.0, (float(np.median(a)), float(np.percentile(a, 95)), float(a.max()))
-    assert first <= 3000.0, first                                      # (expected: a block time of a chunk, ~30 ms; a rotation on top of it would still be inside)
+    assert np.median(a) <= 5.0 and np.percentile(a, 95) <= 50.0 and a.max() <= 200.0, (float(np.median(a)), float(np.percentile(a, 95)), float(a.max()))
+    assert first <= 100.0, first                                       # (a block time of a chunk, ~30 ms)
+    assert sv1["rotations"] == sv0["rotations"], (sv0, sv1)             # nobody had to ask the launch to end
     assert sv1["guest_launches"] > sv0["guest_launches"] and sv1["yielded_waves"] - sv0["yielded_waves"] >= 32 * 8, (sv0, sv1)
 
 

@@ -129,6 +129,9 @@ struct tsx_service {
     std::atomic<uint32_t> fg_inflight{0};
     std::atomic<int64_t> fg_last_ns{INT64_MIN / 2};                  // steady clock at the end of the last foreground batch
     uint64_t guest_launches = 0, readmissions = 0;
+    // Guests come in launches of their own, next to the launch they help (tsx_svc_launch.guest_launch): on a second stream of the lowest priority
+    hipStream_t st_g = nullptr;
+    uint32_t g_launch_id = 0; bool g_launched = false; int64_t g_last_ns = INT64_MIN / 2;
     std::vector<void*> deferred_dev, deferred_host;                  // frees that wait for the kernel to be gone (svc_free_*)
 };
 
@@ -266,6 +269,18 @@ static bool svc_quiet(const tsx_service& s) {
 // Is the service kernel of this device still out?  (mu held.)  When its end is seen for the first time, its duration joins the statistics
 // and what waited for it to be gone is freed: hipFree / hipHostFree wait for EVERY stream of the device, i.e. for a kernel that lives
 // as long as uploads go on - nothing in this library frees device or pinned memory while that kernel may be running (svc_free_*).
+static bool svc_guests_running_locked(tsx_service& s) {
+    if (!s.g_launched) return false;
+    if (__atomic_load_n(&s.h->g_ended_launch, __ATOMIC_ACQUIRE) != s.g_launch_id) return true;
+    s.g_launched = false;
+    return false;
+}
+static void svc_collect_locked(tsx_service& s) {                         // (nothing of the service is alive: what waited for that is freed)
+    if (s.launched || s.g_launched) return;
+    for (void* p : s.deferred_dev) (void)hipFree(p);
+    for (void* p : s.deferred_host) (void)hipHostFree(p);
+    s.deferred_dev.clear(); s.deferred_host.clear();
+}
 static bool svc_running_locked(tsx_service& s) {
     if (!s.launched) return false;
     // the launch's last wave says so itself (tsx_svc_host.ended_launch): nothing is queued behind the kernel that could be asked
@@ -273,12 +288,17 @@ static bool svc_running_locked(tsx_service& s) {
     s.kernel_ms += (double)(s.h->t_last - s.h->t_first) / 1e5;           // 100 MHz ticks
     s.launched = false;
     // a rotation is over with the launch it asked to end - also when a pause overlapped that end (the flag must not survive into the next
-    // launch: svc_rotate and the readmission would stay switched off for its whole life); only the host's stop word stays up while paused
+    // launch: svc_rotate would stay switched off for its whole life); only the host's stop word stays up while paused
     if (s.rotating) { s.rotating = false; if (!s.paused) __atomic_store_n(&s.h->stop, 0u, __ATOMIC_RELEASE); }   // (the device's copy of the word is cleared in front of the next launch)
-    for (void* p : s.deferred_dev) (void)hipFree(p);
-    for (void* p : s.deferred_host) (void)hipHostFree(p);
-    s.deferred_dev.clear(); s.deferred_host.clear();
+    (void)svc_guests_running_locked(s);
+    svc_collect_locked(s);
     return false;
+}
+// Is ANY kernel of the service still out - the launch or its guests?  (What must not free memory, or must wait for the device to be the caller's alone, asks this.)
+static bool svc_alive_locked(tsx_service& s) {
+    const bool a = svc_running_locked(s), g = svc_guests_running_locked(s);
+    if (!a && !g) svc_collect_locked(s);
+    return a || g;
 }
 
 // Start the service kernel (mu held, kernel known to be gone, device current).
@@ -299,14 +319,21 @@ static int svc_launch_locked(tsx_service& s) {
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
     a.keep_waves = g_cfg.svc_keep_waves;
+#ifdef HIPEMU
+    a.guest_idle_ticks = 0;
+#else
     a.guest_idle_ticks = 100000;                                         // 1 ms
+#endif
     a.spread_cus = g_cfg.svc_no_spread ? 0u : (s.cus > s.cus_reserved ? s.cus - s.cus_reserved : s.cus);
+#ifdef HIPEMU
+    // (the CPU harness runs one kernel at a time, its blocks one after the other: guests are part of the launch there, which is how its tests reach
+    //  the guests' code; on the device they come in launches of their own - svc_try_guests_locked)
     if (s.cus_reserved && svc_quiet(s)) {
-        // no fetch for a while: the waves on the reserved CUs work as guests.  Word first, counter second (svc_foreground_begin)
-        __atomic_store_n(&s.h->yield, 0u, __ATOMIC_SEQ_CST);
+        __atomic_store_n(&s.h->yield, 0u, __ATOMIC_SEQ_CST);             // word first, counter second (svc_foreground_begin)
         if (s.fg_inflight.load(std::memory_order_seq_cst) != 0) __atomic_store_n(&s.h->yield, 1u, __ATOMIC_SEQ_CST);
         else a.guests = 1u | (g_cfg.svc_guest_looks << 1);               // (bit 1: guests look at the yield word before every block, bit 2: and while idle)
     }
+#endif
     (void)hipGetLastError();
     a.launch_id = s.launch_id + 1;
     tsx_launch_zstd_service(s.st, s.hd, s.d, s.grid, a);
@@ -316,11 +343,47 @@ static int svc_launch_locked(tsx_service& s) {
     return TSX_OK;
 }
 
+// Guests (mu held, device current): a launch of as many one-wave workgroups as the reserved CUs hold, made when the running launch has more chunks
+// queued than waves, no fetch has been seen for fetch_quiet_ms and no guests are out.  With every other slot of the chip taken the workgroups land
+// on the reserved CUs; one that lands elsewhere (the main launch is still arriving, or the chip is not full after all) leaves at once, and so does
+// every guest that finds the queue dry for a millisecond - so guests are there exactly while the chip is full AND busy, the one regime in which a
+// chip without a free slot works well (profiles/r06_full_chip_with_idle_waves.txt).  The next fetch raises the yield word: they hand their chunks
+// back and leave (tsx_svc_host.yield).
+static void svc_try_guests_locked(tsx_service& s) {
+#ifndef HIPEMU
+    if (!s.cus_reserved || !g_cfg.fetch_quiet_ms || s.paused || s.rotating || !s.launched || !s.st_g) return;
+    if (svc_guests_running_locked(s) || !svc_quiet(s)) return;
+    const int64_t now = steady_ns();
+    if (now - s.g_last_ns < 20000000) return;                            // (a launch whose workgroups all left at once is tried again 20 ms later)
+    uint64_t outstanding = 0;
+    for (const auto& m : s.out) if (!m.done && !__atomic_load_n(m.h_flag, __ATOMIC_ACQUIRE)) outstanding += m.n;
+    const uint32_t gwaves = s.cus_reserved * s.waves_per_cu;
+    if (outstanding <= (uint64_t)(s.grid > gwaves ? s.grid - gwaves : s.grid)) return;     // every queued chunk has a wave of the launch itself
+    s.g_last_ns = now;
+    __atomic_store_n(&s.h->yield, 0u, __ATOMIC_SEQ_CST);                 // word first, counter second (svc_foreground_begin)
+    if (s.fg_inflight.load(std::memory_order_seq_cst) != 0) { __atomic_store_n(&s.h->yield, 1u, __ATOMIC_SEQ_CST); return; }
+    tsx_svc_launch a{};
+    a.sched = g_cfg.zstd_sched; a.poll_ticks = 500; a.idle_exit_ticks = g_cfg.svc_idle_exit_us * 100u;
+    const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
+    a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
+    a.guest_idle_ticks = 100000; a.guest_launch = 1; a.guests = 1u | (g_cfg.svc_guest_looks << 1);
+    a.spread_cus = 0;                                                    // (guests exist because everybody else is busy: nothing to spread)
+    a.launch_id = s.g_launch_id + 1;
+    (void)hipGetLastError();
+    tsx_launch_zstd_service(s.st_g, s.hd, s.d, gwaves, a);
+    if (hipGetLastError() != hipSuccess) return;                         // (no guests this time)
+    s.g_launch_id = a.launch_id; s.g_launched = true; s.guest_launches++;
+#else
+    (void)s;
+#endif
+}
+
 static void svc_destroy(tsx_device& d) {
     if (!d.svc) return;
     tsx_service& s = *d.svc;
     if (s.h) __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
     if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
+    if (s.st_g) { (void)hipStreamSynchronize(s.st_g); (void)hipStreamDestroy(s.st_g); }
     for (void* p : s.deferred_dev) (void)hipFree(p);
     for (void* p : s.deferred_host) (void)hipHostFree(p);
     if (s.h) (void)hipHostFree(s.h);
@@ -354,6 +417,12 @@ static int svc_create(tsx_device& d, int cus) {
             s.st = nullptr;
             HIPCHK(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
         }
+    }
+    {   // ... and the guests' stream, of the same (lowest) priority: a hardware queue of its own in that pool (a second stream of normal priority would
+        // share hardware queues with the fetch side's streams - and a kernel that lives for seconds blocks whatever is queued behind it)
+        int least = 0, greatest = 0;
+        if (g_cfg.svc_normal_priority || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
+            hipStreamCreateWithPriority(&s.st_g, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); s.st_g = nullptr; }     // (no guests then)
     }
     for (uint32_t i = TSX_SVC_MEMBERS; i-- > 0;) s.free_slots.push_back((uint16_t)i);
     // which compute units are there?  (HIP promises nothing about placement: a launch of three 48 KiB workgroups per CU that stay ~30 us each
@@ -435,13 +504,13 @@ static void svc_free_dev(tsx_device* dev, void* p) {
     if (!p) return;
     if (!dev->svc) { (void)hipFree(p); return; }
     std::lock_guard<std::mutex> lk(dev->svc->mu);
-    if (svc_running_locked(*dev->svc)) dev->svc->deferred_dev.push_back(p); else (void)hipFree(p);
+    if (svc_alive_locked(*dev->svc)) dev->svc->deferred_dev.push_back(p); else (void)hipFree(p);
 }
 static void svc_free_host(tsx_device* dev, void* p) {
     if (!p) return;
     if (!dev->svc) { (void)hipHostFree(p); return; }
     std::lock_guard<std::mutex> lk(dev->svc->mu);
-    if (svc_running_locked(*dev->svc)) dev->svc->deferred_host.push_back(p); else (void)hipHostFree(p);
+    if (svc_alive_locked(*dev->svc)) dev->svc->deferred_host.push_back(p); else (void)hipHostFree(p);
 }
 
 // Memory management that needs the memory BACK (an allocation has failed): no launches until svc_resume, the running kernel is told to
@@ -453,7 +522,7 @@ static void svc_pause(tsx_device* dev) {
     s.paused++;
     __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
     s.stop_dirty = true;
-    while (svc_running_locked(s)) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(200)); lk.lock(); }
+    while (svc_alive_locked(s)) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(200)); lk.lock(); }
 }
 // The safety net of the fetch side.  One CU of every shader engine is kept free for it, and a fetch next to saturating uploads takes its
 // ~2 ms - but once in a few hundred fetches (measured: 1 of 271, 2 of 12, 0 of 218 + 218 in four runs) a kernel of a fetch did not start
@@ -1086,15 +1155,8 @@ static int svc_submit(tsx_device* dev, const tsx_zseg& proto, const uint32_t* h_
     *id = s.next_id++;
     s.out.push_back({*id, first, n, slot, false, h_flag});
     s.members++;
-    if (!svc_running_locked(s)) return svc_launch_locked(s);           // (on failure the caller abandons the member: svc_retire)
-    // The running launch left the reserved CUs to fetches (it began that way, or its guests have gone) and no fetch has been seen since
-    // fetch_quiet_ms: it is asked to end - its waves leave after their chunk, the waiting members' watchdog starts the next launch, whose
-    // waves use every CU again.  One chunk time of a thinning chip, once per quiet period.
-    if (s.cus_reserved && !s.rotating && !s.paused && __atomic_load_n(&s.h->yield, __ATOMIC_RELAXED) && svc_quiet(s)) {
-        s.rotating = true; s.readmissions++;
-        __atomic_store_n(&s.h->stop, 1u, __ATOMIC_RELEASE);
-        s.stop_dirty = true;
-    }
+    if (!svc_running_locked(s)) { const int rc = svc_launch_locked(s); if (rc == TSX_OK) svc_try_guests_locked(s); return rc; }     // (on failure the caller abandons the member: svc_retire)
+    svc_try_guests_locked(s);                                           // the queue has just grown: deeper than the launch has waves?  (and quiet?)
     return TSX_OK;
 }
 
@@ -1142,7 +1204,7 @@ extern "C" int tsx_service_quiesce(int device_index) {
     { std::lock_guard<std::mutex> lk(g_mu); if (device_index < 0 || device_index >= (int)g_devs.size()) return TSX_E_INVAL; dev = &g_devs[device_index]; }
     tsx_service& s = *dev->svc;
     for (;;) {
-        { std::lock_guard<std::mutex> lk(s.mu); if (!svc_running_locked(s)) return TSX_OK; }
+        { std::lock_guard<std::mutex> lk(s.mu); if (!svc_alive_locked(s)) return TSX_OK; }
         std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
 }
@@ -1191,7 +1253,7 @@ extern "C" int tsx_debug_service_seed(int device_index, uint32_t published) {
     tsx_device_scope keep;
     if (hipSetDevice(dev->hip_id) != hipSuccess) return TSX_E_DEVICE;
     std::lock_guard<std::mutex> lk(s.mu);
-    if (svc_running_locked(s) || !s.out.empty()) return TSX_E_INVAL;
+    if (svc_alive_locked(s) || !s.out.empty()) return TSX_E_INVAL;
     const uint32_t w[2] = {published, published};
     if (hipMemcpy(&s.d->next, w, 8, hipMemcpyHostToDevice) != hipSuccess) return TSX_E_DEVICE;      // next, pub
     s.published = published;

@@ -115,7 +115,8 @@ struct tsx_svc_host {                // pinned host memory, written by the host,
     // workgroups), and next to guest waves - every wave slot of the chip taken - it waited for the launch to end (profiles/r06_guest_waves_root_cause.md).
     // Plain stores, last writer wins: a value may lag a few chunks behind; the exact words are read once the kernel is gone.
     uint32_t m_chunks, m_live, m_live_max, m_wave_starts, m_reserved_exits, m_skipped, m_yields, m_returned;
-    uint32_t m_relocated, pad2_;
+    uint32_t m_relocated;
+    uint32_t g_ended_launch;         // id of the last GUEST launch that has ended (see tsx_svc_launch.guest_launch)
     tsx_zseg member[TSX_SVC_MEMBERS];
     tsx_svc_ticket ticket[TSX_SVC_TICKETS];
 };
@@ -134,6 +135,7 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
                                      // ticket.  Leaving is a decision of the LAUNCH: with per-wave timers the exits spread over ~0.5 ms, a member published
                                      // inside that window was picked up by the waves that had not left yet, and the launch lived on with a fraction of its
                                      // waves (measured: ONE wave serving 10 240 queued chunks until the 60 s age limit, profiles/r06_guest_waves_root_cause.md)
+    uint32_t g_exited;               // waves of the current guest launch that have left
     uint32_t stat_relocated;         // waves that found themselves on a reserved CU they had not started on (saved and restored by the hardware's scheduler) and left
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
@@ -159,6 +161,10 @@ struct tsx_svc_launch {              // kernel arguments that shape a launch
     uint32_t guests;                 // != 0: the other waves on reserved CUs work too, as GUESTS - they look at tsx_svc_host.yield before every block of
                                      // their chunk (~30 ms apart) and while idle; once it is raised they hand the chunk back (another wave starts it
                                      // again from its first byte) and leave for good.  0: they leave at once (the reservation is in force from the start)
+    uint32_t guest_launch;           // != 0: a launch of GUESTS ONLY, made next to a running launch whose queue is deeper than its waves: as many workgroups as the
+                                     // reserved CUs hold; with every other slot of the chip taken that is where they land - a wave that finds itself anywhere else, or
+                                     // finds the yield word raised, leaves at once.  Guests come and go with the load (they leave when the queue has been dry for
+                                     // guest_idle_ticks); the launch they help stays as it is
     uint32_t spread_cus;             // != 0: compute units a partial load is spread over (the ones the compressor uses); 0 = tickets go to whoever asks first
     uint32_t guest_idle_ticks;       // a guest that has found the queue dry for this long leaves (a chip whose every slot is held by mostly IDLE waves slows the busy ones down)
     uint32_t keep_waves;             // waves that stay on a reserved CU all the same (0 = the CU is left alone; the rest of it - LDS, registers, wave slots - is the room a fetch's workgroups find)

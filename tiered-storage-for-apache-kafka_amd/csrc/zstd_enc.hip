@@ -1968,6 +1968,7 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
         // So a guest that has found nothing to do for guest_idle_ticks (1 ms: longer than the host's poll takes to arrive at a fresh launch)
         // leaves its slot; the next launch - which begins when work arrives after a dry spell - has guests again.
         if (yield) { if (dry_since == 0) dry_since = now; else if (now - dry_since >= a.guest_idle_ticks) return 2; }
+        if (a.guest_launch) { svc_nap(nap); if (nap < 64) nap *= 2; continue; }      // (when the launch they help ends is not for its guests to say)
         if (SVC_LD_DEV(&D->busy) != 0 || quiet_since == 0) quiet_since = now;
         if (now - quiet_since >= a.idle_exit_ticks && SVC_LD_DEV(&D->busy) == 0) { atomicExch(&D->draining, 1u); return 2; }
         svc_nap(nap);
@@ -1977,8 +1978,15 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
 
 static_assert(sizeof(EncLds) <= 5 * 1280, "five 1280-byte LDS granules per chunk: 25 chunks fit a CU's 160 KiB, the registers allow 24");
 // A wave leaves: the last one of the launch tells the host (pinned memory) that the launch is over, and when it began and ended.
-__device__ ZS_NOINLINE static void svc_wave_exit(tsx_svc_host* H, tsx_svc_dev* D, uint32_t launch_id) {
+__device__ ZS_NOINLINE static void svc_wave_exit(tsx_svc_host* H, tsx_svc_dev* D, uint32_t launch_id, uint32_t guest_launch) {
     SVC_ST_MIRROR(&H->m_live, atomicSub(&D->live, 1u) - 1u);
+    if (guest_launch) {                                                  // a guest launch counts, and reports its end, apart
+        if (atomicAdd(&D->g_exited, 1u) + 1u != gridDim.x) return;
+        SVC_ST_DEV(&D->g_exited, 0u);
+        svc_release_system();
+        SVC_ST_SYS(&H->g_ended_launch, launch_id);
+        return;
+    }
     if (atomicAdd(&D->exited, 1u) + 1u != gridDim.x) return;
     // the last wave: the other statistics words as they stand (tsx_svc_host.m_*)
     SVC_ST_MIRROR(&H->m_live_max, SVC_LD_DEV(&D->live_max)); SVC_ST_MIRROR(&H->m_wave_starts, SVC_LD_DEV(&D->stat_wave_starts));
@@ -2005,7 +2013,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     const uint32_t lane = threadIdx.x;
     const uint64_t t_start = svc_now();
     if (lane == 0) {
-        if (atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
+        if (!a.guest_launch && atomicAdd(&D->entered, 1u) == 0u) { SVC_ST_DEV(&D->t_first_lo, (uint32_t)t_start); SVC_ST_DEV(&D->t_first_hi, (uint32_t)(t_start >> 32)); }
         const uint32_t lv = atomicAdd(&D->live, 1u) + 1u;
         atomicMax(&D->live_max, lv);
         SVC_ST_MIRROR(&H->m_live, lv);
@@ -2017,22 +2025,28 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         if (lane == 0) {
             SVC_ST_DEV(&D->poll_stamp, (uint32_t)t_start);
             while ((uint32_t)svc_now() - SVC_LD_DEV(&D->poll_stamp) < a.calibrate_ticks && svc_now() - t_start < 5000000u) svc_nap(1);     // (<= 50 ms whatever happens)
-            svc_wave_exit(H, D, a.launch_id);
+            svc_wave_exit(H, D, a.launch_id, 0u);
         }
         return;
     }
     const uint32_t key = UNI(svc_cu_key());
     const uint32_t* yield = nullptr;                                     // != nullptr: this wave is a guest on a reserved CU
     const uint32_t* off_limits = D->reserved;                            // != nullptr: this wave leaves when it finds itself on a reserved CU (see zstd_compress_chunk)
-    if ((D->reserved[key >> 5] >> (key & 31)) & 1u) {                    // a reserved CU (see tsx_internal.h): the first keep_waves to arrive stay for good,
-        uint32_t stay = 0;                                               // the others work as guests while no fetch is about, or leave at once
-        if (lane == 0) {
+    const bool on_reserved = ((D->reserved[key >> 5] >> (key & 31)) & 1u) != 0;
+    if (a.guest_launch) {                                                // a launch of guests only: the reserved CUs are where it is meant to land
+        uint32_t stay = 0;
+        if (lane == 0 && on_reserved && !zs_yield_asked(&H->yield)) stay = 2;
+        if (!UNI(stay)) { if (lane == 0) svc_wave_exit(H, D, a.launch_id, 1u); return; }
+        off_limits = nullptr; yield = &H->yield;
+    } else if (on_reserved) {                                            // a reserved CU (see tsx_internal.h): the first keep_waves to arrive stay for good,
+        uint32_t stay = 0;                                               // the others work as guests while no fetch is about (a.guests: the CPU harness; on
+        if (lane == 0) {                                                 // the device guests come in launches of their own), or leave at once
             if (a.keep_waves && atomicAdd(&D->kept[key >> 4], 1u) < a.keep_waves) stay = 1;
             else if (a.guests && !zs_yield_asked(&H->yield)) stay = 2;
         }
         stay = UNI(stay);
         if (!stay) {
-            if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id); }
+            if (lane == 0) { atomicAdd(&D->stat_reserved_exits, 1u); svc_wave_exit(H, D, a.launch_id, 0u); }
             return;
         }
         off_limits = nullptr;
@@ -2109,7 +2123,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         }
         __syncthreads();
     }
-    if (lane == 0) svc_wave_exit(H, D, a.launch_id);
+    if (lane == 0) svc_wave_exit(H, D, a.launch_id, a.guest_launch);
 }
 
 // A launch that covers the chip (48 KiB of LDS per one-wave workgroup: three per CU) and notes every CU key it meets.
