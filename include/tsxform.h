@@ -105,8 +105,12 @@ typedef struct tsx_batch_params {
     uint32_t zstd_profile; /* TSX_ZSTD_PROFILE_*                                                    */
 } tsx_batch_params;
 
-/* Which libzstd release the compressor reproduces byte for byte (the reference ships 1.5.6 inside
- * zstd-jni 1.5.6-9, core/build.gradle:29).  1.5.7 adds a block pre-splitter at level 3. */
+/* Which libzstd behaviour the compressor reproduces.  TSX_ZSTD_PROFILE_1_5_7: byte for byte the real libzstd 1.5.7 (checked against
+ * the library itself on every test input).  TSX_ZSTD_PROFILE_1_5_6: the same code WITHOUT 1.5.7's pre-block splitter - an UNVERIFIED
+ * stand-in for the release the reference ships (1.5.6 inside zstd-jni 1.5.6-9, core/build.gradle:29): no libzstd 1.5.6 exists in the
+ * build or test environment, and the 1.5.7 release notes may list more level-3 changes than the splitter (a ratio improvement of the
+ * double-fast parser has been recalled by a reviewer; neither recollection could be checked).  Frames are valid Zstandard either way;
+ * whether they are 1.5.6's bytes is settled where that library exists: tests/golden/make_vectors_from_lib.py + tests/test_golden.py. */
 #define TSX_ZSTD_PROFILE_1_5_6 0u
 #define TSX_ZSTD_PROFILE_1_5_7 1u
 

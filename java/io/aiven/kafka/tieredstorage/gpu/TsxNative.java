@@ -27,7 +27,10 @@ public final class TsxNative {
     public static final int DESC_STATUS = 32;
     public static final int DESC_IV = 36;
 
-    /** TSX_ZSTD_PROFILE_*: which libzstd release the compressor reproduces (INTEGRATION.md, "Zstd profile"). */
+    /**
+     * TSX_ZSTD_PROFILE_*: which libzstd behaviour the compressor reproduces (INTEGRATION.md, "Zstd profile").  1_5_7 is byte-identical to
+     * the real 1.5.7; 1_5_6 is 1.5.7 without its pre-block splitter - an unverified stand-in for the 1.5.6 inside zstd-jni 1.5.6-9.
+     */
     public static final int ZSTD_PROFILE_1_5_6 = 0;
     public static final int ZSTD_PROFILE_1_5_7 = 1;
 

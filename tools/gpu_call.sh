@@ -279,12 +279,13 @@ PY
       [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/lonev.err
       for v in ${arg//+/ }; do
         e=${v%%:*}; cfg=${v#*:}
-        ( [ "$e" != "-" ] && export TSX_FETCH_RESERVED_CUS=$e; timeout 200 python tools/lone_batch_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --no-sampler --batches ${LONE_BATCHES:-8} --configs $cfg 2>> $O/lonev.err | sed "s/^{/{\"reserved_cus_env\": \"$e\", /" >> $O/lonev.jsonl )
+        pre=""; case "$cfg" in *@*) pre="--pre-config ${cfg#*@}"; cfg=${cfg%%@*};; esac
+        ( [ "$e" != "-" ] && export TSX_FETCH_RESERVED_CUS=$e; timeout 200 python tools/lone_batch_probe.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --no-sampler --batches ${LONE_BATCHES:-8} $pre --configs $cfg 2>> $O/lonev.err | sed "s/^{/{\"reserved_cus_env\": \"$e\", /" >> $O/lonev.jsonl )
       done
       python - <<PY
 import json
 for l in open("$O/lonev.jsonl"):
-    j = json.loads(l); print("reserved env", j["reserved_cus_env"], j["config"], "waves", j["waves"], [b["ms"] for b in j["batches"]], "guest launches", sum(b["guest_launches"] for b in j["batches"]), "reserved exits", j["batches"][0]["reserved_exits"])
+    j = json.loads(l); print("reserved env", j["reserved_cus_env"], j["config"], "pre", j.get("pre_config"), "waves", j["waves"], [b["ms"] for b in j["batches"]], "guest launches", sum(b["guest_launches"] for b in j["batches"]), "reserved exits", j["batches"][0]["reserved_exits"])
 PY
       ;;
     keepwaves)

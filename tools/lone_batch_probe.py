@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--pause-ms", type=float, default=20.0)
     ap.add_argument("--prof-lib", default="", help="tools/_libs/libtsxform_prof.so: per-chunk begin / end / CU of every batch (guest waves against the others)")
     ap.add_argument("--no-sampler", action="store_true")
+    ap.add_argument("--pre-config", default="", help="key=value,... set BEFORE tsx_init (e.g. svc_normal_priority=1)")
     ap.add_argument("--bind", action="store_true", help="bind the process to the GPU's NUMA node first (as the other probes do)")
     a = ap.parse_args()
     assert "torch" not in sys.modules
@@ -35,6 +36,9 @@ def main():
     from tsxform import synth
     nat = tsxform._native
     N = nat.Native(a.prof_lib) if a.prof_lib else nat.Native()
+    for kv in (a.pre_config or "").split(","):
+        if kv:
+            N.debug_config(kv.split("=")[0], int(kv.split("=")[1]))
     N.init(1, [0])
     aff = None
     if a.bind:
@@ -97,7 +101,7 @@ def main():
                          "relocated": int(s1["relocated_waves"] - s0["relocated_waves"]),
                          "progress_ms_chunks_live_running": samples[::max(1, len(samples) // 12)]})
             time.sleep(a.pause_ms / 1e3)
-        print(json.dumps({"config": cfg, "cpu_affinity": aff, "sampler": not a.no_sampler, "chunks": n, "pause_ms": a.pause_ms, "waves": int(N.service_stats(0)["waves"]), "batches": rows}), flush=True)
+        print(json.dumps({"config": cfg, "pre_config": a.pre_config, "cpu_affinity": aff, "sampler": not a.no_sampler, "chunks": n, "pause_ms": a.pause_ms, "waves": int(N.service_stats(0)["waves"]), "batches": rows}), flush=True)
 
 
 if __name__ == "__main__":
