@@ -145,7 +145,15 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     th = [threading.Thread(target=loader, args=(t,)) for t in range(T)]
     [x.start() for x in th]
     try:
-        time.sleep(2.5)                                                 # the chip is full
+        time.sleep(2.0)                                                 # the chip is full
+        # the first fetch comes while guests are at work: more waves alive than the launch itself has off the reserved CUs (an idle guest leaves
+        # within a millisecond, so guests that are seen alive are compressing; between two rounds of the callers the queue runs dry and they go -
+        # the next guest launch brings them back)
+        main_waves = sv0["waves"] - sv0["reserved_cus"] * (sv0["waves"] // sv0["compute_units"])
+        t_look = time.perf_counter() + 10.0
+        while gpu.service_stats(0)["live_waves"] < main_waves + 256 and time.perf_counter() < t_look:
+            time.sleep(0.002)
+        guests_seen = gpu.service_stats(0)["live_waves"] - main_waves
         first = fetch()
         lat = []
         t_end = time.perf_counter() + 8.0
@@ -159,7 +167,7 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     a = np.asarray(lat)
     sv1 = gpu.service_stats(0)
     print("fetch under load: first (guests leave) %.2f ms, then n=%d p50=%.2f ms p95=%.2f ms max=%.2f ms; launches asked to end early: %d; guest waves that left %d, chunks handed back %d" %
-          (first, a.size, np.median(a), np.percentile(a, 95), a.max(), sv1["rotations"], sv1["yielded_waves"] - sv0["yielded_waves"], sv1["returned_chunks"] - sv0["returned_chunks"]))
+          (first, a.size, np.median(a), np.percentile(a, 95), a.max(), sv1["rotations"], sv1["yielded_waves"] - sv0["yielded_waves"], sv1["returned_chunks"] - sv0["returned_chunks"]), "; guests alive before the first fetch:", guests_seen)
     ok_bytes = np.array_equal(hbk, want)
     gpu.host_unregister(hfr); gpu.host_unregister(hbk)
     gpu.ctx_destroy(fctx)
@@ -171,7 +179,8 @@ def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     assert np.median(a) <= 5.0 and np.percentile(a, 95) <= 50.0 and a.max() <= 200.0, (float(np.median(a)), float(np.percentile(a, 95)), float(a.max()))
     assert first <= 100.0, first                                       # (a block time of a chunk, ~30 ms)
     assert sv1["rotations"] == sv0["rotations"], (sv0, sv1)             # nobody had to ask the launch to end
-    assert sv1["guest_launches"] > sv0["guest_launches"] and sv1["yielded_waves"] - sv0["yielded_waves"] >= 32 * 8, (sv0, sv1)
+    assert guests_seen >= 256, (guests_seen, sv0, sv1)
+    assert sv1["guest_launches"] > sv0["guest_launches"] and sv1["yielded_waves"] - sv0["yielded_waves"] >= 200, (guests_seen, sv0, sv1)
 
 
 @pytest.mark.timeout(900)

@@ -266,6 +266,18 @@ static bool svc_quiet(const tsx_service& s) {
            steady_ns() - s.fg_last_ns.load(std::memory_order_seq_cst) > (int64_t)g_cfg.fetch_quiet_ms * 1000000;
 }
 
+// A member is about to be published (mu held): the yield word follows the device's quietness - down when no fetch has been seen for fetch_quiet_ms
+// (word first, counter second: svc_foreground_begin does it the other way round, one of the two sees the other), up otherwise.  Guests read it, and
+// so does a wave of the launch itself that the hardware's scheduler has restored onto a reserved CU: on a quiet device it finishes its chunk there.
+static void svc_note_quiet_locked(tsx_service& s) {
+    if (!s.cus_reserved) return;
+    if (svc_quiet(s)) {
+        if (__atomic_load_n(&s.h->yield, __ATOMIC_SEQ_CST) == 0u) return;
+        __atomic_store_n(&s.h->yield, 0u, __ATOMIC_SEQ_CST);
+        if (s.fg_inflight.load(std::memory_order_seq_cst) != 0) __atomic_store_n(&s.h->yield, 1u, __ATOMIC_SEQ_CST);
+    } else if (__atomic_load_n(&s.h->yield, __ATOMIC_SEQ_CST) == 0u) __atomic_store_n(&s.h->yield, 1u, __ATOMIC_SEQ_CST);      // (fetch_quiet_ms was changed under a lowered word)
+}
+
 // ---- service: lifetime ------------------------------------------------------------------------------------------------------------------
 // Is the service kernel of this device still out?  (mu held.)  When its end is seen for the first time, its duration joins the statistics
 // and what waited for it to be gone is freed: hipFree / hipHostFree wait for EVERY stream of the device, i.e. for a kernel that lives
@@ -323,7 +335,7 @@ static int svc_launch_locked(tsx_service& s) {
 #ifdef HIPEMU
     a.guest_idle_ticks = 0;
 #else
-    a.guest_idle_ticks = 100000;                                         // 1 ms
+    a.guest_idle_ticks = 1000000;                                        // 10 ms
 #endif
     a.spread_cus = g_cfg.svc_no_spread ? 0u : (s.cus > s.cus_reserved ? s.cus - s.cus_reserved : s.cus);
 #ifdef HIPEMU
@@ -348,7 +360,8 @@ static int svc_launch_locked(tsx_service& s) {
 // Guests (mu held, device current): a launch of as many one-wave workgroups as the reserved CUs hold, made when the running launch has more chunks
 // queued than waves, no fetch has been seen for fetch_quiet_ms and no guests are out.  With every other slot of the chip taken the workgroups land
 // on the reserved CUs; one that lands elsewhere (the main launch is still arriving, or the chip is not full after all) leaves at once, and so does
-// every guest that finds the queue dry for a millisecond - so guests are there exactly while the chip is full AND busy, the one regime in which a
+// every guest that finds the queue dry for ten milliseconds (callers that resubmit as soon as their batches complete leave the queue dry for 2 - 3 ms between
+// two rounds: the guests stay through that) - so guests are there exactly while the chip is full AND busy, the one regime in which a
 // chip without a free slot works well (profiles/r06_full_chip_with_idle_waves.txt).  The next fetch raises the yield word: they hand their chunks
 // back and leave (tsx_svc_host.yield).
 static void svc_try_guests_locked(tsx_service& s) {
@@ -371,7 +384,7 @@ static void svc_try_guests_locked(tsx_service& s) {
     a.sched = g_cfg.zstd_sched; a.poll_ticks = 500; a.idle_exit_ticks = g_cfg.svc_idle_exit_us * 100u;
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
-    a.guest_idle_ticks = 100000; a.guest_launch = 1; a.guests = 1u | (g_cfg.svc_guest_looks << 1);
+    a.guest_idle_ticks = 1000000; a.guest_launch = 1; a.guests = 1u | (g_cfg.svc_guest_looks << 1);
     a.spread_cus = 0;                                                    // (guests exist because everybody else is busy: nothing to spread)
     a.launch_id = s.g_launch_id + 1;
     (void)hipGetLastError();
@@ -405,6 +418,7 @@ static int svc_create(tsx_device& d, int cus) {
     tsx_service& s = *d.svc;
     HIPCHK(hipHostMalloc((void**)&s.h, sizeof(tsx_svc_host), hipHostMallocMapped | hipHostMallocPortable));
     memset(s.h, 0, sizeof(tsx_svc_host));
+    s.h->yield = 1;                                                      // (cleared when a member is published on a quiet device: svc_note_quiet_locked)
     HIPCHK(hipHostGetDevicePointer((void**)&s.hd, s.h, 0));
     HIPCHK(hipHostMalloc((void**)&s.h_zero, 64, hipHostMallocDefault));
     memset(s.h_zero, 0, 64);
@@ -1148,6 +1162,7 @@ static int svc_submit(tsx_device* dev, const tsx_zseg& proto, const uint32_t* h_
         if (!s.paused && !s.out.empty() && !svc_running_locked(s)) { s.watchdog_launches++; (void)svc_launch_locked(s); }
         s.cv.wait_for(lk, std::chrono::milliseconds(1));
     }
+    svc_note_quiet_locked(s);
     const uint16_t slot = s.free_slots.back(); s.free_slots.pop_back();
     const uint16_t gen = ++s.slot_gen[slot];
     tsx_zseg e = proto;
@@ -1261,6 +1276,9 @@ extern "C" int tsx_debug_service_seed(int device_index, uint32_t published) {
     if (svc_alive_locked(s) || !s.out.empty()) return TSX_E_INVAL;
     const uint32_t w[2] = {published, published};
     if (hipMemcpy(&s.d->next, w, 8, hipMemcpyHostToDevice) != hipSuccess) return TSX_E_DEVICE;      // next, pub
+    const uint32_t fa[2] = {published, 0};
+    static_assert(offsetof(tsx_svc_dev, avail) == offsetof(tsx_svc_dev, fin) + 4, "fin, avail");
+    if (hipMemcpy(&s.d->fin, fa, 8, hipMemcpyHostToDevice) != hipSuccess) return TSX_E_DEVICE;      // fin, avail (nothing outstanding: no right to a ticket)
     s.published = published;
     __atomic_store_n(&s.h->published, published, __ATOMIC_RELEASE);
     return TSX_OK;

@@ -136,6 +136,8 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
                                      // inside that window was picked up by the waves that had not left yet, and the launch lived on with a fraction of its
                                      // waves (measured: ONE wave serving 10 240 queued chunks until the 60 s age limit, profiles/r06_guest_waves_root_cause.md)
     uint32_t g_exited;               // waves of the current guest launch that have left
+    uint32_t fin;                    // tickets whose chunk is finished (or was skipped): pub - fin chunks are outstanding - queued or in progress
+    uint32_t avail;                  // (signed) rights to a ticket: the poll adds what it adds to pub, a wave that decrements it from > 0 takes the next ticket
     uint32_t stat_relocated;         // waves that found themselves on a reserved CU they had not started on (saved and restored by the hardware's scheduler) and left
     uint32_t reserved[128];          // bitmap over CU keys (xcc_id << 8 | HW_ID[15:8]): 1 = reserved for everything but the compressor
     uint32_t seen[128];              // the probe launch's bitmap: CU keys that exist on this chip
@@ -146,9 +148,7 @@ struct tsx_svc_dev {                 // device memory: the waves' shared state
     uint32_t ret_lock, ret_n, stat_yields, stat_returned;
     tsx_svc_ticket ret[TSX_SVC_RETURNED_MAX];
     // chunks in progress per compute unit (by CU key): a partial load is spread over the chip.  The hardware fills a launch's CUs one after the other,
-    // so the first waves to look - the ones that take a lone batch's tickets - sit on ~200 of 256 CUs, up to 21 on one (measured: profiles/r06_where_a_lone_batch_runs.txt);
-    // a chunk next to 20 others takes a third longer than one next to 8.  A wave whose CU already runs more chunks than the device-wide share + 2 lets the
-    // ticket go to a wave elsewhere, a few looks long (svc_take).
+    // and a chunk next to 20 others takes a third longer than one next to 8; so no CU takes more than its share of the outstanding chunks + 1 (svc_take).
     uint32_t cu_busy[4096];
 };
 struct tsx_svc_launch {              // kernel arguments that shape a launch

@@ -107,6 +107,7 @@ __shared__ unsigned long long g_prof[24];
 #define PCNT(k, v) do { if (threadIdx.x == 0) g_prof[k] += (v); } while (0)
 #define PTW(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); PT(k); } while (0)   /* drain, then lap: stage latency */
 #endif
+__shared__ unsigned long long g_prof_take;
 static unsigned long long* g_prof_out = nullptr;                      // device buffer: 24 u64 per chunk
 extern "C" void tsx_debug_set_prof(void* dev_ptr) { g_prof_out = (unsigned long long*)dev_ptr; }
 #else
@@ -1762,11 +1763,11 @@ __device__ __forceinline__ static bool zstd_compress_chunk(EncLds& L, const uint
     int cur = 0;                 // index of the confirmed Huffman table (L.huf[cur]); a candidate is built in L.huf[cur ^ 1]
     bool first = true;
     while (remaining) {
-        if (yield || reserved) {                                        // a guest: is the CU wanted back?  anybody else: am I (still) off the reserved CUs?
-            uint32_t y = 0;
+        if (yield || reserved) {                                        // a guest: is the CU wanted back?  anybody else: am I (still) off the reserved CUs -
+            uint32_t y = 0;                                             // and if I am not (restored there by the hardware's scheduler): is the CU wanted?
             if (lane == 0) {
-                if (yield) y = zs_yield_asked(yield);
-                else { const uint32_t k = svc_cu_key(); y = (reserved[k >> 5] >> (k & 31)) & 1u; }
+                if (reserved) { const uint32_t k = svc_cu_key(); y = (reserved[k >> 5] >> (k & 31)) & 1u; if (y && yield) y = zs_yield_asked(yield); }
+                else y = zs_yield_asked(yield);
             }
             if (UNI(y)) return true;
         }
@@ -1927,7 +1928,7 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
                                                 const uint32_t key, uint32_t* ticket, uint32_t* chunk_out) {
     const uint64_t max_age = ((uint64_t)a.max_age_ticks_hi << 32) | a.max_age_ticks_lo;
     uint64_t quiet_since = 0, dry_since = 0;
-    uint32_t nap = 1, looks = 0, deferred = 0;
+    uint32_t nap = 1, looks = 0, turned_away = 1;
     for (;;) {
         const uint64_t now = svc_now();
         if (SVC_LD_DEV(&D->stop)) return 2;
@@ -1939,7 +1940,7 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
             const uint32_t n = SVC_LD_DEV(&D->ret_n);
             if (n) { *ticket = SVC_LD_DEV(&D->ret[n - 1u].member_gen); *chunk_out = SVC_LD_DEV(&D->ret[n - 1u].chunk); SVC_ST_DEV(&D->ret_n, n - 1u); }
             svc_ret_unlock(D);
-            if (n) return 3;
+            if (n) { atomicAdd(&D->cu_busy[key], 1u); return 3; }
             atomicSub(&D->busy, 1u);
         }
         if (SVC_LD_DEV(&D->draining)) return 2;                          // the launch is ending (below): no more tickets for it - the host starts the next one
@@ -1950,22 +1951,38 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
             const uint32_t p = SVC_LD_SYS(&H->published);
             if (SVC_LD_SYS(&H->stop)) { SVC_ST_DEV(&D->stop, 1u); return 2; }
             uint32_t old = SVC_LD_DEV(&D->pub);
-            while ((int32_t)(p - old) > 0) { const uint32_t prev = atomicCAS(&D->pub, old, p); if (prev == old) break; old = prev; }
+            while ((int32_t)(p - old) > 0) { const uint32_t prev = atomicCAS(&D->pub, old, p); if (prev == old) { atomicAdd(&D->avail, p - old); break; } old = prev; }   // (as many rights as tickets)
         }
         const uint32_t nx = SVC_LD_DEV(&D->next), pb = SVC_LD_DEV(&D->pub);
         if ((int32_t)(pb - nx) > 0) {
-            // spread a partial load (tsx_svc_dev.cu_busy): not me, if my CU is already ahead of the others - for three looks at most
-            if (a.spread_cus && deferred < 3u && SVC_LD_DEV(&D->cu_busy[key]) * a.spread_cus > SVC_LD_DEV(&D->busy) + 2u * a.spread_cus) { deferred++; svc_nap(1); continue; }
-            atomicAdd(&D->busy, 1u);                                     // before the ticket is taken: busy >= waves that hold one
-            if (atomicCAS(&D->next, nx, nx + 1u) == nx) { *ticket = nx; return 1; }
-            atomicSub(&D->busy, 1u);
+            // Tickets are waiting.  Two things decide whether this wave gets one:
+            // - its CU's share (tsx_svc_dev.cu_busy): a partial load is spread evenly over the compressor's CUs - no CU runs more chunks than the
+            //   outstanding ones (queued + in progress) divided by the CUs, rounded up, plus one.  The slot on the CU is reserved first (an atomic on
+            //   the CU's own word), so that the waves of one CU cannot all pass the check at once;
+            // - the semaphore tsx_svc_dev.avail: a right to one ticket is an atomic decrement that found it positive, and only then is `next`
+            //   advanced - by a fetch-add that cannot fail.  (Until round 6 the ticket was a compare-and-swap on `next`: with 5000 idle waves going
+            //   for a fresh batch's 2048 tickets almost every attempt lost - its value of `next` was stale by the time the atomic was served - and
+            //   the tickets left at 20 per millisecond: the last chunk of a lone batch began 105 ms after the first, profiles/r06_ticket_storm.txt.)
+            // A wave that is turned away looks again after a nap that doubles (3.5 - 56 us).
+            const uint32_t limit = a.spread_cus ? ((pb - SVC_LD_DEV(&D->fin)) + a.spread_cus - 1u) / a.spread_cus + 1u : 0xFFFFFFFFu;     // (published - finished = outstanding)
+            if (atomicAdd(&D->cu_busy[key], 1u) < limit) {
+                if ((int32_t)atomicSub(&D->avail, 1u) > 0) {
+                    atomicAdd(&D->busy, 1u);                             // before `next` moves: whoever finds the queue dry finds busy != 0 (the idle exit looks at both)
+                    svc_fence_device();
+                    *ticket = atomicAdd(&D->next, 1u);
+                    return 1;
+                }
+                atomicAdd(&D->avail, 1u);
+            }
+            atomicSub(&D->cu_busy[key], 1u);
+            svc_nap(turned_away); if (turned_away < 16u) turned_away *= 2u;
             continue;
         }
         // A guest does not wait for work.  With EVERY wave slot of the chip held and most of the waves idle, the busy ones crawl: a lone
         // 2048-chunk batch took 1.1 - 9.8 s instead of 1.1 s, whether the idle waves were guests, waves kept on the reserved CUs or ordinary
         // waves of a launch without any reservation; with as little as a third of one CU per shader engine free it is 1.1 s every time
         // (profiles/r06_full_chip_with_idle_waves.txt).  A chip that is full AND busy is fine (that is the saturated regime guests exist for).
-        // So a guest that has found nothing to do for guest_idle_ticks (1 ms: longer than the host's poll takes to arrive at a fresh launch)
+        // So a guest that has found nothing to do for guest_idle_ticks (10 ms: the gap between two rounds of callers that resubmit at once is 2 - 3 ms)
         // leaves its slot; the next launch - which begins when work arrives after a dry spell - has guests again.
         if (yield) { if (dry_since == 0) dry_since = now; else if (now - dry_since >= a.guest_idle_ticks) return 2; }
         if (a.guest_launch) { svc_nap(nap); if (nap < 64) nap *= 2; continue; }      // (when the launch they help ends is not for its guests to say)
@@ -2061,7 +2078,10 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
             const uint32_t k = svc_cu_key();
             if (off_limits && ((off_limits[k >> 5] >> (k & 31)) & 1u)) { SVC_ST_MIRROR(&H->m_relocated, atomicAdd(&D->stat_relocated, 1u) + 1u); got = 2; }
             else got = svc_take(H, D, a, t_start, yield, k, &ticket, &chunk);
-            if (got == 1 || got == 3) { atomicAdd(&D->cu_busy[k], 1u); key_busy = k; }
+            if (got == 1 || got == 3) key_busy = k;                       // (svc_take has counted the chunk on this CU)
+#ifdef TSX_PROF
+            g_prof_take = wall_clock64();
+#endif
         }
         key_busy = UNI(key_busy);
         got = UNI(got); ticket = UNI(ticket); chunk = UNI(chunk);
@@ -2079,7 +2099,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         const uint64_t w0 = svc_word(w, 0), w1 = svc_word(w, 1);
         const uint32_t n = (uint32_t)w0, profile = (uint32_t)(w0 >> 32), gen = (uint32_t)w1;
         if (slot >= TSX_SVC_MEMBERS || (gen & 0xFFFFu) != (mg >> 16) || chunk >= n) {          // an abandoned member's ticket
-            if (lane == 0) { atomicAdd(&D->stat_skipped, 1u); atomicSub(&D->cu_busy[key_busy], 1u); atomicSub(&D->busy, 1u); }
+            if (lane == 0) { atomicAdd(&D->stat_skipped, 1u); atomicAdd(&D->fin, 1u); atomicSub(&D->cu_busy[key_busy], 1u); atomicSub(&D->busy, 1u); }
             continue;
         }
         tsx_chain_fuse fuse;
@@ -2088,7 +2108,10 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         { const uint64_t f = svc_word(w, 13); fuse.self_status = (uint32_t)f; fuse.key_on_host = (uint32_t)(f >> 32); }
         uint32_t* const done = (uint32_t*)svc_word(w, 14); uint32_t* const flag = (uint32_t*)svc_word(w, 15);
         const bool handed_back = zstd_compress_chunk(L, (const uint8_t*)svc_word(w, 2), (tsx_chunk_desc*)svc_word(w, 3), (uint8_t*)svc_word(w, 4), svc_word(w, 5),
-                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, (a.guests & 2u) ? yield : nullptr, off_limits ZS_PROF_ARG);
+                            (uint32_t*)svc_word(w, 6), (int32_t*)svc_word(w, 7), (uint8_t*)svc_word(w, 8), profile, a.sched, fuse, chunk, off_limits ? &H->yield : (a.guests & 2u) ? yield : nullptr, off_limits ZS_PROF_ARG);
+#ifdef TSX_PROF
+        if (lane == 0 && prof_out && !handed_back) { prof_out[(size_t)chunk * 24 + 21] = t_start; prof_out[(size_t)chunk * 24 + 22] = g_prof_take; prof_out[(size_t)chunk * 24 + 19] |= (unsigned long long)key_busy << 20; }   // [21], [22]: when this wave began, when it had the ticket
+#endif
         if (handed_back) {
             // a fetch has arrived: the chunk goes back to the queue - every lane's stores into its workspace are complete and released (as
             // at the end of a finished chunk: the next wave may sit on another XCD, behind another L2) before another wave can start it
@@ -2111,6 +2134,7 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
         if (lane == 0) {
             svc_release_system();
             SVC_ST_MIRROR(&H->m_chunks, atomicAdd(&D->stat_chunks, 1u) + 1u);
+            atomicAdd(&D->fin, 1u);
             if (atomicAdd(done, 1u) + 1u == n) {
                 atomicExch(done, 0u);                                    // ready for the context's next member (ordered before it by the flag)
                 svc_release_system();

@@ -87,8 +87,11 @@ def main():
         res["where"] = {"guest_chunks": int(guest.sum()), "other_chunks": int((1 - guest).sum()),
                         "chunk_ms_p0_50_90_99_100": {"guests": q(dur[guest == 1]), "others": q(dur[guest == 0])},
                         "begin_ms_p0_50_90_99_100": {"guests": q(beg[guest == 1]), "others": q(beg[guest == 0])},
+                        "wave_start_ms_p0_50_90_99_100": q((p[:, 21] - t0) / 1e5), "ticket_taken_ms_p0_50_90_99_100": q((p[:, 22] - t0) / 1e5),
+                        "ticket_to_begin_us_p0_50_90_99_100": q((p[:, 2] - p[:, 22]) / 1e2), "distinct_waves": int(np.unique(p[:, 21]).size),
                         "batch_ms_first_begin_to_last_end": round(float((p[:, 3].max() - t0) / 1e5), 1),
                         "slowest_20": sorted([(round(float(dur[i]), 1), round(float(beg[i]), 1), int(guest[i]), int(key[i])) for i in np.argsort(-dur)[:20]], reverse=True),
+                        "chunks_that_ended_on_another_cu": int(((p[:, 19] >> 20) & 0xFFF != key).sum()), "chunks_per_cu_max_where_taken": int(np.bincount(((p[:, 19] >> 20) & 0xFFF).astype(np.int64)).max()),
                         "chunks_per_cu_max": int(np.bincount(key.astype(np.int64)).max()), "cus_used": int((np.bincount(key.astype(np.int64)) > 0).sum())}
     mean = p.mean(axis=0)
     res["chunks"] = n
