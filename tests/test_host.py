@@ -19,8 +19,8 @@ def host_tests(oracle):
     return BIN
 
 
-def _run(args, env=None):
-    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=1500)
+def _run(args, env=None, timeout=1500):
+    p = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=timeout)
     assert p.returncode == 0 and " 0 failed" in p.stdout, p.stdout[-4000:]
     return p.stdout
 
@@ -54,7 +54,7 @@ def test_host_layer_threads_under_thread_sanitizer(host_tests, emu):
 @pytest.mark.gpu
 def test_host_chain_on_gpu(host_tests):
     import tsxform
-    out = _run([host_tests, "backend", tsxform._native.LIB_PATH, "full"])
+    out = _run([host_tests, "backend", tsxform._native.LIB_PATH, "full"], timeout=600)          # (~1 min on the device)
     assert "gfx950" in out and "ChunkManager.getChunk" in out and "SegmentManifestV1SerdeTest" in out and "GpuChunkCache" in out
 
 

@@ -84,6 +84,39 @@ def test_cu_probe_found_every_compute_unit_and_the_reservation_holds(gpu):
         gpu.ctx_destroy(c)
 
 
+@pytest.mark.timeout(300)
+def test_small_members_next_to_thousands_of_idle_waves(gpu, oracle):
+    """Batches of 1 - 7 small chunks, one after the other, two threads: every launch of the service has ~5000 idle waves looking at a queue that
+    holds a handful of tickets.  The ticket semaphore must show its few rights to somebody: waves that decremented it blindly kept it negative
+    around the clock and a 7-chunk member stood still for as long as anyone waited (the host tests' GpuTransformFinisher case on the device;
+    the CPU harness runs one workgroup at a time and cannot see it).  Here: 2 x 150 batches in well under a minute, bytes as the oracle's."""
+    flags = nat.COMPRESS | nat.ENCRYPT | nat.CRC
+    sets = [[synth.gen_chunk("K" if (i + k) % 2 else "B", 900 + k, 0, i, 3000 + 577 * i) for i in range(k)] for k in range(1, 8)]
+    refs = [pc.check_transform_vs_oracle(gpu, oracle, flags, cs)[0] for cs in sets]
+    errors = []
+
+    def worker(t):
+        try:
+            ctx = gpu.ctx_create(0, 8, 16384)
+            for it in range(150):
+                k = (it + t) % 7
+                got, d = pc.run_transform(gpu, flags, sets[k], ctx=ctx)
+                if got != refs[k] or not (d["status"] == 0).all():
+                    errors.append((t, it))
+            gpu.ctx_destroy(ctx)
+        except Exception as e:                                          # noqa: BLE001
+            errors.append(repr(e))
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    took = time.perf_counter() - t0
+    print("2 x 150 batches of 1 - 7 small chunks: %.2f s" % took)
+    assert not errors, errors[:3]
+    assert took < 60.0, took
+
+
 @pytest.mark.timeout(600)
 def test_a_fetch_stays_fast_while_uploads_fill_the_chip(gpu, oracle):
     """Four callers keep 4 x 2048 four-MiB chunks queued at the compressor (more than the chip holds) while this thread restores one chunk

@@ -46,6 +46,7 @@ struct tsx_cfg {
     uint32_t svc_waves_per_cu = 0;        // workgroups of a service launch per CU (0 = what the runtime says is resident at once; measurements only)
     bool svc_normal_priority = false;     // the service's stream like any other (default: the device's LOWEST stream priority, a hardware queue of its own pool)
     bool trace = false;                   // timestamps of a batch's phases on stderr (tools/fetch_block_probe.py)
+    uint32_t svc_idle_nap_max = 0;        // measurements: tsx_svc_launch.idle_nap_max
     bool svc_no_spread = false;           // measurements: tickets to whoever asks first (no spreading of a partial load over the CUs)
     uint32_t svc_guest_looks = 3;         // measurements: which looks at the yield word guest waves make (1: before every block, 2: while idle)
 };
@@ -76,7 +77,7 @@ extern "C" long long tsx_debug_config(const char* key, long long value) {
     CFG_FIELD(reserved_cus, uint32_t) CFG_FIELD(svc_max_launch_ms, uint32_t) CFG_FIELD(svc_idle_exit_us, uint32_t) CFG_FIELD(pool_idle_bytes, long long)
     CFG_FIELD(zstd_sched, uint32_t) CFG_FIELD(dec_block_chunks, uint32_t) CFG_FIELD(comp_pieces, uint32_t) CFG_FIELD(sub_bytes, long long)
     CFG_FIELD(stages_separate, bool) CFG_FIELD(no_pipeline, bool) CFG_FIELD(no_zero_copy_out, bool) CFG_FIELD(zero_copy_packed, bool)
-    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(fetch_quiet_ms, uint32_t) CFG_FIELD(trace, bool) CFG_FIELD(svc_guest_looks, uint32_t) CFG_FIELD(svc_no_spread, bool)
+    CFG_FIELD(gcm_setup_kernel, bool) CFG_FIELD(no_dec_pieces, bool) CFG_FIELD(debug, bool) CFG_FIELD(svc_normal_priority, bool) CFG_FIELD(svc_waves_per_cu, uint32_t) CFG_FIELD(svc_keep_waves, uint32_t) CFG_FIELD(fetch_quiet_ms, uint32_t) CFG_FIELD(trace, bool) CFG_FIELD(svc_guest_looks, uint32_t) CFG_FIELD(svc_no_spread, bool) CFG_FIELD(svc_idle_nap_max, uint32_t)
 #undef CFG_FIELD
     return TSX_E_INVAL;
 }
@@ -332,6 +333,7 @@ static int svc_launch_locked(tsx_service& s) {
     const uint64_t age = (uint64_t)g_cfg.svc_max_launch_ms * 100000ull;
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
     a.keep_waves = g_cfg.svc_keep_waves;
+    a.idle_nap_max = g_cfg.svc_idle_nap_max;
 #ifdef HIPEMU
     a.guest_idle_ticks = 0;
 #else

@@ -167,6 +167,7 @@ struct tsx_svc_launch {              // kernel arguments that shape a launch
                                      // guest_idle_ticks); the launch they help stays as it is
     uint32_t spread_cus;             // != 0: compute units a partial load is spread over (the ones the compressor uses); 0 = tickets go to whoever asks first
     uint32_t guest_idle_ticks;       // a guest that has found the queue dry for this long leaves (a chip whose every slot is held by mostly IDLE waves slows the busy ones down)
+    uint32_t idle_nap_max;           // longest nap of an idle wave between two looks at the queue, in 3.5 us (0 = 64: 224 us)
     uint32_t keep_waves;             // waves that stay on a reserved CU all the same (0 = the CU is left alone; the rest of it - LDS, registers, wave slots - is the room a fetch's workgroups find)
 };
 void tsx_launch_zstd_service(hipStream_t st, tsx_svc_host* hd, tsx_svc_dev* d, uint32_t grid, tsx_svc_launch a);

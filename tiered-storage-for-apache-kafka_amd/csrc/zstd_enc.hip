@@ -1965,16 +1965,23 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
             //   the tickets left at 20 per millisecond: the last chunk of a lone batch began 105 ms after the first, profiles/r06_ticket_storm.txt.)
             // A wave that is turned away looks again after a nap that doubles (3.5 - 56 us).
             const uint32_t limit = a.spread_cus ? ((pb - SVC_LD_DEV(&D->fin)) + a.spread_cus - 1u) / a.spread_cus + 1u : 0xFFFFFFFFu;     // (published - finished = outstanding)
-            if (atomicAdd(&D->cu_busy[key], 1u) < limit) {
-                if ((int32_t)atomicSub(&D->avail, 1u) > 0) {
-                    atomicAdd(&D->busy, 1u);                             // before `next` moves: whoever finds the queue dry finds busy != 0 (the idle exit looks at both)
-                    svc_fence_device();
-                    *ticket = atomicAdd(&D->next, 1u);
-                    return 1;
+            // Look before the read-modify-write, both times: a wave that decrements a spent semaphore holds it one lower until it has put the right
+            // back, and with thousands of idle waves doing that around the clock a SMALL member's rights (7 tickets against ~170 waves inside that
+            // window at any moment) never showed as positive to anybody - the host tests' 7-chunk batches stood still on the device (the CPU
+            // harness runs one workgroup at a time and cannot see it; tests/test_zzzz_gpu_service.py::test_small_members_next_to_thousands_of_idle_waves).
+            // Waves that only LOAD a spent semaphore leave it alone: it shows its true value as soon as the last loser has put its right back.
+            if (SVC_LD_DEV(&D->cu_busy[key]) < limit && (int32_t)SVC_LD_DEV(&D->avail) > 0) {
+                if (atomicAdd(&D->cu_busy[key], 1u) < limit) {
+                    if ((int32_t)atomicSub(&D->avail, 1u) > 0) {
+                        atomicAdd(&D->busy, 1u);                         // before `next` moves: whoever finds the queue dry finds busy != 0 (the idle exit looks at both)
+                        svc_fence_device();
+                        *ticket = atomicAdd(&D->next, 1u);
+                        return 1;
+                    }
+                    atomicAdd(&D->avail, 1u);
                 }
-                atomicAdd(&D->avail, 1u);
+                atomicSub(&D->cu_busy[key], 1u);
             }
-            atomicSub(&D->cu_busy[key], 1u);
             svc_nap(turned_away); if (turned_away < 16u) turned_away *= 2u;
             continue;
         }
@@ -1989,7 +1996,7 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
         if (SVC_LD_DEV(&D->busy) != 0 || quiet_since == 0) quiet_since = now;
         if (now - quiet_since >= a.idle_exit_ticks && SVC_LD_DEV(&D->busy) == 0) { atomicExch(&D->draining, 1u); return 2; }
         svc_nap(nap);
-        if (nap < 64) nap *= 2;
+        if (nap < (a.idle_nap_max ? a.idle_nap_max : 64u)) nap *= 2;
     }
 }
 

@@ -295,6 +295,26 @@ PY
       for k in ${arg//,/ }; do
         timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers 5 --seconds ${MIXED_SECONDS:-14} --config svc_keep_waves=$k --tag "keep_waves=$k" 2>> $O/keepwaves.err | tee -a $O/keepwaves.jsonl
       done ;;
+    benchdrv)
+      # the driver's command, verbatim
+      timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+      python - <<PY
+import json
+try:
+    j = json.loads(open("$O/bench_driver_cmd.json").read().strip().splitlines()[-1])
+    print("value", j["value"], "ms/step", j["ms_per_step"], "one at a time", j["config"]["gibs_one_batch_at_a_time"], "sustained", j["sustained"]["value"], "value_B", j["value_B"]["value"], j["value_B"]["value_B_1_5_6"]["value"])
+    print("roofline", json.dumps({k: v for k, v in j["roofline"].items() if k != "line_rate_probe"})[:1200])
+    print("mixed_load", json.dumps(j["mixed_load"])[:900])
+except Exception as e: print("benchdrv failed", e); print(open("$O/bench_driver_cmd.err").read()[-1500:])
+PY
+      ;;
+    satcfg)
+      # the saturated regime (5 callers x 2048-chunk device-resident batches, no fetches) under configurations set BEFORE tsx_init, e.g. satcfg:svc_waves_per_cu=23+svc_waves_per_cu=24
+      export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
+      [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/satcfg.err
+      for cfg in ${arg//+/ }; do
+        timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers ${SAT_CALLERS:-5} --seconds ${MIXED_SECONDS:-14} --no-fetch --config $cfg --tag "$cfg" 2>> $O/satcfg.err | tee -a $O/satcfg.jsonl | cut -c1-700
+      done ;;
     *) echo "unknown section $name" ;;
   esac
 done
