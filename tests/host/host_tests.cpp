@@ -650,8 +650,8 @@ static void backendTests(bool full) {
             std::atomic<int> go{0};
             for (int i = 0; i < 8; i++) th.emplace_back([&, i] {
                 go++; while (go.load() < 8) std::this_thread::yield();
-                std::this_thread::sleep_for(std::chrono::milliseconds(5 * i));           // arrive IN ORDER (a miss joins the open batch only when it continues it), inside the leader's
-                                                                                          // wait: 300 us apart was not enough under ThreadSanitizer - two threads swapped places
+                while (cache.stats().misses < i) std::this_thread::yield();             // arrive IN ORDER (a miss joins the open batch only when it continues it): thread i goes in when the
+                                                                                          // misses of 0 .. i - 1 are registered - sleeps of 5 ms x i swapped two threads next to a busy compiler
                 ok[(size_t)i] = cache.getChunk("k.log", m, i) == plain(i);
             });
             for (auto& x : th) x.join();

@@ -388,6 +388,7 @@ static void svc_try_guests_locked(tsx_service& s) {
     a.max_age_ticks_lo = (uint32_t)age; a.max_age_ticks_hi = (uint32_t)(age >> 32);
     a.guest_idle_ticks = 1000000; a.guest_launch = 1; a.guests = 1u | (g_cfg.svc_guest_looks << 1);
     a.spread_cus = 0;                                                    // (guests exist because everybody else is busy: nothing to spread)
+    a.main_waves = s.grid > gwaves ? s.grid - gwaves : s.grid;
     a.launch_id = s.g_launch_id + 1;
     (void)hipGetLastError();
     tsx_launch_zstd_service(s.st_g, s.hd, s.d, gwaves, a);

@@ -166,7 +166,8 @@ struct tsx_svc_launch {              // kernel arguments that shape a launch
                                      // finds the yield word raised, leaves at once.  Guests come and go with the load (they leave when the queue has been dry for
                                      // guest_idle_ticks); the launch they help stays as it is
     uint32_t spread_cus;             // != 0: compute units a partial load is spread over (the ones the compressor uses); 0 = tickets go to whoever asks first
-    uint32_t guest_idle_ticks;       // a guest that has found the queue dry for this long leaves (a chip whose every slot is held by mostly IDLE waves slows the busy ones down)
+    uint32_t guest_idle_ticks;       // a guest that has found the queue dry for this long leaves when the chip is mostly idle (a chip whose every slot is held by mostly IDLE waves slows the busy ones down)
+    uint32_t main_waves;             // guest launches: the waves of the launch they help - while more than half of them are busy a guest waits out a dry queue (50 x guest_idle_ticks)
     uint32_t idle_nap_max;           // longest nap of an idle wave between two looks at the queue, in 3.5 us (0 = 64: 224 us)
     uint32_t keep_waves;             // waves that stay on a reserved CU all the same (0 = the CU is left alone; the rest of it - LDS, registers, wave slots - is the room a fetch's workgroups find)
 };

@@ -1924,8 +1924,9 @@ __device__ ZS_NOINLINE static void svc_return_chunk(tsx_svc_dev* D, uint32_t mem
 }
 // (3): a chunk that a guest handed back, in *ticket / *chunk_out (member slot | generation, chunk index) - taken before any fresh ticket.
 // `yield` != nullptr: this wave is a guest and leaves (2) as soon as the word is raised.
+// `moved`: a wave of the launch itself that sits on a reserved CU (restored there) - a guest for as long as nobody wants the CU.
 __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_dev* D, const tsx_svc_launch a, const uint64_t t_start, const uint32_t* yield,
-                                                const uint32_t key, uint32_t* ticket, uint32_t* chunk_out) {
+                                                const uint32_t key, uint32_t* ticket, uint32_t* chunk_out, const bool moved) {
     const uint64_t max_age = ((uint64_t)a.max_age_ticks_hi << 32) | a.max_age_ticks_lo;
     uint64_t quiet_since = 0, dry_since = 0;
     uint32_t nap = 1, looks = 0, turned_away = 1;
@@ -1933,7 +1934,7 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
         const uint64_t now = svc_now();
         if (SVC_LD_DEV(&D->stop)) return 2;
         if (max_age && now - t_start > max_age) return 2;
-        if (yield && (a.guests & 4u) && (looks++ & 7u) == 0u && zs_yield_asked(yield)) return 2;     // (an idle guest: one PCIe read per eight looks, <= 2 ms apart)
+        if (yield && ((a.guests & 4u) || moved) && (looks++ & 7u) == 0u && zs_yield_asked(yield)) return 2;     // (an idle guest: one PCIe read per eight looks, <= 2 ms apart)
         if (SVC_LD_DEV(&D->ret_n)) {
             atomicAdd(&D->busy, 1u);
             svc_ret_lock(D);
@@ -1991,7 +1992,13 @@ __device__ ZS_NOINLINE static uint32_t svc_take(const tsx_svc_host* H, tsx_svc_d
         // (profiles/r06_full_chip_with_idle_waves.txt).  A chip that is full AND busy is fine (that is the saturated regime guests exist for).
         // So a guest that has found nothing to do for guest_idle_ticks (10 ms: the gap between two rounds of callers that resubmit at once is 2 - 3 ms)
         // leaves its slot; the next launch - which begins when work arrives after a dry spell - has guests again.
-        if (yield) { if (dry_since == 0) dry_since = now; else if (now - dry_since >= a.guest_idle_ticks) return 2; }
+        // While more than half of the launch they help is busy the chip is not "mostly idle": the queue of callers that resubmit as their batches
+        // complete runs dry for milliseconds at a time, a guest that leaves then is not replaced before all guests have left (one guest launch at a
+        // time), and a saturated run went on with 291 of 768 guests (profiles/r06_ticket_storm.txt 6).  Then a guest waits 50 times as long.
+        if (yield) {
+            if (dry_since == 0) dry_since = now;
+            else if (now - dry_since >= a.guest_idle_ticks && (SVC_LD_DEV(&D->busy) * 2u < a.main_waves || now - dry_since >= 50ull * a.guest_idle_ticks)) return 2;
+        }
         if (a.guest_launch) { svc_nap(nap); if (nap < 64) nap *= 2; continue; }      // (when the launch they help ends is not for its guests to say)
         if (SVC_LD_DEV(&D->busy) != 0 || quiet_since == 0) quiet_since = now;
         if (now - quiet_since >= a.idle_exit_ticks && SVC_LD_DEV(&D->busy) == 0) { atomicExch(&D->draining, 1u); return 2; }
@@ -2059,7 +2066,10 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     const bool on_reserved = ((D->reserved[key >> 5] >> (key & 31)) & 1u) != 0;
     if (a.guest_launch) {                                                // a launch of guests only: the reserved CUs are where it is meant to land
         uint32_t stay = 0;
-        if (lane == 0 && on_reserved && !zs_yield_asked(&H->yield)) stay = 2;
+        // (Wherever it lands.  Until late in round 6 a guest off the reserved CUs left at once - and of 736 - 768 guests 288 - 767 stayed, by run: slots
+        //  that the launch itself had not filled swallowed guest after guest, each free again the moment its guest had left, faster than the reserved CUs
+        //  filled.  The launch they help arrived 3 ms ago: nobody is waiting for those slots, a guest there is simply one more wave.)
+        if (lane == 0 && !zs_yield_asked(&H->yield)) stay = 2;
         if (!UNI(stay)) { if (lane == 0) svc_wave_exit(H, D, a.launch_id, 1u); return; }
         off_limits = nullptr; yield = &H->yield;
     } else if (on_reserved) {                                            // a reserved CU (see tsx_internal.h): the first keep_waves to arrive stay for good,
@@ -2081,10 +2091,14 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     for (;;) {
         uint32_t got = 0, ticket = 0, chunk = 0;
         if (lane == 0) {
-            // (between two chunks: where is this wave now?  Restored onto a reserved CU, it leaves before it takes another ticket)
+            // (between two chunks: where is this wave now?  Restored onto a reserved CU, it leaves before it takes another ticket - when the CU is
+            //  wanted.  On a quiet device (yield word down) it works on like a guest: every restore used to cost the launch those waves for the rest of
+            //  its life - a saturated run seen going from 6143 to 4153 live waves in 12 s, profiles/r06_ticket_storm.txt 6)
             const uint32_t k = svc_cu_key();
-            if (off_limits && ((off_limits[k >> 5] >> (k & 31)) & 1u)) { SVC_ST_MIRROR(&H->m_relocated, atomicAdd(&D->stat_relocated, 1u) + 1u); got = 2; }
-            else got = svc_take(H, D, a, t_start, yield, k, &ticket, &chunk);
+            const bool moved = off_limits && ((off_limits[k >> 5] >> (k & 31)) & 1u);
+            if (moved && zs_yield_asked(&H->yield)) got = 2;
+            else got = svc_take(H, D, a, t_start, moved ? &H->yield : yield, k, &ticket, &chunk, moved);
+            if (moved && got == 2) SVC_ST_MIRROR(&H->m_relocated, atomicAdd(&D->stat_relocated, 1u) + 1u);
             if (got == 1 || got == 3) key_busy = k;                       // (svc_take has counted the chunk on this CU)
 #ifdef TSX_PROF
             g_prof_take = wall_clock64();

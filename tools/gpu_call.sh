@@ -313,7 +313,7 @@ PY
       export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-16}
       [ -f /dev/shm/tsx_mix_src.npy ] || timeout 200 python tools/broker_leg.py --gen /dev/shm/tsx_mix_src.npy /dev/shm/tsx_mix_ivs.npy 1 256 4194304 K > /dev/null 2>> $O/satcfg.err
       for cfg in ${arg//+/ }; do
-        timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers ${SAT_CALLERS:-5} --seconds ${MIXED_SECONDS:-14} --no-fetch --config $cfg --tag "$cfg" 2>> $O/satcfg.err | tee -a $O/satcfg.jsonl | cut -c1-700
+        timeout 120 python tools/mixed_load_notorch.py --src /dev/shm/tsx_mix_src.npy --ivs /dev/shm/tsx_mix_ivs.npy --shape batches --callers ${SAT_CALLERS:-5} --seconds ${MIXED_SECONDS:-14} --no-fetch ${SAT_SAMPLE:+--sample-service} --config $cfg --tag "$cfg" 2>> $O/satcfg.err | tee -a $O/satcfg.jsonl | cut -c1-700
       done ;;
     *) echo "unknown section $name" ;;
   esac

@@ -172,7 +172,7 @@ def run(args):
     out = {"tag": args.tag, "process": "no torch: the system's HIP runtime", "upload_shape": args.shape, "compress_callers": T, "chunks_offered": T * n, "reserved_cus": st["reserved_cus"],
            "service_launches": st["launches"], "watchdog_launches": st["watchdog_launches"], "cpu_affinity": affinity, "fetching": not args.no_fetch,
            "compress_gibs_whole_window": round(sum(done) * n * CH / GiB / el, 3), "fetch_idle_ms": idle}
-    out["service"] = {k: st[k] - sv0[k] for k in ("launches", "guest_launches", "yielded_waves", "returned_chunks", "readmissions", "rotations")}
+    out["service"] = {k: st[k] - sv0[k] for k in ("launches", "guest_launches", "yielded_waves", "returned_chunks", "readmissions", "rotations", "wave_starts", "reserved_exits", "relocated_waves")}
     out["completions_at_s"] = [round(float(x - t0), 2) for x in sorted(stamps)]; out["window_s"] = round(el, 2)
     if samples:
         # chunks the device finished per 100 ms sample (a hole shows as a run of zeros), and the samples around the slowest second
