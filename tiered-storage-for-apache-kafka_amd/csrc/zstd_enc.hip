@@ -2066,10 +2066,11 @@ __global__ __launch_bounds__(LANES, ZS_WAVES_PER_SIMD) void zstd_service_kernel(
     const bool on_reserved = ((D->reserved[key >> 5] >> (key & 31)) & 1u) != 0;
     if (a.guest_launch) {                                                // a launch of guests only: the reserved CUs are where it is meant to land
         uint32_t stay = 0;
-        // (Wherever it lands.  Until late in round 6 a guest off the reserved CUs left at once - and of 736 - 768 guests 288 - 767 stayed, by run: slots
-        //  that the launch itself had not filled swallowed guest after guest, each free again the moment its guest had left, faster than the reserved CUs
-        //  filled.  The launch they help arrived 3 ms ago: nobody is waiting for those slots, a guest there is simply one more wave.)
-        if (lane == 0 && !zs_yield_asked(&H->yield)) stay = 2;
+        // (A guest that lands anywhere else leaves at once.  Slots that the launch itself had not filled swallow guest after guest that way - each is free
+        //  again the moment its guest has left - and of 736 - 768 guests 288 - 767 stay, by run.  Letting them stay wherever they land was tried: every slot
+        //  of the chip is held then, the hardware's scheduler saved and restored the waves in two runs of four, and those runs lost 10 % - for 224 waves
+        //  more that the saturated regime, bound by its line requests, has no use for: profiles/r06_ticket_storm.txt 6.)
+        if (lane == 0 && on_reserved && !zs_yield_asked(&H->yield)) stay = 2;
         if (!UNI(stay)) { if (lane == 0) svc_wave_exit(H, D, a.launch_id, 1u); return; }
         off_limits = nullptr; yield = &H->yield;
     } else if (on_reserved) {                                            // a reserved CU (see tsx_internal.h): the first keep_waves to arrive stay for good,
