@@ -160,7 +160,7 @@ typedef struct tsx_config {
                                         compressor).  Once no fetch (no batch of ordinary kernels) has run for this long, a launch of the
                                         compressor's kernel has waves on the reserved CUs too, as GUESTS: they work for as long as the
                                         queue has work for them - a chip that is full AND busy is what they are for; a guest that finds
-                                        the queue dry for 1 ms gives its slot back - and the next fetch makes them hand their chunks
+                                        the queue dry for 10 ms (500 while most of the chip is busy) gives its slot back - and the next fetch makes them hand their chunks
                                         back and leave, which costs that ONE fetch a block time of a chunk (~30 ms); the CUs then stay
                                         reserved until it has been quiet again.  Measured (round 6, MI355X): bench.py value 18.2 -> 20.5,
                                         continuously fed 19.8 -> 22.3 GiB/s.  Why it was opt-in in round 5 and what was wrong then:
