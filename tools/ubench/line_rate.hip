@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
     for (int a = 0; a < 3; a++) { CHK(hipMalloc(&b[a], (size_t)per * stride * 4)); CHK(hipMemset(b[a], 1, (size_t)per * stride * 4)); }
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     float best = 1e30f, ms = 0;
-    for (int rep = 0; rep < 3; rep++) {
+    for (int rep = 0; rep < 9; rep++) {                    // best of eight: a ceiling is a best case, and a box has bad tenths of a second (37 G requests/s where the same
+                                                           // box gave 46 five minutes earlier, with two timed launches - the compressor's own rate then showed as 1.18 of its "peak")
         CHK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k, dim3(nwg), dim3(64), 0, 0, b[0], b[1], b[2], per, stride, table_words, out, iters, R, W, X);
         CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
