@@ -36,7 +36,7 @@ def test_cu_probe_found_every_compute_unit_and_the_reservation_holds(gpu):
     s0 = gpu.service_stats(0)
     assert s0["compute_units"] == 256 and s0["cu_keys_seen"] == 256, s0
     assert s0["shader_engines"] == 32 and s0["reserved_cus"] == 32, s0
-    assert s0["waves"] in (256 * 23, 256 * 24), s0                     # (6384 B of LDS = five 1280-byte granules: 25 fit, the registers allow 24; some boxes hold 23)
+    assert s0["waves"] in (256 * 23, 256 * 24), s0                     # (6384 B of LDS = five 1280-byte granules: 25 fit, the registers allow 24; a calibration that is cut short says 23)
     per_cu = s0["waves"] // 256
     chunks = [synth.gen_chunk("K", 3, 0, i, 100000) for i in range(32)]
     gpu.service_quiesce(0)

@@ -496,12 +496,20 @@ static int svc_create(tsx_device& d, int cus) {
     // r05a-r05n, profiles/r05_service_resident_waves_and_pending_workgroups.txt): launches of 256 x 24 against the 256 x 21 that fit (the
     // kernel's 6704 bytes of LDS are allocated as 7680) kept 768 workgroups pending, and a fetch issued meanwhile came back when the launch
     // ended - up to its age limit later.
-    // How many fit is MEASURED: a launch of 32 workgroups per CU whose waves just stay for 300 us counts the most that were ever resident
-    // at once (registers, LDS with its allocation granularity, scratch slots - whatever limits it; the runtime's occupancy query said 24
-    // where 21 fit).  tsx_init runs on a device this process is not using yet.
-    for (int pass = 0; pass < 3; pass++) {
-        // (twice at least, and a third time when the two disagree: the first launch of a process also loads the code object)
-        tsx_svc_launch c{}; c.launch_id = ++s.launch_id; c.calibrate_ticks = 50000;       // leave when nobody has arrived for 500 us
+    // How many fit is MEASURED: a launch of 32 workgroups per CU whose waves stay until no workgroup has ARRIVED for 2 ms counts the most that
+    // were ever resident at once (registers, LDS with its allocation granularity, scratch slots - whatever limits it; the runtime's occupancy
+    // query said 24 where 21 fit).  The window was 500 us for most of round 6: the last few dozen workgroups of such a launch can arrive later
+    // than that behind the others (6094 - 6133 resident "measured" on a chip that holds 6144), the division below rounded that down to 23 per
+    // CU, and the service ran with 5888 waves instead of 6144 in most processes of some boxes - the "boxes that hold 23": they do not.  With
+    // 2 ms every pass sees 6137 - 6144 and the best of the passes is 6144 (four processes of four).  Up to four passes, until the best is a
+    // whole number of workgroups per CU twice in a row or at all after the second pass.  tsx_init runs on a device this process is not using yet.
+    for (int pass = 0; pass < 4; pass++) {
+        // (twice at least: the first launch of a process also loads the code object)
+#ifdef HIPEMU
+        tsx_svc_launch c{}; c.launch_id = ++s.launch_id; c.calibrate_ticks = 50000;       // (the CPU harness runs the workgroups one after the other: each waits its window out)
+#else
+        tsx_svc_launch c{}; c.launch_id = ++s.launch_id; c.calibrate_ticks = 200000;      // leave when nobody has arrived for 2 ms
+#endif
         (void)hipGetLastError();
         tsx_launch_zstd_service(s.st, s.hd, s.d, s.cus * 32u, c);
         HIPCHK(hipStreamSynchronize(s.st));
@@ -510,7 +518,8 @@ static int svc_create(tsx_device& d, int cus) {
         const uint32_t before = s.resident;
         if (lm[1] > s.resident) s.resident = lm[1];
         HIPCHK(hipMemcpy(&s.d->live_max, s.h_zero, 4, hipMemcpyHostToDevice));
-        if (pass == 1 && lm[1] == before) break;
+        if (g_cfg.debug) fprintf(stderr, "[tsxform] device %d: calibration launch %d: %u workgroups resident at once\n", d.hip_id, pass, lm[1]);
+        if (pass >= 1 && (lm[1] == before || s.resident % s.cus == 0)) break;
     }
     const uint32_t usable = s.cus;
     uint32_t per_cu = g_cfg.svc_waves_per_cu ? g_cfg.svc_waves_per_cu : s.resident / usable;
