@@ -11,12 +11,33 @@
 #include <stdio.h>
 #include <stdlib.h>
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("{\"error\": \"%s: %s\"}\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+// `depth` > 1: that many iterations' reads are in flight before their writes follow, and the next index does not wait for the data - the
+// compressor's parser speculates over several positions too; with depth 1 (what round 6 quoted until its last day) every iteration waits for the
+// previous one's data, the waves are latency-bound, and the compressor was measured ABOVE that "ceiling" on some boxes (1.02 - 1.05).
 __global__ __launch_bounds__(64, 6) void k(uint32_t* __restrict__ b0, uint32_t* __restrict__ b1, uint32_t* __restrict__ b2, uint32_t per, size_t stride_words,
-                                          uint32_t table_words, unsigned long long* out, int iters, int R, int W, int X) {
+                                          uint32_t table_words, unsigned long long* out, int iters, int R, int W, int X, int depth) {
     const uint32_t lane = threadIdx.x, wg = blockIdx.x;
     uint32_t* base = wg / per == 0 ? b0 : wg / per == 1 ? b1 : b2;
     uint32_t* tab = base + (size_t)(wg % per) * stride_words;
     uint32_t x = lane * 2654435761u + wg * 40503u + 1;
+    if (depth > 1) {
+        uint32_t acc = 0;
+        for (int i = 0; i < iters; i += 4) {
+            uint32_t idx[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { x = x * 1664525u + 1013904223u; idx[u] = (x >> 8) % table_words; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (int)lane < R ? tab[idx[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if ((int)lane < W) tab[idx[u]] = v[u] + 1;
+                if ((int)lane >= 32 && (int)lane < 32 + X) tab[(idx[u] * 7 + 13) % table_words] = x + u;
+                acc += v[u];
+            }
+        }
+        if (acc == 0x12345677u) out[wg] = 1;
+        return;
+    }
     for (int i = 0; i < iters; i++) {
         x = x * 1664525u + 1013904223u;
         const uint32_t idx = (x >> 8) % table_words;
@@ -29,7 +50,7 @@ __global__ __launch_bounds__(64, 6) void k(uint32_t* __restrict__ b0, uint32_t* 
 }
 int main(int argc, char** argv) {
     const int nwg = argc > 1 ? atoi(argv[1]) : 6144, iters = argc > 2 ? atoi(argv[2]) : 20000;
-    const int R = argc > 3 ? atoi(argv[3]) : 25, W = argc > 4 ? atoi(argv[4]) : 18, X = argc > 5 ? atoi(argv[5]) : 6;
+    const int R = argc > 3 ? atoi(argv[3]) : 25, W = argc > 4 ? atoi(argv[4]) : 18, X = argc > 5 ? atoi(argv[5]) : 6, depth = argc > 6 ? atoi(argv[6]) : 1;
     if (nwg < 3 || R > 32 || W > R || X > 32) { printf("{\"error\": \"bad arguments\"}\n"); return 2; }
     const uint32_t table_words = 196608;                   // 768 KiB: hashLong + hashSmall of one chunk
     const size_t stride = 532608;                          // words: ZS_WS_BYTES = 2.03 MiB
@@ -42,11 +63,11 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 9; rep++) {                    // best of eight: a ceiling is a best case, and a box has bad tenths of a second (37 G requests/s where the same
                                                            // box gave 46 five minutes earlier, with two timed launches - the compressor's own rate then showed as 1.18 of its "peak")
         CHK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k, dim3(nwg), dim3(64), 0, 0, b[0], b[1], b[2], per, stride, table_words, out, iters, R, W, X);
+        hipLaunchKernelGGL(k, dim3(nwg), dim3(64), 0, 0, b[0], b[1], b[2], per, stride, table_words, out, iters, R, W, X, depth);
         CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
         if (rep && ms < best) best = ms;                   // (the first launch also faults the pages in)
     }
-    printf("{\"waves\": %d, \"iters\": %d, \"reads\": %d, \"rewrites\": %d, \"blind_stores\": %d, \"ms\": %.3f, \"g_requests_per_s\": %.2f}\n", nwg, iters, R, W, X, best,
+    printf("{\"waves\": %d, \"iters\": %d, \"reads\": %d, \"rewrites\": %d, \"blind_stores\": %d, \"reads_in_flight_per_lane\": %d, \"ms\": %.3f, \"g_requests_per_s\": %.2f}\n", nwg, iters, R, W, X, depth > 1 ? 4 : 1, best,
            (double)nwg * iters * (R + W + X) / best / 1e6);
     return 0;
 }
