@@ -67,6 +67,11 @@ int main(int argc, char** argv) {
     const int sets = getenv("LINE_RATE_SETS") ? atoi(getenv("LINE_RATE_SETS")) : 1;
     uint32_t* first[3] = {nullptr, nullptr, nullptr};
     for (int set = 0; set < sets; set++) {
+        if (getenv("LINE_RATE_ONE_SLAB")) {                // the three table areas as thirds of ONE allocation
+            CHK(hipMalloc(&b[0], (size_t)per * stride * 4 * 3)); CHK(hipMemset(b[0], 1, (size_t)per * stride * 4 * 3));
+            b[1] = b[0] + (size_t)per * stride; b[2] = b[1] + (size_t)per * stride;
+            if (set == 0) for (int a = 0; a < 3; a++) first[a] = b[a];
+        } else
         for (int a = 0; a < 3; a++) { CHK(hipMalloc(&b[a], (size_t)per * stride * 4)); CHK(hipMemset(b[a], 1, (size_t)per * stride * 4)); if (set == 0) first[a] = b[a]; }
         if (sets > 1) {
             float bs = 1e30f;
@@ -76,7 +81,23 @@ int main(int argc, char** argv) {
                 CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
                 if (rep && ms < bs) bs = ms;
             }
-            printf("{\"set\": %d, \"address\": \"%p\", \"g_requests_per_s\": %.2f}\n", set, (void*)b[0], (double)nwg * iters * (R + W + X) / bs / 1e6);
+            printf("{\"set\": %d, \"address\": \"%p\", \"g_requests_per_s\": %.2f", set, (void*)b[0], (double)nwg * iters * (R + W + X) / bs / 1e6);
+            if (getenv("LINE_RATE_EACH")) {                // each of the set's three allocations alone (all waves on it, three per region), then the pairs
+                const int combos[6][3] = {{0, 0, 0}, {1, 1, 1}, {2, 2, 2}, {0, 1, 0}, {0, 2, 0}, {1, 2, 1}};
+                printf(", \"alone_0_1_2_pairs_01_02_12\": [");
+                for (int cbo = 0; cbo < 6; cbo++) {
+                    float bb = 1e30f;
+                    for (int rep = 0; rep < 3; rep++) {
+                        CHK(hipEventRecord(e0, 0));
+                        hipLaunchKernelGGL(k, dim3(nwg), dim3(64), 0, 0, b[combos[cbo][0]], b[combos[cbo][1]], b[combos[cbo][2]], per, stride, table_words, out, iters, R, W, X, depth);
+                        CHK(hipEventRecord(e1, 0)); CHK(hipEventSynchronize(e1)); CHK(hipEventElapsedTime(&ms, e0, e1));
+                        if (rep && ms < bb) bb = ms;
+                    }
+                    printf("%s%.2f", cbo ? ", " : "", (double)nwg * iters * (R + W + X) / bb / 1e6);
+                }
+                printf("]");
+            }
+            printf("}\n");
         }
     }
     if (sets > 1) for (int a = 0; a < 3; a++) b[a] = first[a];
