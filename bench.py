@@ -346,7 +346,10 @@ def main():
         try:
             runs = []
             for mixargs in (["6144", "20000", "25", "18", "6"], ["6144", "20000", "25", "0", "0"], ["6144", "20000", "25", "18", "6", "4"]):   # the parser's mix; reads alone; the mix with four reads in flight per lane
-                pr_ = subprocess.run([exe] + mixargs, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+                # (four sets of tables for the parser's mix, the best one counts: pairs of multi-GB allocations share a "side" of device memory or not -
+                #  37.6 / 45.7 / 50.3 G requests/s by set, profiles/r06_workspace_placement.txt - and a ceiling is the best case)
+                pr_ = subprocess.run([exe] + mixargs, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120,
+                                     env=dict(os.environ, LINE_RATE_SETS="4") if mixargs[3] != "0" else None)
                 runs.append(json.loads(pr_.stdout.strip().splitlines()[-1]))
             line_rate = {"parser_mix": runs[0], "reads_only": runs[1], "parser_mix_pipelined": runs[2], "tool": "tools/ubench/line_rate.hip (child process on the same GPU, before the warm-up)"}
         except Exception as e:                                           # noqa: BLE001 - a diagnosis, never a reason to lose the line
@@ -744,9 +747,10 @@ def main():
             binding = {"resource": "random 64-B line requests L2<->HBM (table probes + insertions)", "requests_per_launch": int(req),
                        "requests_per_sequence": rec.get("requests_per_sequence"), "achieved": round(rate, 2), "unit": "G requests/s"}
             if line_rate and "parser_mix" in line_rate:
-                pk = max(float(line_rate["parser_mix"]["g_requests_per_s"]), float((line_rate.get("parser_mix_pipelined") or {}).get("g_requests_per_s", 0.0)))      # (the better of: every iteration waits for its data / four reads in flight)
+                pk = max(float(line_rate["parser_mix"].get("g_requests_per_s_best_set", line_rate["parser_mix"]["g_requests_per_s"])),
+                         float((line_rate.get("parser_mix_pipelined") or {}).get("g_requests_per_s_best_set", 0.0)))      # (the better of: every iteration waits for its data / four reads in flight)
                 binding.update({"peak": pk, "frac": round(rate / pk, 3), "peak_reads_only": line_rate["reads_only"]["g_requests_per_s"],
-                                "peak_source": "tools/ubench/line_rate on this box right before the timed region: %d waves x %d iterations of %d reads + %d rewrites + %d blind stores"
+                                "peak_source": "tools/ubench/line_rate on this box right before the timed region: %d waves x %d iterations of %d reads + %d rewrites + %d blind stores, the best of four sets of tables"
                                                % (line_rate["parser_mix"]["waves"], line_rate["parser_mix"]["iters"], line_rate["parser_mix"]["reads"],
                                                   line_rate["parser_mix"]["rewrites"], line_rate["parser_mix"]["blind_stores"])})
                 if rate > pk:
