@@ -391,7 +391,7 @@ def main():
     if svc0 is not None:
         N.service_quiesce(0)
         svc1 = N.service_stats(0)
-        svc = {k: svc1[k] - svc0[k] for k in ("launches", "watchdog_launches", "members", "chunks", "kernel_ms", "device_chunks", "wave_starts", "reserved_exits", "guest_launches", "yielded_waves")}
+        svc = {k: svc1[k] - svc0[k] for k in ("launches", "watchdog_launches", "members", "chunks", "kernel_ms", "device_chunks", "wave_starts", "reserved_exits", "guest_launches", "yielded_waves", "relocated_waves")}
         svc.update({k: svc1[k] for k in ("waves", "compute_units", "cu_keys_seen", "reserved_cus")})
     for t in range(1, T):
         assert (ds[t]["status"] == 0).all() and (ds[t]["dst_len"] == d["dst_len"]).all() and (ds[t]["crc32c"] == d["crc32c"]).all()
@@ -723,7 +723,10 @@ def main():
         alg = cpl * (CH + mean_out)
         launches_meta = {"launches_in_timed_region": int(svc["launches"]), "chunks_per_launch": round(cpl, 1), "started_by_watchdog": int(svc["watchdog_launches"]),
                          "waves_per_launch": int(svc["waves"]), "reserved_cus": int(svc["reserved_cus"]),
-                         "launches_with_guest_waves_on_the_reserved_cus": int(svc["guest_launches"]), "compute_units": int(svc["compute_units"]), "cu_keys_seen": int(svc["cu_keys_seen"])}
+                         "launches_with_guest_waves_on_the_reserved_cus": int(svc["guest_launches"]), "compute_units": int(svc["compute_units"]), "cu_keys_seen": int(svc["cu_keys_seen"]),
+                         # waves that the hardware's scheduler saved and restored onto a reserved CU, counted when they leave it: a timed region that
+                         # met such an event is up to 10 % slower
+                         "waves_that_left_reserved_cus_after_a_save_restore": int(svc["relocated_waves"])}
     achieved = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM bytes per launch of that kernel from the committed PMC passes (tools/pmc_zstd.sh -> profiles/pmc_traffic.json:
     # FETCH_SIZE + WRITE_SIZE of the same kernel build and workload); null when no such measurement is recorded
