@@ -537,7 +537,9 @@ def main():
             for i in range(n):
                 srcb[i * CH:(i + 1) * CH] = hb[i % DIST] if rehearse else torch.from_numpy(hb[i % DIST]).to(dev)
             bdst = [Mem.empty(n * slot) for _ in range(T)]               # (the timed region's outputs stay as they are: verified and restored below)
-            reps_b = 2
+            # as many batches as the timed region has steps (the driver's command: 5 callers x 4 = 20), so that value_B reads next to `value` -
+            # both include the ramp and the drain of their callers; never fewer than two per caller
+            reps_b = max(2, -(-args.steps // T))
             legs = {}
             for pname, pval in (("1_5_7", nat.ZSTD_PROFILE_1_5_7), ("1_5_6", nat.ZSTD_PROFILE_1_5_6)):
                 pb = nat.Native.make_params(flags, synth.KEY, synth.AAD, zstd_profile=pval)
@@ -574,7 +576,7 @@ def main():
                                "checked_against": "libzstd %s + OpenSSL" % o.zstd_version() if pname == "1_5_7" else "oracle/zstd_l3.c profile 0 (unverified stand-in for libzstd 1.5.6) + OpenSSL"}
             value_b = {"metric": "GiB/s of original bytes, same chain and batch shape, content B (Kafka v2 record batches, %d distinct chunks replicated)" % DIST,
                        "distinct_chunks": DIST, "generated_in_s": round(gen_s, 1), **legs["1_5_7"], "value_B_1_5_6": legs["1_5_6"],
-                       "note": "the timed batches include the ramp and drain of %d callers x %d batches (compare with sustained.whole_run_gibs_incl_ramp_and_drain, not with value); "
+                       "note": "timed like `value`: %d callers x %d batches one after the other, ramp and drain of the callers included (rounds 5 and 6 before this line timed 2 batches per caller); "
                                "profile 1_5_6 = 1.5.7 without the pre-block splitter: what a broker with the reference's zstd-jni 1.5.6-9 would select" % (T, reps_b)}
             del srcb, bdst
         except Exception as ex:                                          # noqa: BLE001 - reported, never fatal for the line
