@@ -179,6 +179,23 @@ def broker_leg_first(args):
         shutil.rmtree(tmpd, ignore_errors=True)
 
 
+def _device_state_under_load(out, after_s):
+    """rocm-smi's view of the GPU a few seconds into a saturated leg (clocks, power, cap, temperatures), into `out`.  Reported, never used:
+    a slow box should be told from a slow process by something other than the result."""
+    time.sleep(after_s)
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showtemp", "--showperflevel", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        j = json.loads(r.stdout.decode() or "{}")
+        dev_i = int(os.environ.get("LOCAL_RANK", "0"))
+        card = j.get("card%d" % dev_i) or (next(iter(j.values())) if j else {})
+        keep = ("sclk", "mclk", "fclk", "socclk", "power", "temperature", "performance level")
+        out.update({k: v for k, v in card.items() if any(w in k.lower() for w in keep)})
+        out["sampled_at_s"] = after_s
+    except Exception as e:                                 # noqa: BLE001 - a diagnostic
+        out["error"] = repr(e)[:160]
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -410,6 +427,7 @@ def main():
     # the reference) keep work queued: 5 callers, started a quarter of a second apart, 10 batches each; the rate is the slope of
     # (batches completed) over time across the middle 60 % of the run, i.e. without the ramp at either end.
     sustained = None
+    box_state = {}
     if rank == 0 and world == 1 and workload == "full" and T > 1 and not split and not args.no_sustained:
         TS, BS, stag = (5, 10, 0.25) if not rehearse else (5, 3, 0.01)
         nbytes = (lambda b: b.size) if rehearse else (lambda b: b.numel())
@@ -429,8 +447,14 @@ def main():
 
         ts0 = time.perf_counter()
         th = [threading.Thread(target=feeder, args=(t,)) for t in range(TS)]
+        # one look at the device UNDER this load (clocks, power, power cap, temperatures): the same build gives 18.5 - 21.8 GiB/s by box
+        smi = threading.Thread(target=_device_state_under_load, args=(box_state, 3.0)) if not rehearse else None
         [x.start() for x in th]
+        if smi is not None:
+            smi.start()
         [x.join() for x in th]
+        if smi is not None:
+            smi.join()
         fence()
         whole = time.perf_counter() - ts0
         for t in range(TS):
@@ -443,7 +467,7 @@ def main():
                      "value": round(slope * batch_gib, 4), "unit": "GiB/s", "callers": TS, "batches": TS * BS,
                      "method": "least-squares slope of batches completed over time, completions %d..%d of %d (no ramp-up, no drain)" % (k0, k1 - 1, len(done_at)),
                      "whole_run_gibs_incl_ramp_and_drain": round(TS * BS * batch_gib / whole, 4),
-                     "ms_between_completions": round(1e3 / slope, 2)}
+                     "ms_between_completions": round(1e3 / slope, 2), "device_state_under_this_load": box_state or None}
         for c in xctx:
             N.ctx_destroy(c)
         del xdst, sdst
