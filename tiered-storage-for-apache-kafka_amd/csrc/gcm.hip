@@ -342,7 +342,20 @@ __global__ __launch_bounds__(TSX_GCM_THREADS) void gcm_ctr_ghash_kernel(
     }
 }
 
+// H^e out of the key's tables: H^(e mod 512) is an entry of hpow[], every set bit above costs one multiplication by H^(2^k) - at most
+// nine for a 4 MiB chunk (gf_pow_h of gcm_dev.h multiplies once per set bit of e: up to 17, each a 128-step bit loop).
+__device__ static tsx_gf128 gf_pow_h_tab(const tsx_gcm_key* key, uint32_t e) {
+    tsx_gf128 r = key->hpow[e & 511u];
+    e >>= 9;
+    for (int k = 9; e; k++, e >>= 1)
+        if (e & 1u) r = gf_mul(r, key->hpow2[k]);
+    return r;
+}
+
 // One wave per chunk: stitch the sub-block GHASH values, add AAD and length blocks, E_K(J0), tag.
+// The terms of the sum are independent - sub-block s carries H^(blocks behind it + 2), the AAD's Horner value H^(nb + 1), the length block
+// H - so the AAD and length terms are two more items of the same loop, on lanes of their own, instead of ~20 multiplications one after
+// the other on lane 0 behind the reduction (a single-chunk fetch spent 93 us here: profiles/r06_dec_single_chunk_kernel_stats.txt).
 __global__ __launch_bounds__(64) void gcm_final_kernel(const tsx_aes_tables* __restrict__ aes, const tsx_gcm_key* __restrict__ key,
                                                        const tsx_gcm_chunk* __restrict__ chunks, uint32_t max_sub,
                                                        const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
@@ -351,33 +364,33 @@ __global__ __launch_bounds__(64) void gcm_final_kernel(const tsx_aes_tables* __r
     const tsx_gcm_chunk ch = chunks[ci];
     if (ch.skip) return;
     const uint32_t n = ch.len, nb = (n + 15) >> 4;
+    const uint32_t nsub = (nb + (uint32_t)TSX_GCM_SUB_BLOCKS - 1) / (uint32_t)TSX_GCM_SUB_BLOCKS;
+    // AAD blocks: Horner with H (every lane computes the same value: as long as one lane doing it), scaled below past the ciphertext and the length block
+    const uint32_t alen = key->aad_len;
+    tsx_gf128 a; a.hi = 0; a.lo = 0;
+    for (uint32_t o = 0; o < alen; o += 16) {
+        tsx_gf128 x = gf_from_bytes(key->aad + o, min(16u, alen - o));
+        a.hi ^= x.hi; a.lo ^= x.lo;
+        a = gf_mul(a, key->h);
+    }
     tsx_gf128 acc; acc.hi = 0; acc.lo = 0;
-    for (uint32_t sub = lane; sub * TSX_GCM_SUB_BLOCKS < nb; sub += 64) {
-        const uint32_t* pp = partials + ((size_t)ci * max_sub + sub) * 4;
-        tsx_gf128 z; z.hi = ((uint64_t)pp[1] << 32) | pp[0]; z.lo = ((uint64_t)pp[3] << 32) | pp[2];
-        uint32_t jend = min((sub + 1) * (uint32_t)TSX_GCM_SUB_BLOCKS, nb);
-        tsx_gf128 r = gf_mul(z, gf_pow_h(key, nb - jend + 2));         // block j carries H^(nb-j+1): length block follows
+    for (uint32_t it = lane; it < nsub + 2; it += 64) {
+        tsx_gf128 z; uint32_t e;
+        if (it < nsub) {
+            const uint32_t* pp = partials + ((size_t)ci * max_sub + it) * 4;
+            z.hi = ((uint64_t)pp[1] << 32) | pp[0]; z.lo = ((uint64_t)pp[3] << 32) | pp[2];
+            const uint32_t jend = min((it + 1) * (uint32_t)TSX_GCM_SUB_BLOCKS, nb);
+            e = nb - jend + 2;                                          // block j carries H^(nb-j+1): length block follows
+        } else if (it == nsub) {
+            z = a; e = nb + 1;                                          // (zero without AAD)
+        } else {
+            z.hi = (uint64_t)alen * 8; z.lo = (uint64_t)n * 8; e = 1;   // length block [len(A)]64 || [len(C)]64 in bits, times H
+        }
+        const tsx_gf128 r = gf_mul(z, gf_pow_h_tab(key, e));
         acc.hi ^= r.hi; acc.lo ^= r.lo;
     }
     for (int o = 32; o; o >>= 1) { acc.hi ^= __shfl_xor(acc.hi, o); acc.lo ^= __shfl_xor(acc.lo, o); }
     if (lane != 0) return;
-    // AAD blocks: Horner with H, then scaled past the ciphertext and the length block
-    const uint32_t alen = key->aad_len;
-    if (alen) {
-        tsx_gf128 a; a.hi = 0; a.lo = 0;
-        for (uint32_t o = 0; o < alen; o += 16) {
-            tsx_gf128 x = gf_from_bytes(key->aad + o, min(16u, alen - o));
-            a.hi ^= x.hi; a.lo ^= x.lo;
-            a = gf_mul(a, key->h);
-        }
-        tsx_gf128 r = gf_mul(a, gf_pow_h(key, nb + 1));
-        acc.hi ^= r.hi; acc.lo ^= r.lo;
-    }
-    {   // length block [len(A)]64 || [len(C)]64 in bits, times H
-        tsx_gf128 l; l.hi = (uint64_t)alen * 8; l.lo = (uint64_t)n * 8;
-        tsx_gf128 r = gf_mul(l, key->h);
-        acc.hi ^= r.hi; acc.lo ^= r.lo;
-    }
     const uint8_t* ivp = decrypt ? in + ch.in_off : ch.iv;
     uint32_t k0 = (uint32_t)ivp[0] | ((uint32_t)ivp[1] << 8) | ((uint32_t)ivp[2] << 16) | ((uint32_t)ivp[3] << 24);
     uint32_t k1 = (uint32_t)ivp[4] | ((uint32_t)ivp[5] << 8) | ((uint32_t)ivp[6] << 16) | ((uint32_t)ivp[7] << 24);
