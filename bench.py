@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 # the legs below are more than 4: the process asks for 16, as INTEGRATION.md tells a broker's launcher to (must be set before the
 # runtime initialises, i.e. before torch is imported; an explicit setting wins).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# N > 1: RCCL shares device memory between the ranks through dmabuf handles; the pool's host driver supports no other kind
+# (`hipIpcGetMemHandle: invalid argument` without this).  Exported on the GPU boxes already - a default for a launcher whose environment lacks it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # torch and the HIP tools want a temporary directory; a box whose /tmp is missing or full (seen once on the GPU pool) must not cost the line
 try:
     import tempfile
