@@ -185,3 +185,29 @@ def test_eight_ranks_as_the_driver_launches_them(emu, oracle):
     assert j["n_gpus"] == 8 and j["scaling"] == "strong" and c["segments_total"] == 1 and c["chunks_of_rank0"] == 2
     assert c["process_group"]["world"] == 8 and c["process_group"]["ran"][:3] == ["barrier", "all_reduce(MAX)", "all_gather(sizes)"]
     assert c["chunk_index_positions_sha"] and c["object_gathered_on_rank0_sha"] and j["detransform"]["round_trip_exact"] is True
+
+
+def test_device_state_sample_reads_rocm_smi_json(tmp_path, monkeypatch):
+    """bench.py's look at the device under load (`sustained.device_state_under_this_load`): clocks, power, cap and temperatures of THIS rank's
+    card out of `rocm-smi --json`; a missing or failing tool costs a field, never the line."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\ncat <<'J'\n" + json.dumps({
+        "card0": {"sclk clock speed:": "(2397Mhz)", "mclk clock speed:": "(2000Mhz)", "Max Graphics Package Power (W)": "1400.0",
+                  "Current Socket Graphics Package Power (W)": "1231.0", "Temperature (Sensor junction) (C)": "51.0", "Unique ID": "0xabc"},
+        "card1": {"sclk clock speed:": "(132Mhz)", "Current Socket Graphics Package Power (W)": "140.0"}}) + "\nJ\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    out = {}
+    b._device_state_under_load(out, 0.0)
+    assert out["sclk clock speed:"] == "(2397Mhz)" and out["Max Graphics Package Power (W)"] == "1400.0" and "Unique ID" not in out
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    out = {}
+    b._device_state_under_load(out, 0.0)
+    assert out["sclk clock speed:"] == "(132Mhz)"
+    fake.write_text("#!/bin/sh\nexit 3\n")
+    out = {}
+    b._device_state_under_load(out, 0.0)
+    assert "sclk clock speed:" not in out                          # nothing to report; no exception
