@@ -153,3 +153,19 @@ def test_host_carryless_multiplier_equals_the_bit_loop(emu):
     f.argtypes = [ctypes.c_uint32]; f.restype = ctypes.c_int
     r = f(200000)
     assert r in (0, -1), "%d products differ" % r
+
+
+def test_gcm_tag_stitching_where_the_items_wrap_around_the_wave(emu, oracle):
+    """gcm_final_kernel stitches one item per 64 KiB sub-block plus the AAD term and the length term over the wave's 64 lanes: with 62 sub-blocks
+    the two extra items are lanes 62 and 63, with 63 and 64 they begin the loop's second trip, beyond that some sub-blocks do too.  Encrypt-only
+    chunks around 4 MiB against the oracle (OpenSSL-checked GCM), and back through the tag check (EncryptionChunkEnumeration.java:66-84,
+    DecryptionChunkEnumeration.java:54-62)."""
+    sub = 65536
+    sizes = [61 * sub + 16, 62 * sub - 1, 62 * sub, 62 * sub + 1, 63 * sub, 64 * sub, 64 * sub + 1, 66 * sub + 5]
+    chunks = pc.edge_chunks("R", sizes)
+    outs, _ = pc.check_transform_vs_oracle(emu, oracle, nat.ENCRYPT, chunks)
+    back, d2 = pc.run_detransform(emu, nat.ENCRYPT, outs, sizes)
+    assert (d2["status"] == 0).all() and all(back[i] == chunks[i].tobytes() for i in range(len(sizes)))
+    bad = bytearray(outs[3]); bad[-17] ^= 1                                   # the last ciphertext byte of the 62-sub-blocks-and-one-byte chunk
+    _, d3 = pc.run_detransform(emu, nat.ENCRYPT, [bytes(bad)], [sizes[3]])
+    assert d3["status"][0] == nat.E_TAG_MISMATCH
